@@ -1,0 +1,85 @@
+"""ctypes binding of lib3dioumatch_hip.so (the C ABI declared in include/pn2_hip.h and
+include/iou3d_hip.h).  PyTorch is used by the callers for device memory and streams only.
+
+There is NO CPU fallback: if the shared library is missing this module raises ImportError,
+and every device entry point raises RuntimeError for non-GPU tensors.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib3dioumatch_hip.so")
+
+_c_int, _c_float, _vp, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+_SIGNATURES = {
+    "pn2_furthest_point_sampling": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
+    "pn2_gather_points": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
+    "pn2_gather_points_grad": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
+    "pn2_ball_query": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp, _sz, _vp],
+    "pn2_ball_query_workspace_bytes": [_c_int, _c_int, _c_int, _c_int],
+    "pn2_group_points": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
+    "pn2_group_points_grad": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
+    "pn2_three_nn": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "pn2_three_interpolate": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "pn2_three_interpolate_grad": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "pn2_query_and_group": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _vp, _vp,
+                            _vp, _vp, _vp, _vp, _sz, _vp],
+    "pn2_error_string": [_c_int],
+    "iou3d_boxes_overlap_bev": [_c_int, _vp, _c_int, _vp, _vp, _vp],
+    "iou3d_boxes_iou_bev": [_c_int, _vp, _c_int, _vp, _vp, _vp],
+    "iou3d_boxes_iou3d": [_c_int, _vp, _c_int, _vp, _vp, _vp],
+    "iou3d_nms_mask": [_vp, _vp, _c_int, _c_float, _vp],
+    "iou3d_nms_normal_mask": [_vp, _vp, _c_int, _c_float, _vp],
+    "iou3d_nms": [_vp, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp],
+    "iou3d_boxes_iou_bev_cpu": [_c_int, _vp, _c_int, _vp, _vp],
+}
+_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_error_string": ctypes.c_char_p}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "3dioumatch_amd: %s is missing -- build it with `python 3dioumatch_amd/build.py` "
+            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == ABI mismatch, fail loudly
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, _c_int)
+    return lib
+
+
+lib = _load()
+
+
+def check(code, what):
+    """Turn a non-zero hipError_t return into a Python exception (never exit())."""
+    if code != 0:
+        msg = lib.pn2_error_string(int(code))
+        raise RuntimeError("%s failed: HIP error %d (%s)" %
+                           (what, code, msg.decode() if msg else "?"))
+
+
+def current_stream_ptr(device):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+_workspaces = {}
+
+
+def workspace(device, nbytes):
+    """Per-device scratch buffer (grow-only), allocated through torch's caching allocator."""
+    import torch
+    if nbytes <= 0:
+        return None, 0
+    key = (device.type, device.index)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf, buf.numel()

@@ -1,0 +1,274 @@
+// 3dioumatch_amd/csrc/iou3d.hip -- rotated-box BEV overlap / IoU / 3-D IoU matrices and NMS
+// for gfx950.
+//
+// Semantics: reference iou3d_nms_kernel.cu (K10 :249-262, K11 :264-278, K12 :280-324,
+// K13 :341-385), host scan iou3d_nms.cpp:121-134, Python epilogue iou3d_nms_utils.py:60-79,
+// CPU op iou3d_cpu.cpp:232-252.  Geometry: box_geom.h.
+//
+// Design:
+//  * pair matrices: 256-lane workgroups own a 16x16 tile of the (Na,Nb) matrix; the 32 boxes
+//    of the tile are pre-processed ONCE into LDS (rotated corners, cos/sin, inflated half
+//    extents) -- the reference redoes that per pair and its cos/sin per corner test;
+//  * the dynamically indexed polygon (<=16 vertices + polar angles) lives in LDS, laid out
+//    [slot][lane] so the 64 lanes of a wave never collide on a bank (no scratch memory);
+//  * far-apart / z-disjoint pairs exit before any trigonometry with the exact value 0;
+//  * NMS: one LANE per (row, column) pair and a wave ballot to form each 64-bit mask word
+//    (the reference gives each thread a whole row and loops 64 columns serially); the greedy
+//    scan runs on the device in a single wavefront, so nms needs no device->host mask copy.
+#include "common.h"
+#include "box_geom.h"
+
+namespace {
+
+using boxgeom::BoxPre;
+
+constexpr int kPolySlots = boxgeom::kMaxPoly * 3;  // x, y, angle per vertex
+
+// polygon store in LDS: element (slot s, lane t) at base[s*256 + t]
+struct LdsPoly {
+  float *base;
+  __device__ __forceinline__ float &x(int i) { return base[(i * 3 + 0) * 256]; }
+  __device__ __forceinline__ float &y(int i) { return base[(i * 3 + 1) * 256]; }
+  __device__ __forceinline__ float &a(int i) { return base[(i * 3 + 2) * 256]; }
+};
+
+struct HostPoly {
+  float vx[boxgeom::kMaxPoly], vy[boxgeom::kMaxPoly], va[boxgeom::kMaxPoly];
+  float &x(int i) { return vx[i]; }
+  float &y(int i) { return vy[i]; }
+  float &a(int i) { return va[i]; }
+};
+
+enum PairMode { kOverlap = 0, kIouBev = 1, kIou3d = 2 };
+
+template <int MODE>
+__device__ __forceinline__ float pair_value(const float *a, const float *b, const BoxPre &A,
+                                            const BoxPre &B, LdsPoly &st) {
+  if (MODE == kOverlap) return boxgeom::overlap_area(A, B, st);
+  if (MODE == kIouBev) {  // iou_bev, :228-235
+    const float sa = a[3] * a[4], sb = b[3] * b[4];
+    const float ov = boxgeom::overlap_area(A, B, st);
+    return ov / fmaxf(sa + sb - ov, 1e-8f);
+  }
+  // boxes_iou3d_gpu epilogue, iou3d_nms_utils.py:60-79
+  const float a_max = a[2] + a[5] / 2, a_min = a[2] - a[5] / 2;
+  const float b_max = b[2] + b[5] / 2, b_min = b[2] - b[5] / 2;
+  const float max_of_min = a_min > b_min ? a_min : b_min;
+  const float min_of_max = a_max < b_max ? a_max : b_max;
+  float h = min_of_max - max_of_min;
+  if (h < 0.f) h = 0.f;
+  const float ov_bev = h > 0.f ? boxgeom::overlap_area(A, B, st) : 0.f;
+  const float ov3d = ov_bev * h;
+  const float vol_a = a[3] * a[4] * a[5], vol_b = b[3] * b[4] * b[5];
+  float den = vol_a + vol_b - ov3d;
+  if (den < 1e-6f) den = 1e-6f;
+  return ov3d / den;
+}
+
+// ans[i,j] for a 16x16 tile; threadIdx.x = 16*row + col
+template <int MODE>
+__global__ void __launch_bounds__(256)
+pair_matrix_kernel(int na, const float *__restrict__ boxes_a, int nb,
+                   const float *__restrict__ boxes_b, float *__restrict__ ans) {
+  __shared__ float poly[kPolySlots * 256];
+  __shared__ BoxPre pre[32];
+  __shared__ float raw[32 * 7];
+  const int tid = threadIdx.x;
+  const int row0 = blockIdx.y * 16, col0 = blockIdx.x * 16;
+  if (tid < 32) {
+    const bool is_a = tid < 16;
+    const int g = is_a ? row0 + tid : col0 + (tid - 16);
+    const bool ok = is_a ? g < na : g < nb;
+    const float *src = (is_a ? boxes_a : boxes_b) + (size_t)(ok ? g : 0) * 7;
+    float bx[7];
+#pragma unroll
+    for (int d = 0; d < 7; ++d) { bx[d] = src[d]; raw[tid * 7 + d] = bx[d]; }
+    boxgeom::box_prepare(bx, pre[tid]);
+  }
+  __syncthreads();
+  const int r = tid >> 4, cidx = tid & 15;
+  const int gi = row0 + r, gj = col0 + cidx;
+  if (gi >= na || gj >= nb) return;
+  const BoxPre A = pre[r];
+  const BoxPre B = pre[16 + cidx];
+  LdsPoly st{poly + tid};
+  ans[(size_t)gi * nb + gj] = pair_value<MODE>(raw + r * 7, raw + (16 + cidx) * 7, A, B, st);
+}
+
+// iou_bev_3D (:237-247) / iou_normal (:327-338) as used by the NMS kernels
+template <bool NORMAL>
+__device__ __forceinline__ float nms_iou(const float *a, const float *b, const BoxPre &A,
+                                         const BoxPre &B, LdsPoly &st) {
+  if (NORMAL) {
+    const float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2);
+    const float right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
+    const float top = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2);
+    const float bottom = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
+    const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+    const float inter = width * height;
+    const float sa = a[3] * a[4], sb = b[3] * b[4];
+    return inter / fmaxf(sa + sb - inter, 1e-8f);
+  }
+  const float sa = a[3] * a[4] * a[5], sb = b[3] * b[4] * b[5];
+  const float top = fmaxf(a[2] - a[5] / 2, b[2] - b[5] / 2);
+  const float bottom = fminf(a[2] + a[5] / 2, b[2] + b[5] / 2);
+  const float height = fmaxf(bottom - top, 0.f);
+  const float ov = height > 0.f ? boxgeom::overlap_area(A, B, st) : 0.f;
+  const float s_overlap = ov * height;
+  return s_overlap / fmaxf(sa + sb - s_overlap, 1e-8f);
+}
+
+// One workgroup = 16 rows x one 64-column tile; each wave walks 4 rows, its 64 lanes are
+// the 64 columns; the mask word is the wave ballot.  Lower-triangle tiles are skipped
+// unless FULL (the scan never reads them, iou3d_nms.cpp:129-131).
+template <bool NORMAL>
+__global__ void __launch_bounds__(256)
+nms_mask_kernel(int n, float thresh, int full, const float *__restrict__ boxes,
+                unsigned long long *__restrict__ mask) {
+  __shared__ float poly[kPolySlots * 256];
+  __shared__ BoxPre pre[80];
+  __shared__ float raw[80 * 7];
+  const int tid = threadIdx.x;
+  const int cb = blockIdx.x;
+  const int row0 = blockIdx.y * 16;
+  const int rb = row0 >> 6;
+  if (!full && cb < rb) return;  // uniform for the whole workgroup
+  const int col_blocks = (n + 63) / 64;
+  if (tid < 80) {
+    const int g = tid < 64 ? cb * 64 + tid : row0 + (tid - 64);
+    const float *src = boxes + (size_t)(g < n ? g : 0) * 7;
+    float bx[7];
+#pragma unroll
+    for (int d = 0; d < 7; ++d) { bx[d] = src[d]; raw[tid * 7 + d] = bx[d]; }
+    if (!NORMAL) boxgeom::box_prepare(bx, pre[tid]);
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int gc = cb * 64 + lane;
+  LdsPoly st{poly + tid};
+  for (int it = 0; it < 4; ++it) {
+    const int rl = wave * 4 + it;
+    const int gr = row0 + rl;
+    if (gr >= n) break;  // wave-uniform
+    bool bit = false;
+    const bool test = gc < n && !(rb == cb && gc <= gr);
+    if (test)
+      bit = nms_iou<NORMAL>(raw + (64 + rl) * 7, raw + lane * 7, pre[64 + rl], pre[lane], st) >
+            thresh;
+    const unsigned long long word = __ballot(bit);
+    if (lane == 0) mask[(size_t)gr * col_blocks + cb] = word;
+  }
+}
+
+// Greedy scan, iou3d_nms.cpp:121-134, in one wavefront.  remv lives in LDS.
+__global__ void __launch_bounds__(64)
+nms_scan_kernel(const unsigned long long *__restrict__ mask, int n, int col_blocks,
+                long long *__restrict__ keep, int *__restrict__ num_out) {
+  extern __shared__ unsigned long long remv[];
+  const int lane = threadIdx.x;
+  for (int l = lane; l < col_blocks; l += kWave) remv[l] = 0ull;
+  __syncthreads();
+  int num = 0;
+  for (int i = 0; i < n; ++i) {
+    const int nblock = i >> 6, inblock = i & 63;
+    const unsigned long long w = remv[nblock];
+    if (!((w >> inblock) & 1ull)) {  // wave-uniform
+      if (lane == 0) keep[num] = i;
+      ++num;
+      const unsigned long long *p = mask + (size_t)i * col_blocks;
+      for (int l = nblock + lane; l < col_blocks; l += kWave) remv[l] |= p[l];
+      __syncthreads();
+    }
+  }
+  if (lane == 0) *num_out = num;
+}
+
+}  // namespace
+
+#define IOU3D_API extern "C" __attribute__((visibility("default")))
+
+template <int MODE>
+static int launch_pairs(int na, const float *a, int nb, const float *b, float *ans,
+                        void *stream_) {
+  if (na <= 0 || nb <= 0) return 0;
+  dim3 grid(pn2_ceil_div(nb, 16), pn2_ceil_div(na, 16));
+  hipLaunchKernelGGL(pair_matrix_kernel<MODE>, grid, dim3(256), 0, (hipStream_t)stream_, na, a,
+                     nb, b, ans);
+  return pn2_launch_status();
+}
+
+IOU3D_API int iou3d_boxes_overlap_bev(int num_a, const float *boxes_a, int num_b,
+                                      const float *boxes_b, float *ans, void *stream) {
+  return launch_pairs<kOverlap>(num_a, boxes_a, num_b, boxes_b, ans, stream);
+}
+
+IOU3D_API int iou3d_boxes_iou_bev(int num_a, const float *boxes_a, int num_b,
+                                  const float *boxes_b, float *ans, void *stream) {
+  return launch_pairs<kIouBev>(num_a, boxes_a, num_b, boxes_b, ans, stream);
+}
+
+IOU3D_API int iou3d_boxes_iou3d(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
+                                float *ans, void *stream) {
+  return launch_pairs<kIou3d>(num_a, boxes_a, num_b, boxes_b, ans, stream);
+}
+
+static int launch_mask(const float *boxes, unsigned long long *mask, int n, float thresh,
+                       bool normal, int full, hipStream_t stream) {
+  if (n <= 0) return 0;
+  dim3 grid((n + 63) / 64, pn2_ceil_div(n, 16));
+  if (normal)
+    hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(256), 0, stream, n, thresh, full, boxes,
+                       mask);
+  else
+    hipLaunchKernelGGL(nms_mask_kernel<false>, grid, dim3(256), 0, stream, n, thresh, full, boxes,
+                       mask);
+  return pn2_launch_status();
+}
+
+IOU3D_API int iou3d_nms_mask(const float *boxes, unsigned long long *mask, int boxes_num,
+                             float thresh, void *stream) {
+  return launch_mask(boxes, mask, boxes_num, thresh, false, 1, (hipStream_t)stream);
+}
+
+IOU3D_API int iou3d_nms_normal_mask(const float *boxes, unsigned long long *mask, int boxes_num,
+                                    float thresh, void *stream) {
+  return launch_mask(boxes, mask, boxes_num, thresh, true, 1, (hipStream_t)stream);
+}
+
+IOU3D_API int iou3d_nms(const float *boxes, int boxes_num, float thresh, int normal,
+                        unsigned long long *mask_ws, long long *keep_dev, int *num_out_dev,
+                        void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (boxes_num <= 0) return (int)hipMemsetAsync(num_out_dev, 0, sizeof(int), stream);
+  int rc = launch_mask(boxes, mask_ws, boxes_num, thresh, normal != 0, 0, stream);
+  if (rc != 0) return rc;
+  const int col_blocks = (boxes_num + 63) / 64;
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), sizeof(unsigned long long) * col_blocks,
+                     stream, mask_ws, boxes_num, col_blocks, keep_dev, num_out_dev);
+  return pn2_launch_status();
+}
+
+// The reference's only native CPU op on this path (iou3d_cpu.cpp:232-252): host pointers,
+// one thread, same arithmetic.  This is an API-mandated CPU operator, not a fallback for
+// the device entry points above.
+IOU3D_API int iou3d_boxes_iou_bev_cpu(int num_a, const float *boxes_a, int num_b,
+                                      const float *boxes_b, float *ans) {
+  if (num_a <= 0 || num_b <= 0) return 0;
+  BoxPre *pb = new BoxPre[num_b];
+  for (int j = 0; j < num_b; ++j) boxgeom::box_prepare(boxes_b + (size_t)j * 7, pb[j]);
+  HostPoly st;
+  for (int i = 0; i < num_a; ++i) {
+    const float *a = boxes_a + (size_t)i * 7;
+    BoxPre A;
+    boxgeom::box_prepare(a, A);
+    const float sa = a[3] * a[4];
+    for (int j = 0; j < num_b; ++j) {
+      const float *b = boxes_b + (size_t)j * 7;
+      const float sb = b[3] * b[4];
+      const float ov = boxgeom::overlap_area(A, pb[j], st);
+      ans[(size_t)i * num_b + j] = ov / fmaxf(sa + sb - ov, 1e-8f);
+    }
+  }
+  delete[] pb;
+  return 0;
+}

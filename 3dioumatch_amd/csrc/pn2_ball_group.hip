@@ -1,0 +1,331 @@
+// 3dioumatch_amd/csrc/pn2_ball_group.hip -- ball query + neighbourhood gather/scatter, gfx950.
+//
+// Semantics: reference ball_query_gpu.cu:14-49 (K4), group_points_gpu.cu:13-33 (K5),
+// :48-69 (K6); restated in SURVEY App. A.3/A.4.  The reference launches ONE block per
+// cloud and lets each thread scan all N points serially with stride-3 loads.
+//
+// Design here (brute-force tier; the cell-list tier for large clouds lives in
+// pn2_ball_grid.hip):
+//  * one 64-lane wavefront owns QW centroids (coordinates wave-uniform), lanes own 64
+//    CONSECUTIVE points per step (coalesced loads, points reused for all QW centroids);
+//  * hits are compacted IN INDEX ORDER with a wave ballot + prefix popcount, so the
+//    "first nsample indices, ascending" contract holds by construction and the early exit
+//    (cnt == nsample) is wave-uniform -- no lane ever idles waiting for a slower centroid;
+//  * the reference's "pre-fill the row with the first hit" (ball_query_gpu.cu:39-43) becomes
+//    a tail fill after the scan; rows without a hit are written as zeros, so the output
+//    needs no pre-zeroing.
+#include "common.h"
+
+namespace {
+
+template <int QW>
+__global__ void __launch_bounds__(256)
+ball_query_bf_kernel(int n, int m, float radius2, int nsample,
+                     const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+                     int *__restrict__ idx) {
+  const int b = blockIdx.y;
+  const int lane = lane_id();
+  const int wave = threadIdx.x / kWave;
+  const int j0 = (blockIdx.x * (256 / kWave) + wave) * QW;
+  if (j0 >= m) return;
+  const float *pts = xyz + (size_t)b * n * 3;
+  const float *ctr = new_xyz + ((size_t)b * m + j0) * 3;
+  int *rows = idx + ((size_t)b * m + j0) * nsample;
+
+  float cx[QW], cy[QW], cz[QW];
+  int cnt[QW], first[QW];
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+    const bool live = j0 + q < m;
+    cx[q] = live ? ctr[q * 3 + 0] : 0.f;
+    cy[q] = live ? ctr[q * 3 + 1] : 0.f;
+    cz[q] = live ? ctr[q * 3 + 2] : 0.f;
+    cnt[q] = live ? 0 : nsample;  // dead slots count as already full
+    first[q] = 0;
+  }
+
+  for (int base = 0; base < n; base += kWave) {
+    bool any_open = false;
+#pragma unroll
+    for (int q = 0; q < QW; ++q) any_open |= cnt[q] < nsample;
+    if (!any_open) break;  // wave-uniform
+    const int k = base + lane;
+    const bool valid = k < n;
+    const float x = valid ? pts[k * 3 + 0] : 0.f;
+    const float y = valid ? pts[k * 3 + 1] : 0.f;
+    const float z = valid ? pts[k * 3 + 2] : 0.f;
+#pragma unroll
+    for (int q = 0; q < QW; ++q) {
+      if (cnt[q] < nsample) {  // wave-uniform
+        const float d2 = sqdist3(cx[q], cy[q], cz[q], x, y, z);
+        const bool hit = valid && d2 < radius2;
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+          if (cnt[q] == 0) first[q] = base + __builtin_ctzll(mask);
+          const int slot = cnt[q] + mask_rank(mask);
+          if (hit && slot < nsample) rows[(size_t)q * nsample + slot] = k;
+          cnt[q] += __popcll(mask);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+    if (j0 + q < m) {
+      const int have = cnt[q] < nsample ? cnt[q] : nsample;
+      for (int s = have + lane; s < nsample; s += kWave) rows[(size_t)q * nsample + s] = first[q];
+    }
+  }
+}
+
+// out[b,l,e] = points[b,l,idx[b,e]],  e over npoints*nsample  (group_points_gpu.cu:13-33).
+// Each lane owns 4 consecutive e (16-byte idx load / 16-byte stores when VEC) and walks
+// CPT... channels, so an index is fetched once per channel group.
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+group_points_kernel(int c, int n, int mns, const float *__restrict__ points,
+                    const int *__restrict__ idx, float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= mns) return;
+  const int *ib = idx + (size_t)b * mns + e;
+  int i0, i1 = 0, i2 = 0, i3 = 0;
+  const int live = mns - e < 4 ? mns - e : 4;
+  if (VEC) {
+    const int4 v = *reinterpret_cast<const int4 *>(ib);
+    i0 = v.x; i1 = v.y; i2 = v.z; i3 = v.w;
+  } else {
+    i0 = ib[0];
+    if (live > 1) i1 = ib[1];
+    if (live > 2) i2 = ib[2];
+    if (live > 3) i3 = ib[3];
+  }
+  for (int l = blockIdx.y; l < c; l += gridDim.y) {
+    const float *src = points + ((size_t)b * c + l) * n;
+    float *dst = out + ((size_t)b * c + l) * mns + e;
+    if (VEC) {
+      float4 v;
+      v.x = src[i0]; v.y = src[i1]; v.z = src[i2]; v.w = src[i3];
+      *reinterpret_cast<float4 *>(dst) = v;
+    } else {
+      dst[0] = src[i0];
+      if (live > 1) dst[1] = src[i1];
+      if (live > 2) dst[2] = src[i2];
+      if (live > 3) dst[3] = src[i3];
+    }
+  }
+}
+
+// grad_points[b,l,idx[b,e]] += grad_out[b,l,e]   (group_points_gpu.cu:48-69)
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+group_points_grad_kernel(int c, int n, int mns, const float *__restrict__ grad_out,
+                         const int *__restrict__ idx, float *__restrict__ grad_points) {
+  const int b = blockIdx.z;
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= mns) return;
+  const int *ib = idx + (size_t)b * mns + e;
+  int i0, i1 = 0, i2 = 0, i3 = 0;
+  const int live = mns - e < 4 ? mns - e : 4;
+  if (VEC) {
+    const int4 v = *reinterpret_cast<const int4 *>(ib);
+    i0 = v.x; i1 = v.y; i2 = v.z; i3 = v.w;
+  } else {
+    i0 = ib[0];
+    if (live > 1) i1 = ib[1];
+    if (live > 2) i2 = ib[2];
+    if (live > 3) i3 = ib[3];
+  }
+  for (int l = blockIdx.y; l < c; l += gridDim.y) {
+    float *dst = grad_points + ((size_t)b * c + l) * n;
+    const float *src = grad_out + ((size_t)b * c + l) * mns + e;
+    if (VEC) {
+      const float4 g = *reinterpret_cast<const float4 *>(src);
+      // first-hit padding repeats one index many times in a row: merge equal neighbours
+      // before touching memory (fewer same-address atomics)
+      float a0 = g.x, a1 = g.y, a2 = g.z, a3 = g.w;
+      if (i1 == i0) { a1 = __fadd_rn(a0, a1); a0 = 0.f; }
+      if (i2 == i1) { a2 = __fadd_rn(a1, a2); a1 = 0.f; }
+      if (i3 == i2) { a3 = __fadd_rn(a2, a3); a2 = 0.f; }
+      if (i1 != i0) atomicAdd(dst + i0, a0);
+      if (i2 != i1) atomicAdd(dst + i1, a1);
+      if (i3 != i2) atomicAdd(dst + i2, a2);
+      atomicAdd(dst + i3, a3);
+    } else {
+      atomicAdd(dst + i0, src[0]);
+      if (live > 1) atomicAdd(dst + i1, src[1]);
+      if (live > 2) atomicAdd(dst + i2, src[2]);
+      if (live > 3) atomicAdd(dst + i3, src[3]);
+    }
+  }
+}
+
+// Fused tail of QueryAndGroup (pointnet2_utils.py:348-358): given idx, write the
+// (b, 3+c, m, ns) tensor: channels 0..2 = xyz[idx] - centroid (optionally * 1/radius),
+// channels 3.. = features[idx].
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+group_concat_kernel(int c, int n, int m, int ns, float inv_radius, int normalize,
+                    const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+                    const float *__restrict__ features, const int *__restrict__ idx,
+                    float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int mns = m * ns;
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= mns) return;
+  const int live = mns - e < 4 ? mns - e : 4;
+  const int *ib = idx + (size_t)b * mns + e;
+  int ii[4] = {0, 0, 0, 0};
+  if (VEC) {
+    const int4 v = *reinterpret_cast<const int4 *>(ib);
+    ii[0] = v.x; ii[1] = v.y; ii[2] = v.z; ii[3] = v.w;
+  } else {
+    for (int t = 0; t < live; ++t) ii[t] = ib[t];
+  }
+  const int ctot = 3 + c;
+  if (blockIdx.y == 0) {
+    const float *pts = xyz + (size_t)b * n * 3;
+    const float *ctr = new_xyz + (size_t)b * m * 3;
+    float r[3][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = (e + (t < live ? t : 0)) / ns;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        float v = __fsub_rn(pts[ii[t] * 3 + d], ctr[j * 3 + d]);
+        if (normalize) v = __fmul_rn(v, inv_radius);
+        r[d][t] = v;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      float *dst = out + ((size_t)b * ctot + d) * mns + e;
+      if (VEC) {
+        *reinterpret_cast<float4 *>(dst) = make_float4(r[d][0], r[d][1], r[d][2], r[d][3]);
+      } else {
+        for (int t = 0; t < live; ++t) dst[t] = r[d][t];
+      }
+    }
+  }
+  for (int l = blockIdx.y; l < c; l += gridDim.y) {
+    const float *src = features + ((size_t)b * c + l) * n;
+    float *dst = out + ((size_t)b * ctot + 3 + l) * mns + e;
+    if (VEC) {
+      *reinterpret_cast<float4 *>(dst) = make_float4(src[ii[0]], src[ii[1]], src[ii[2]], src[ii[3]]);
+    } else {
+      for (int t = 0; t < live; ++t) dst[t] = src[ii[t]];
+    }
+  }
+}
+
+int channel_groups(int c, int per_thread) {
+  int g = (c + per_thread - 1) / per_thread;
+  if (g < 1) g = 1;
+  if (g > 65535) g = 65535;
+  return g;
+}
+
+}  // namespace
+
+int pn2_ball_query_grid_try(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                            const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
+                            hipStream_t stream, int *handled);
+size_t pn2_ball_query_grid_workspace(int b, int n, int m, int nsample);
+
+PN2_API size_t pn2_ball_query_workspace_bytes(int b, int n, int m, int nsample) {
+  return pn2_ball_query_grid_workspace(b, n, m, nsample);
+}
+
+PN2_API int pn2_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                           const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
+                           void *stream_) {
+  if (b <= 0 || m <= 0 || nsample <= 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n <= 0) {
+    return (int)hipMemsetAsync(idx, 0, sizeof(int) * (size_t)b * m * nsample, stream);
+  }
+  int handled = 0;
+  const int rc = pn2_ball_query_grid_try(b, n, m, radius, nsample, new_xyz, xyz, idx, workspace,
+                                         workspace_bytes, stream, &handled);
+  if (rc != 0 || handled) return rc;
+
+  const float radius2 = radius * radius;  // fp32 product, as ball_query_gpu.cu:27
+  // centroids per wave: as many as keeps >= ~1024 workgroups in flight
+  const long long total = (long long)b * m;
+  int qw = 8;
+  while (qw > 1 && total / (4 * qw) < 1024) qw >>= 1;
+  dim3 grid(pn2_ceil_div(m, 4 * qw), b);
+  switch (qw) {
+    case 8:
+      hipLaunchKernelGGL(ball_query_bf_kernel<8>, grid, dim3(256), 0, stream, n, m, radius2,
+                         nsample, new_xyz, xyz, idx);
+      break;
+    case 4:
+      hipLaunchKernelGGL(ball_query_bf_kernel<4>, grid, dim3(256), 0, stream, n, m, radius2,
+                         nsample, new_xyz, xyz, idx);
+      break;
+    case 2:
+      hipLaunchKernelGGL(ball_query_bf_kernel<2>, grid, dim3(256), 0, stream, n, m, radius2,
+                         nsample, new_xyz, xyz, idx);
+      break;
+    default:
+      hipLaunchKernelGGL(ball_query_bf_kernel<1>, grid, dim3(256), 0, stream, n, m, radius2,
+                         nsample, new_xyz, xyz, idx);
+  }
+  return pn2_launch_status();
+}
+
+PN2_API int pn2_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                             const int *idx, float *out, void *stream_) {
+  const long long mns = (long long)npoints * nsample;
+  if (b <= 0 || c <= 0 || mns <= 0) return 0;
+  (void)n;
+  dim3 grid(pn2_ceil_div(mns, 1024), channel_groups(c, 8), b);
+  if (mns % 4 == 0)
+    hipLaunchKernelGGL(group_points_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream_, c, n,
+                       (int)mns, points, idx, out);
+  else
+    hipLaunchKernelGGL(group_points_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream_, c,
+                       n, (int)mns, points, idx, out);
+  return pn2_launch_status();
+}
+
+PN2_API int pn2_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                                  const float *grad_out, const int *idx, float *grad_points,
+                                  void *stream_) {
+  if (b <= 0 || c <= 0 || n <= 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * n, stream);
+  if (e != hipSuccess) return (int)e;
+  const long long mns = (long long)npoints * nsample;
+  if (mns <= 0) return 0;
+  dim3 grid(pn2_ceil_div(mns, 1024), channel_groups(c, 8), b);
+  if (mns % 4 == 0)
+    hipLaunchKernelGGL(group_points_grad_kernel<true>, grid, dim3(256), 0, stream, c, n, (int)mns,
+                       grad_out, idx, grad_points);
+  else
+    hipLaunchKernelGGL(group_points_grad_kernel<false>, grid, dim3(256), 0, stream, c, n,
+                       (int)mns, grad_out, idx, grad_points);
+  return pn2_launch_status();
+}
+
+PN2_API int pn2_query_and_group(int b, int n, int m, int c, float radius, int nsample,
+                                int normalize_xyz, const float *new_xyz, const float *xyz,
+                                const float *features, int *idx, float *out, void *workspace,
+                                size_t workspace_bytes, void *stream_) {
+  if (b <= 0 || m <= 0 || nsample <= 0) return 0;
+  if (c > 0 && !features) return (int)hipErrorInvalidValue;
+  int rc = pn2_ball_query(b, n, m, radius, nsample, new_xyz, xyz, idx, workspace,
+                          workspace_bytes, stream_);
+  if (rc != 0) return rc;
+  const long long mns = (long long)m * nsample;
+  dim3 grid(pn2_ceil_div(mns, 1024), channel_groups(c, 8), b);
+  const float inv_radius = 1.0f / radius;  // torch divides by a scalar as x * (1/r)
+  if (mns % 4 == 0)
+    hipLaunchKernelGGL(group_concat_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream_, c, n,
+                       m, nsample, inv_radius, normalize_xyz, new_xyz, xyz, features, idx, out);
+  else
+    hipLaunchKernelGGL(group_concat_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream_, c,
+                       n, m, nsample, inv_radius, normalize_xyz, new_xyz, xyz, features, idx, out);
+  return pn2_launch_status();
+}

@@ -1,0 +1,242 @@
+// 3dioumatch_amd/csrc/pn2_sampling.hip -- furthest point sampling + index gather for gfx950.
+//
+// Semantics: reference pointnet2/_ext_src/src/sampling_gpu.cu (K1 :75-234, K2 :13-35,
+// K3 :39-62), restated in SURVEY App. A.1/A.2.  Design is new:
+//
+//  * FPS.  The reference runs ONE 512-thread block per cloud and re-streams xyz+temp from
+//    global memory every round.  Here a cloud's points live in VGPRs for the whole call
+//    (x, y, z, running min distance: 16 B/point, up to 16 points per lane at 1024 lanes),
+//    a round is: per-lane update -> 64-lane wave argmax (cross-lane shuffles) -> one LDS
+//    slot per wave -> ONE workgroup barrier (double-buffered slots) -> every wave redundantly
+//    reduces the <=16 slots.  Clouds larger than the register budget fall back to a
+//    streaming variant (temp in the caller's scratch buffer).
+//  * Exact index parity.  The reference's result depends on its reduction tree: among equal
+//    maxima the winner minimises bitreverse(k mod bs) and then k, where bs = 2^floor(log2 n)
+//    capped at 512 (cuda_utils.h:20-24).  That order is reproduced by comparing
+//    (value, key(k)) with key = bitrev(k mod bs) << 22 | k, independent of how many lanes
+//    or waves this kernel uses.
+//  * Points with |p|^2 <= 1e-3 never take part (sampling_gpu.cu:105-106); they are given a
+//    running distance of -1, which can neither be selected (best starts at -1, strict >)
+//    nor change (min(d, -1) = -1).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned fps_key(int k, int log2bs) {
+  const unsigned low = (unsigned)k & ((1u << log2bs) - 1u);
+  const unsigned rev = log2bs ? (__brev(low) >> (32 - log2bs)) : 0u;
+  return (rev << 22) | (unsigned)k;  // k < 2^22 (checked on the host)
+}
+
+// true when candidate (va, ia) beats (vb, ib) under the reference's total order
+__device__ __forceinline__ bool fps_better(float va, int ia, float vb, int ib, int log2bs) {
+  return va > vb || (va == vb && fps_key(ia, log2bs) < fps_key(ib, log2bs));
+}
+
+__device__ __forceinline__ void fps_wave_argmax(float &v, int &i, int log2bs) {
+#pragma unroll
+  for (int off = kWave / 2; off >= 1; off >>= 1) {
+    const float ov = __shfl_xor(v, off, kWave);
+    const int oi = __shfl_xor(i, off, kWave);
+    if (fps_better(ov, oi, v, i, log2bs)) { v = ov; i = oi; }
+  }
+}
+
+// Combine the per-wave winners.  slot_* is one of two buffers (round parity), so one
+// barrier per round is enough: a wave can only overwrite a buffer two rounds later, i.e.
+// after every wave has passed the barrier that follows its reads of that buffer.
+template <int NW>
+__device__ __forceinline__ int fps_block_argmax(float v, int i, float *slot_v, int *slot_i,
+                                                int log2bs) {
+  if (lane_id() == 0) {
+    slot_v[threadIdx.x / kWave] = v;
+    slot_i[threadIdx.x / kWave] = i;
+  }
+  __syncthreads();
+  float bv = slot_v[0];
+  int bi = slot_i[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) {
+    const float ov = slot_v[w];
+    const int oi = slot_i[w];
+    if (fps_better(ov, oi, bv, bi, log2bs)) { bv = ov; bi = oi; }
+  }
+  return bi;
+}
+
+__device__ __forceinline__ bool fps_skipped(float x, float y, float z) {
+  const float mag = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+  return (double)mag <= 1e-3;  // double compare: the reference's literal is a double
+}
+
+// Register-resident FPS: THREADS lanes, each owning points tid + i*THREADS, i < PPT.
+// THREADS is a multiple of the reference block size bs, so k mod bs is constant per lane
+// and the lane-local scan in ascending i already honours the tie order.
+template <int THREADS, int PPT>
+__global__ void __launch_bounds__(THREADS)
+fps_reg_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
+               int *__restrict__ idxs) {
+  constexpr int NW = THREADS / kWave;
+  __shared__ float slot_v[2][NW];
+  __shared__ int slot_i[2][NW];
+  const int tid = threadIdx.x;
+  const float *pts = dataset + (size_t)blockIdx.x * n * 3;
+  int *out = idxs + (size_t)blockIdx.x * m;
+
+  float px[PPT], py[PPT], pz[PPT], td[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = tid + i * THREADS;
+    if (k < n) {
+      px[i] = pts[k * 3 + 0];
+      py[i] = pts[k * 3 + 1];
+      pz[i] = pts[k * 3 + 2];
+      td[i] = fps_skipped(px[i], py[i], pz[i]) ? -1.0f : 1e10f;
+    } else {
+      px[i] = py[i] = pz[i] = 0.f;
+      td[i] = -1.0f;
+    }
+  }
+  int old = 0;
+  if (tid == 0) out[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
+    float best = -1.0f;
+    int besti = 0;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float d = sqdist3(px[i], py[i], pz[i], x1, y1, z1);
+      const float d2 = fminf(d, td[i]);
+      td[i] = d2;
+      if (d2 > best) { best = d2; besti = tid + i * THREADS; }
+    }
+    fps_wave_argmax(best, besti, log2bs);
+    old = fps_block_argmax<NW>(best, besti, slot_v[j & 1], slot_i[j & 1], log2bs);
+    if (tid == 0) out[j] = old;
+  }
+}
+
+// Streaming FPS for clouds beyond the register budget: xyz and the running distances are
+// re-read from memory (L2-resident) every round, exactly the reference's data flow but with
+// 1024 lanes.  THREADS (1024) is a multiple of bs (<= 512), see above.
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
+fps_stream_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
+                  float *__restrict__ temp, int *__restrict__ idxs) {
+  constexpr int NW = THREADS / kWave;
+  __shared__ float slot_v[2][NW];
+  __shared__ int slot_i[2][NW];
+  const int tid = threadIdx.x;
+  const float *pts = dataset + (size_t)blockIdx.x * n * 3;
+  float *tmp = temp + (size_t)blockIdx.x * n;
+  int *out = idxs + (size_t)blockIdx.x * m;
+
+  for (int k = tid; k < n; k += THREADS)
+    tmp[k] = fps_skipped(pts[k * 3 + 0], pts[k * 3 + 1], pts[k * 3 + 2]) ? -1.0f : 1e10f;
+  int old = 0;
+  if (tid == 0) out[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
+    float best = -1.0f;
+    int besti = 0;
+    for (int k = tid; k < n; k += THREADS) {
+      const float d = sqdist3(pts[k * 3 + 0], pts[k * 3 + 1], pts[k * 3 + 2], x1, y1, z1);
+      const float d2 = fminf(d, tmp[k]);
+      tmp[k] = d2;
+      if (d2 > best) { best = d2; besti = k; }
+    }
+    fps_wave_argmax(best, besti, log2bs);
+    old = fps_block_argmax<NW>(best, besti, slot_v[j & 1], slot_i[j & 1], log2bs);
+    if (tid == 0) out[j] = old;
+  }
+}
+
+// out[b,c,j] = points[b,c,idx[b,j]]   (sampling_gpu.cu:13-25)
+__global__ void __launch_bounds__(256)
+gather_points_kernel(int c, int n, int m, const float *__restrict__ points,
+                     const int *__restrict__ idx, float *__restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const int b = blockIdx.z;
+  const int a = idx[(size_t)b * m + j];
+  for (int l = blockIdx.y; l < c; l += gridDim.y)
+    out[((size_t)b * c + l) * m + j] = points[((size_t)b * c + l) * n + a];
+}
+
+// grad_points[b,c,idx[b,j]] += grad_out[b,c,j]   (sampling_gpu.cu:39-52)
+__global__ void __launch_bounds__(256)
+gather_points_grad_kernel(int c, int n, int m, const float *__restrict__ grad_out,
+                          const int *__restrict__ idx, float *__restrict__ grad_points) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const int b = blockIdx.z;
+  const int a = idx[(size_t)b * m + j];
+  for (int l = blockIdx.y; l < c; l += gridDim.y)
+    atomicAdd(grad_points + ((size_t)b * c + l) * n + a, grad_out[((size_t)b * c + l) * m + j]);
+}
+
+int ref_log2_block(int n) {
+  // log2 of the reference's block size: opt_n_threads(n), cuda_utils.h:20-24
+  int l = 0;
+  while ((2 << l) <= n && l < 9) ++l;
+  return l;
+}
+
+}  // namespace
+
+PN2_API int pn2_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
+                                        int *idxs, void *stream_) {
+  if (b <= 0 || m <= 0) return 0;
+  if (n <= 0 || n >= (1 << 22)) return (int)hipErrorInvalidValue;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int log2bs = ref_log2_block(n);
+#define FPS_REG(T, P)                                                                     \
+  hipLaunchKernelGGL((fps_reg_kernel<T, P>), dim3(b), dim3(T), 0, stream, n, m, log2bs,   \
+                     dataset, idxs)
+  if (n < 512) {            // bs <= 256 divides 256
+    FPS_REG(256, 2);
+  } else if (n <= 512) {
+    FPS_REG(512, 1);
+  } else if (n <= 1024) {
+    FPS_REG(512, 2);
+  } else if (n <= 2048) {
+    FPS_REG(512, 4);
+  } else if (n <= 4096) {
+    FPS_REG(1024, 4);
+  } else if (n <= 8192) {
+    FPS_REG(1024, 8);
+  } else if (n <= 16384) {
+    FPS_REG(1024, 16);
+  } else {
+    if (!temp) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, stream, n, m, log2bs,
+                       dataset, temp, idxs);
+  }
+#undef FPS_REG
+  return pn2_launch_status();
+}
+
+PN2_API int pn2_gather_points(int b, int c, int n, int npoints, const float *points,
+                              const int *idx, float *out, void *stream_) {
+  if (b <= 0 || c <= 0 || npoints <= 0) return 0;
+  (void)n;
+  dim3 grid(pn2_ceil_div(npoints, 256), c < 65535 ? c : 65535, b);
+  hipLaunchKernelGGL(gather_points_kernel, grid, dim3(256), 0, (hipStream_t)stream_, c, n,
+                     npoints, points, idx, out);
+  return pn2_launch_status();
+}
+
+PN2_API int pn2_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                                   const int *idx, float *grad_points, void *stream_) {
+  if (b <= 0 || c <= 0 || n <= 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * n, stream);
+  if (e != hipSuccess) return (int)e;
+  if (npoints <= 0) return 0;
+  dim3 grid(pn2_ceil_div(npoints, 256), c < 65535 ? c : 65535, b);
+  hipLaunchKernelGGL(gather_points_grad_kernel, grid, dim3(256), 0, stream, c, n, npoints,
+                     grad_out, idx, grad_points);
+  return pn2_launch_status();
+}
+
+PN2_API const char *pn2_error_string(int code) { return hipGetErrorString((hipError_t)code); }

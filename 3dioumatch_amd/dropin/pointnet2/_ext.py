@@ -1,0 +1,223 @@
+"""pointnet2._ext -- drop-in for the reference's compiled extension of the same name
+(pybind surface: pointnet2/_ext_src/src/bindings.cpp:11-24), backed by the gfx950 HIP library
+through its C ABI (include/pn2_hip.h).
+
+Same nine functions, same argument order, same outputs.  Differences, all on the lenient
+side:
+  * errors are Python exceptions (the reference exit()s on a failed launch, cuda_utils.h:35-44);
+  * CPU tensors raise RuntimeError("CPU not supported"), as the reference does
+    (e.g. ball_query.cpp:33) -- there is no CPU path here either;
+  * three_interpolate_grad computes the true gradient (the reference dispatches its forward
+    kernel by mistake, interpolate.cpp:95).
+"""
+import importlib.util
+import os
+import sys
+
+import torch
+
+
+def _load_lib():
+    name = "_3dioumatch_amd_lib"
+    if name in sys.modules:
+        return sys.modules[name]
+    path = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                         "..", "..", "_lib.py"))
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    try:
+        spec.loader.exec_module(mod)
+    except BaseException:
+        del sys.modules[name]
+        raise
+    return mod
+
+
+_L = _load_lib()
+_lib = _L.lib
+
+
+def _chk_f32(t, name):
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be a contiguous tensor" % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s must be a float tensor" % name)
+
+
+def _chk_i32(t, name):
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be a contiguous tensor" % name)
+    if t.dtype != torch.int32:
+        raise RuntimeError("%s must be an int tensor" % name)
+
+
+def _chk_dev(first, *rest):
+    if not first.is_cuda:
+        raise RuntimeError("CPU not supported")
+    for t, name in rest:
+        if not t.is_cuda:
+            raise RuntimeError("%s must be a CUDA tensor" % name)
+        if t.device != first.device:
+            raise RuntimeError("%s must be on %s" % (name, first.device))
+
+
+def _stream(t):
+    return _L.current_stream_ptr(t.device)
+
+
+def gather_points(points, idx):
+    """points (B,C,N) f32, idx (B,m) i32 -> (B,C,m).  sampling.cpp:20-44"""
+    _chk_f32(points, "points"); _chk_i32(idx, "idx"); _chk_dev(points, (idx, "idx"))
+    b, c, n = points.shape
+    m = idx.shape[1]
+    out = torch.empty((b, c, m), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        _L.check(_lib.pn2_gather_points(b, c, n, m, points.data_ptr(), idx.data_ptr(),
+                                        out.data_ptr(), _stream(points)), "gather_points")
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    """grad_out (B,C,m), idx (B,m) -> (B,C,n) scatter-add.  sampling.cpp:46-68"""
+    _chk_f32(grad_out, "grad_out"); _chk_i32(idx, "idx"); _chk_dev(grad_out, (idx, "idx"))
+    b, c, m = grad_out.shape
+    out = torch.empty((b, c, int(n)), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        _L.check(_lib.pn2_gather_points_grad(b, c, int(n), m, grad_out.data_ptr(), idx.data_ptr(),
+                                             out.data_ptr(), _stream(grad_out)),
+                 "gather_points_grad")
+    return out
+
+
+def furthest_point_sampling(points, nsamples):
+    """points (B,N,3) f32 -> (B,nsamples) i32, index-exact.  sampling.cpp:70-91"""
+    _chk_f32(points, "points")
+    if not points.is_cuda:
+        raise RuntimeError("CPU not supported")
+    b, n, _ = points.shape
+    nsamples = int(nsamples)
+    out = torch.zeros((b, nsamples), dtype=torch.int32, device=points.device)
+    temp = torch.empty((b, n), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        _L.check(_lib.pn2_furthest_point_sampling(b, n, nsamples, points.data_ptr(),
+                                                  temp.data_ptr(), out.data_ptr(),
+                                                  _stream(points)), "furthest_point_sampling")
+    return out
+
+
+def three_nn(unknowns, knows):
+    """unknowns (B,n,3), knows (B,m,3) -> [dist2 (B,n,3) f32, idx (B,n,3) i32].
+    interpolate.cpp:19-45"""
+    _chk_f32(unknowns, "unknowns"); _chk_f32(knows, "knows")
+    _chk_dev(unknowns, (knows, "knows"))
+    b, n, _ = unknowns.shape
+    m = knows.shape[1]
+    dist2 = torch.empty((b, n, 3), dtype=torch.float32, device=unknowns.device)
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=unknowns.device)
+    with torch.cuda.device(unknowns.device):
+        _L.check(_lib.pn2_three_nn(b, n, m, unknowns.data_ptr(), knows.data_ptr(),
+                                   dist2.data_ptr(), idx.data_ptr(), _stream(unknowns)),
+                 "three_nn")
+    return [dist2, idx]
+
+
+def three_interpolate(points, idx, weight):
+    """points (B,C,m), idx (B,n,3) i32, weight (B,n,3) -> (B,C,n).  interpolate.cpp:47-75"""
+    _chk_f32(points, "points"); _chk_i32(idx, "idx"); _chk_f32(weight, "weight")
+    _chk_dev(points, (idx, "idx"), (weight, "weight"))
+    b, c, m = points.shape
+    n = idx.shape[1]
+    out = torch.empty((b, c, n), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        _L.check(_lib.pn2_three_interpolate(b, c, m, n, points.data_ptr(), idx.data_ptr(),
+                                            weight.data_ptr(), out.data_ptr(), _stream(points)),
+                 "three_interpolate")
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    """grad_out (B,C,n), idx, weight -> (B,C,m): the intended scatter-add
+    (interpolate_gpu.cu:121-148); see module docstring."""
+    _chk_f32(grad_out, "grad_out"); _chk_i32(idx, "idx"); _chk_f32(weight, "weight")
+    _chk_dev(grad_out, (idx, "idx"), (weight, "weight"))
+    b, c, n = grad_out.shape
+    out = torch.empty((b, c, int(m)), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        _L.check(_lib.pn2_three_interpolate_grad(b, c, n, int(m), grad_out.data_ptr(),
+                                                 idx.data_ptr(), weight.data_ptr(),
+                                                 out.data_ptr(), _stream(grad_out)),
+                 "three_interpolate_grad")
+    return out
+
+
+def _ball_ws(t, b, n, m, nsample):
+    need = int(_lib.pn2_ball_query_workspace_bytes(b, n, m, nsample))
+    buf, size = _L.workspace(t.device, need)
+    return (buf.data_ptr() if buf is not None else None), size
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """new_xyz (B,m,3), xyz (B,N,3) -> idx (B,m,nsample) i32 (note: new_xyz FIRST).
+    ball_query.cpp:13-37"""
+    _chk_f32(new_xyz, "new_xyz"); _chk_f32(xyz, "xyz"); _chk_dev(new_xyz, (xyz, "xyz"))
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    nsample = int(nsample)
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
+    with torch.cuda.device(new_xyz.device):
+        ws, ws_size = _ball_ws(new_xyz, b, n, m, nsample)
+        _L.check(_lib.pn2_ball_query(b, n, m, float(radius), nsample, new_xyz.data_ptr(),
+                                     xyz.data_ptr(), idx.data_ptr(), ws, ws_size,
+                                     _stream(new_xyz)), "ball_query")
+    return idx
+
+
+def group_points(points, idx):
+    """points (B,C,N), idx (B,m,ns) i32 -> (B,C,m,ns).  group_points.cpp:17-40"""
+    _chk_f32(points, "points"); _chk_i32(idx, "idx"); _chk_dev(points, (idx, "idx"))
+    b, c, n = points.shape
+    _, m, ns = idx.shape
+    out = torch.empty((b, c, m, ns), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        _L.check(_lib.pn2_group_points(b, c, n, m, ns, points.data_ptr(), idx.data_ptr(),
+                                       out.data_ptr(), _stream(points)), "group_points")
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    """grad_out (B,C,m,ns), idx -> (B,C,n) scatter-add.  group_points.cpp:42-65"""
+    _chk_f32(grad_out, "grad_out"); _chk_i32(idx, "idx"); _chk_dev(grad_out, (idx, "idx"))
+    b, c, m, ns = grad_out.shape
+    out = torch.empty((b, c, int(n)), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        _L.check(_lib.pn2_group_points_grad(b, c, int(n), m, ns, grad_out.data_ptr(),
+                                            idx.data_ptr(), out.data_ptr(), _stream(grad_out)),
+                 "group_points_grad")
+    return out
+
+
+# ---- addition (not in the reference's pybind surface) ------------------------------------
+def query_and_group(new_xyz, xyz, features, radius, nsample, normalize_xyz):
+    """Fused QueryAndGroup front end (pointnet2_utils.py:335-358): returns
+    (idx (B,m,ns) i32, grouped (B,3+C,m,ns) f32) with channels 0..2 = relative xyz
+    (optionally / radius) and 3.. = gathered features (features may be None)."""
+    _chk_f32(new_xyz, "new_xyz"); _chk_f32(xyz, "xyz"); _chk_dev(new_xyz, (xyz, "xyz"))
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    c = 0
+    fptr = None
+    if features is not None:
+        _chk_f32(features, "features"); _chk_dev(new_xyz, (features, "features"))
+        c = features.shape[1]
+        fptr = features.data_ptr()
+    nsample = int(nsample)
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
+    out = torch.empty((b, 3 + c, m, nsample), dtype=torch.float32, device=new_xyz.device)
+    with torch.cuda.device(new_xyz.device):
+        ws, ws_size = _ball_ws(new_xyz, b, n, m, nsample)
+        _L.check(_lib.pn2_query_and_group(b, n, m, c, float(radius), nsample,
+                                          1 if normalize_xyz else 0, new_xyz.data_ptr(),
+                                          xyz.data_ptr(), fptr, idx.data_ptr(), out.data_ptr(),
+                                          ws, ws_size, _stream(new_xyz)), "query_and_group")
+    return idx, out

@@ -1,0 +1,105 @@
+/*
+ * include/pn2_hip.h -- C ABI of the MI355X-native PointNet++ set-abstraction operators.
+ *
+ * Drop-in boundary for 3DIoUMatch's `pointnet2._ext` (reference pybind surface:
+ * pointnet2/_ext_src/src/bindings.cpp:11-24).  Every entry point below replaces one of
+ * the reference's C-level launchers (the `*_kernel_wrapper` functions the pybind layer
+ * calls); the argument order and meaning are the reference's, with two additions:
+ *   - an explicit `hipStream_t` (passed as void*) -- the reference takes the current
+ *     torch stream implicitly (at::cuda::getCurrentCUDAStream(), e.g. ball_query_gpu.cu:54);
+ *   - an `int` return (hipError_t value, 0 = success) instead of fprintf+exit(-1)
+ *     (cuda_utils.h:35-44).
+ * Pointers are DEVICE pointers unless stated.  No torch types cross this boundary.
+ *
+ * Layouts (all contiguous, as the reference requires via CHECK_CONTIGUOUS, utils.h:16-19):
+ *   xyz / new_xyz / unknown / known : (B, N, 3) float32
+ *   points / features / grads       : (B, C, N) float32
+ *   idx                             : int32
+ */
+#ifndef PN2_HIP_H
+#define PN2_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* replaces furthest_point_sampling_kernel_wrapper (sampling.cpp:16-18, sampling_gpu.cu:180-234).
+ * dataset (b,n,3); temp (b,n) scratch -- contents on entry are ignored (the reference's
+ * pybind layer fills it with 1e10, sampling.cpp:78-80; this library initialises it itself);
+ * idxs (b,m) int32, idxs[:,0] = 0.  Index-exact vs the reference, including its
+ * tie-breaking order and its |p|^2 <= 1e-3 skip rule. */
+int pn2_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
+                                int *idxs, void *stream);
+
+/* replaces gather_points_kernel_wrapper (sampling.cpp:9-11, sampling_gpu.cu:13-35).
+ * points (b,c,n), idx (b,npoints) -> out (b,c,npoints). */
+int pn2_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx,
+                      float *out, void *stream);
+
+/* replaces gather_points_grad_kernel_wrapper (sampling.cpp:12-14, sampling_gpu.cu:39-62).
+ * grad_out (b,c,npoints), idx (b,npoints) -> grad_points (b,c,n); the callee zeroes
+ * grad_points first (the reference relies on torch::zeros, sampling.cpp:57-59). */
+int pn2_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                           const int *idx, float *grad_points, void *stream);
+
+/* replaces query_ball_point_kernel_wrapper (ball_query.cpp:9-11, ball_query_gpu.cu:14-59).
+ * new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample): first nsample point indices (ascending)
+ * with squared distance < radius*radius, remaining slots padded with the first hit, all-zero
+ * row when there is no hit.  The callee writes every element of idx (no pre-zeroing needed).
+ * workspace: device scratch of at least pn2_ball_query_workspace_bytes(b,n,m,nsample) bytes
+ * (may be NULL when that function returns 0). */
+int pn2_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                   const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
+                   void *stream);
+size_t pn2_ball_query_workspace_bytes(int b, int n, int m, int nsample);
+
+/* replaces group_points_kernel_wrapper (group_points.cpp:9-11, group_points_gpu.cu:13-46).
+ * points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample). */
+int pn2_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                     const int *idx, float *out, void *stream);
+
+/* replaces group_points_grad_kernel_wrapper (group_points.cpp:13-15, group_points_gpu.cu:48-80).
+ * grad_out (b,c,npoints,nsample), idx -> grad_points (b,c,n); callee zeroes grad_points. */
+int pn2_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                          const int *idx, float *grad_points, void *stream);
+
+/* replaces three_nn_kernel_wrapper (interpolate.cpp:9-10, interpolate_gpu.cu:14-73).
+ * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) SQUARED distances, idx (b,n,3). */
+int pn2_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                 int *idx, void *stream);
+
+/* replaces three_interpolate_kernel_wrapper (interpolate.cpp:11-13, interpolate_gpu.cu:77-117).
+ * points (b,c,m), idx (b,n,3), weight (b,n,3) -> out (b,c,n). */
+int pn2_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                          const float *weight, float *out, void *stream);
+
+/* replaces three_interpolate_grad_kernel_wrapper (interpolate.cpp:14-17,
+ * interpolate_gpu.cu:121-159) -- the INTENDED scatter-add.  The reference's pybind layer
+ * never reaches that launcher (interpolate.cpp:95 dispatches the forward kernel instead,
+ * SURVEY section 0 defect 1); this entry point computes the true gradient.
+ * grad_out (b,c,n), idx (b,n,3), weight (b,n,3) -> grad_points (b,c,m); callee zeroes it. */
+int pn2_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                               const int *idx, const float *weight, float *grad_points,
+                               void *stream);
+
+/* ---- additions (no reference counterpart; the reference composes these in Python) ---- */
+
+/* Fused QueryAndGroup front end (pointnet2_utils.py:335-358): ball query, gather of xyz and
+ * of the C feature channels, centroid subtraction and optional 1/radius scaling, written once
+ * into the concatenated (b, 3+c, m, nsample) tensor the shared MLP consumes.  features may be
+ * NULL (c == 0).  idx (b,m,nsample) is also returned (needed by the backward pass).
+ * normalize_xyz != 0 divides the relative xyz by radius (pointnet2_utils.py:352-353). */
+int pn2_query_and_group(int b, int n, int m, int c, float radius, int nsample, int normalize_xyz,
+                        const float *new_xyz, const float *xyz, const float *features,
+                        int *idx, float *out, void *workspace, size_t workspace_bytes,
+                        void *stream);
+
+/* Human-readable text for a non-zero return value (hipGetErrorString). */
+const char *pn2_error_string(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PN2_HIP_H */

@@ -1,0 +1,229 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+numpy/ctypes front-end of the CPU checker (oracle/pn2_oracle.c, oracle/iou3d_oracle.c)
+and, when present, of the compiled reference (oracle/_ref/libiou3d_ref.so, built from
+the reference's own iou3d_cpu.cpp by `make -C oracle ref`).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product package (3dioumatch_amd/) never does.
+
+Function names mirror the reference's pybind surface (pointnet2/_ext_src/src/bindings.cpp:11-24,
+OpenPCDet/pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp:11-17) so that a test reads like a call
+into the reference extension; arguments and results are numpy arrays.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i32p = ctypes.POINTER(ctypes.c_int)
+_i64p = ctypes.POINTER(ctypes.c_longlong)
+_u64p = ctypes.POINTER(ctypes.c_ulonglong)
+
+
+def build(force=False):
+    """Compile the C restatement (and the reference shim when /root/reference exists)."""
+    need = force or not all(
+        os.path.exists(os.path.join(_HERE, n)) for n in ("liboracle.so", "liboracle_omp.so"))
+    if need:
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "all"])
+    ref_so = os.path.join(_HERE, "_ref", "libiou3d_ref.so")
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(ref_so)):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_f32p)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_i32p)
+
+
+class Oracle:
+    """One loaded copy of the checker; omp=True selects the OpenMP build (all host cores)."""
+
+    def __init__(self, omp=False):
+        build()
+        name = "liboracle_omp.so" if omp else "liboracle.so"
+        self.lib = ctypes.CDLL(os.path.join(_HERE, name))
+        self.omp = omp
+        self.lib.iou3do_box_overlap.restype = ctypes.c_float
+        self.lib.pn2o_num_threads.restype = ctypes.c_int
+        self.lib.pn2o_opt_n_threads.restype = ctypes.c_int
+
+    @property
+    def cores(self):
+        return int(self.lib.pn2o_num_threads()) if self.omp else 1
+
+    # ---- pointnet2._ext surface -------------------------------------------------
+    def furthest_point_sampling(self, points, nsamples):
+        points, pp = _f(points)
+        b, n, _ = points.shape
+        temp = np.empty((b, n), np.float32)
+        out = np.zeros((b, nsamples), np.int32)
+        self.lib.pn2o_furthest_point_sampling(b, n, int(nsamples), pp,
+                                              temp.ctypes.data_as(_f32p),
+                                              out.ctypes.data_as(_i32p))
+        return out
+
+    def gather_points(self, points, idx):
+        points, pp = _f(points)
+        idx, ip = _i(idx)
+        b, c, n = points.shape
+        m = idx.shape[1]
+        out = np.zeros((b, c, m), np.float32)
+        self.lib.pn2o_gather_points(b, c, n, m, pp, ip, out.ctypes.data_as(_f32p))
+        return out
+
+    def gather_points_grad(self, grad_out, idx, n):
+        grad_out, gp = _f(grad_out)
+        idx, ip = _i(idx)
+        b, c, m = grad_out.shape
+        out = np.zeros((b, c, n), np.float32)
+        self.lib.pn2o_gather_points_grad(b, c, int(n), m, gp, ip, out.ctypes.data_as(_f32p))
+        return out
+
+    def ball_query(self, new_xyz, xyz, radius, nsample):
+        new_xyz, qp = _f(new_xyz)
+        xyz, pp = _f(xyz)
+        b, n, _ = xyz.shape
+        m = new_xyz.shape[1]
+        out = np.zeros((b, m, nsample), np.int32)
+        self.lib.pn2o_ball_query(b, n, m, ctypes.c_float(radius), int(nsample), qp, pp,
+                                 out.ctypes.data_as(_i32p))
+        return out
+
+    def group_points(self, points, idx):
+        points, pp = _f(points)
+        idx, ip = _i(idx)
+        b, c, n = points.shape
+        _, m, ns = idx.shape
+        out = np.zeros((b, c, m, ns), np.float32)
+        self.lib.pn2o_group_points(b, c, n, m, ns, pp, ip, out.ctypes.data_as(_f32p))
+        return out
+
+    def group_points_grad(self, grad_out, idx, n):
+        grad_out, gp = _f(grad_out)
+        idx, ip = _i(idx)
+        b, c, m, ns = grad_out.shape
+        out = np.zeros((b, c, n), np.float32)
+        self.lib.pn2o_group_points_grad(b, c, int(n), m, ns, gp, ip,
+                                        out.ctypes.data_as(_f32p))
+        return out
+
+    def three_nn(self, unknown, known):
+        unknown, up = _f(unknown)
+        known, kp = _f(known)
+        b, n, _ = unknown.shape
+        m = known.shape[1]
+        dist2 = np.zeros((b, n, 3), np.float32)
+        idx = np.zeros((b, n, 3), np.int32)
+        self.lib.pn2o_three_nn(b, n, m, up, kp, dist2.ctypes.data_as(_f32p),
+                               idx.ctypes.data_as(_i32p))
+        return dist2, idx
+
+    def three_interpolate(self, points, idx, weight):
+        points, pp = _f(points)
+        idx, ip = _i(idx)
+        weight, wp = _f(weight)
+        b, c, m = points.shape
+        n = idx.shape[1]
+        out = np.zeros((b, c, n), np.float32)
+        self.lib.pn2o_three_interpolate(b, c, m, n, pp, ip, wp, out.ctypes.data_as(_f32p))
+        return out
+
+    def three_interpolate_grad(self, grad_out, idx, weight, m):
+        grad_out, gp = _f(grad_out)
+        idx, ip = _i(idx)
+        weight, wp = _f(weight)
+        b, c, n = grad_out.shape
+        out = np.zeros((b, c, m), np.float32)
+        self.lib.pn2o_three_interpolate_grad(b, c, n, int(m), gp, ip, wp,
+                                             out.ctypes.data_as(_f32p))
+        return out
+
+    def three_interpolate_grad_as_executed(self, grad_out, idx, weight, m):
+        """What the reference's mis-dispatched backward really returns."""
+        grad_out, gp = _f(grad_out)
+        idx, ip = _i(idx)
+        weight, wp = _f(weight)
+        b, c, n = grad_out.shape
+        out = np.zeros((b, c, m), np.float32)
+        self.lib.pn2o_three_interpolate_grad_as_executed(b, c, n, int(m), gp, ip, wp,
+                                                         out.ctypes.data_as(_f32p))
+        return out
+
+    # ---- iou3d_nms_cuda surface --------------------------------------------------
+    def _pairwise(self, fn, boxes_a, boxes_b):
+        boxes_a, ap = _f(boxes_a)
+        boxes_b, bp = _f(boxes_b)
+        na, nb = boxes_a.shape[0], boxes_b.shape[0]
+        out = np.zeros((na, nb), np.float32)
+        fn(na, ap, nb, bp, out.ctypes.data_as(_f32p))
+        return out
+
+    def boxes_overlap_bev(self, boxes_a, boxes_b):
+        return self._pairwise(self.lib.iou3do_boxes_overlap_bev, boxes_a, boxes_b)
+
+    def boxes_iou_bev(self, boxes_a, boxes_b):
+        return self._pairwise(self.lib.iou3do_boxes_iou_bev, boxes_a, boxes_b)
+
+    def boxes_iou3d(self, boxes_a, boxes_b):
+        """= Python wrapper boxes_iou3d_gpu (iou3d_nms_utils.py:48-81) in one call."""
+        return self._pairwise(self.lib.iou3do_boxes_iou3d, boxes_a, boxes_b)
+
+    def _nms(self, fn, boxes, thresh):
+        boxes, bp = _f(boxes)
+        n = boxes.shape[0]
+        cb = (n + 63) // 64
+        keep = np.zeros(max(n, 1), np.int64)
+        mask = np.zeros((max(n, 1), max(cb, 1)), np.uint64)
+        k = fn(bp, n, ctypes.c_float(thresh), keep.ctypes.data_as(_i64p),
+               mask.ctypes.data_as(_u64p))
+        return keep[:k].copy(), mask[:n, :cb].copy()
+
+    def nms(self, boxes_sorted, thresh):
+        """boxes already sorted by score (desc). Returns (kept indices int64, mask u64)."""
+        return self._nms(self.lib.iou3do_nms, boxes_sorted, thresh)
+
+    def nms_normal(self, boxes_sorted, thresh):
+        return self._nms(self.lib.iou3do_nms_normal, boxes_sorted, thresh)
+
+
+class Reference:
+    """The reference's own compiled CPU code (oracle/_ref). Raises if it was not built."""
+
+    def __init__(self):
+        path = os.path.join(_HERE, "_ref", "libiou3d_ref.so")
+        if not os.path.exists(path):
+            build()
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        import torch  # noqa: F401  (libtorch symbols must be resident before dlopen)
+        self.lib = ctypes.CDLL(path)
+
+    def boxes_iou_bev_cpu(self, boxes_a, boxes_b):
+        boxes_a, ap = _f(boxes_a)
+        boxes_b, bp = _f(boxes_b)
+        out = np.zeros((boxes_a.shape[0], boxes_b.shape[0]), np.float32)
+        self.lib.ref_boxes_iou_bev_cpu(boxes_a.shape[0], ap, boxes_b.shape[0], bp,
+                                       out.ctypes.data_as(_f32p))
+        return out
+
+    def box_overlap(self, boxes_a, boxes_b):
+        boxes_a, ap = _f(boxes_a)
+        boxes_b, bp = _f(boxes_b)
+        out = np.zeros((boxes_a.shape[0], boxes_b.shape[0]), np.float32)
+        self.lib.ref_box_overlap_matrix(boxes_a.shape[0], ap, boxes_b.shape[0], bp,
+                                        out.ctypes.data_as(_f32p))
+        return out
+
+
+def have_reference():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libiou3d_ref.so"))
