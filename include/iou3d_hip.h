@@ -54,7 +54,8 @@ int iou3d_boxes_iou_bev_cpu(int num_a, const float *boxes_a_host, int num_b,
 
 /* ---- addition (the reference composes this in Python, iou3d_nms_utils.py:48-81) ---- */
 
-/* 3-D IoU matrix in one kernel: BEV overlap x z-overlap / clamp(vol_a+vol_b-ov3d, 1e-6). */
+/* replaces the Python composition boxes_iou3d_gpu (iou3d_nms_utils.py:48-81): 3-D IoU matrix in
+ * one kernel: BEV overlap x z-overlap / clamp(vol_a + vol_b - ov3d, 1e-6). */
 int iou3d_boxes_iou3d(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
                       float *ans_iou3d, void *stream);
 

@@ -53,6 +53,7 @@ int pn2_gather_points_grad(int b, int c, int n, int npoints, const float *grad_o
 int pn2_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                    const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
                    void *stream);
+/* scratch size for pn2_ball_query above (the reference needs none, ball_query.cpp:24-33) */
 size_t pn2_ball_query_workspace_bytes(int b, int n, int m, int nsample);
 
 /* replaces group_points_kernel_wrapper (group_points.cpp:9-11, group_points_gpu.cu:13-46).
@@ -96,7 +97,8 @@ int pn2_query_and_group(int b, int n, int m, int c, float radius, int nsample, i
                         int *idx, float *out, void *workspace, size_t workspace_bytes,
                         void *stream);
 
-/* Human-readable text for a non-zero return value (hipGetErrorString). */
+/* Human-readable text for a non-zero return value (hipGetErrorString); stands in for the
+ * message the reference prints before exit(-1) in CUDA_CHECK_ERRORS (cuda_utils.h:35-44). */
 const char *pn2_error_string(int code);
 
 #ifdef __cplusplus

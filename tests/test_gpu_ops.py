@@ -1,0 +1,349 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP operator, called through the
+C ABI by the drop-in modules, against the CPU oracle on the same seeded inputs and against the
+committed golden vectors.
+
+Bars (BASELINE.json north_star): indices bit-exact for FPS / ball_query / three_nn; gathers
+bit-exact (pure copies); IoU, interpolated features and the atomic scatter-adds within 1e-4
+(tolerance stated in each test).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+# ------------------------------------------------------------------------------------- FPS
+@pytest.mark.parametrize("key", ["U", "E", "n100", "n600", "n1500", "allskip"])
+def test_fps_golden(ext, key):
+    g = golden("ops_fps.npz")
+    got = ext.furthest_point_sampling(dev(g["xyz_" + key]), int(g["m_" + key]))
+    assert got.dtype == torch.int32
+    assert np.array_equal(got.cpu().numpy(), g["idx_" + key])
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 2), (63, 10), (64, 64), (511, 60), (512, 100),
+                                 (513, 100), (1024, 128), (2048, 256), (3000, 200),
+                                 (5000, 128), (9000, 96), (16384, 64), (20000, 48)])
+def test_fps_sizes_vs_oracle(ext, oracle, synth, n, m):
+    # exercises every kernel instantiation (register tiers and the streaming tier) with
+    # duplicates (ties) and near-origin (skipped) points present
+    xyz = synth.cloud_edge_cases(2, n, 1.0, seed=100 + n, near_origin=min(4, n // 8),
+                                 duplicates=min(32, n // 8)) if n >= 16 else \
+        synth.cloud_uniform(2, n, 1.0, seed=n)
+    want = oracle.furthest_point_sampling(xyz, m)
+    got = ext.furthest_point_sampling(dev(xyz), m).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_fps_all_ties(ext, oracle):
+    # every point identical: the winner is decided purely by the reduction-tree order
+    xyz = np.ones((1, 1024, 3), np.float32)
+    want = oracle.furthest_point_sampling(xyz, 16)
+    assert np.array_equal(ext.furthest_point_sampling(dev(xyz), 16).cpu().numpy(), want)
+    # two far clusters of exact duplicates
+    xyz = np.ones((1, 2000, 3), np.float32)
+    xyz[0, 1000:] = 5.0
+    want = oracle.furthest_point_sampling(xyz, 32)
+    assert np.array_equal(ext.furthest_point_sampling(dev(xyz), 32).cpu().numpy(), want)
+
+
+def test_fps_config2_properties(ext, synth):
+    """BASELINE config 2 size (B=8, N=40000 -> 2048): size-independent properties -- index 0
+    first, all indices distinct and in range, and the defining greedy property checked on a
+    strided subset of rounds with an fp32 re-computation."""
+    xyz = synth.cloud_uniform(8, 40000, synth.cube_side(40000, 0.2, 64), seed=1)
+    idx = ext.furthest_point_sampling(dev(xyz), 2048).cpu().numpy()
+    assert idx.shape == (8, 2048) and np.all(idx[:, 0] == 0)
+    assert idx.min() >= 0 and idx.max() < 40000
+    for b in range(8):
+        assert len(np.unique(idx[b])) == 2048
+    b = 3
+    p = xyz[b]
+    temp = np.full(40000, 1e10, np.float32)
+    for j in range(1, 40):
+        d = p - p[idx[b, j - 1]]
+        dd = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        temp = np.minimum(temp, dd)
+        assert temp[idx[b, j]] == temp.max()
+
+
+# --------------------------------------------------------------------------- gather / group
+def test_gather_golden(ext):
+    g = golden("ops_gather.npz")
+    out = ext.gather_points(dev(g["points"]), dev(g["idx"]))
+    assert np.array_equal(bits(out.cpu().numpy()), bits(g["out"]))
+    grad = ext.gather_points_grad(dev(g["grad_out"]), dev(g["idx"]), 500).cpu().numpy()
+    np.testing.assert_allclose(grad, g["grad"], rtol=0, atol=1e-4)  # atomics: order-free sum
+
+
+def test_ballquery_group_golden(ext):
+    g = golden("ops_ballquery_group.npz")
+    for t in range(5):
+        r, ns = float(g["r_%d" % t]), int(g["ns_%d" % t])
+        xyz, new_xyz = dev(g["xyz_%d" % t]), dev(g["new_xyz_%d" % t])
+        idx = ext.ball_query(new_xyz, xyz, r, ns)
+        assert idx.dtype == torch.int32
+        assert np.array_equal(idx.cpu().numpy(), g["idx_%d" % t]), t
+        if "feats_%d" % t in g:
+            grouped = ext.group_points(dev(g["feats_%d" % t]), idx)
+            assert np.array_equal(bits(grouped.cpu().numpy()), bits(g["grouped_%d" % t]))
+            gg = ext.group_points_grad(dev(g["gout_%d" % t]), idx, xyz.shape[1]).cpu().numpy()
+            np.testing.assert_allclose(gg, g["ggrad_%d" % t], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("b,n,m,r,ns", [(2, 4096, 512, 0.2, 32), (3, 1000, 77, 0.3, 16),
+                                        (1, 130, 130, 0.5, 7), (2, 64, 5, 10.0, 128),
+                                        (1, 5000, 300, 0.15, 64), (2, 2048, 1024, 0.4, 32),
+                                        (1, 70, 9, 0.0, 4)])
+def test_ballquery_vs_oracle(ext, oracle, synth, b, n, m, r, ns):
+    # ragged sizes (n, m not multiples of 64), radius 0 (no hit anywhere -> zero rows),
+    # huge radius (every row full after the first 128 points)
+    xyz = synth.cloud_uniform(b, n, synth.cube_side(n, max(r, 0.1), ns), seed=n + m)
+    new_xyz = xyz[:, :m].copy() if m <= n else synth.cloud_uniform(b, m, 1.0, seed=5)
+    want = oracle.ball_query(new_xyz, xyz, r, ns)
+    got = ext.ball_query(dev(new_xyz), dev(xyz), r, ns).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("c,n,m,ns", [(1, 500, 33, 7), (3, 4096, 512, 32), (37, 700, 64, 16),
+                                      (128, 2048, 256, 32)])
+def test_group_vs_oracle(ext, oracle, c, n, m, ns):
+    g = np.random.default_rng(c + n)
+    pts = g.standard_normal((2, c, n)).astype(np.float32)
+    idx = g.integers(0, n, (2, m, ns)).astype(np.int32)
+    idx[:, :, ns // 2:] = idx[:, :, :1]  # first-hit style padding: repeated indices
+    out = ext.group_points(dev(pts), dev(idx)).cpu().numpy()
+    assert np.array_equal(bits(out), bits(oracle.group_points(pts, idx)))
+    gout = g.standard_normal(out.shape).astype(np.float32)
+    got = ext.group_points_grad(dev(gout), dev(idx), n).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.group_points_grad(gout, idx, n), rtol=0, atol=1e-4)
+
+
+def test_query_and_group_fused(ext, oracle, synth):
+    """Fused front end == reference composition (pointnet2_utils.py:335-358) done with the
+    oracle: idx exact, gathered features exact, relative xyz within 1 ulp-level 1e-6."""
+    b, n, m, c, r, ns = 2, 3000, 200, 5, 0.25, 24
+    xyz = synth.cloud_uniform(b, n, synth.cube_side(n, r, ns), seed=9)
+    new_xyz = xyz[:, :m].copy()
+    feats = np.random.default_rng(3).standard_normal((b, c, n)).astype(np.float32)
+    want_idx = oracle.ball_query(new_xyz, xyz, r, ns)
+    gx = oracle.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), want_idx)
+    gx = gx - new_xyz.transpose(0, 2, 1)[..., None]
+    gf = oracle.group_points(feats, want_idx)
+    for normalize in (False, True):
+        idx, out = ext.query_and_group(dev(new_xyz), dev(xyz), dev(feats), r, ns, normalize)
+        assert np.array_equal(idx.cpu().numpy(), want_idx)
+        out = out.cpu().numpy()
+        assert out.shape == (b, 3 + c, m, ns)
+        assert np.array_equal(bits(out[:, 3:]), bits(gf))
+        ref_xyz = gx / np.float32(r) if normalize else gx
+        np.testing.assert_allclose(out[:, :3], ref_xyz, rtol=0, atol=1e-6)
+    idx, out = ext.query_and_group(dev(new_xyz), dev(xyz), None, r, ns, False)
+    assert out.shape == (b, 3, m, ns)
+
+
+def test_north_star_pair_config2_properties(ext, synth):
+    """B=8, N=40000, m=2048, r=0.2, ns=64 (the roofline target): properties that do not need
+    the oracle at full size -- rows ascending then padded with the first hit, every listed
+    index inside the ball, nothing smaller missed (checked on sampled rows), group == fancy
+    indexing."""
+    b, n, m, r, ns = 8, 40000, 2048, 0.2, 64
+    xyz = synth.cloud_uniform(b, n, synth.cube_side(n, r, ns), seed=1)
+    d_xyz = dev(xyz)
+    fps = ext.furthest_point_sampling(d_xyz, m)
+    new_xyz = ext.gather_points(d_xyz.transpose(1, 2).contiguous(), fps).transpose(1, 2).contiguous()
+    idx = ext.ball_query(new_xyz, d_xyz, r, ns).cpu().numpy()
+    cen = new_xyz.cpu().numpy()
+    r2 = np.float32(r) * np.float32(r)
+    rng = np.random.default_rng(0)
+    for bi, j in zip(rng.integers(0, b, 200), rng.integers(0, m, 200)):
+        d = cen[bi, j] - xyz[bi]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        hits = np.nonzero(d2 < r2)[0][:ns]
+        want = np.full(ns, hits[0])
+        want[:len(hits)] = hits
+        assert np.array_equal(idx[bi, j], want)
+    feats = d_xyz.transpose(1, 2).contiguous()
+    grouped = ext.group_points(feats, dev(idx))
+    want = torch.gather(feats.unsqueeze(2).expand(b, 3, m, n), 3,
+                        dev(idx).long().unsqueeze(1).expand(b, 3, m, ns))
+    assert torch.equal(grouped, want)
+
+
+# ------------------------------------------------------------------------------ three_nn etc.
+def test_interp_golden(ext):
+    g = golden("ops_interp.npz")
+    d2, idx = ext.three_nn(dev(g["unknown"]), dev(g["known"]))
+    assert np.array_equal(idx.cpu().numpy(), g["idx"])
+    assert np.array_equal(bits(d2.cpu().numpy()), bits(g["dist2"]))
+    d2s, idxs = ext.three_nn(dev(g["unknown"][:, :9]), dev(g["known"][:, :2]))
+    assert np.array_equal(bits(d2s.cpu().numpy()), bits(g["dist2_small"]))
+    assert np.array_equal(idxs.cpu().numpy(), g["idx_small"])
+    out = ext.three_interpolate(dev(g["feats"]), dev(g["idx"]), dev(g["weight"]))
+    np.testing.assert_allclose(out.cpu().numpy(), g["interp"], rtol=0, atol=1e-4)
+    assert np.array_equal(bits(out.cpu().numpy()), bits(g["interp"]))  # same op order: exact
+    grad = ext.three_interpolate_grad(dev(g["grad_out"]), dev(g["idx"]), dev(g["weight"]), 300)
+    np.testing.assert_allclose(grad.cpu().numpy(), g["grad"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 4096, 1024), (1, 1000, 1500), (3, 37, 5), (1, 2500, 2049)])
+def test_three_nn_vs_oracle(ext, oracle, synth, b, n, m):
+    unk = synth.cloud_uniform(b, n, 2.0, seed=n)
+    kn = synth.cloud_uniform(b, m, 2.0, seed=m + 1)
+    kn[:, m // 2] = kn[:, 0]  # duplicate known point -> distance ties
+    wd, wi = oracle.three_nn(unk, kn)
+    d2, idx = ext.three_nn(dev(unk), dev(kn))
+    assert np.array_equal(idx.cpu().numpy(), wi)
+    assert np.array_equal(bits(d2.cpu().numpy()), bits(wd))
+
+
+def test_gridconv_three_nn_properties(ext, synth):
+    """GridConv size (B=8, 32768 x 1024): distances sorted, indices valid, and exact against a
+    torch fp32 top-3 on sampled queries."""
+    unk = synth.cloud_uniform(8, 32768, 3.0, seed=2)
+    kn = synth.cloud_uniform(8, 1024, 3.0, seed=3)
+    d2, idx = ext.three_nn(dev(unk), dev(kn))
+    assert bool((d2[..., 0] <= d2[..., 1]).all()) and bool((d2[..., 1] <= d2[..., 2]).all())
+    assert int(idx.min()) >= 0 and int(idx.max()) < 1024
+    u = dev(unk[:, :256])
+    k = dev(kn)
+    diff = u[:, :, None, :] - k[:, None, :, :]
+    dd = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+    want = torch.sort(dd, dim=2, stable=True)
+    assert torch.equal(idx[:, :256].long(), want.indices[..., :3])
+
+
+# ------------------------------------------------------------------------------------ IoU / NMS
+@pytest.mark.parametrize("tag", ["oriented", "aligned", "kat"])
+def test_iou_vs_reference_golden(iou_ext, tag):
+    """Device BEV overlap / IoU against vectors from the REFERENCE's compiled CPU code;
+    tolerance 1e-4 (device sin/cos/atan2 differ from glibc in the last ulps)."""
+    g = golden("iou_bev_cpu_ref.npz")
+    a, b = dev(g["a_" + tag]), dev(g["b_" + tag])
+    ov = torch.zeros(a.shape[0], b.shape[0], device=DEV)
+    iou_ext.boxes_overlap_bev_gpu(a, b, ov)
+    np.testing.assert_allclose(ov.cpu().numpy(), g["overlap_" + tag], rtol=0, atol=1e-4)
+    iou = torch.zeros_like(ov)
+    iou_ext.boxes_iou_bev_gpu(a, b, iou)
+    np.testing.assert_allclose(iou.cpu().numpy(), g["iou_bev_" + tag], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("na,nb,seed,aligned", [(64, 64, 0, False), (256, 256, 1, False),
+                                                (256, 256, 2, True), (33, 70, 3, False),
+                                                (1, 1, 4, False), (17, 300, 5, True)])
+def test_iou3d_vs_oracle(oracle, synth, na, nb, seed, aligned):
+    import importlib
+    ut = importlib.import_module("pcdet.ops.iou3d_nms.iou3d_nms_utils")
+    n = max(na, nb)
+    a, b = synth.boxes_pair(n, seed=seed, axis_aligned=aligned)
+    a, b = a[:na], b[:nb]
+    got = ut.boxes_iou3d_gpu(dev(a), dev(b)).cpu().numpy()
+    want = oracle.boxes_iou3d(a, b)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4)
+    assert (want > 0).any() or n == 1
+
+
+def test_iou3d_known_answers_and_empty(synth):
+    import importlib
+    ut = importlib.import_module("pcdet.ops.iou3d_nms.iou3d_nms_utils")
+    a, b = synth.box_kats()
+    iou = ut.boxes_iou3d_gpu(dev(a), dev(b)).cpu().numpy()
+    assert abs(iou[0, 0] - 0.125) < 1e-5 and iou[1, 1] == 0.0 and iou[5, 5] == 0.0
+    g = golden("iou3d_nms_oracle.npz")
+    np.testing.assert_allclose(iou, g["iou3d_kat"], rtol=0, atol=1e-4)
+    empty = ut.boxes_iou3d_gpu(dev(a[:0]), dev(b))
+    assert tuple(empty.shape) == (0, len(b))
+
+
+def test_train_step_iou_shape_properties(synth):
+    """(B*K) x (B*64) = 2048 x 512 as compute_iou_labels issues it: IoU in [0,1], symmetric
+    under swapping the operands, and identical boxes give ~1."""
+    import importlib
+    ut = importlib.import_module("pcdet.ops.iou3d_nms.iou3d_nms_utils")
+    a, b = synth.boxes_pair(2048, seed=8)
+    a_d, b_d = dev(a), dev(b[:512])
+    iou = ut.boxes_iou3d_gpu(a_d, b_d)
+    assert float(iou.min()) >= 0.0 and float(iou.max()) <= 1.0 + 1e-4
+    iou_t = ut.boxes_iou3d_gpu(b_d, a_d)
+    assert float((iou - iou_t.t()).abs().max()) <= 1e-4
+    self_iou = ut.boxes_iou3d_gpu(a_d[:256], a_d[:256]).diagonal()
+    assert float((self_iou - 1).abs().max()) < 5e-2
+
+
+def _mask_words(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def test_nms_vs_oracle(iou_ext, oracle, synth):
+    import importlib
+    L = importlib.import_module("3dioumatch_amd._lib")
+    g = golden("iou3d_nms_oracle.npz")
+    boxes = g["nms_boxes"]
+    n = len(boxes)
+    d = dev(boxes)
+    cb = (n + 63) // 64
+    for thr, tag in ((0.25, "0p25"), (0.5, "0p5")):
+        for normal, kkey, mkey in ((False, "keep_", "mask_"), (True, "keepn_", "maskn_")):
+            keep = torch.empty(n, dtype=torch.int64)
+            fn = iou_ext.nms_normal_gpu if normal else iou_ext.nms_gpu
+            num = fn(d, keep, thr)
+            assert np.array_equal(keep[:num].numpy(), g[kkey + tag]), (thr, normal)
+            keep32 = torch.empty(n, dtype=torch.int32)
+            assert fn(d, keep32, thr) == num and np.array_equal(keep32[:num].numpy(), g[kkey + tag])
+            # the full mask through the launcher-level ABI, bit for bit
+            mask = torch.zeros(n * cb, dtype=torch.int64, device=DEV)
+            mfn = L.lib.iou3d_nms_normal_mask if normal else L.lib.iou3d_nms_mask
+            L.check(mfn(d.data_ptr(), mask.data_ptr(), n, thr,
+                        torch.cuda.current_stream().cuda_stream), "mask")
+            torch.cuda.synchronize()
+            want = g[mkey + tag]
+            got = _mask_words(mask).reshape(n, cb)
+            flips = np.count_nonzero(got != want)
+            assert flips == 0, "%d mask words differ (IoU within ulps of the threshold?)" % flips
+
+
+def test_nms_wrapper_and_stress_size(oracle, synth):
+    import importlib
+    ut = importlib.import_module("pcdet.ops.iou3d_nms.iou3d_nms_utils")
+    boxes, scores = synth.boxes_scored(1024, seed=12, spread=8.0)
+    perm = np.random.default_rng(1).permutation(1024)
+    keep, _ = ut.nms_gpu(dev(boxes[perm]), dev(scores[perm]), 0.25)
+    want, _ = oracle.nms(boxes, 0.25)
+    inv = np.argsort(perm)  # index in the shuffled array of sorted box i is where perm == i
+    got_sorted = np.array([np.nonzero(perm[k] == np.arange(1024))[0][0] for k in keep.cpu().numpy()])
+    assert len(got_sorted) == len(want)
+    assert np.array_equal(got_sorted, want)
+    assert inv.shape == (1024,)
+    keep_n, _ = ut.nms_normal_gpu(dev(boxes), dev(scores), 0.5)
+    want_n, _ = oracle.nms_normal(boxes, 0.5)
+    assert np.array_equal(keep_n.cpu().numpy(), want_n)
+    k1, _ = ut.nms_gpu(dev(boxes), dev(scores), 0.25, pre_maxsize=100)
+    w1, _ = oracle.nms(boxes[:100], 0.25)
+    assert np.array_equal(k1.cpu().numpy(), w1)
+
+
+def test_streams_and_second_device_context(ext, oracle, synth):
+    """Kernels run on torch's CURRENT stream (the reference's iou3d launches use the legacy
+    default stream): results issued on a side stream are ordered with that stream."""
+    xyz = synth.cloud_uniform(2, 2000, 1.5, seed=77)
+    want = oracle.furthest_point_sampling(xyz, 64)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        d = dev(xyz)
+        got = ext.furthest_point_sampling(d, 64)
+        idx = ext.ball_query(d[:, :64].contiguous(), d, 0.3, 16)
+    s.synchronize()
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(xyz[:, :64], xyz, 0.3, 16))
