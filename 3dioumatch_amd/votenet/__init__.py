@@ -1,0 +1,8 @@
+"""Host-side mirror of the VoteNet-IoU callers of the hot path (reference models/*.py), used
+by bench.py and the train-step tests.  The reference's own model files also run unchanged on
+top of `3dioumatch_amd/dropin`."""
+from .backbone import Pointnet2Backbone  # noqa: F401
+from .config import DatasetConfig, scannet_config, sunrgbd_config  # noqa: F401
+from .detector import VoteNet  # noqa: F401
+from .heads import GridConv, ProposalModule, VotingModule  # noqa: F401
+from .losses import get_labeled_loss  # noqa: F401

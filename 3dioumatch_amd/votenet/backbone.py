@@ -1,0 +1,59 @@
+"""PointNet++ backbone of VoteNet (4 set-abstraction + 2 feature-propagation layers).
+
+Host-side mirror of the reference models/backbone_module.py (hyper-parameters :35-72, forward
+:105-133): same attribute names (sa1..sa4, fp1, fp2 -> same state_dict keys), same end_points
+keys, int32 index tensors.  Every custom operator underneath is a gfx950 HIP kernel.
+"""
+import torch.nn as nn
+
+from pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
+
+# (npoint, radius, nsample, mlp widths after the input width) -- backbone_module.py:38-69
+SA_SPECS = (
+    (2048, 0.2, 64, (64, 64, 128)),
+    (1024, 0.4, 32, (128, 128, 256)),
+    (512, 0.8, 16, (128, 128, 256)),
+    (256, 1.2, 16, (128, 128, 256)),
+)
+
+
+class Pointnet2Backbone(nn.Module):
+    """input (B, N, 3 + input_feature_dim) -> end_points with sa{1..4}_{xyz,features,inds},
+    fp2_{features,xyz,inds}; fp2 = 1024 seeds with 256 channels."""
+
+    def __init__(self, input_feature_dim=0):
+        super().__init__()
+        width = input_feature_dim
+        for i, (npoint, radius, nsample, mlp) in enumerate(SA_SPECS, start=1):
+            setattr(self, "sa%d" % i, PointnetSAModuleVotes(
+                npoint=npoint, radius=radius, nsample=nsample, mlp=[width, *mlp],
+                use_xyz=True, normalize_xyz=True))
+            width = mlp[-1]
+        self.fp1 = PointnetFPModule(mlp=[256 + 256, 256, 256])
+        self.fp2 = PointnetFPModule(mlp=[256 + 256, 256, 256])
+
+    @staticmethod
+    def _break_up_pc(pc):
+        xyz = pc[..., 0:3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        return xyz, features
+
+    def forward(self, pointcloud, end_points=None):
+        end_points = end_points if end_points else {}
+        xyz, features = self._break_up_pc(pointcloud)
+        for i in range(1, 5):
+            xyz, features, inds = getattr(self, "sa%d" % i)(xyz, features)
+            end_points["sa%d_xyz" % i] = xyz
+            end_points["sa%d_features" % i] = features
+            if i <= 2:
+                end_points["sa%d_inds" % i] = inds
+        features = self.fp1(end_points["sa3_xyz"], end_points["sa4_xyz"],
+                            end_points["sa3_features"], end_points["sa4_features"])
+        features = self.fp2(end_points["sa2_xyz"], end_points["sa3_xyz"],
+                            end_points["sa2_features"], features)
+        end_points["fp2_features"] = features
+        end_points["fp2_xyz"] = end_points["sa2_xyz"]
+        num_seed = end_points["fp2_xyz"].shape[1]
+        # seeds are the first num_seed FPS picks of SA1: indices into the input cloud
+        end_points["fp2_inds"] = end_points["sa1_inds"][:, 0:num_seed]
+        return end_points

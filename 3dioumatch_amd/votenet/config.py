@@ -1,0 +1,51 @@
+"""Dataset constants the detector heads and losses need (class / heading-bin / size-cluster
+counts, mean box sizes, class<->angle/size decoding).
+
+Mirrors the interface of the reference's ScannetDatasetConfig (scannet/model_util_scannet.py:19-83:
+18 classes, 1 heading bin -> heading == 0, 18 size clusters) and SunrgbdDatasetConfig
+(sunrgbd/model_util_sunrgbd.py:19-129: 10 classes, 12 heading bins, 10 size clusters).  The
+reference loads its mean sizes from dataset files; there is no dataset here, so the mean sizes
+are SYNTHETIC (seeded), which is all the throughput metric needs.
+"""
+import numpy as np
+import torch
+
+
+class DatasetConfig(object):
+    def __init__(self, num_class, num_heading_bin, num_size_cluster, seed=0):
+        self.num_class = num_class
+        self.num_heading_bin = num_heading_bin
+        self.num_size_cluster = num_size_cluster
+        g = np.random.default_rng(seed)
+        self.mean_size_arr = g.uniform(0.3, 1.8, (num_size_cluster, 3)).astype(np.float32)
+        self._mean_size_dev = {}
+
+    def mean_size(self, device):
+        key = str(device)
+        if key not in self._mean_size_dev:
+            self._mean_size_dev[key] = torch.from_numpy(self.mean_size_arr).to(device)
+        return self._mean_size_dev[key]
+
+    def class2angle_gpu(self, pred_cls, residual, to_label_format=True):
+        """heading class + residual -> angle.  One bin (ScanNet): always 0
+        (model_util_scannet.py:50-54); otherwise class*2pi/N + residual wrapped to (-pi, pi]
+        (model_util_sunrgbd.py class2angle_gpu)."""
+        if self.num_heading_bin == 1:
+            return torch.zeros(pred_cls.shape, device=pred_cls.device)
+        angle_per_class = 2 * np.pi / float(self.num_heading_bin)
+        angle = pred_cls.float() * angle_per_class + residual
+        if to_label_format:
+            angle = angle - (angle > np.pi).float() * (2 * np.pi)
+        return angle
+
+    def class2size_gpu(self, pred_cls, residual):
+        """size class + residual -> box size (model_util_scannet.py:56-58)."""
+        return self.mean_size(residual.device)[pred_cls, :] + residual
+
+
+def scannet_config():
+    return DatasetConfig(num_class=18, num_heading_bin=1, num_size_cluster=18, seed=18)
+
+
+def sunrgbd_config():
+    return DatasetConfig(num_class=10, num_heading_bin=12, num_size_cluster=10, seed=10)

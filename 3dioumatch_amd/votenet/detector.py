@@ -1,0 +1,108 @@
+"""VoteNet with the IoU-estimation branch (3DIoUMatch's detector).
+
+Host-side mirror of the reference models/votenet_iou_branch.py:24-188: same constructor
+arguments, sub-module names (backbone_net, vgen, pnet, grid_conv -> state_dict keys), the
+same three forwards (forward, forward_with_pred_jitter, forward_onlyiou_faster) and the same
+end_points keys.  `forward(inputs, mode=...)` additionally routes the custom forwards through
+nn.Module.__call__, so DistributedDataParallel hooks see them (the reference calls the custom
+method directly on the wrapper, which breaks under DataParallel/DDP -- SURVEY section 0).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .backbone import Pointnet2Backbone
+from .heads import GridConv, ProposalModule, VotingModule
+
+
+class VoteNet(nn.Module):
+    def __init__(self, num_class, num_heading_bin, num_size_cluster, mean_size_arr, dataset_config,
+                 input_feature_dim=0, num_proposal=128, vote_factor=1, sampling='vote_fps',
+                 query_feats='seed'):
+        super().__init__()
+        assert mean_size_arr.shape[0] == num_size_cluster
+        self.num_class = num_class
+        self.num_heading_bin = num_heading_bin
+        self.num_size_cluster = num_size_cluster
+        self.mean_size_arr = mean_size_arr
+        self.dataset_config = dataset_config
+        self.input_feature_dim = input_feature_dim
+        self.num_proposal = num_proposal
+        self.vote_factor = vote_factor
+        self.sampling = sampling
+        self.backbone_net = Pointnet2Backbone(input_feature_dim=self.input_feature_dim)
+        self.vgen = VotingModule(self.vote_factor, 256)
+        self.pnet = ProposalModule(num_class, num_heading_bin, num_size_cluster, mean_size_arr,
+                                   num_proposal, sampling, query_feats=query_feats)
+        self.grid_conv = GridConv(num_class, num_heading_bin, num_size_cluster, mean_size_arr,
+                                  num_proposal, sampling, query_feats=query_feats)
+        self.register_buffer("_mean_size", torch.from_numpy(mean_size_arr.astype(np.float32)),
+                             persistent=False)
+
+    def forward_backbone(self, inputs):
+        end_points = self.backbone_net(inputs['point_clouds'], {})
+        xyz, features = end_points['fp2_xyz'], end_points['fp2_features']
+        end_points['seed_inds'] = end_points['fp2_inds']
+        end_points['seed_xyz'] = xyz
+        end_points['seed_features'] = features
+        xyz, features = self.vgen(xyz, features)
+        features = features.div(torch.norm(features, p=2, dim=1).unsqueeze(1))
+        end_points['vote_xyz'] = xyz
+        end_points['vote_features'] = features
+        return self.pnet(xyz, features, end_points)
+
+    def calculate_bbox(self, end_points):
+        """arg-max size/heading class -> (center, HALF size, heading); votenet_iou_branch.py:111-137"""
+        size_scores, size_residuals = end_points['size_scores'], end_points['size_residuals']
+        b, k = size_scores.shape[:2]
+        size_class = torch.argmax(size_scores, -1)
+        size_residual = torch.gather(
+            size_residuals, 2, size_class.view(b, k, 1, 1).expand(-1, -1, -1, 3)).squeeze(2)
+        size_base = torch.index_select(self._mean_size, 0, size_class.view(-1)).view(b, k, 3)
+        size = (size_base + size_residual) / 2
+        size = torch.where(size < 0, torch.full_like(size, 1e-6), size)
+        heading_class = torch.argmax(end_points['heading_scores'], -1)
+        heading_residual = torch.gather(end_points['heading_residuals'], 2,
+                                        heading_class.unsqueeze(-1)).squeeze(2)
+        heading = self.dataset_config.class2angle_gpu(heading_class, heading_residual)
+        end_points['size'] = size
+        end_points['heading'] = heading
+        return end_points['center'], size, heading
+
+    def forward(self, inputs, iou_opt=False, mode='plain'):
+        if mode == 'jitter':
+            return self.forward_with_pred_jitter(inputs)
+        end_points = self.forward_backbone(inputs)
+        center, size, heading = self.calculate_bbox(end_points)
+        if iou_opt:
+            center.retain_grad()
+            size.retain_grad()
+            if heading.requires_grad:
+                heading.retain_grad()
+            return self.grid_conv(center, size, heading, end_points)
+        return self.grid_conv(center.detach(), size.detach(), heading.detach(), end_points)
+
+    def forward_with_pred_jitter(self, inputs):
+        """Predicted boxes + one jittered copy of each go through the IoU branch together
+        (votenet_iou_branch.py:157-181): K -> 2K boxes."""
+        end_points = self.forward_backbone(inputs)
+        center, size, heading = self.calculate_bbox(end_points)
+        k = heading.shape[1]
+        center_jitter = center + size * torch.randn(size.shape, device=size.device) * 0.3
+        size_jitter = size + size * torch.randn(size.shape, device=size.device) * 0.3
+        size_jitter = torch.clamp(size_jitter, min=1e-8)
+        heading_jitter = heading.clone()
+        all_center = torch.cat([center, center_jitter], dim=1)
+        all_size = torch.cat([size, size_jitter], dim=1)
+        all_heading = torch.cat([heading, heading_jitter], dim=1)
+        end_points = self.grid_conv(all_center.detach(), all_size.detach(), all_heading.detach(),
+                                    end_points)
+        end_points['iou_scores_jitter'] = end_points['iou_scores'][:, k:]
+        end_points['iou_scores'] = end_points['iou_scores'][:, :k]
+        end_points['jitter_center'] = center_jitter
+        end_points['jitter_size'] = size_jitter * 2
+        end_points['jitter_heading'] = heading_jitter
+        return end_points
+
+    def forward_onlyiou_faster(self, end_points, center, size, heading):
+        return self.grid_conv(center, size, heading, end_points)

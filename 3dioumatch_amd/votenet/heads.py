@@ -1,0 +1,190 @@
+"""Voting, proposal and IoU-estimation heads of VoteNet-IoU.
+
+Host-side mirror of the reference models/voting_module.py:15-65, models/proposal_module.py:24-125
+and models/grid_conv_module.py:22-116: same attribute names (-> state_dict keys), same
+end_points keys and tensor shapes.  Device-agnostic (the reference hard-codes .cuda()).
+
+GridConv differs in HOW, not in WHAT: the reference materialises the three nearest seeds of
+every grid point with torch.gather / per-batch index_select lists (a (B, K*64*3, 256) tensor,
+~0.8 GB at B=8, K=512) and re-derives the distances; here the distances come straight from the
+three_nn kernel and the weighted sum is the three_interpolate kernel (same three products
+summed left to right), since the seed features are detached on this branch.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from pointnet2 import pointnet2_utils
+from pointnet2 import pytorch_utils as pt_utils
+from pointnet2.pointnet2_modules import PointnetSAModuleVotes
+
+
+class VotingModule(nn.Module):
+    """seed (xyz, features) -> votes: xyz + offset, features + residual (vote_factor per seed)."""
+
+    def __init__(self, vote_factor, seed_feature_dim):
+        super().__init__()
+        self.vote_factor = vote_factor
+        self.in_dim = seed_feature_dim
+        self.out_dim = self.in_dim  # residual features: widths must agree
+        self.conv1 = nn.Conv1d(self.in_dim, self.in_dim, 1)
+        self.conv2 = nn.Conv1d(self.in_dim, self.in_dim, 1)
+        self.conv3 = nn.Conv1d(self.in_dim, (3 + self.out_dim) * self.vote_factor, 1)
+        self.bn1 = nn.BatchNorm1d(self.in_dim)
+        self.bn2 = nn.BatchNorm1d(self.in_dim)
+
+    def forward(self, seed_xyz, seed_features):
+        b, num_seed = seed_xyz.shape[:2]
+        net = F.relu(self.bn1(self.conv1(seed_features)))
+        net = F.relu(self.bn2(self.conv2(net)))
+        net = self.conv3(net).transpose(2, 1).view(b, num_seed, self.vote_factor, 3 + self.out_dim)
+        vote_xyz = (seed_xyz.unsqueeze(2) + net[..., 0:3]).reshape(b, num_seed * self.vote_factor, 3)
+        vote_features = seed_features.transpose(2, 1).unsqueeze(2) + net[..., 3:]
+        vote_features = vote_features.reshape(b, num_seed * self.vote_factor, self.out_dim)
+        return vote_xyz, vote_features.transpose(2, 1).contiguous()
+
+
+def decode_scores(net, end_points, num_class, num_heading_bin, num_size_cluster, mean_size):
+    """Split the proposal head output (B, C, K) into the named predictions
+    (proposal_module.py:24-54); mean_size is a (num_size_cluster, 3) tensor."""
+    t = net.transpose(2, 1)
+    b, k = t.shape[:2]
+    nh, ns = num_heading_bin, num_size_cluster
+    end_points['objectness_scores'] = t[:, :, 0:2]
+    end_points['center'] = end_points['aggregated_vote_xyz'] + t[:, :, 2:5]
+    end_points['heading_scores'] = t[:, :, 5:5 + nh]
+    hrn = t[:, :, 5 + nh:5 + nh * 2]
+    end_points['heading_residuals_normalized'] = hrn  # in [-1, 1]
+    end_points['heading_residuals'] = hrn * (np.pi / nh)
+    end_points['size_scores'] = t[:, :, 5 + nh * 2:5 + nh * 2 + ns]
+    srn = t[:, :, 5 + nh * 2 + ns:5 + nh * 2 + ns * 4].reshape(b, k, ns, 3)
+    srn = F.softplus(srn) - 1
+    end_points['size_residuals_normalized'] = srn
+    end_points['size_residuals'] = srn * mean_size.unsqueeze(0).unsqueeze(0)
+    end_points['sem_cls_scores'] = t[:, :, 5 + nh * 2 + ns * 4:]
+    return end_points
+
+
+class ProposalModule(nn.Module):
+    """Vote aggregation (one SA layer, r=0.3, ns=16) + proposal head."""
+
+    def __init__(self, num_class, num_heading_bin, num_size_cluster, mean_size_arr, num_proposal,
+                 sampling, seed_feat_dim=256, query_feats='seed'):
+        super().__init__()
+        self.num_class = num_class
+        self.num_heading_bin = num_heading_bin
+        self.num_size_cluster = num_size_cluster
+        self.mean_size_arr = mean_size_arr
+        self.num_proposal = num_proposal
+        self.sampling = sampling
+        self.seed_feat_dim = seed_feat_dim
+        self.query_feats = query_feats
+        self.vote_aggregation = PointnetSAModuleVotes(
+            npoint=self.num_proposal, radius=0.3, nsample=16,
+            mlp=[self.seed_feat_dim, 128, 128, 128], use_xyz=True, normalize_xyz=True)
+        out_width = 2 + 3 + num_heading_bin * 2 + num_size_cluster * 4 + self.num_class
+        self.conv1 = nn.Conv1d(128, 128, 1)
+        self.conv2 = nn.Conv1d(128, 128, 1)
+        self.conv3 = nn.Conv1d(128, out_width, 1)
+        self.bn1 = nn.BatchNorm1d(128)
+        self.bn2 = nn.BatchNorm1d(128)
+        self.register_buffer("_mean_size", torch.from_numpy(mean_size_arr.astype(np.float32)),
+                             persistent=False)
+
+    def forward(self, xyz, features, end_points):
+        if self.sampling == 'vote_fps':
+            xyz, features, sample_inds = self.vote_aggregation(xyz, features)
+        elif self.sampling == 'seed_fps':
+            # FPS on the seeds, then aggregate the votes of the chosen seeds
+            sample_inds = pointnet2_utils.furthest_point_sample(end_points['seed_xyz'],
+                                                                self.num_proposal)
+            xyz, features, _ = self.vote_aggregation(xyz, features, sample_inds)
+        elif self.sampling == 'random':
+            b, num_seed = end_points['seed_xyz'].shape[:2]
+            sample_inds = torch.randint(0, num_seed, (b, self.num_proposal), dtype=torch.int,
+                                        device=xyz.device)
+            xyz, features, _ = self.vote_aggregation(xyz, features, sample_inds)
+        else:
+            raise ValueError('Unknown sampling strategy: %s' % (self.sampling,))
+        end_points['aggregated_vote_xyz'] = xyz
+        end_points['aggregated_vote_inds'] = sample_inds
+        net = F.relu(self.bn1(self.conv1(features)))
+        net = F.relu(self.bn2(self.conv2(net)))
+        net = self.conv3(net)
+        return decode_scores(net, end_points, self.num_class, self.num_heading_bin,
+                             self.num_size_cluster, self._mean_size)
+
+
+def rot_z(t):
+    """(...,) angles -> (..., 3, 3) rotation about the upright axis, the reference's rot_gpu
+    (utils/box_util.py:292-306): [[c, s, 0], [-s, c, 0], [0, 0, 1]]."""
+    c, s = torch.cos(t), torch.sin(t)
+    zero, one = torch.zeros_like(c), torch.ones_like(c)
+    return torch.stack([c, s, zero, -s, c, zero, zero, zero, one], dim=-1).view(*t.shape, 3, 3)
+
+
+class GridConv(nn.Module):
+    """IoU branch: a 4x4x4 grid inside each box, features interpolated from the 3 nearest
+    seeds, shared MLP, max-pool, IoU head."""
+
+    GRID = 4
+
+    def __init__(self, num_class, num_heading_bin, num_size_cluster, mean_size_arr, num_proposal,
+                 sampling, seed_feat_dim=256, query_feats='seed', iou_class_depend=True):
+        super().__init__()
+        self.num_class = num_class
+        self.num_heading_bin = num_heading_bin
+        self.num_size_cluster = num_size_cluster
+        self.mean_size_arr = mean_size_arr
+        self.num_proposal = num_proposal
+        self.sampling = sampling
+        self.seed_feat_dim = seed_feat_dim
+        self.query_feats = query_feats
+        self.iou_class_depend = iou_class_depend
+        self.iou_size = num_class if self.iou_class_depend else 1
+        self.mlp_before_iou = pt_utils.SharedMLP([self.seed_feat_dim + 3, 128, 128, 128], bn=True)
+        self.conv1_iou = nn.Conv1d(128, 128, 1)
+        self.conv2_iou = nn.Conv1d(128, 128, 1)
+        self.conv3_iou = nn.Conv1d(128, 3 + num_heading_bin * 2 + num_size_cluster * 3 + self.iou_size, 1)
+        self.bn1_iou = nn.BatchNorm1d(128)
+        self.bn2_iou = nn.BatchNorm1d(128)
+
+    def _origin(self, end_points):
+        if self.query_feats == 'vote':
+            return end_points['vote_xyz'], end_points['vote_features']
+        if self.query_feats == 'seed':
+            return end_points['seed_xyz'], end_points['seed_features']
+        if self.query_feats == 'seed+vote':
+            return end_points['seed_xyz'], end_points['vote_features']
+        raise NotImplementedError()
+
+    def forward(self, center, size, heading, end_points):
+        origin_xyz, origin_features = self._origin(end_points)
+        origin_xyz = origin_xyz.detach().contiguous()
+        origin_features = origin_features.detach().contiguous()
+        b, k = size.shape[:2]
+        g = self.GRID
+        g3 = g * g * g
+        step = torch.linspace(-1, 1, g, device=size.device)
+        # unit grid, x slowest / z fastest: (g3, 3)
+        unit = torch.stack(torch.meshgrid(step, step, step, indexing='ij'), dim=-1).view(g3, 3)
+        local = unit.view(1, 1, g3, 3) * size.unsqueeze(2)  # (B, K, 64, 3): half-sizes scale it
+        rot = rot_z(heading).view(-1, 3, 3)
+        whole = torch.bmm(local.view(b * k, g3, 3), rot.transpose(1, 2)).view(b, k, g3, 3)
+        whole = (whole + center.unsqueeze(2)).view(b, k * g3, 3).contiguous()
+        relative = whole - center.unsqueeze(2).expand(-1, -1, g3, -1).reshape(b, k * g3, 3)
+
+        dist, idx = pointnet2_utils.three_nn(whole, origin_xyz)
+        weight = 1 / (dist + 1e-8)
+        weight = (weight / torch.sum(weight, dim=2, keepdim=True)).contiguous()
+        interp = pointnet2_utils.three_interpolate(origin_features, idx, weight)  # (B, C, K*64)
+        feats = torch.cat([relative.transpose(1, 2).reshape(b, 3, k, g3),
+                           interp.view(b, -1, k, g3)], dim=1)
+        feats = self.mlp_before_iou(feats)
+        iou_features = torch.max(feats, dim=3)[0]
+        net = F.relu(self.bn1_iou(self.conv1_iou(iou_features)))
+        net = F.relu(self.bn2_iou(self.conv2_iou(net)))
+        net = self.conv3_iou(net)
+        end_points['iou_scores'] = net.transpose(2, 1)[:, :, -self.iou_size:]
+        return end_points

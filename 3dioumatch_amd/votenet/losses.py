@@ -1,0 +1,276 @@
+"""Supervised VoteNet-IoU losses (stage-1 pretraining and the labeled half of stage 2).
+
+Host-side mirror of the reference models/loss_helper_labeled.py (compute_vote_loss :28-74,
+compute_objectness_loss :77-123, compute_box_and_sem_cls_loss :126-297, get_labeled_loss
+:300-370), models/loss_helper_iou.py (compute_iou_labels :52-112) and utils/nn_distance.py
+(huber_loss :16-33, nn_distance :35-62): same end_points keys in and out, same loss weights.
+Device-agnostic.  The IoU labels come from the gfx950 kernel behind
+pcdet.ops.iou3d_nms.iou3d_nms_utils.boxes_iou3d_gpu.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from pcdet.ops.iou3d_nms.iou3d_nms_utils import boxes_iou3d_gpu
+
+FAR_THRESHOLD = 0.6
+NEAR_THRESHOLD = 0.3
+GT_VOTE_FACTOR = 3  # GT votes stored per point
+OBJECTNESS_CLS_WEIGHTS = [0.2, 0.8]
+
+
+def huber_loss(error, delta=1.0):
+    """0.5*x^2 for |x| <= delta, delta*(|x| - 0.5*delta) beyond."""
+    abs_error = torch.abs(error)
+    quadratic = torch.clamp(abs_error, max=delta)
+    return 0.5 * quadratic ** 2 + delta * (abs_error - quadratic)
+
+
+def nn_distance(pc1, pc2, l1smooth=False, delta=1.0, l1=False):
+    """Chamfer-style nearest neighbours between (B,N,C) and (B,M,C):
+    returns dist1 (B,N), idx1 (B,N), dist2 (B,M), idx2 (B,M)."""
+    diff = pc1.unsqueeze(2) - pc2.unsqueeze(1)  # (B,N,M,C)
+    if l1smooth:
+        dist = torch.sum(huber_loss(diff, delta), dim=-1)
+    elif l1:
+        dist = torch.sum(torch.abs(diff), dim=-1)
+    else:
+        dist = torch.sum(diff ** 2, dim=-1)
+    dist1, idx1 = torch.min(dist, dim=2)
+    dist2, idx2 = torch.min(dist, dim=1)
+    return dist1, idx1, dist2, idx2
+
+
+def _masked_mean(values, mask):
+    return torch.sum(values * mask) / (torch.sum(mask) + 1e-6)
+
+
+def _labels(end_points, inds):
+    """GT tensors of the supervised samples; empty GT slots get centre -1000 so that they can
+    never be matched (loss_helper_iou.py:56-58)."""
+    center = end_points['center_label'][inds, ...].clone()
+    empty = (1 - end_points['box_label_mask'][inds, ...]).unsqueeze(-1).expand(-1, -1, 3).bool()
+    center[empty] = -1000
+    return (center, end_points['heading_class_label'][inds, ...],
+            end_points['heading_residual_label'][inds, ...],
+            end_points['size_class_label'][inds, ...],
+            end_points['size_residual_label'][inds, ...])
+
+
+def compute_vote_loss(end_points, supervised_inds):
+    """A seed inside an object must vote for (one of) its object centre(s): min L1 distance
+    between the predicted votes and the 3 stored GT votes, averaged over object seeds."""
+    b = supervised_inds.shape[0]
+    seed_xyz = end_points['seed_xyz'][supervised_inds, ...]
+    num_seed = seed_xyz.shape[1]
+    vote_xyz = end_points['vote_xyz'][supervised_inds, ...]
+    seed_inds = end_points['seed_inds'][supervised_inds, ...].long()
+    mask = torch.gather(end_points['vote_label_mask'], 1, seed_inds)
+    gt_votes = torch.gather(end_points['vote_label'], 1,
+                            seed_inds.view(b, num_seed, 1).expand(-1, -1, 3 * GT_VOTE_FACTOR))
+    gt_votes = gt_votes + seed_xyz.repeat(1, 1, 3)
+    _, _, dist2, _ = nn_distance(vote_xyz.view(b * num_seed, -1, 3),
+                                 gt_votes.view(b * num_seed, GT_VOTE_FACTOR, 3), l1=True)
+    votes_dist = torch.min(dist2, dim=1)[0].view(b, num_seed)
+    return _masked_mean(votes_dist, mask.float())
+
+
+def compute_objectness_loss(end_points, supervised_inds):
+    """Proposals within 0.3 m of a GT centre are positives, beyond 0.6 m negatives, the rest
+    ignored; weighted cross-entropy.  Also returns the nearest-GT assignment."""
+    agg = end_points['aggregated_vote_xyz'][supervised_inds, ...]
+    gt_center = _labels(end_points, supervised_inds)[0]
+    dist1, ind1, _, _ = nn_distance(agg, gt_center)
+    dist = torch.sqrt(dist1 + 1e-6)
+    label = (dist < NEAR_THRESHOLD).long()
+    mask = ((dist < NEAR_THRESHOLD) | (dist > FAR_THRESHOLD)).float()
+    scores = end_points['objectness_scores'][supervised_inds, ...]
+    weights = torch.tensor(OBJECTNESS_CLS_WEIGHTS, device=scores.device)
+    ce = F.cross_entropy(scores.transpose(2, 1), label, weight=weights, reduction='none')
+    return _masked_mean(ce, mask), label, mask, ind1
+
+
+def _block_diagonal_max(iou, b, pred_num):
+    """(B*P, B*G) all-pairs IoU -> per-scene (max IoU, argmax GT) of shape (B, P):
+    loss_helper_iou.py:106-111."""
+    best, assignment = iou.view(b * pred_num, b, -1).max(dim=2)
+    scene = torch.arange(b, device=iou.device).unsqueeze(1).expand(-1, pred_num).reshape(-1, 1)
+    return (best.gather(dim=1, index=scene).view(b, -1).detach(),
+            assignment.gather(dim=1, index=scene).view(b, -1))
+
+
+def _gt_boxes(end_points, inds, config):
+    center, h_cls, h_res, s_cls, s_res = _labels(end_points, inds)
+    gt_size = config.class2size_gpu(s_cls, s_res)
+    gt_angle = config.class2angle_gpu(h_cls, h_res)
+    return torch.cat([center, gt_size, -gt_angle[:, :, None]], dim=2)  # heading sign flips
+
+
+def compute_iou_labels(end_points, unsupervised_inds, pred_votes, pred_center, pred_sem_cls,
+                       pred_objectness, pred_heading_scores, pred_heading_residuals,
+                       pred_size_scores, pred_size_residuals, config_dict, reverse=False):
+    """3-D IoU between every decoded prediction and every GT box of its scene."""
+    config = config_dict['dataset_config']
+    gt_center = _labels(end_points, unsupervised_inds)[0]
+    h_cls = torch.argmax(pred_heading_scores, -1)
+    h_res = torch.gather(pred_heading_residuals, 2, h_cls.unsqueeze(-1)).squeeze(2)
+    s_cls = torch.argmax(pred_size_scores, -1)
+    s_res = torch.gather(pred_size_residuals, 2,
+                         s_cls.unsqueeze(-1).unsqueeze(-1).repeat(1, 1, 1, 3)).squeeze(2)
+    dist1, object_assignment, _, _ = nn_distance(pred_votes, gt_center)
+    objectness_label = (torch.sqrt(dist1 + 1e-6) < NEAR_THRESHOLD).long()
+    b = dist1.shape[0]
+
+    gt_bbox = _gt_boxes(end_points, unsupervised_inds, config)
+    pred_size = config.class2size_gpu(s_cls.detach(), s_res)
+    pred_size = torch.where(pred_size <= 0, torch.full_like(pred_size, 1e-6), pred_size)
+    if config.num_heading_bin == 1:
+        pred_angle = torch.zeros(pred_size.shape[:2], device=pred_size.device)
+    else:
+        pred_angle = config.class2angle_gpu(h_cls.detach(), h_res)
+    pred_bbox = torch.cat([pred_center, pred_size, -pred_angle[:, :, None]], dim=2)
+    end_points['pred_bbox'] = pred_bbox
+    pred_num, gt_num = pred_bbox.shape[1], gt_bbox.shape[1]
+    if reverse:
+        iou = boxes_iou3d_gpu(gt_bbox.view(-1, 7), pred_bbox.view(-1, 7))
+        iou = iou.view(b * gt_num, b, -1)
+        scene = torch.arange(b, device=iou.device).unsqueeze(1).expand(-1, gt_num * pred_num)
+        scene = scene.reshape(-1, 1, pred_num)
+        return iou.gather(dim=1, index=scene).view(b, -1, pred_num).detach()
+    iou = boxes_iou3d_gpu(pred_bbox.view(-1, 7), gt_bbox.view(-1, 7))
+    iou_labels, object_assignment = _block_diagonal_max(iou, b, pred_num)
+    return iou_labels, objectness_label, object_assignment
+
+
+def compute_box_and_sem_cls_loss(end_points, supervised_inds, dataset_config, config_dict):
+    nh, ns = dataset_config.num_heading_bin, dataset_config.num_size_cluster
+    assign = end_points['object_assignment']
+    b = assign.shape[0]
+    obj = end_points['objectness_label'].float()
+    sup = supervised_inds
+
+    def pick(key):
+        return torch.gather(end_points[key][sup, ...], 1, assign)
+
+    # centre: chamfer between predicted centres (positives) and GT centres (real boxes)
+    dist1, _, dist2, _ = nn_distance(end_points['center'][sup, ...],
+                                     end_points['center_label'][sup, ...][:, :, 0:3])
+    box_label_mask = end_points['box_label_mask'][sup, ...]
+    center_loss = _masked_mean(dist1, obj) + _masked_mean(dist2, box_label_mask)
+
+    # heading: class + residual of the assigned GT
+    h_cls_label = pick('heading_class_label')
+    heading_class_loss = _masked_mean(
+        F.cross_entropy(end_points['heading_scores'][sup, ...].transpose(2, 1), h_cls_label,
+                        reduction='none'), obj)
+    h_res_label = pick('heading_residual_label') / (np.pi / nh)
+    h_onehot = F.one_hot(h_cls_label, nh).float()
+    h_res_pred = torch.sum(end_points['heading_residuals_normalized'][sup, ...] * h_onehot, -1)
+    heading_reg_loss = _masked_mean(huber_loss(h_res_pred - h_res_label, delta=1.0), obj)
+
+    # size: class + normalised residual
+    s_cls_label = pick('size_class_label')
+    size_class_loss = _masked_mean(
+        F.cross_entropy(end_points['size_scores'][sup, ...].transpose(2, 1), s_cls_label,
+                        reduction='none'), obj)
+    s_res_label = torch.gather(end_points['size_residual_label'][sup, ...], 1,
+                               assign.unsqueeze(-1).repeat(1, 1, 3))
+    s_onehot = F.one_hot(s_cls_label, ns).float().unsqueeze(-1).repeat(1, 1, 1, 3)
+    s_res_pred = torch.sum(end_points['size_residuals_normalized'][sup, ...] * s_onehot, 2)
+    mean_size = dataset_config.mean_size(s_res_pred.device).unsqueeze(0).unsqueeze(0)
+    mean_size_label = torch.sum(s_onehot * mean_size, 2)
+    size_reg_loss = _masked_mean(
+        torch.mean(huber_loss(s_res_pred - s_res_label / mean_size_label, delta=1.0), -1), obj)
+
+    # semantic class
+    sem_label = pick('sem_cls_label')
+    sem_scores = end_points['sem_cls_scores'][sup, ...]
+    sem_cls_loss = _masked_mean(
+        F.cross_entropy(sem_scores.transpose(2, 1), sem_label, reduction='none'), obj)
+    end_points['cls_acc'] = _masked_mean((sem_label == sem_scores.argmax(dim=-1)).float(), obj)
+
+    # IoU labels of the decoded predictions, and the IoU-estimation losses
+    iou_labels, _, iou_assignment = compute_iou_labels(
+        end_points, sup, end_points['aggregated_vote_xyz'][sup, ...],
+        end_points['center'][sup, ...], None, None, end_points['heading_scores'][sup, ...],
+        end_points['heading_residuals'][sup, ...], end_points['size_scores'][sup, ...],
+        end_points['size_residuals'][sup, ...], config_dict={'dataset_config': dataset_config})
+    end_points['pred_iou_value'] = iou_labels.mean()
+    end_points['pred_iou_obj_value'] = _masked_mean(iou_labels, obj)
+    end_points['obj_count'] = torch.sum(obj)
+
+    if 'jitter_center' in end_points:
+        gt_bbox = _gt_boxes(end_points, sup, dataset_config)
+        pred_bbox = torch.cat([end_points['jitter_center'][sup, ...],
+                               end_points['jitter_size'][sup, ...],
+                               -end_points['jitter_heading'][sup, ...][:, :, None]], dim=2)
+        pred_num = pred_bbox.shape[1]
+        jitter_iou = boxes_iou3d_gpu(pred_bbox.view(-1, 7), gt_bbox.view(-1, 7))
+        jitter_iou_labels, jitter_assign = _block_diagonal_max(jitter_iou, b, pred_num)
+        jitter_sem = torch.gather(end_points['sem_cls_label'][sup, ...], 1, jitter_assign)
+        jitter_pred = torch.sigmoid(end_points['iou_scores_jitter'][sup, ...])
+        jitter_pred = torch.gather(jitter_pred, 2, jitter_sem.unsqueeze(-1)).squeeze(-1) \
+            if jitter_pred.shape[2] > 1 else jitter_pred.squeeze(-1)
+        jitter_acc = torch.abs(jitter_pred - jitter_iou_labels)
+        end_points['jitter_iou_acc'] = jitter_acc.mean()
+        end_points['jitter_iou_acc_obj'] = jitter_acc.sum() / (jitter_acc.numel() + 1e-6)
+        end_points['jitter_iou_loss'] = \
+            huber_loss(jitter_pred - jitter_iou_labels, delta=1.0).sum() / (jitter_acc.numel() + 1e-6)
+
+    if 'iou_scores' in end_points:
+        iou_pred = torch.sigmoid(end_points['iou_scores'][sup, ...])
+        if iou_pred.shape[2] > 1:
+            iou_sem = torch.gather(end_points['sem_cls_label'][sup, ...], 1, iou_assignment)
+            iou_pred = torch.gather(iou_pred, 2, iou_sem.unsqueeze(-1)).squeeze(-1)
+        else:
+            iou_pred = iou_pred.squeeze(-1)
+        iou_acc = torch.abs(iou_pred - iou_labels)
+        end_points['iou_acc'] = iou_acc.mean()
+        end_points['iou_acc_obj'] = _masked_mean(iou_acc, obj)
+        end_points['iou_loss'] = huber_loss(iou_pred - iou_labels, delta=1.0).mean()
+
+    return (center_loss, heading_class_loss, heading_reg_loss, size_class_loss, size_reg_loss,
+            sem_cls_loss)
+
+
+def get_labeled_loss(end_points, dataset_config, config_dict=None):
+    """10 * (vote + 0.5*objectness + box + 0.1*sem_cls + iou [+ jitter_iou]) over the samples
+    with supervised_mask == 1; fills end_points with every intermediate loss / statistic."""
+    supervised_inds = torch.nonzero(end_points['supervised_mask']).squeeze(1).long()
+
+    end_points['vote_loss'] = compute_vote_loss(end_points, supervised_inds)
+    objectness_loss, objectness_label, objectness_mask, object_assignment = \
+        compute_objectness_loss(end_points, supervised_inds)
+    end_points['objectness_loss'] = objectness_loss
+    end_points['objectness_label'] = objectness_label
+    end_points['objectness_mask'] = objectness_mask
+    end_points['object_assignment'] = object_assignment
+    total = float(objectness_label.shape[0] * objectness_label.shape[1])
+    end_points['pos_ratio'] = torch.sum(objectness_label.float()) / total
+    end_points['neg_ratio'] = torch.sum(objectness_mask.float()) / total - end_points['pos_ratio']
+
+    (center_loss, heading_cls_loss, heading_reg_loss, size_cls_loss, size_reg_loss,
+     sem_cls_loss) = compute_box_and_sem_cls_loss(end_points, supervised_inds, dataset_config,
+                                                  config_dict)
+    end_points['center_loss'] = center_loss
+    end_points['heading_cls_loss'] = heading_cls_loss
+    end_points['heading_reg_loss'] = heading_reg_loss
+    end_points['size_cls_loss'] = size_cls_loss
+    end_points['size_reg_loss'] = size_reg_loss
+    end_points['sem_cls_loss'] = sem_cls_loss
+    box_loss = 0.1 * heading_cls_loss + heading_reg_loss + 0.1 * size_cls_loss + size_reg_loss \
+        + center_loss
+    end_points['box_loss'] = box_loss
+
+    loss = end_points['vote_loss'] + 0.5 * objectness_loss + box_loss + 0.1 * sem_cls_loss
+    loss = loss + end_points['iou_loss']
+    if 'jitter_iou_loss' in end_points:
+        loss = loss + end_points['jitter_iou_loss']
+    loss = loss * 10
+    end_points['detection_loss'] = loss
+    end_points['loss'] = loss
+
+    obj_pred = torch.argmax(end_points['objectness_scores'][supervised_inds, ...], 2)
+    end_points['obj_acc'] = _masked_mean((obj_pred == objectness_label.long()).float(),
+                                         objectness_mask)
+    return loss, end_points
