@@ -160,6 +160,61 @@ group_points_grad_kernel(int c, int n, int mns, const float *__restrict__ grad_o
   }
 }
 
+// Scatter-add with the destination rows privatised in LDS (n*4 bytes per channel): one
+// workgroup owns CPW channels of one cloud, streams their grad_out rows once (coalesced
+// 16-byte loads), accumulates with LDS atomics (ds_add_f32) and writes each (b,c,:) row back
+// exactly once -- no global atomics, no pre-zeroing.  Used whenever a row fits (n <= 16384);
+// the global-atomic kernel above remains for huge n (SA1, where C <= 4 anyway).
+template <int CPW, bool VEC>
+__global__ void __launch_bounds__(1024)
+group_points_grad_lds_kernel(int c, int n, int mns, const float *__restrict__ grad_out,
+                             const int *__restrict__ idx, float *__restrict__ grad_points) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];
+  const int b = blockIdx.y;
+  const int l0 = blockIdx.x * CPW;
+  const int nc = c - l0 < CPW ? c - l0 : CPW;
+  for (int t = threadIdx.x; t < nc * n; t += 1024) acc[t] = 0.f;
+  __syncthreads();
+  const int *ib = idx + (size_t)b * mns;
+  const float *src = grad_out + ((size_t)b * c + l0) * mns;
+  for (int e = threadIdx.x * 4; e < mns; e += 1024 * 4) {
+    int i0, i1 = 0, i2 = 0, i3 = 0;
+    const int live = mns - e < 4 ? mns - e : 4;
+    if (VEC) {
+      const int4 v = *reinterpret_cast<const int4 *>(ib + e);
+      i0 = v.x; i1 = v.y; i2 = v.z; i3 = v.w;
+    } else {
+      i0 = ib[e];
+      if (live > 1) i1 = ib[e + 1];
+      if (live > 2) i2 = ib[e + 2];
+      if (live > 3) i3 = ib[e + 3];
+    }
+#pragma unroll
+    for (int cc = 0; cc < CPW; ++cc) {
+      if (cc < nc) {
+        float *row = acc + cc * n;
+        const float *g = src + (size_t)cc * mns + e;
+        if (VEC) {
+          const float4 v = *reinterpret_cast<const float4 *>(g);
+          float a0 = v.x, a1 = v.y, a2 = v.z, a3 = v.w;
+          if (i1 == i0) { a1 = __fadd_rn(a0, a1); } else { atomicAdd(row + i0, a0); }
+          if (i2 == i1) { a2 = __fadd_rn(a1, a2); } else { atomicAdd(row + i1, a1); }
+          if (i3 == i2) { a3 = __fadd_rn(a2, a3); } else { atomicAdd(row + i2, a2); }
+          atomicAdd(row + i3, a3);
+        } else {
+          atomicAdd(row + i0, g[0]);
+          if (live > 1) atomicAdd(row + i1, g[1]);
+          if (live > 2) atomicAdd(row + i2, g[2]);
+          if (live > 3) atomicAdd(row + i3, g[3]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float *dst = grad_points + ((size_t)b * c + l0) * n;
+  for (int t = threadIdx.x; t < nc * n; t += 1024) dst[t] = acc[t];
+}
+
 // Fused tail of QueryAndGroup (pointnet2_utils.py:348-358): given idx, write the
 // (b, 3+c, m, ns) tensor: channels 0..2 = xyz[idx] - centroid (optionally * 1/radius),
 // channels 3.. = features[idx].
@@ -290,14 +345,41 @@ PN2_API int pn2_group_points(int b, int c, int n, int npoints, int nsample, cons
   return pn2_launch_status();
 }
 
+template <int CPW>
+static void launch_grad_lds(int b, int c, int n, long long mns, const float *grad_out,
+                            const int *idx, float *grad_points, hipStream_t stream) {
+  dim3 grid(pn2_ceil_div(c, CPW), b);
+  const size_t lds = sizeof(float) * (size_t)CPW * n;
+  if (mns % 4 == 0)
+    hipLaunchKernelGGL((group_points_grad_lds_kernel<CPW, true>), grid, dim3(1024), lds, stream, c,
+                       n, (int)mns, grad_out, idx, grad_points);
+  else
+    hipLaunchKernelGGL((group_points_grad_lds_kernel<CPW, false>), grid, dim3(1024), lds, stream,
+                       c, n, (int)mns, grad_out, idx, grad_points);
+}
+
 PN2_API int pn2_group_points_grad(int b, int c, int n, int npoints, int nsample,
                                   const float *grad_out, const int *idx, float *grad_points,
                                   void *stream_) {
   if (b <= 0 || c <= 0 || n <= 0) return 0;
   hipStream_t stream = (hipStream_t)stream_;
+  const long long mns = (long long)npoints * nsample;
+  if (mns > 0 && n <= 16384) {
+    // LDS-privatised rows: the largest channel group that fits 64 KiB and still leaves
+    // >= 512 workgroups (2 per CU) in flight
+    int cpw = 8;
+    while (cpw > 1 && ((long long)cpw * n * 4 > 65536 || (long long)b * ((c + cpw - 1) / cpw) < 512))
+      cpw >>= 1;
+    switch (cpw) {
+      case 8: launch_grad_lds<8>(b, c, n, mns, grad_out, idx, grad_points, stream); break;
+      case 4: launch_grad_lds<4>(b, c, n, mns, grad_out, idx, grad_points, stream); break;
+      case 2: launch_grad_lds<2>(b, c, n, mns, grad_out, idx, grad_points, stream); break;
+      default: launch_grad_lds<1>(b, c, n, mns, grad_out, idx, grad_points, stream);
+    }
+    return pn2_launch_status();
+  }
   hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * n, stream);
   if (e != hipSuccess) return (int)e;
-  const long long mns = (long long)npoints * nsample;
   if (mns <= 0) return 0;
   dim3 grid(pn2_ceil_div(mns, 1024), channel_groups(c, 8), b);
   if (mns % 4 == 0)

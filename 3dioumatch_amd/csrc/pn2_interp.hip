@@ -67,23 +67,41 @@ three_nn_kernel(int n, int m, const float *__restrict__ unknown,
   }
 }
 
-// out[b,l,j] = p[i1]*w1 + p[i2]*w2 + p[i3]*w3, left to right (interpolate_gpu.cu:77-106)
+// out[b,l,j] = p[i1]*w1 + p[i2]*w2 + p[i3]*w3, left to right (interpolate_gpu.cu:77-106).
+// A lane owns JP consecutive query points (JP = 4 -> one 16-byte store per channel) and
+// walks a group of channels, so 12 independent gathers are in flight per channel step.
+template <int JP>
 __global__ void __launch_bounds__(256)
 three_interpolate_kernel(int c, int m, int n, const float *__restrict__ points,
                          const int *__restrict__ idx, const float *__restrict__ weight,
                          float *__restrict__ out) {
   const int b = blockIdx.z;
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  const int *ib = idx + ((size_t)b * n + j) * 3;
-  const float *wb = weight + ((size_t)b * n + j) * 3;
-  const int i1 = ib[0], i2 = ib[1], i3 = ib[2];
-  const float w1 = wb[0], w2 = wb[1], w3 = wb[2];
+  const int j0 = (blockIdx.x * 256 + threadIdx.x) * JP;
+  if (j0 >= n) return;
+  int ii[JP][3];
+  float ww[JP][3];
+#pragma unroll
+  for (int t = 0; t < JP; ++t) {
+    const int j = j0 + t < n ? j0 + t : n - 1;
+    const int *ib = idx + ((size_t)b * n + j) * 3;
+    const float *wb = weight + ((size_t)b * n + j) * 3;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { ii[t][q] = ib[q]; ww[t][q] = wb[q]; }
+  }
   for (int l = blockIdx.y; l < c; l += gridDim.y) {
     const float *src = points + ((size_t)b * c + l) * m;
-    out[((size_t)b * c + l) * n + j] =
-        __fadd_rn(__fadd_rn(__fmul_rn(src[i1], w1), __fmul_rn(src[i2], w2)),
-                  __fmul_rn(src[i3], w3));
+    float r[JP];
+#pragma unroll
+    for (int t = 0; t < JP; ++t)
+      r[t] = __fadd_rn(__fadd_rn(__fmul_rn(src[ii[t][0]], ww[t][0]),
+                                 __fmul_rn(src[ii[t][1]], ww[t][1])),
+                       __fmul_rn(src[ii[t][2]], ww[t][2]));
+    float *dst = out + ((size_t)b * c + l) * n + j0;
+    if (JP == 4) {
+      *reinterpret_cast<float4 *>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+      dst[0] = r[0];
+    }
   }
 }
 
@@ -130,9 +148,15 @@ PN2_API int pn2_three_interpolate(int b, int c, int m, int n, const float *point
                                   const int *idx, const float *weight, float *out,
                                   void *stream_) {
   if (b <= 0 || c <= 0 || n <= 0) return 0;
-  dim3 grid(pn2_ceil_div(n, 256), interp_channel_groups(c), b);
-  hipLaunchKernelGGL(three_interpolate_kernel, grid, dim3(256), 0, (hipStream_t)stream_, c, m, n,
-                     points, idx, weight, out);
+  if (n % 4 == 0) {
+    dim3 grid(pn2_ceil_div(n, 1024), interp_channel_groups(c), b);
+    hipLaunchKernelGGL(three_interpolate_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream_, c,
+                       m, n, points, idx, weight, out);
+  } else {
+    dim3 grid(pn2_ceil_div(n, 256), interp_channel_groups(c), b);
+    hipLaunchKernelGGL(three_interpolate_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream_, c,
+                       m, n, points, idx, weight, out);
+  }
   return pn2_launch_status();
 }
 

@@ -28,40 +28,100 @@ __device__ __forceinline__ unsigned fps_key(int k, int log2bs) {
   return (rev << 22) | (unsigned)k;  // k < 2^22 (checked on the host)
 }
 
-// true when candidate (va, ia) beats (vb, ib) under the reference's total order
-__device__ __forceinline__ bool fps_better(float va, int ia, float vb, int ib, int log2bs) {
-  return va > vb || (va == vb && fps_key(ia, log2bs) < fps_key(ib, log2bs));
+// ---- cross-lane reductions without LDS round trips -------------------------------------
+// quad_perm / row_half_mirror / row_mirror DPP moves give the xor-1/2 and mirror-4/8
+// exchanges inside a 16-lane row; gfx950's v_permlane16_swap / v_permlane32_swap exchange
+// rows and wave halves.  Every lane ends up with the reduction of all 64 lanes.  (A shuffle
+// based reduction costs 12 ds_bpermute round trips per round here; this costs none.)
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_mov(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
 }
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kRowHalfMirror = 0x141, kRowMirror = 0x140;
 
-__device__ __forceinline__ void fps_wave_argmax(float &v, int &i, int log2bs) {
-#pragma unroll
-  for (int off = kWave / 2; off >= 1; off >>= 1) {
-    const float ov = __shfl_xor(v, off, kWave);
-    const int oi = __shfl_xor(i, off, kWave);
-    if (fps_better(ov, oi, v, i, log2bs)) { v = ov; i = oi; }
+// NB: read the two results of a permlane swap into scalars before reinterpreting them;
+// __builtin_bit_cast applied directly to an element of the returned vector folds both
+// elements into element 0 (clang 22 / ROCm 7.2), silently dropping half of the exchange.
+template <bool HALF>
+__device__ __forceinline__ void swap_rows(unsigned v, unsigned &r0, unsigned &r1) {
+  if (HALF) {
+    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    r0 = r[0]; r1 = r[1];
+  } else {
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    r0 = r[0]; r1 = r[1];
   }
 }
 
-// Combine the per-wave winners.  slot_* is one of two buffers (round parity), so one
-// barrier per round is enough: a wave can only overwrite a buffer two rounds later, i.e.
-// after every wave has passed the barrier that follows its reads of that buffer.
+__device__ __forceinline__ float wave_max_f32(float v) {
+#define FPS_STEP(CTRL) { const float o = __builtin_bit_cast(float, dpp_mov<CTRL>(__builtin_bit_cast(unsigned, v))); v = o > v ? o : v; }
+  FPS_STEP(kQuadXor1) FPS_STEP(kQuadXor2) FPS_STEP(kRowHalfMirror) FPS_STEP(kRowMirror)
+#undef FPS_STEP
+  unsigned r0, r1;
+  swap_rows<false>(__builtin_bit_cast(unsigned, v), r0, r1);
+  float f0 = __builtin_bit_cast(float, r0), f1 = __builtin_bit_cast(float, r1);
+  v = f0 > f1 ? f0 : f1;
+  swap_rows<true>(__builtin_bit_cast(unsigned, v), r0, r1);
+  f0 = __builtin_bit_cast(float, r0); f1 = __builtin_bit_cast(float, r1);
+  return f0 > f1 ? f0 : f1;
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#define FPS_STEP(CTRL) { const unsigned o = dpp_mov<CTRL>(v); v = o < v ? o : v; }
+  FPS_STEP(kQuadXor1) FPS_STEP(kQuadXor2) FPS_STEP(kRowHalfMirror) FPS_STEP(kRowMirror)
+#undef FPS_STEP
+  unsigned r0, r1;
+  swap_rows<false>(v, r0, r1);
+  v = r0 < r1 ? r0 : r1;
+  swap_rows<true>(v, r0, r1);
+  return r0 < r1 ? r0 : r1;
+}
+
+// Lane (wave-uniform) holding the best candidate under the reference's order: largest value,
+// ties broken by the smallest key.  The common case (a unique maximum) needs one float
+// reduction and one ballot; only real ties pay for the key reduction.
+__device__ __forceinline__ int wave_argmax_lane(float v, int idx, int log2bs) {
+  const float m = wave_max_f32(v);
+  const unsigned long long tie = __ballot(v == m);
+  if (__popcll(tie) <= 1) return tie ? __builtin_ctzll(tie) : 0;
+  const unsigned key = (v == m) ? fps_key(idx, log2bs) : 0xFFFFFFFFu;
+  const unsigned mk = wave_min_u32(key);
+  return __builtin_ctzll(__ballot(key == mk));
+}
+
+struct FpsPick { int idx; float x, y, z; };
+
+// One candidate per lane (value v, point index idx, its coordinates) -> the workgroup's pick,
+// known to every lane together with its coordinates (so the next round needs no dependent
+// global load).  slot: NW x 8 floats of LDS for this round's parity; ONE barrier per round:
+// a wave can only overwrite a parity buffer two rounds later, i.e. after every wave has
+// passed the barrier that follows its reads of that buffer.
 template <int NW>
-__device__ __forceinline__ int fps_block_argmax(float v, int i, float *slot_v, int *slot_i,
-                                                int log2bs) {
-  if (lane_id() == 0) {
-    slot_v[threadIdx.x / kWave] = v;
-    slot_i[threadIdx.x / kWave] = i;
+__device__ __forceinline__ FpsPick fps_block_pick(float v, int idx, float x, float y, float z,
+                                                  float *slot, int log2bs) {
+  const int lane = lane_id();
+  const int w = threadIdx.x / kWave;
+  const int win = wave_argmax_lane(v, idx, log2bs);
+  if (lane == win) {
+    float4 a = make_float4(v, __builtin_bit_cast(float, idx), x, y);
+    *reinterpret_cast<float4 *>(slot + w * 8) = a;
+    slot[w * 8 + 4] = z;
   }
   __syncthreads();
-  float bv = slot_v[0];
-  int bi = slot_i[0];
-#pragma unroll
-  for (int w = 1; w < NW; ++w) {
-    const float ov = slot_v[w];
-    const int oi = slot_i[w];
-    if (fps_better(ov, oi, bv, bi, log2bs)) { bv = ov; bi = oi; }
+  float sv = -2.0f, sx = 0.f, sy = 0.f, sz = 0.f;  // -2 < every real candidate (>= -1)
+  int si = 0;
+  if (lane < NW) {
+    const float4 a = *reinterpret_cast<const float4 *>(slot + lane * 8);
+    sv = a.x; si = __builtin_bit_cast(int, a.y); sx = a.z; sy = a.w;
+    sz = slot[lane * 8 + 4];
   }
-  return bi;
+  const int best = wave_argmax_lane(sv, si, log2bs);
+  FpsPick p;
+  p.idx = __builtin_amdgcn_readlane(si, best);
+  p.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sx), best));
+  p.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sy), best));
+  p.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sz), best));
+  return p;
 }
 
 __device__ __forceinline__ bool fps_skipped(float x, float y, float z) {
@@ -77,8 +137,7 @@ __global__ void __launch_bounds__(THREADS)
 fps_reg_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
                int *__restrict__ idxs) {
   constexpr int NW = THREADS / kWave;
-  __shared__ float slot_v[2][NW];
-  __shared__ int slot_i[2][NW];
+  __shared__ __attribute__((aligned(16))) float slots[2][NW * 8];
   const int tid = threadIdx.x;
   const float *pts = dataset + (size_t)blockIdx.x * n * 3;
   int *out = idxs + (size_t)blockIdx.x * m;
@@ -97,22 +156,22 @@ fps_reg_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
       td[i] = -1.0f;
     }
   }
-  int old = 0;
   if (tid == 0) out[0] = 0;
+  float x1 = pts[0], y1 = pts[1], z1 = pts[2];
   for (int j = 1; j < m; ++j) {
-    const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
-    float best = -1.0f;
+    float best = -1.0f, bx = x1, by = y1, bz = z1;
     int besti = 0;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
       const float d = sqdist3(px[i], py[i], pz[i], x1, y1, z1);
       const float d2 = fminf(d, td[i]);
       td[i] = d2;
-      if (d2 > best) { best = d2; besti = tid + i * THREADS; }
+      if (d2 > best) { best = d2; besti = tid + i * THREADS; bx = px[i]; by = py[i]; bz = pz[i]; }
     }
-    fps_wave_argmax(best, besti, log2bs);
-    old = fps_block_argmax<NW>(best, besti, slot_v[j & 1], slot_i[j & 1], log2bs);
-    if (tid == 0) out[j] = old;
+    const FpsPick p = fps_block_pick<NW>(best, besti, bx, by, bz, slots[j & 1], log2bs);
+    // no candidate anywhere (every point skipped): the reference re-reads point 0
+    if (p.idx == 0) { x1 = pts[0]; y1 = pts[1]; z1 = pts[2]; } else { x1 = p.x; y1 = p.y; z1 = p.z; }
+    if (tid == 0) out[j] = p.idx;
   }
 }
 
@@ -124,8 +183,7 @@ __global__ void __launch_bounds__(THREADS)
 fps_stream_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
                   float *__restrict__ temp, int *__restrict__ idxs) {
   constexpr int NW = THREADS / kWave;
-  __shared__ float slot_v[2][NW];
-  __shared__ int slot_i[2][NW];
+  __shared__ __attribute__((aligned(16))) float slots[2][NW * 8];
   const int tid = threadIdx.x;
   const float *pts = dataset + (size_t)blockIdx.x * n * 3;
   float *tmp = temp + (size_t)blockIdx.x * n;
@@ -133,21 +191,21 @@ fps_stream_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
 
   for (int k = tid; k < n; k += THREADS)
     tmp[k] = fps_skipped(pts[k * 3 + 0], pts[k * 3 + 1], pts[k * 3 + 2]) ? -1.0f : 1e10f;
-  int old = 0;
   if (tid == 0) out[0] = 0;
+  float x1 = pts[0], y1 = pts[1], z1 = pts[2];
   for (int j = 1; j < m; ++j) {
-    const float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
-    float best = -1.0f;
+    float best = -1.0f, bx = x1, by = y1, bz = z1;
     int besti = 0;
     for (int k = tid; k < n; k += THREADS) {
-      const float d = sqdist3(pts[k * 3 + 0], pts[k * 3 + 1], pts[k * 3 + 2], x1, y1, z1);
+      const float x = pts[k * 3 + 0], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
+      const float d = sqdist3(x, y, z, x1, y1, z1);
       const float d2 = fminf(d, tmp[k]);
       tmp[k] = d2;
-      if (d2 > best) { best = d2; besti = k; }
+      if (d2 > best) { best = d2; besti = k; bx = x; by = y; bz = z; }
     }
-    fps_wave_argmax(best, besti, log2bs);
-    old = fps_block_argmax<NW>(best, besti, slot_v[j & 1], slot_i[j & 1], log2bs);
-    if (tid == 0) out[j] = old;
+    const FpsPick p = fps_block_pick<NW>(best, besti, bx, by, bz, slots[j & 1], log2bs);
+    if (p.idx == 0) { x1 = pts[0]; y1 = pts[1]; z1 = pts[2]; } else { x1 = p.x; y1 = p.y; z1 = p.z; }
+    if (tid == 0) out[j] = p.idx;
   }
 }
 
