@@ -15,6 +15,8 @@ _c_int, _c_float, _vp, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctyp
 # name -> argtypes (restype is int unless listed in _RESTYPE)
 _SIGNATURES = {
     "pn2_furthest_point_sampling": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
+    "pn2_furthest_point_sampling_ws": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _sz, _vp],
+    "pn2_fps_workspace_bytes": [_c_int, _c_int, _c_int],
     "pn2_gather_points": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
     "pn2_gather_points_grad": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
     "pn2_ball_query": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp, _sz, _vp],
@@ -35,7 +37,7 @@ _SIGNATURES = {
     "iou3d_nms": [_vp, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp],
     "iou3d_boxes_iou_bev_cpu": [_c_int, _vp, _c_int, _vp, _vp],
 }
-_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_error_string": ctypes.c_char_p}
+_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_fps_workspace_bytes": _sz, "pn2_error_string": ctypes.c_char_p}
 
 EXPORTS = tuple(_SIGNATURES)
 

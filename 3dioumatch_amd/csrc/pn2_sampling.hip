@@ -18,116 +18,14 @@
 //  * Points with |p|^2 <= 1e-3 never take part (sampling_gpu.cu:105-106); they are given a
 //    running distance of -1, which can neither be selected (best starts at -1, strict >)
 //    nor change (min(d, -1) = -1).
+#include <stdlib.h>
+
 #include "common.h"
+#include "fps_common.h"
 
 namespace {
 
-__device__ __forceinline__ unsigned fps_key(int k, int log2bs) {
-  const unsigned low = (unsigned)k & ((1u << log2bs) - 1u);
-  const unsigned rev = log2bs ? (__brev(low) >> (32 - log2bs)) : 0u;
-  return (rev << 22) | (unsigned)k;  // k < 2^22 (checked on the host)
-}
-
-// ---- cross-lane reductions without LDS round trips -------------------------------------
-// quad_perm / row_half_mirror / row_mirror DPP moves give the xor-1/2 and mirror-4/8
-// exchanges inside a 16-lane row; gfx950's v_permlane16_swap / v_permlane32_swap exchange
-// rows and wave halves.  Every lane ends up with the reduction of all 64 lanes.  (A shuffle
-// based reduction costs 12 ds_bpermute round trips per round here; this costs none.)
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_mov(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
-}
-constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kRowHalfMirror = 0x141, kRowMirror = 0x140;
-
-// NB: read the two results of a permlane swap into scalars before reinterpreting them;
-// __builtin_bit_cast applied directly to an element of the returned vector folds both
-// elements into element 0 (clang 22 / ROCm 7.2), silently dropping half of the exchange.
-template <bool HALF>
-__device__ __forceinline__ void swap_rows(unsigned v, unsigned &r0, unsigned &r1) {
-  if (HALF) {
-    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    r0 = r[0]; r1 = r[1];
-  } else {
-    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-    r0 = r[0]; r1 = r[1];
-  }
-}
-
-__device__ __forceinline__ float wave_max_f32(float v) {
-#define FPS_STEP(CTRL) { const float o = __builtin_bit_cast(float, dpp_mov<CTRL>(__builtin_bit_cast(unsigned, v))); v = o > v ? o : v; }
-  FPS_STEP(kQuadXor1) FPS_STEP(kQuadXor2) FPS_STEP(kRowHalfMirror) FPS_STEP(kRowMirror)
-#undef FPS_STEP
-  unsigned r0, r1;
-  swap_rows<false>(__builtin_bit_cast(unsigned, v), r0, r1);
-  float f0 = __builtin_bit_cast(float, r0), f1 = __builtin_bit_cast(float, r1);
-  v = f0 > f1 ? f0 : f1;
-  swap_rows<true>(__builtin_bit_cast(unsigned, v), r0, r1);
-  f0 = __builtin_bit_cast(float, r0); f1 = __builtin_bit_cast(float, r1);
-  return f0 > f1 ? f0 : f1;
-}
-
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-#define FPS_STEP(CTRL) { const unsigned o = dpp_mov<CTRL>(v); v = o < v ? o : v; }
-  FPS_STEP(kQuadXor1) FPS_STEP(kQuadXor2) FPS_STEP(kRowHalfMirror) FPS_STEP(kRowMirror)
-#undef FPS_STEP
-  unsigned r0, r1;
-  swap_rows<false>(v, r0, r1);
-  v = r0 < r1 ? r0 : r1;
-  swap_rows<true>(v, r0, r1);
-  return r0 < r1 ? r0 : r1;
-}
-
-// Lane (wave-uniform) holding the best candidate under the reference's order: largest value,
-// ties broken by the smallest key.  The common case (a unique maximum) needs one float
-// reduction and one ballot; only real ties pay for the key reduction.
-__device__ __forceinline__ int wave_argmax_lane(float v, int idx, int log2bs) {
-  const float m = wave_max_f32(v);
-  const unsigned long long tie = __ballot(v == m);
-  if (__popcll(tie) <= 1) return tie ? __builtin_ctzll(tie) : 0;
-  const unsigned key = (v == m) ? fps_key(idx, log2bs) : 0xFFFFFFFFu;
-  const unsigned mk = wave_min_u32(key);
-  return __builtin_ctzll(__ballot(key == mk));
-}
-
-struct FpsPick { int idx; float x, y, z; };
-
-// One candidate per lane (value v, point index idx, its coordinates) -> the workgroup's pick,
-// known to every lane together with its coordinates (so the next round needs no dependent
-// global load).  slot: NW x 8 floats of LDS for this round's parity; ONE barrier per round:
-// a wave can only overwrite a parity buffer two rounds later, i.e. after every wave has
-// passed the barrier that follows its reads of that buffer.
-template <int NW>
-__device__ __forceinline__ FpsPick fps_block_pick(float v, int idx, float x, float y, float z,
-                                                  float *slot, int log2bs) {
-  const int lane = lane_id();
-  const int w = threadIdx.x / kWave;
-  const int win = wave_argmax_lane(v, idx, log2bs);
-  if (lane == win) {
-    float4 a = make_float4(v, __builtin_bit_cast(float, idx), x, y);
-    *reinterpret_cast<float4 *>(slot + w * 8) = a;
-    slot[w * 8 + 4] = z;
-  }
-  __syncthreads();
-  float sv = -2.0f, sx = 0.f, sy = 0.f, sz = 0.f;  // -2 < every real candidate (>= -1)
-  int si = 0;
-  if (lane < NW) {
-    const float4 a = *reinterpret_cast<const float4 *>(slot + lane * 8);
-    sv = a.x; si = __builtin_bit_cast(int, a.y); sx = a.z; sy = a.w;
-    sz = slot[lane * 8 + 4];
-  }
-  const int best = wave_argmax_lane(sv, si, log2bs);
-  FpsPick p;
-  p.idx = __builtin_amdgcn_readlane(si, best);
-  p.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sx), best));
-  p.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sy), best));
-  p.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sz), best));
-  return p;
-}
-
-__device__ __forceinline__ bool fps_skipped(float x, float y, float z) {
-  const float mag = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
-  return (double)mag <= 1e-3;  // double compare: the reference's literal is a double
-}
+using namespace fps;
 
 // Register-resident FPS: THREADS lanes, each owning points tid + i*THREADS, i < PPT.
 // THREADS is a multiple of the reference block size bs, so k mod bs is constant per lane
@@ -242,12 +140,44 @@ int ref_log2_block(int n) {
 
 }  // namespace
 
-PN2_API int pn2_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
-                                        int *idxs, void *stream_) {
+size_t pn2_fps_bucket_scratch_bytes(int b, int n);
+int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, void *scratch,
+                       size_t scratch_bytes, int *idxs, hipStream_t stream, int *handled);
+
+// clouds with at least this many points use the bucketed (spatially pruned) tier when a
+// workspace is supplied; overridable for experiments with PN2_FPS_BUCKET_MIN_N
+static int fps_bucket_min_n() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("PN2_FPS_BUCKET_MIN_N");
+    v = e ? atoi(e) : 8192;
+    if (v < 1) v = 1;
+  }
+  return v;
+}
+
+PN2_API size_t pn2_fps_workspace_bytes(int b, int n, int m) {
+  (void)m;
+  if (n >= fps_bucket_min_n()) {
+    const size_t s = pn2_fps_bucket_scratch_bytes(b, n);
+    if (s) return s;
+  }
+  return n > 16384 ? sizeof(float) * (size_t)b * n : 0;  // streaming tier: (b,n) distances
+}
+
+PN2_API int pn2_furthest_point_sampling_ws(int b, int n, int m, const float *dataset,
+                                           int *idxs, void *workspace, size_t workspace_bytes,
+                                           void *stream_) {
   if (b <= 0 || m <= 0) return 0;
   if (n <= 0 || n >= (1 << 22)) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
   const int log2bs = ref_log2_block(n);
+  if (n >= fps_bucket_min_n()) {
+    int handled = 0;
+    const int rc = pn2_fps_bucket_try(b, n, m, log2bs, dataset, workspace, workspace_bytes, idxs,
+                                      stream, &handled);
+    if (rc != 0 || handled) return rc;
+  }
 #define FPS_REG(T, P)                                                                     \
   hipLaunchKernelGGL((fps_reg_kernel<T, P>), dim3(b), dim3(T), 0, stream, n, m, log2bs,   \
                      dataset, idxs)
@@ -266,12 +196,24 @@ PN2_API int pn2_furthest_point_sampling(int b, int n, int m, const float *datase
   } else if (n <= 16384) {
     FPS_REG(1024, 16);
   } else {
-    if (!temp) return (int)hipErrorInvalidValue;
+    if (!workspace || workspace_bytes < sizeof(float) * (size_t)b * n)
+      return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, stream, n, m, log2bs,
-                       dataset, temp, idxs);
+                       dataset, (float *)workspace, idxs);
   }
 #undef FPS_REG
   return pn2_launch_status();
+}
+
+// Reference-shaped entry point: `temp` is the (b,n) float scratch of the reference ABI, which
+// is enough for the register and streaming tiers (the bucketed tier needs the larger
+// workspace of pn2_furthest_point_sampling_ws).
+PN2_API int pn2_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
+                                        int *idxs, void *stream_) {
+  if (n > 16384 && !temp) return (int)hipErrorInvalidValue;
+  // a (b,n) float buffer is too small for the bucketed tier, so that tier declines by itself
+  return pn2_furthest_point_sampling_ws(b, n, m, dataset, idxs, temp,
+                                        temp ? sizeof(float) * (size_t)b * n : 0, stream_);
 }
 
 PN2_API int pn2_gather_points(int b, int c, int n, int npoints, const float *points,

@@ -98,11 +98,13 @@ def furthest_point_sampling(points, nsamples):
     b, n, _ = points.shape
     nsamples = int(nsamples)
     out = torch.zeros((b, nsamples), dtype=torch.int32, device=points.device)
-    temp = torch.empty((b, n), dtype=torch.float32, device=points.device)
     with torch.cuda.device(points.device):
-        _L.check(_lib.pn2_furthest_point_sampling(b, n, nsamples, points.data_ptr(),
-                                                  temp.data_ptr(), out.data_ptr(),
-                                                  _stream(points)), "furthest_point_sampling")
+        need = int(_lib.pn2_fps_workspace_bytes(b, n, nsamples))
+        # private scratch per call (the reference allocates its `temp` per call as well)
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=points.device)
+        _L.check(_lib.pn2_furthest_point_sampling_ws(b, n, nsamples, points.data_ptr(),
+                                                     out.data_ptr(), ws.data_ptr(), need,
+                                                     _stream(points)), "furthest_point_sampling")
     return out
 
 

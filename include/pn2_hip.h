@@ -33,6 +33,17 @@ extern "C" {
 int pn2_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
                                 int *idxs, void *stream);
 
+/* Same operator with a caller-provided workspace of pn2_fps_workspace_bytes(b,n,m) bytes
+ * (replaces furthest_point_sampling_kernel_wrapper, sampling.cpp:16-18, like the entry point
+ * above).  Large clouds then run the bucketed tier: the cloud is sorted once into spatial
+ * buckets and each of the m-1 rounds only touches buckets whose bounding box is closer to the
+ * new sample than their largest running distance -- same indices, ~10x fewer bytes per round. */
+int pn2_furthest_point_sampling_ws(int b, int n, int m, const float *dataset, int *idxs,
+                                   void *workspace, size_t workspace_bytes, void *stream);
+/* workspace size for pn2_furthest_point_sampling_ws; the reference's counterpart is the (b,n)
+ * float `temp` tensor it allocates per call (sampling.cpp:78-80) */
+size_t pn2_fps_workspace_bytes(int b, int n, int m);
+
 /* replaces gather_points_kernel_wrapper (sampling.cpp:9-11, sampling_gpu.cu:13-35).
  * points (b,c,n), idx (b,npoints) -> out (b,c,npoints). */
 int pn2_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx,

@@ -347,3 +347,40 @@ def test_streams_and_second_device_context(ext, oracle, synth):
     s.synchronize()
     assert np.array_equal(got.cpu().numpy(), want)
     assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(xyz[:, :64], xyz, 0.3, 16))
+
+
+def test_fps_bucket_tier_small_clouds_subprocess(synth):
+    """Force the bucketed (spatially pruned) FPS tier onto SMALL clouds, where the oracle is
+    cheap, including heavy ties, skipped points, all-skipped and n not a multiple of 64.
+    The tier threshold is read once per process, hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import importlib, sys, numpy as np, torch
+sys.path.insert(0, %r)
+importlib.import_module("3dioumatch_amd")
+ext = importlib.import_module("pointnet2._ext")
+synth = importlib.import_module("3dioumatch_amd.synth")
+from oracle.oracle import Oracle
+o = Oracle(omp=True)
+cases = []
+for n, m, seed in [(64, 20, 1), (65, 30, 2), (700, 200, 3), (1000, 128, 4), (3000, 300, 5),
+                   (5000, 512, 6), (12000, 256, 7)]:
+    cases.append((synth.cloud_edge_cases(2, n, 1.0, seed=seed, near_origin=min(6, n // 8),
+                                         duplicates=min(48, n // 6)), m))
+cases.append((np.ones((1, 900, 3), np.float32), 40))                 # every point identical
+two = np.ones((1, 2000, 3), np.float32); two[0, 1000:] = 5.0
+cases.append((two, 64))                                               # two clusters of duplicates
+cases.append((np.zeros((1, 300, 3), np.float32), 16))                 # every point skipped
+cases.append((synth.cloud_room(2, 6000, seed=9), 400))                # points on planes
+for xyz, m in cases:
+    got = ext.furthest_point_sampling(torch.from_numpy(xyz).cuda(), m).cpu().numpy()
+    want = o.furthest_point_sampling(xyz, m)
+    assert np.array_equal(got, want), (xyz.shape, m, np.nonzero(got != want))
+print("BUCKET_TIER_OK", len(cases))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PN2_FPS_BUCKET_MIN_N="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "BUCKET_TIER_OK" in r.stdout, r.stdout + r.stderr
