@@ -44,9 +44,9 @@ def test_library_exports_every_declared_symbol(header):
 @pytest.mark.parametrize("header", HEADERS)
 def test_every_declaration_cites_the_reference(header):
     text, names = declared(header)
-    for n in names:
-        start = text.index(n + "(") if (n + "(") in text else text.index(n)
-        comment = text[:start].rsplit("/*", 1)[-1]
+    for mt in DECL.finditer(text):
+        n = mt.group(1)
+        comment = text[:mt.start()].rsplit("/*", 1)[-1]
         assert re.search(r"\.(cpp|cu|py|h):\d+", comment), "no reference file:line above %s" % n
 
 
