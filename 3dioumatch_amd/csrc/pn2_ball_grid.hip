@@ -1,11 +1,254 @@
-// 3dioumatch_amd/csrc/pn2_ball_grid.hip -- cell-list tier of ball_query (large clouds).
-// Placeholder: reports "not handled" so pn2_ball_query uses the brute-force tier.
+// 3dioumatch_amd/csrc/pn2_ball_grid.hip -- cell-list tier of ball_query for large clouds.
+//
+// Semantics: ball_query_gpu.cu:14-49 (first nsample indices in ascending order with
+// d2 < r^2, tail padded with the first hit, zero row without a hit); SURVEY App. A.3.
+//
+// The brute-force formulation needs B*m*N distance tests (6.6e8 at B=8, N=40000, m=2048:
+// VALU-bound, ~0.4 ms) for 8 MB of compulsory traffic.  This tier brings the work down to the
+// ~27 cells around each centroid:
+//
+//   build  : every point goes into a cell of side 1.001*r of a 32^3 PERIODIC lattice
+//            (cell = floor(p / side) mod 32 per axis -- no bounding box pass, far-apart cells
+//            may alias, which only adds candidates that the exact distance test rejects).
+//            Cells are fixed-capacity slot arrays of (x, y, z, index) filled through one
+//            returning atomic per point; an overflowing cell flags the cloud.
+//   query  : one wavefront per centroid.  Lanes 0..26 fetch the 27 neighbour cell counts;
+//            the nine x-rows of three cells are streamed 64 candidates at a time (all loads
+//            issued before the first use), hits are compacted into an LDS list by ballot
+//            rank, then the <=64 smallest indices are selected and ordered IN REGISTERS with a
+//            64-lane bitonic network built from DPP row moves and permlane swaps (no LDS, no
+//            scratch): chunk 0 is sorted ascending, every further chunk descending and folded
+//            in with one min + a 6-stage bitonic merge.  Lane s then writes slot s of the row.
+//            Flagged clouds, rows with more than kMaxHits hits and nsample > 64 fall back to
+//            the brute-force scan of ball_common.h inside the same launch.
+//
+// The order in which atomics fill a cell is irrelevant: selection and ordering are by index.
 #include "common.h"
+#include "ball_common.h"
 
-int pn2_ball_query_grid_try(int, int, int, float, int, const float *, const float *, int *, void *,
-                            size_t, hipStream_t, int *handled) {
-  *handled = 0;
-  return 0;
+namespace {
+
+constexpr int kG = 32;                  // lattice cells per axis (periodic)
+constexpr int kCellsPerCloud = kG * kG * kG;
+constexpr int kCap = 64;                // slots per cell
+constexpr int kMaxHits = 256;           // LDS hit list per wave
+constexpr int kRowSlots = 3 * kCap;     // candidates in one x-row of cells (<= 192)
+constexpr int kRowPasses = kRowSlots / kWave;  // 3
+
+struct GridWs {
+  int *cnt;        // [b][kCellsPerCloud]
+  int *flags;      // [b] overflow
+  float4 *slots;   // [b][kCellsPerCloud][kCap]
+};
+
+__host__ __device__ inline size_t grid_cnt_bytes(int b) {
+  return sizeof(int) * ((size_t)b * kCellsPerCloud + (size_t)((b + 63) / 64) * 64);
 }
 
-size_t pn2_ball_query_grid_workspace(int, int, int, int) { return 0; }
+__device__ __forceinline__ int cell_coord(float v, float inv_side) {
+  return (int)floorf(v * inv_side);
+}
+
+__device__ __forceinline__ int cell_index(int cx, int cy, int cz) {
+  return ((cz & (kG - 1)) * kG + (cy & (kG - 1))) * kG + (cx & (kG - 1));
+}
+
+__global__ void __launch_bounds__(256)
+grid_build_kernel(int n, float inv_side, const float *__restrict__ xyz, int *__restrict__ cnt,
+                  int *__restrict__ flags, float4 *__restrict__ slots) {
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const float *p = xyz + ((size_t)b * n + k) * 3;
+  const float x = p[0], y = p[1], z = p[2];
+  const int c = cell_index(cell_coord(x, inv_side), cell_coord(y, inv_side),
+                           cell_coord(z, inv_side));
+  const size_t cell = (size_t)b * kCellsPerCloud + c;
+  const int slot = atomicAdd(cnt + cell, 1);
+  if (slot < kCap)
+    slots[cell * kCap + slot] = make_float4(x, y, z, __builtin_bit_cast(float, k));
+  else
+    flags[b] = 1;
+}
+
+// ---- 64-lane bitonic network on unsigned keys, entirely in registers ---------------------
+template <int CTRL>
+__device__ __forceinline__ unsigned dppu(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+// value held by lane (lane ^ D)
+template <int D>
+__device__ __forceinline__ unsigned partner(unsigned v, int lane) {
+  if (D == 1) return dppu<0xB1>(v);                  // quad_perm [1,0,3,2]
+  if (D == 2) return dppu<0x4E>(v);                  // quad_perm [2,3,0,1]
+  if (D == 4) {                                      // row_shl:4 / row_shr:4
+    const unsigned up = dppu<0x104>(v), dn = dppu<0x114>(v);
+    return (lane & 4) ? dn : up;
+  }
+  if (D == 8) return dppu<0x128>(v);                 // row_ror:8
+  unsigned r0, r1;
+  if (D == 16) {
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    r0 = r[0]; r1 = r[1];
+    return (lane & 16) ? r0 : r1;
+  }
+  auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  r0 = r[0]; r1 = r[1];
+  return (lane & 32) ? r0 : r1;
+}
+
+template <int D>
+__device__ __forceinline__ unsigned cmpx(unsigned v, int lane, bool ascending) {
+  const unsigned p = partner<D>(v, lane);
+  const bool lower = (lane & D) == 0;
+  const unsigned lo = v < p ? v : p, hi = v < p ? p : v;
+  return (lower == ascending) ? lo : hi;
+}
+
+// merge a bitonic sequence of 64 keys into ascending (or descending) order
+__device__ __forceinline__ unsigned bitonic_merge64(unsigned v, int lane, bool asc) {
+  v = cmpx<32>(v, lane, asc); v = cmpx<16>(v, lane, asc); v = cmpx<8>(v, lane, asc);
+  v = cmpx<4>(v, lane, asc);  v = cmpx<2>(v, lane, asc);  v = cmpx<1>(v, lane, asc);
+  return v;
+}
+
+__device__ __forceinline__ unsigned bitonic_sort64(unsigned v, int lane, bool asc) {
+#define DIR(K) (((lane & (K)) == 0) == asc)
+  v = cmpx<1>(v, lane, DIR(2));
+  v = cmpx<2>(v, lane, DIR(4)); v = cmpx<1>(v, lane, DIR(4));
+  v = cmpx<4>(v, lane, DIR(8)); v = cmpx<2>(v, lane, DIR(8)); v = cmpx<1>(v, lane, DIR(8));
+  v = cmpx<8>(v, lane, DIR(16)); v = cmpx<4>(v, lane, DIR(16)); v = cmpx<2>(v, lane, DIR(16));
+  v = cmpx<1>(v, lane, DIR(16));
+  v = cmpx<16>(v, lane, DIR(32)); v = cmpx<8>(v, lane, DIR(32)); v = cmpx<4>(v, lane, DIR(32));
+  v = cmpx<2>(v, lane, DIR(32)); v = cmpx<1>(v, lane, DIR(32));
+#undef DIR
+  return bitonic_merge64(v, lane, asc);
+}
+
+__global__ void __launch_bounds__(256)
+grid_query_kernel(int n, int m, float radius2, float inv_side, int nsample,
+                  const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+                  const int *__restrict__ cnt, const int *__restrict__ flags,
+                  const float4 *__restrict__ slots, int *__restrict__ idx) {
+  __shared__ unsigned hits[256 / kWave][kMaxHits];
+  const int b = blockIdx.y;
+  const int lane = lane_id();
+  const int wave = threadIdx.x / kWave;
+  const int j = blockIdx.x * (256 / kWave) + wave;
+  if (j >= m) return;  // whole wave
+  const float *pts = xyz + (size_t)b * n * 3;
+  const float *ctr = new_xyz + ((size_t)b * m + j) * 3;
+  int *row = idx + ((size_t)b * m + j) * nsample;
+  if (flags[b] != 0) {  // a cell of this cloud overflowed: exact brute-force scan instead
+    ball_query_wave_scan<1>(pts, n, ctr, 1, radius2, nsample, row);
+    return;
+  }
+  const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
+  const int gx = cell_coord(cx, inv_side), gy = cell_coord(cy, inv_side),
+            gz = cell_coord(cz, inv_side);
+
+  // counts of the 27 neighbour cells: lane l <-> (dz, dy, dx) = (l/9, (l/3)%3, l%3) - 1
+  int my_cell = 0, my_cnt = 0;
+  if (lane < 27) {
+    my_cell = cell_index(gx + lane % 3 - 1, gy + (lane / 3) % 3 - 1, gz + lane / 9 - 1);
+    my_cnt = cnt[(size_t)b * kCellsPerCloud + my_cell];
+    my_cnt = my_cnt < kCap ? my_cnt : kCap;
+  }
+  const float4 *cloud_slots = slots + (size_t)b * kCellsPerCloud * kCap;
+
+  // ---- stream the nine x-rows; hits go to the LDS list in arrival order --------------------
+  int total = 0;
+  unsigned *list = hits[wave];
+#pragma unroll 1
+  for (int r = 0; r < 9; ++r) {
+    const int c0 = __builtin_amdgcn_readlane(my_cnt, r * 3 + 0);
+    const int c1 = __builtin_amdgcn_readlane(my_cnt, r * 3 + 1);
+    const int c2 = __builtin_amdgcn_readlane(my_cnt, r * 3 + 2);
+    const int e0 = __builtin_amdgcn_readlane(my_cell, r * 3 + 0);
+    const int e1 = __builtin_amdgcn_readlane(my_cell, r * 3 + 1);
+    const int e2 = __builtin_amdgcn_readlane(my_cell, r * 3 + 2);
+    const int rc = c0 + c1 + c2;
+    float4 q[kRowPasses];
+    bool live[kRowPasses];
+#pragma unroll
+    for (int p = 0; p < kRowPasses; ++p) {  // issue every load of the row first
+      const int t = p * kWave + lane;
+      live[p] = t < rc;
+      int cell = e0, s = t;
+      if (t >= c0) { cell = e1; s = t - c0; }
+      if (t >= c0 + c1) { cell = e2; s = t - c0 - c1; }
+      q[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p * kWave < rc && live[p]) q[p] = cloud_slots[(size_t)cell * kCap + s];
+    }
+#pragma unroll
+    for (int p = 0; p < kRowPasses; ++p) {
+      if (p * kWave < rc) {  // wave-uniform
+        const float d2 = sqdist3(cx, cy, cz, q[p].x, q[p].y, q[p].z);
+        const bool hit = live[p] && d2 < radius2;
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+          const int pos = total + mask_rank(mask);
+          if (hit && pos < kMaxHits) list[pos] = __builtin_bit_cast(unsigned, q[p].w);
+          total += __popcll(mask);
+        }
+      }
+    }
+  }
+  if (total > kMaxHits) {  // very dense ball: exact brute-force scan for this centroid
+    ball_query_wave_scan<1>(pts, n, ctr, 1, radius2, nsample, row);
+    return;
+  }
+  if (total == 0) {
+    for (int s = lane; s < nsample; s += kWave) row[s] = 0;
+    return;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- the 64 smallest indices, ascending, one per lane --------------------------------------
+  const unsigned kNone = 0xFFFFFFFFu;
+  unsigned a = lane < total ? list[lane] : kNone;
+  a = bitonic_sort64(a, lane, true);
+  for (int base = kWave; base < total; base += kWave) {
+    unsigned c = base + lane < total ? list[base + lane] : kNone;
+    c = bitonic_sort64(c, lane, false);   // descending: lane i holds the (63-i)-th smallest
+    a = a < c ? a : c;                    // the 64 smallest of the union (a bitonic sequence)
+    a = bitonic_merge64(a, lane, true);
+  }
+  const unsigned first = (unsigned)__builtin_amdgcn_readlane((int)a, 0);
+  const int have = total < kWave ? total : kWave;
+  if (lane < nsample) row[lane] = (int)(lane < have ? a : first);
+}
+
+}  // namespace
+
+size_t pn2_ball_query_grid_workspace(int b, int n, int m, int nsample) {
+  (void)m;
+  if (n < 4096 || nsample > kWave) return 0;
+  return grid_cnt_bytes(b) + sizeof(float4) * (size_t)b * kCellsPerCloud * kCap;
+}
+
+int pn2_ball_query_grid_try(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                            const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
+                            hipStream_t stream, int *handled) {
+  *handled = 0;
+  const size_t need = pn2_ball_query_grid_workspace(b, n, m, nsample);
+  if (need == 0 || workspace == nullptr || workspace_bytes < need) return 0;
+  if (!(radius > 1e-6f) || !(radius < 1e6f)) return 0;  // also rejects NaN
+  char *ws = reinterpret_cast<char *>(workspace);
+  int *cnt = reinterpret_cast<int *>(ws);
+  int *flags = cnt + (size_t)b * kCellsPerCloud;
+  float4 *slots = reinterpret_cast<float4 *>(ws + grid_cnt_bytes(b));
+  hipError_t e = hipMemsetAsync(cnt, 0, grid_cnt_bytes(b), stream);
+  if (e != hipSuccess) return (int)e;
+  const float inv_side = 1.0f / (radius * 1.001f);
+  hipLaunchKernelGGL(grid_build_kernel, dim3(pn2_ceil_div(n, 256), b), dim3(256), 0, stream, n,
+                     inv_side, xyz, cnt, flags, slots);
+  const float radius2 = radius * radius;  // fp32 product, as ball_query_gpu.cu:27
+  hipLaunchKernelGGL(grid_query_kernel, dim3(pn2_ceil_div(m, 256 / kWave), b), dim3(256), 0,
+                     stream, n, m, radius2, inv_side, nsample, new_xyz, xyz, cnt, flags, slots,
+                     idx);
+  *handled = 1;
+  return pn2_launch_status();
+}

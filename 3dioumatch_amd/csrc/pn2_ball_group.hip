@@ -15,6 +15,7 @@
 //    a tail fill after the scan; rows without a hit are written as zeros, so the output
 //    needs no pre-zeroing.
 #include "common.h"
+#include "ball_common.h"
 
 namespace {
 
@@ -24,58 +25,12 @@ ball_query_bf_kernel(int n, int m, float radius2, int nsample,
                      const float *__restrict__ new_xyz, const float *__restrict__ xyz,
                      int *__restrict__ idx) {
   const int b = blockIdx.y;
-  const int lane = lane_id();
   const int wave = threadIdx.x / kWave;
   const int j0 = (blockIdx.x * (256 / kWave) + wave) * QW;
   if (j0 >= m) return;
-  const float *pts = xyz + (size_t)b * n * 3;
-  const float *ctr = new_xyz + ((size_t)b * m + j0) * 3;
-  int *rows = idx + ((size_t)b * m + j0) * nsample;
-
-  float cx[QW], cy[QW], cz[QW];
-  int cnt[QW], first[QW];
-#pragma unroll
-  for (int q = 0; q < QW; ++q) {
-    const bool live = j0 + q < m;
-    cx[q] = live ? ctr[q * 3 + 0] : 0.f;
-    cy[q] = live ? ctr[q * 3 + 1] : 0.f;
-    cz[q] = live ? ctr[q * 3 + 2] : 0.f;
-    cnt[q] = live ? 0 : nsample;  // dead slots count as already full
-    first[q] = 0;
-  }
-
-  for (int base = 0; base < n; base += kWave) {
-    bool any_open = false;
-#pragma unroll
-    for (int q = 0; q < QW; ++q) any_open |= cnt[q] < nsample;
-    if (!any_open) break;  // wave-uniform
-    const int k = base + lane;
-    const bool valid = k < n;
-    const float x = valid ? pts[k * 3 + 0] : 0.f;
-    const float y = valid ? pts[k * 3 + 1] : 0.f;
-    const float z = valid ? pts[k * 3 + 2] : 0.f;
-#pragma unroll
-    for (int q = 0; q < QW; ++q) {
-      if (cnt[q] < nsample) {  // wave-uniform
-        const float d2 = sqdist3(cx[q], cy[q], cz[q], x, y, z);
-        const bool hit = valid && d2 < radius2;
-        const unsigned long long mask = __ballot(hit);
-        if (mask) {
-          if (cnt[q] == 0) first[q] = base + __builtin_ctzll(mask);
-          const int slot = cnt[q] + mask_rank(mask);
-          if (hit && slot < nsample) rows[(size_t)q * nsample + slot] = k;
-          cnt[q] += __popcll(mask);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < QW; ++q) {
-    if (j0 + q < m) {
-      const int have = cnt[q] < nsample ? cnt[q] : nsample;
-      for (int s = have + lane; s < nsample; s += kWave) rows[(size_t)q * nsample + s] = first[q];
-    }
-  }
+  ball_query_wave_scan<QW>(xyz + (size_t)b * n * 3, n, new_xyz + ((size_t)b * m + j0) * 3,
+                           m - j0 < QW ? m - j0 : QW, radius2, nsample,
+                           idx + ((size_t)b * m + j0) * nsample);
 }
 
 // out[b,l,e] = points[b,l,idx[b,e]],  e over npoints*nsample  (group_points_gpu.cu:13-33).

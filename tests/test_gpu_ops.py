@@ -384,3 +384,38 @@ print("BUCKET_TIER_OK", len(cases))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "BUCKET_TIER_OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("case", ["aliasing", "overflow", "dense_hits", "negative", "ns_small",
+                                  "ns_over_64", "tiny_radius"])
+def test_ballquery_cell_list_tier_edge_cases(ext, oracle_omp, synth, case):
+    """The cell-list tier (n >= 4096, nsample <= 64) against the oracle where its special
+    paths trigger: lattice aliasing (cloud wider than 32 cells), cell overflow (> 64 points
+    in one cell -> flagged cloud -> in-launch brute force), > 256 hits in a ball, negative
+    coordinates, small nsample, nsample > 64 (tier declines), radius so small that balls hold
+    only their own centroid."""
+    g = np.random.default_rng(11)
+    b, n, m, r, ns = 2, 6000, 300, 0.2, 64
+    xyz = synth.cloud_uniform(b, n, 2.0, seed=21)
+    if case == "aliasing":
+        xyz = synth.cloud_uniform(b, n, 30.0, seed=22)       # 150 cells wide: aliases 4-5x
+        xyz[:, ::2] *= 0.1                                      # plus a dense core
+    elif case == "overflow":
+        xyz[0, :500] = 0.5 + g.random((500, 3), dtype=np.float32) * 0.05   # 500 points in one cell
+    elif case == "dense_hits":
+        r, ns = 0.6, 64                                        # ~ 680 hits per ball
+    elif case == "negative":
+        xyz = xyz - 5.0
+        xyz[1] *= -1.0
+    elif case == "ns_small":
+        ns = 5
+    elif case == "ns_over_64":
+        ns = 100
+    elif case == "tiny_radius":
+        r = 1e-4
+    cen = xyz[:, g.permutation(n)[:m]].copy()
+    cen[:, -1] = 1000.0                                        # empty ball -> zero row
+    want = oracle_omp.ball_query(cen, xyz, r, ns)
+    got = ext.ball_query(dev(cen), dev(xyz), r, ns).cpu().numpy()
+    assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+    assert np.all(got[:, -1] == 0)
