@@ -6,3 +6,4 @@ from .config import DatasetConfig, scannet_config, sunrgbd_config  # noqa: F401
 from .detector import VoteNet  # noqa: F401
 from .heads import GridConv, ProposalModule, VotingModule  # noqa: F401
 from .losses import get_labeled_loss  # noqa: F401
+from .step import SupervisedStep, update_ema_variables, lr_at, bn_momentum_at  # noqa: F401

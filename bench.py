@@ -51,27 +51,10 @@ def parse():
 
 
 def build_step(V, cfg, device, world, local_rank):
-    net = V.VoteNet(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster, cfg.mean_size_arr,
-                    cfg, input_feature_dim=1, num_proposal=KPROP, sampling="seed_fps")
-    torch.manual_seed(0)
-    net = net.to(device).train()
-    model = net
-    if world > 1:
-        # one flat bucket (4.26 MB of fp32 grads), buffers stay per replica like the
-        # reference's per-GPU BatchNorm (no SyncBN)
-        model = torch.nn.parallel.DistributedDataParallel(
-            net, device_ids=[local_rank], broadcast_buffers=False, bucket_cap_mb=32,
-            gradient_as_bucket_view=True)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0)
+    runner = V.SupervisedStep(cfg, device, world_size=world, num_proposal=KPROP, lr=1e-3)
 
     def step(batch):
-        opt.zero_grad(set_to_none=True)
-        end_points = model(batch, mode="jitter")
-        end_points.update(batch)
-        loss, _ = V.get_labeled_loss(end_points, cfg, {"dataset_config": cfg})
-        loss.backward()
-        opt.step()
-        return loss
+        return runner(batch)[0]
 
     return step
 

@@ -1,0 +1,116 @@
+"""Data-parallel train step on the CPU: world_size 2, gloo, oracle stand-ins for the extensions
+(so the N>1 path of 3dioumatch_amd/votenet/step.py is covered without GPUs).
+
+Checks: (1) after backward every rank holds the SAME gradient and it equals the mean of the
+per-rank gradients computed without DDP; (2) parameters stay bit-identical across ranks after
+the Adam step; (3) BatchNorm buffers are NOT synchronised (per-replica BN, like the reference);
+(4) the EMA teacher update matches train.py:285-289 and needs no communication.
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_pkg
+
+B, N, K = 1, 2600, 32
+
+
+def _install_standins():
+    load_pkg()
+    from oracle import standin
+    from oracle.oracle import Oracle
+    o = Oracle(omp=False)
+    utils = importlib.import_module("pointnet2.pointnet2_utils")
+    losses = importlib.import_module("3dioumatch_amd.votenet.losses")
+    utils._ext = standin.make(o)
+    losses.boxes_iou3d_gpu = lambda a, b: torch.from_numpy(
+        o.boxes_iou3d(a.detach().numpy(), b.detach().numpy()))
+
+
+def _batch(V, cfg, seed):
+    data = importlib.import_module("3dioumatch_amd.votenet.data")
+    return data.make_batch(B, N, cfg, seed=seed, num_objects=5)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_standins()
+    V = importlib.import_module("3dioumatch_amd.votenet")
+    step_mod = importlib.import_module("3dioumatch_amd.votenet.step")
+    cfg = V.scannet_config()
+    runner = V.SupervisedStep(cfg, torch.device("cpu"), world_size=world, num_proposal=K)
+    torch.manual_seed(100 + rank)  # jitter noise differs per rank, like the data
+    loss, _ = runner(_batch(V, cfg, seed=200 + rank))
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank),
+             grad=step_mod.flat_grads(runner.net).numpy(),
+             params=step_mod.flat_params(runner.net).numpy(),
+             bn_mean=runner.net.backbone_net.sa1.mlp_module.layer0.bn.bn.running_mean.numpy(),
+             loss=float(loss))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_gloo(tmp_path):
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    # (1) identical, all-reduced gradients on both ranks
+    assert np.array_equal(r0["grad"], r1["grad"])
+    # (2) identical parameters after the optimizer step
+    assert np.array_equal(r0["params"], r1["params"])
+    # (3) per-replica BatchNorm statistics (different data -> different running means)
+    assert not np.array_equal(r0["bn_mean"], r1["bn_mean"])
+    assert np.isfinite(r0["loss"]) and np.isfinite(r1["loss"]) and r0["loss"] != r1["loss"]
+
+    # the all-reduced gradient is the MEAN of the two single-process gradients
+    _install_standins()
+    V = importlib.import_module("3dioumatch_amd.votenet")
+    step_mod = importlib.import_module("3dioumatch_amd.votenet.step")
+    cfg = V.scannet_config()
+    singles = []
+    for rank in range(world):
+        runner = V.SupervisedStep(cfg, torch.device("cpu"), world_size=1, num_proposal=K)
+        torch.manual_seed(100 + rank)
+        runner.optimizer.zero_grad(set_to_none=True)
+        batch = _batch(V, cfg, seed=200 + rank)
+        ep = runner.model(batch, mode="jitter")
+        ep.update(batch)
+        loss, _ = V.get_labeled_loss(ep, cfg, {"dataset_config": cfg})
+        loss.backward()
+        singles.append(step_mod.flat_grads(runner.net).numpy())
+    want = (singles[0] + singles[1]) / 2
+    err = np.linalg.norm(r0["grad"] - want) / np.linalg.norm(want)
+    assert err < 1e-5, err
+
+
+def test_ema_update_and_schedules():
+    load_pkg()
+    V = importlib.import_module("3dioumatch_amd.votenet")
+    step_mod = importlib.import_module("3dioumatch_amd.votenet.step")
+    cfg = V.scannet_config()
+    student = step_mod.build_detector(cfg, num_proposal=16, seed=1)
+    teacher = step_mod.build_detector(cfg, num_proposal=16, seed=2)
+    ref = [p.detach().clone() for p in teacher.parameters()]
+    for step, alpha in ((0, 0.999), (5, 0.999), (5000, 0.999)):
+        a = min(1 - 1 / (step + 1), alpha)
+        ref = [r * a + (1 - a) * s.detach() for r, s in zip(ref, student.parameters())]
+        V.update_ema_variables(student, teacher, alpha, step)
+        for r, t in zip(ref, teacher.parameters()):
+            assert torch.allclose(r, t, atol=1e-7)
+    # buffers (BatchNorm statistics) are not touched by the EMA (parameters() only)
+    assert V.lr_at(0) == 1e-3 and abs(V.lr_at(450) - 1e-4) < 1e-12 and abs(V.lr_at(900) - 1e-6) < 1e-15
+    assert V.bn_momentum_at(0) == 0.5 and V.bn_momentum_at(20) == 0.25
+    assert V.bn_momentum_at(10000) == 0.001
