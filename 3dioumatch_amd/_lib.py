@@ -29,6 +29,16 @@ _SIGNATURES = {
     "pn2_query_and_group": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _vp, _vp,
                             _vp, _vp, _vp, _vp, _sz, _vp],
     "pn2_error_string": [_c_int],
+    "mlp_bn_workspace_floats": [_c_int, _c_int, _c_int],
+    "mlp_bn_train_stats": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _c_float, _c_float, _vp, _vp, _vp,
+                           _vp, _vp, _vp, _vp, _vp],
+    "mlp_bn_eval_coeff": [_c_int, _vp, _vp, _c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mlp_bn_relu_apply": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "mlp_bn_relu_pool": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mlp_bn_relu_backward": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                             _vp, _vp, _vp, _vp, _vp],
+    "mlp_bn_relu_pool_backward": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "iou3d_boxes_overlap_bev": [_c_int, _vp, _c_int, _vp, _vp, _vp],
     "iou3d_boxes_iou_bev": [_c_int, _vp, _c_int, _vp, _vp, _vp],
     "iou3d_boxes_iou3d": [_c_int, _vp, _c_int, _vp, _vp, _vp],
@@ -37,7 +47,7 @@ _SIGNATURES = {
     "iou3d_nms": [_vp, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp],
     "iou3d_boxes_iou_bev_cpu": [_c_int, _vp, _c_int, _vp, _vp],
 }
-_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_fps_workspace_bytes": _sz, "pn2_error_string": ctypes.c_char_p}
+_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_fps_workspace_bytes": _sz, "mlp_bn_workspace_floats": _sz, "pn2_error_string": ctypes.c_char_p}
 
 EXPORTS = tuple(_SIGNATURES)
 

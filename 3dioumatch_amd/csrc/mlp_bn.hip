@@ -1,0 +1,459 @@
+// 3dioumatch_amd/csrc/mlp_bn.hip -- fused BatchNorm(+ReLU)(+max-pool over nsample) for the
+// grouped shared MLP of the set-abstraction layers, forward and backward, gfx950.
+//
+// What it replaces: in the reference a shared-MLP layer is nn.Conv2d(1x1) -> nn.BatchNorm2d ->
+// nn.ReLU (pointnet2/pytorch_utils.py:14-39,70-124) followed, after the last layer, by
+// F.max_pool2d over the nsample axis (pointnet2/pointnet2_modules.py:256-262).  On GB-scale
+// activations (B,C,npoint,nsample) that is, per layer, two reads + one write for the batch
+// norm, one read + one write for the ReLU and one more read for the pooling, and about eight
+// passes in the backward.  Here (training mode):
+//   forward : stats (1 read) -> finalize (tiny) -> apply BN+ReLU (1 read, 1 write), or for the
+//             last layer apply BN+ReLU+max over nsample (1 read, tiny write + arg-max);
+//   backward: sums (read y, dz) -> finalize (tiny) -> dy (read y, dz; 1 write); the ReLU mask
+//             and the normalised activation are RECOMPUTED from y, so neither z nor a mask
+//             is stored; for the pooled layer the sums come from the (B,C,npoint) tensors alone.
+// Statistics: per-slice shifted sums -> (n, mean, M2) -> Chan combination in double, i.e.
+// Welford-quality means/variances independent of the slice count.
+//
+// Layout: y, z, dz, dy are (B, C, R) contiguous with R = npoint*nsample (or npoint for the
+// 1-D case); per-channel vectors are length C.
+#include "common.h"
+
+namespace {
+
+constexpr int kBnThreads = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = kWave / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// sum of two values over the workgroup; result valid in thread 0
+__device__ __forceinline__ void block_sum2(float &a, float &b, float *scratch) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int w = threadIdx.x / kWave;
+  if (lane_id() == 0) { scratch[w * 2] = a; scratch[w * 2 + 1] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = 0.f; b = 0.f;
+    for (int q = 0; q < kBnThreads / kWave; ++q) { a += scratch[q * 2]; b += scratch[q * 2 + 1]; }
+  }
+}
+
+// ---- forward statistics: one (n, mean, M2) triple per (channel, batch, slice) ---------------
+__global__ void __launch_bounds__(kBnThreads)
+bn_partial_stats_kernel(int c, int r, int slices, const float *__restrict__ y,
+                        float *__restrict__ partial) {
+  __shared__ float scratch[2 * kBnThreads / kWave];
+  const int s = blockIdx.x, ch = blockIdx.y, b = blockIdx.z;
+  const int per = (r + slices - 1) / slices;
+  const int lo = s * per, hi = lo + per < r ? lo + per : r;
+  const float *src = y + ((size_t)b * c + ch) * r;
+  const int n = hi - lo;
+  float a1 = 0.f, a2 = 0.f;
+  const float shift = n > 0 ? src[lo] : 0.f;  // shifted sums: no cancellation in the variance
+  for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) {
+    const float d = src[i] - shift;
+    a1 += d;
+    a2 += d * d;
+  }
+  block_sum2(a1, a2, scratch);
+  if (threadIdx.x == 0) {
+    float *out = partial + ((size_t)ch * gridDim.z * slices + (size_t)b * slices + s) * 3;
+    const float fn = (float)n;
+    out[0] = fn;
+    out[1] = n > 0 ? shift + a1 / fn : 0.f;
+    out[2] = n > 0 ? a2 - a1 * a1 / fn : 0.f;
+  }
+}
+
+// ---- finalize: Chan combination, running statistics, affine coefficients ------------------
+__global__ void __launch_bounds__(256)
+bn_finalize_kernel(int c, int parts, const float *__restrict__ partial,
+                   const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                   float momentum, float *__restrict__ running_mean,
+                   float *__restrict__ running_var, float *__restrict__ mean_out,
+                   float *__restrict__ invstd_out, float *__restrict__ scale_out,
+                   float *__restrict__ shift_out) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  const float *p = partial + (size_t)ch * parts * 3;
+  for (int q = 0; q < parts; ++q) {
+    const double nb = p[q * 3], mb = p[q * 3 + 1], m2b = p[q * 3 + 2];
+    if (nb > 0.0) {
+      const double tot = n + nb, delta = mb - mean;
+      mean += delta * nb / tot;
+      m2 += m2b + delta * delta * n * nb / tot;
+      n = tot;
+    }
+  }
+  const double var = n > 0.0 ? m2 / n : 0.0;  // biased, used for normalisation
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float fmean = (float)mean;
+  mean_out[ch] = fmean;
+  invstd_out[ch] = invstd;
+  const float sc = gamma[ch] * invstd;
+  scale_out[ch] = sc;
+  shift_out[ch] = beta[ch] - fmean * sc;
+  if (running_mean != nullptr) {  // nn.BatchNorm: unbiased variance in the running estimate
+    const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
+    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * fmean;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+  }
+}
+
+// eval mode: coefficients from the running statistics
+__global__ void __launch_bounds__(256)
+bn_eval_coeff_kernel(int c, const float *__restrict__ gamma, const float *__restrict__ beta,
+                     float eps, const float *__restrict__ running_mean,
+                     const float *__restrict__ running_var, float *__restrict__ mean_out,
+                     float *__restrict__ invstd_out, float *__restrict__ scale_out,
+                     float *__restrict__ shift_out) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  const float invstd = 1.0f / sqrtf(running_var[ch] + eps);
+  mean_out[ch] = running_mean[ch];
+  invstd_out[ch] = invstd;
+  const float sc = gamma[ch] * invstd;
+  scale_out[ch] = sc;
+  shift_out[ch] = beta[ch] - running_mean[ch] * sc;
+}
+
+// ---- z = relu(y*scale + shift) ---------------------------------------------------------------
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+bn_relu_apply_kernel(int c, int r, const float *__restrict__ y, const float *__restrict__ scale,
+                     const float *__restrict__ shift, float *__restrict__ z) {
+  const int ch = blockIdx.y, b = blockIdx.z;
+  const float sc = scale[ch], sh = shift[ch];
+  const size_t base = ((size_t)b * c + ch) * r;
+  if (VEC) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= r) return;
+    const float4 v = *reinterpret_cast<const float4 *>(y + base + i);
+    float4 o;
+    o.x = fmaxf(v.x * sc + sh, 0.f); o.y = fmaxf(v.y * sc + sh, 0.f);
+    o.z = fmaxf(v.z * sc + sh, 0.f); o.w = fmaxf(v.w * sc + sh, 0.f);
+    *reinterpret_cast<float4 *>(z + base + i) = o;
+  } else {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < r) z[base + i] = fmaxf(y[base + i] * sc + sh, 0.f);
+  }
+}
+
+// ---- pooled = max_k relu(y[..., j, k]*scale + shift), plus arg-max and the winning y ---------
+// LPR lanes share one row of NS = 4*LPR samples (16-byte loads, coalesced over the wave);
+// the row maximum is formed with xor-shuffles inside the LPR-lane group.
+template <int LPR>
+__global__ void __launch_bounds__(256)
+bn_relu_pool_kernel(int c, int m, const float *__restrict__ y, const float *__restrict__ scale,
+                    const float *__restrict__ shift, float *__restrict__ pooled,
+                    int *__restrict__ argmax, float *__restrict__ ymax) {
+  constexpr int NS = LPR * 4;
+  const int ch = blockIdx.y, b = blockIdx.z;
+  const int row = (blockIdx.x * 256 + threadIdx.x) / LPR;
+  const int sub = threadIdx.x % LPR;
+  const float sc = scale[ch], sh = shift[ch];
+  const bool live = row < m;
+  const size_t base = (((size_t)b * c + ch) * m + (live ? row : 0)) * NS + sub * 4;
+  const float4 v = *reinterpret_cast<const float4 *>(y + base);
+  float best = fmaxf(v.x * sc + sh, 0.f), by = v.x;
+  int bk = sub * 4;
+  float t;
+  t = fmaxf(v.y * sc + sh, 0.f); if (t > best) { best = t; by = v.y; bk = sub * 4 + 1; }
+  t = fmaxf(v.z * sc + sh, 0.f); if (t > best) { best = t; by = v.z; bk = sub * 4 + 2; }
+  t = fmaxf(v.w * sc + sh, 0.f); if (t > best) { best = t; by = v.w; bk = sub * 4 + 3; }
+#pragma unroll
+  for (int off = 1; off < LPR; off <<= 1) {
+    const float ob = __shfl_xor(best, off, kWave);
+    const float oy = __shfl_xor(by, off, kWave);
+    const int ok = __shfl_xor(bk, off, kWave);
+    if (ob > best || (ob == best && ok < bk)) { best = ob; by = oy; bk = ok; }  // first max wins
+  }
+  if (live && sub == 0) {
+    const size_t o = ((size_t)b * c + ch) * m + row;
+    pooled[o] = best;
+    argmax[o] = bk;
+    ymax[o] = by;
+  }
+}
+
+// generic nsample (not a multiple of 4 or > 64): one lane per row
+__global__ void __launch_bounds__(256)
+bn_relu_pool_generic_kernel(int c, int m, int ns, const float *__restrict__ y,
+                            const float *__restrict__ scale, const float *__restrict__ shift,
+                            float *__restrict__ pooled, int *__restrict__ argmax,
+                            float *__restrict__ ymax) {
+  const int ch = blockIdx.y, b = blockIdx.z;
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= m) return;
+  const float sc = scale[ch], sh = shift[ch];
+  const float *src = y + (((size_t)b * c + ch) * m + row) * ns;
+  float best = fmaxf(src[0] * sc + sh, 0.f), by = src[0];
+  int bk = 0;
+  for (int k = 1; k < ns; ++k) {
+    const float t = fmaxf(src[k] * sc + sh, 0.f);
+    if (t > best) { best = t; by = src[k]; bk = k; }
+  }
+  const size_t o = ((size_t)b * c + ch) * m + row;
+  pooled[o] = best; argmax[o] = bk; ymax[o] = by;
+}
+
+// ---- backward sums: s1 = sum dzh, s2 = sum dzh * xhat, dzh = dz * [y*scale+shift > 0] --------
+__global__ void __launch_bounds__(kBnThreads)
+bn_relu_bwd_partial_kernel(int c, int r, int slices, const float *__restrict__ y,
+                           const float *__restrict__ dz, const float *__restrict__ scale,
+                           const float *__restrict__ shift, const float *__restrict__ mean,
+                           const float *__restrict__ invstd, float *__restrict__ partial) {
+  __shared__ float scratch[2 * kBnThreads / kWave];
+  const int s = blockIdx.x, ch = blockIdx.y, b = blockIdx.z;
+  const int per = (r + slices - 1) / slices;
+  const int lo = s * per, hi = lo + per < r ? lo + per : r;
+  const size_t base = ((size_t)b * c + ch) * r;
+  const float sc = scale[ch], sh = shift[ch], mu = mean[ch], is = invstd[ch];
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += kBnThreads) {
+    const float yy = y[base + i];
+    const float g = (yy * sc + sh > 0.f) ? dz[base + i] : 0.f;
+    s1 += g;
+    s2 += g * ((yy - mu) * is);
+  }
+  block_sum2(s1, s2, scratch);
+  if (threadIdx.x == 0) {
+    float *out = partial + ((size_t)ch * gridDim.z * slices + (size_t)b * slices + s) * 2;
+    out[0] = s1;
+    out[1] = s2;
+  }
+}
+
+// pooled layer: the same sums from the (B,C,m) tensors (dz is non-zero only at the arg-max)
+__global__ void __launch_bounds__(kBnThreads)
+pool_bwd_partial_kernel(int c, int m, const float *__restrict__ dpooled,
+                        const float *__restrict__ ymax, const float *__restrict__ scale,
+                        const float *__restrict__ shift, const float *__restrict__ mean,
+                        const float *__restrict__ invstd, float *__restrict__ partial) {
+  __shared__ float scratch[2 * kBnThreads / kWave];
+  const int ch = blockIdx.y, b = blockIdx.z;
+  const size_t base = ((size_t)b * c + ch) * m;
+  const float sc = scale[ch], sh = shift[ch], mu = mean[ch], is = invstd[ch];
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < m; i += kBnThreads) {
+    const float yy = ymax[base + i];
+    const float g = (yy * sc + sh > 0.f) ? dpooled[base + i] : 0.f;
+    s1 += g;
+    s2 += g * ((yy - mu) * is);
+  }
+  block_sum2(s1, s2, scratch);
+  if (threadIdx.x == 0) {
+    float *out = partial + ((size_t)ch * gridDim.z + b) * 2;
+    out[0] = s1;
+    out[1] = s2;
+  }
+}
+
+// dgamma = s2, dbeta = s1, and the per-channel coefficients of dy (training mode)
+__global__ void __launch_bounds__(256)
+bn_bwd_finalize_kernel(int c, int parts, double count, int training,
+                       const float *__restrict__ partial, const float *__restrict__ gamma,
+                       const float *__restrict__ invstd, float *__restrict__ dgamma,
+                       float *__restrict__ dbeta, float *__restrict__ coef) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  double s1 = 0.0, s2 = 0.0;
+  const float *p = partial + (size_t)ch * parts * 2;
+  for (int q = 0; q < parts; ++q) { s1 += p[q * 2]; s2 += p[q * 2 + 1]; }
+  dbeta[ch] = (float)s1;
+  dgamma[ch] = (float)s2;
+  coef[ch * 3 + 0] = gamma[ch] * invstd[ch];
+  // eval mode: statistics are constants, dy = gamma*invstd*dzh
+  coef[ch * 3 + 1] = training ? (float)(s1 / count) : 0.f;
+  coef[ch * 3 + 2] = training ? (float)(s2 / count) : 0.f;
+}
+
+// dy = a * (dzh - c1 - xhat*c2)
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+bn_relu_bwd_apply_kernel(int c, int r, const float *__restrict__ y, const float *__restrict__ dz,
+                         const float *__restrict__ scale, const float *__restrict__ shift,
+                         const float *__restrict__ mean, const float *__restrict__ invstd,
+                         const float *__restrict__ coef, float *__restrict__ dy) {
+  const int ch = blockIdx.y, b = blockIdx.z;
+  const float sc = scale[ch], sh = shift[ch], mu = mean[ch], is = invstd[ch];
+  const float a = coef[ch * 3], c1 = coef[ch * 3 + 1], c2 = coef[ch * 3 + 2];
+  const size_t base = ((size_t)b * c + ch) * r;
+  if (VEC) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= r) return;
+    const float4 yy = *reinterpret_cast<const float4 *>(y + base + i);
+    const float4 g = *reinterpret_cast<const float4 *>(dz + base + i);
+    float4 o;
+    o.x = a * (((yy.x * sc + sh > 0.f) ? g.x : 0.f) - c1 - ((yy.x - mu) * is) * c2);
+    o.y = a * (((yy.y * sc + sh > 0.f) ? g.y : 0.f) - c1 - ((yy.y - mu) * is) * c2);
+    o.z = a * (((yy.z * sc + sh > 0.f) ? g.z : 0.f) - c1 - ((yy.z - mu) * is) * c2);
+    o.w = a * (((yy.w * sc + sh > 0.f) ? g.w : 0.f) - c1 - ((yy.w - mu) * is) * c2);
+    *reinterpret_cast<float4 *>(dy + base + i) = o;
+  } else {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < r) {
+      const float yy = y[base + i];
+      dy[base + i] = a * (((yy * sc + sh > 0.f) ? dz[base + i] : 0.f) - c1 - ((yy - mu) * is) * c2);
+    }
+  }
+}
+
+// pooled layer: dy[b,c,j,k] = a * ([k == argmax && relu'] * dpooled - c1 - xhat*c2)
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+pool_bwd_apply_kernel(int c, int m, int ns, const float *__restrict__ y,
+                      const float *__restrict__ dpooled, const int *__restrict__ argmax,
+                      const float *__restrict__ scale, const float *__restrict__ shift,
+                      const float *__restrict__ mean, const float *__restrict__ invstd,
+                      const float *__restrict__ coef, float *__restrict__ dy) {
+  const int ch = blockIdx.y, b = blockIdx.z;
+  const float sc = scale[ch], sh = shift[ch], mu = mean[ch], is = invstd[ch];
+  const float a = coef[ch * 3], c1 = coef[ch * 3 + 1], c2 = coef[ch * 3 + 2];
+  const int r = m * ns;
+  const size_t base = ((size_t)b * c + ch) * r;
+  const size_t pbase = ((size_t)b * c + ch) * m;
+  const int i0 = (blockIdx.x * 256 + threadIdx.x) * (VEC ? 4 : 1);
+  if (i0 >= r) return;
+  float out[4];
+#pragma unroll
+  for (int t = 0; t < (VEC ? 4 : 1); ++t) {
+    const int i = i0 + t;
+    const int row = i / ns, k = i - row * ns;
+    const float yy = y[base + i];
+    float g = 0.f;
+    if (argmax[pbase + row] == k && yy * sc + sh > 0.f) g = dpooled[pbase + row];
+    out[t] = a * (g - c1 - ((yy - mu) * is) * c2);
+  }
+  if (VEC) *reinterpret_cast<float4 *>(dy + base + i0) = make_float4(out[0], out[1], out[2], out[3]);
+  else dy[base + i0] = out[0];
+}
+
+int slices_for(int r) {
+  int s = r / 8192;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return s;
+}
+
+}  // namespace
+
+#define MLP_API extern "C" __attribute__((visibility("default")))
+
+// number of floats of scratch the statistics kernels need
+MLP_API size_t mlp_bn_workspace_floats(int b, int c, int r) {
+  return (size_t)c * b * slices_for(r) * 3;
+}
+
+// Training-mode forward statistics + coefficients.  running_* may be NULL.
+MLP_API int mlp_bn_train_stats(int b, int c, int r, const float *y, const float *gamma,
+                               const float *beta, float eps, float momentum, float *running_mean,
+                               float *running_var, float *mean, float *invstd, float *scale,
+                               float *shift, float *workspace, void *stream_) {
+  if (b <= 0 || c <= 0 || r <= 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int slices = slices_for(r);
+  hipLaunchKernelGGL(bn_partial_stats_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream, c,
+                     r, slices, y, workspace);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(pn2_ceil_div(c, 256)), dim3(256), 0, stream, c,
+                     b * slices, workspace, gamma, beta, eps, momentum, running_mean,
+                     running_var, mean, invstd, scale, shift);
+  return pn2_launch_status();
+}
+
+MLP_API int mlp_bn_eval_coeff(int c, const float *gamma, const float *beta, float eps,
+                              const float *running_mean, const float *running_var, float *mean,
+                              float *invstd, float *scale, float *shift, void *stream_) {
+  if (c <= 0) return 0;
+  hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(pn2_ceil_div(c, 256)), dim3(256), 0,
+                     (hipStream_t)stream_, c, gamma, beta, eps, running_mean, running_var, mean,
+                     invstd, scale, shift);
+  return pn2_launch_status();
+}
+
+MLP_API int mlp_bn_relu_apply(int b, int c, int r, const float *y, const float *scale,
+                              const float *shift, float *z, void *stream_) {
+  if (b <= 0 || c <= 0 || r <= 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (r % 4 == 0)
+    hipLaunchKernelGGL(bn_relu_apply_kernel<true>, dim3(pn2_ceil_div(r, 1024), c, b), dim3(256), 0,
+                       stream, c, r, y, scale, shift, z);
+  else
+    hipLaunchKernelGGL(bn_relu_apply_kernel<false>, dim3(pn2_ceil_div(r, 256), c, b), dim3(256), 0,
+                       stream, c, r, y, scale, shift, z);
+  return pn2_launch_status();
+}
+
+MLP_API int mlp_bn_relu_pool(int b, int c, int m, int ns, const float *y, const float *scale,
+                             const float *shift, float *pooled, int *argmax, float *ymax,
+                             void *stream_) {
+  if (b <= 0 || c <= 0 || m <= 0 || ns <= 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+#define POOL(LPR)                                                                              \
+  hipLaunchKernelGGL(bn_relu_pool_kernel<LPR>, dim3(pn2_ceil_div((long long)m * LPR, 256), c, b), \
+                     dim3(256), 0, stream, c, m, y, scale, shift, pooled, argmax, ymax)
+  switch (ns) {
+    case 4: POOL(1); break;
+    case 8: POOL(2); break;
+    case 16: POOL(4); break;
+    case 32: POOL(8); break;
+    case 64: POOL(16); break;
+    default:
+      hipLaunchKernelGGL(bn_relu_pool_generic_kernel, dim3(pn2_ceil_div(m, 256), c, b), dim3(256),
+                         0, stream, c, m, ns, y, scale, shift, pooled, argmax, ymax);
+  }
+#undef POOL
+  return pn2_launch_status();
+}
+
+// dz (b,c,r) -> dy (b,c,r), dgamma, dbeta.  coef: 3*c floats of scratch; workspace as above.
+MLP_API int mlp_bn_relu_backward(int b, int c, int r, int training, const float *y,
+                                 const float *dz, const float *gamma, const float *scale,
+                                 const float *shift, const float *mean, const float *invstd,
+                                 float *dy, float *dgamma, float *dbeta, float *coef,
+                                 float *workspace, void *stream_) {
+  if (b <= 0 || c <= 0 || r <= 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int slices = slices_for(r);
+  hipLaunchKernelGGL(bn_relu_bwd_partial_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream,
+                     c, r, slices, y, dz, scale, shift, mean, invstd, workspace);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn2_ceil_div(c, 256)), dim3(256), 0, stream, c,
+                     b * slices, (double)b * (double)r, training, workspace, gamma, invstd, dgamma,
+                     dbeta, coef);
+  if (r % 4 == 0)
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<true>, dim3(pn2_ceil_div(r, 1024), c, b), dim3(256),
+                       0, stream, c, r, y, dz, scale, shift, mean, invstd, coef, dy);
+  else
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<false>, dim3(pn2_ceil_div(r, 256), c, b), dim3(256),
+                       0, stream, c, r, y, dz, scale, shift, mean, invstd, coef, dy);
+  return pn2_launch_status();
+}
+
+// pooled layer backward: dpooled (b,c,m) -> dy (b,c,m,ns)
+MLP_API int mlp_bn_relu_pool_backward(int b, int c, int m, int ns, int training, const float *y,
+                                      const float *dpooled, const int *argmax, const float *ymax,
+                                      const float *gamma, const float *scale, const float *shift,
+                                      const float *mean, const float *invstd, float *dy,
+                                      float *dgamma, float *dbeta, float *coef, float *workspace,
+                                      void *stream_) {
+  if (b <= 0 || c <= 0 || m <= 0 || ns <= 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(pool_bwd_partial_kernel, dim3(1, c, b), dim3(kBnThreads), 0, stream, c, m,
+                     dpooled, ymax, scale, shift, mean, invstd, workspace);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn2_ceil_div(c, 256)), dim3(256), 0, stream, c,
+                     b, (double)b * (double)m * (double)ns, training, workspace, gamma, invstd,
+                     dgamma, dbeta, coef);
+  const long long r = (long long)m * ns;
+  if (r % 4 == 0)
+    hipLaunchKernelGGL(pool_bwd_apply_kernel<true>, dim3(pn2_ceil_div(r, 1024), c, b), dim3(256), 0,
+                       stream, c, m, ns, y, dpooled, argmax, scale, shift, mean, invstd, coef, dy);
+  else
+    hipLaunchKernelGGL(pool_bwd_apply_kernel<false>, dim3(pn2_ceil_div(r, 256), c, b), dim3(256), 0,
+                       stream, c, m, ns, y, dpooled, argmax, scale, shift, mean, invstd, coef, dy);
+  return pn2_launch_status();
+}

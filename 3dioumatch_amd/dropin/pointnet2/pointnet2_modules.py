@@ -64,7 +64,7 @@ class _PointnetSAModuleBase(nn.Module):
     def _multi_scale(self, xyz, new_xyz, features):
         outs = []
         for grouper, mlp in zip(self.groupers, self.mlps):
-            outs.append(_pool_max(mlp(grouper(xyz, new_xyz, features))))
+            outs.append(mlp.forward_pooled(grouper(xyz, new_xyz, features)))
         return torch.cat(outs, dim=1)
 
     def forward(self, xyz, features=None):
@@ -127,7 +127,7 @@ class PointnetSAModuleVotes(nn.Module):
 
     def _pool(self, feats, grouped_xyz):
         if self.pooling == 'max':
-            return _pool_max(feats)
+            return _pool_max(feats)  # (the forward below pools inside the shared MLP instead)
         if self.pooling == 'avg':
             return feats.mean(dim=3)
         if self.pooling == 'rbf':
@@ -145,7 +145,10 @@ class PointnetSAModuleVotes(nn.Module):
             new_xyz = None
         grouped = self.grouper(xyz, new_xyz, features)
         unique_cnt = grouped[2] if self.ret_unique_cnt else None
-        new_features = self._pool(self.mlp_module(grouped[0]), grouped[1])
+        if self.pooling == 'max':  # BN + ReLU + max over nsample fused into the last layer
+            new_features = self.mlp_module.forward_pooled(grouped[0])
+        else:
+            new_features = self._pool(self.mlp_module(grouped[0]), grouped[1])
         if self.ret_unique_cnt:
             return new_xyz, new_features, inds, unique_cnt
         return new_xyz, new_features, inds
@@ -167,7 +170,7 @@ class PointnetSAModuleMSGVotes(nn.Module):
             new_xyz, inds = _sample_centroids(xyz, self.npoint, inds)
         else:
             new_xyz = None
-        outs = [_pool_max(mlp(grouper(xyz, new_xyz, features)))
+        outs = [mlp.forward_pooled(grouper(xyz, new_xyz, features))
                 for grouper, mlp in zip(self.groupers, self.mlps)]
         return new_xyz, torch.cat(outs, dim=1), inds
 
@@ -211,7 +214,7 @@ class PointnetLFPModuleMSG(nn.Module):
     def forward(self, xyz2, xyz1, features2, features1):
         outs = []
         for grouper, mlp in zip(self.groupers, self.mlps):
-            feats = _pool_max(mlp(grouper(xyz1, xyz2, features1)))
+            feats = mlp.forward_pooled(grouper(xyz1, xyz2, features1))
             if features2 is not None:
                 feats = torch.cat([feats, features2], dim=1)
             outs.append(self.post_mlp(feats.unsqueeze(-1)))

@@ -6,7 +6,11 @@ pointnet2/pytorch_utils.py:14-39 (SharedMLP), :42-67 (BatchNorm wrappers), :70-1
 (_ConvBase), :127-236 (Conv1d/2d/3d), :239-270 (FC), :272-299 (BN momentum scheduler), so
 checkpoints are interchangeable.  The implementation is written fresh around one builder.
 """
+import os
+
+import torch
 import torch.nn as nn
+from torch.autograd import Function
 
 
 class _BNBase(nn.Sequential):
@@ -84,9 +88,65 @@ Conv3d = _conv_class(nn.Conv3d, BatchNorm3d, (1, 1, 1))
 Conv3d.__name__ = Conv3d.__qualname__ = "Conv3d"
 
 
+class _BNReLU(Function):
+    """z = relu(batch_norm(y)) with the fused gfx950 kernels (pointnet2._mlp_ext).  Saves y and
+    four per-channel vectors; the ReLU mask and x-hat are recomputed in the backward."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, momentum, eps, training):
+        from pointnet2 import _mlp_ext as K
+        y = y.contiguous()
+        mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, running_mean, running_var,
+                                                       momentum, eps, training)
+        ctx.save_for_backward(y, gamma, scale, shift, mean, invstd)
+        ctx.training = training
+        return K.bn_relu_apply(y, scale, shift)
+
+    @staticmethod
+    def backward(ctx, dz):
+        from pointnet2 import _mlp_ext as K
+        y, gamma, scale, shift, mean, invstd = ctx.saved_tensors
+        dy, dgamma, dbeta = K.bn_relu_backward(y, dz.contiguous(), gamma, scale, shift, mean,
+                                               invstd, ctx.training)
+        return dy, dgamma, dbeta, None, None, None, None, None
+
+
+class _BNReLUMaxPool(Function):
+    """(B,C,m,ns) -> (B,C,m): max over nsample of relu(batch_norm(y)) in one pass."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, momentum, eps, training):
+        from pointnet2 import _mlp_ext as K
+        y = y.contiguous()
+        mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, running_mean, running_var,
+                                                       momentum, eps, training)
+        pooled, argmax, ymax = K.bn_relu_pool(y, scale, shift)
+        ctx.save_for_backward(y, gamma, scale, shift, mean, invstd, argmax, ymax)
+        ctx.training = training
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        from pointnet2 import _mlp_ext as K
+        y, gamma, scale, shift, mean, invstd, argmax, ymax = ctx.saved_tensors
+        dy, dgamma, dbeta = K.bn_relu_pool_backward(y, dpooled.contiguous(), argmax, ymax, gamma,
+                                                    scale, shift, mean, invstd, ctx.training)
+        return dy, dgamma, dbeta, None, None, None, None, None
+
+
+def _fused_enabled():
+    return os.environ.get("PN2_FUSED_MLP", "1") != "0"
+
+
 class SharedMLP(nn.Sequential):
     """Stack of 1x1 Conv2d (+BN+ReLU) layers `layer0..layerK` applied to a (B, C, npoint,
-    nsample) tensor: the grouped shared MLP of a set-abstraction layer."""
+    nsample) tensor: the grouped shared MLP of a set-abstraction layer.
+
+    Same module tree as the reference (pytorch_utils.py:14-39).  On the GPU, layers of the
+    standard shape conv(1x1, no bias) -> BatchNorm2d -> ReLU run their BatchNorm/ReLU (and, via
+    forward_pooled, the max-pool over nsample that follows the last layer in every SA module)
+    through the fused kernels of pointnet2._mlp_ext; any other configuration, and CPU tensors,
+    use the plain torch modules."""
 
     def __init__(self, args, *, bn=False, activation=nn.ReLU(inplace=True), preact=False,
                  first=False, name=""):
@@ -97,6 +157,47 @@ class SharedMLP(nn.Sequential):
                 name + "layer{}".format(i),
                 Conv2d(args[i], args[i + 1], bn=bn and not plain,
                        activation=None if plain else activation, preact=preact))
+
+    @staticmethod
+    def _fusable(layer):
+        kids = dict(layer.named_children())
+        if set(kids) != {"conv", "bn", "activation"} or list(kids)[0] != "conv":
+            return False
+        conv, bn_wrap, act = kids["conv"], kids["bn"], kids["activation"]
+        bns = list(bn_wrap.children())
+        return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.bias is None
+                and conv.stride == (1, 1) and conv.padding == (0, 0) and len(bns) == 1
+                and isinstance(bns[0], nn.BatchNorm2d) and bns[0].affine
+                and bns[0].track_running_stats and bns[0].momentum is not None
+                and isinstance(act, nn.ReLU))
+
+    def _use_fused(self, x):
+        return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and len(self) > 0
+                and _fused_enabled() and all(self._fusable(layer) for layer in self))
+
+    def _run(self, x, pool):
+        layers = list(self)
+        for i, layer in enumerate(layers):
+            bn = next(layer.bn.children())
+            y = layer.conv(x)
+            training = bn.training
+            if training:
+                bn.num_batches_tracked.add_(1)
+            op = _BNReLUMaxPool if (pool and i == len(layers) - 1) else _BNReLU
+            x = op.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum,
+                         bn.eps, training)
+        return x
+
+    def forward(self, x):
+        if self._use_fused(x):
+            return self._run(x, pool=False)
+        return super().forward(x)
+
+    def forward_pooled(self, x):
+        """max over the last axis of forward(x): (B, C, npoint, nsample) -> (B, C', npoint)."""
+        if self._use_fused(x):
+            return self._run(x, pool=True)
+        return torch.max(super().forward(x), dim=3)[0]
 
 
 class FC(nn.Sequential):

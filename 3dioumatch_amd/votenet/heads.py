@@ -181,8 +181,7 @@ class GridConv(nn.Module):
         interp = pointnet2_utils.three_interpolate(origin_features, idx, weight)  # (B, C, K*64)
         feats = torch.cat([relative.transpose(1, 2).reshape(b, 3, k, g3),
                            interp.view(b, -1, k, g3)], dim=1)
-        feats = self.mlp_before_iou(feats)
-        iou_features = torch.max(feats, dim=3)[0]
+        iou_features = self.mlp_before_iou.forward_pooled(feats)
         net = F.relu(self.bn1_iou(self.conv1_iou(iou_features)))
         net = F.relu(self.bn2_iou(self.conv2_iou(net)))
         net = self.conv3_iou(net)

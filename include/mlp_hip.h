@@ -1,0 +1,74 @@
+/*
+ * include/mlp_hip.h -- C ABI of the fused BatchNorm(+ReLU)(+max-pool) kernels of the grouped
+ * shared MLP (MI355X / gfx950).
+ *
+ * The reference has no native code for this part of the hot path: it stacks
+ * nn.Conv2d(1x1) + nn.BatchNorm2d + nn.ReLU (pointnet2/pytorch_utils.py:14-39,70-124) and pools
+ * with F.max_pool2d (pointnet2/pointnet2_modules.py:256-262), i.e. cuDNN/ATen kernels.  These
+ * entry points replace the BatchNorm2d / ReLU / max_pool2d launches of one layer (forward and
+ * backward); the 1x1 convolution stays a GEMM.
+ *
+ * Tensors are (B, C, R) float32, contiguous, R = npoint*nsample; per-channel vectors have C
+ * entries; pointers are DEVICE pointers; every call returns a hipError_t (0 = success) and runs
+ * on the given hipStream_t (void*).  `workspace` holds mlp_bn_workspace_floats(b,c,r) floats.
+ */
+#ifndef MLP_HIP_H
+#define MLP_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* scratch (in floats) for the statistics passes below; replaces cuDNN's internal workspace of
+ * nn.BatchNorm2d (pytorch_utils.py:42-67) */
+size_t mlp_bn_workspace_floats(int b, int c, int r);
+
+/* replaces the statistics half of nn.BatchNorm2d in training mode (pytorch_utils.py:53-57 via
+ * torch.nn.functional.batch_norm): batch mean / biased variance per channel (Welford-quality:
+ * shifted partial sums combined with Chan's formula in double), running_mean / running_var
+ * update with `momentum` (unbiased variance, as torch), and the affine coefficients
+ * scale = gamma*invstd, shift = beta - mean*scale.  running_* may be NULL. */
+int mlp_bn_train_stats(int b, int c, int r, const float *y, const float *gamma, const float *beta,
+                       float eps, float momentum, float *running_mean, float *running_var,
+                       float *mean, float *invstd, float *scale, float *shift, float *workspace,
+                       void *stream);
+
+/* eval-mode coefficients from the running statistics (nn.BatchNorm2d.eval(), pytorch_utils.py:53-57) */
+int mlp_bn_eval_coeff(int c, const float *gamma, const float *beta, float eps,
+                      const float *running_mean, const float *running_var, float *mean,
+                      float *invstd, float *scale, float *shift, void *stream);
+
+/* replaces the normalisation half of nn.BatchNorm2d followed by nn.ReLU (pytorch_utils.py:108-124):
+ * z = max(y*scale + shift, 0) */
+int mlp_bn_relu_apply(int b, int c, int r, const float *y, const float *scale, const float *shift,
+                      float *z, void *stream);
+
+/* replaces BatchNorm2d + ReLU + F.max_pool2d(kernel=[1,nsample]) of the LAST shared-MLP layer
+ * (pointnet2_modules.py:256-262): y (b,c,m,ns) -> pooled (b,c,m), plus the arg-max sample and
+ * the pre-activation that attained it (kept for the backward pass). */
+int mlp_bn_relu_pool(int b, int c, int m, int ns, const float *y, const float *scale,
+                     const float *shift, float *pooled, int *argmax, float *ymax, void *stream);
+
+/* replaces the autograd backward of ReLU + BatchNorm2d (pytorch_utils.py:108-124): given dz,
+ * returns dy (to be fed to the convolution backward), dgamma, dbeta.  The ReLU mask and the
+ * normalised activation are recomputed from y.  training != 0: batch statistics take part in
+ * the gradient; training == 0: statistics are constants.  coef: 3*c floats of scratch. */
+int mlp_bn_relu_backward(int b, int c, int r, int training, const float *y, const float *dz,
+                         const float *gamma, const float *scale, const float *shift,
+                         const float *mean, const float *invstd, float *dy, float *dgamma,
+                         float *dbeta, float *coef, float *workspace, void *stream);
+
+/* replaces the autograd backward of max_pool2d + ReLU + BatchNorm2d of the last layer
+ * (pointnet2_modules.py:256-262): dpooled (b,c,m) -> dy (b,c,m,ns), dgamma, dbeta. */
+int mlp_bn_relu_pool_backward(int b, int c, int m, int ns, int training, const float *y,
+                              const float *dpooled, const int *argmax, const float *ymax,
+                              const float *gamma, const float *scale, const float *shift,
+                              const float *mean, const float *invstd, float *dy, float *dgamma,
+                              float *dbeta, float *coef, float *workspace, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLP_HIP_H */
