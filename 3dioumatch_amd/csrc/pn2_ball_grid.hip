@@ -10,8 +10,9 @@
 //   build  : every point goes into a cell of side 1.001*r of a 32^3 PERIODIC lattice
 //            (cell = floor(p / side) mod 32 per axis -- no bounding box pass, far-apart cells
 //            may alias, which only adds candidates that the exact distance test rejects).
-//            Cells are fixed-capacity slot arrays of (x, y, z, index) filled through one
-//            returning atomic per point; an overflowing cell flags the cloud.
+//            Cells are fixed-capacity slot arrays of (x, y, z, index); each workgroup owns a
+//            slab of z-layers and ranks its points with LDS atomics (no global atomics, no
+//            counter memset); an overflowing cell flags the cloud.
 //   query  : one wavefront per centroid.  Lanes 0..26 fetch the 27 neighbour cell counts;
 //            the nine x-rows of three cells are streamed 64 candidates at a time (all loads
 //            issued before the first use), hits are compacted into an LDS list by ballot
@@ -42,7 +43,7 @@ struct GridWs {
 };
 
 __host__ __device__ inline size_t grid_cnt_bytes(int b) {
-  return sizeof(int) * ((size_t)b * kCellsPerCloud + (size_t)((b + 63) / 64) * 64);
+  return sizeof(int) * ((size_t)b * kCellsPerCloud + (size_t)((b * 16 + 63) / 64) * 64);
 }
 
 __device__ __forceinline__ int cell_coord(float v, float inv_side) {
@@ -53,22 +54,58 @@ __device__ __forceinline__ int cell_index(int cx, int cy, int cz) {
   return ((cz & (kG - 1)) * kG + (cy & (kG - 1))) * kG + (cx & (kG - 1));
 }
 
-__global__ void __launch_bounds__(256)
+// Build without global atomics and without a memset: the lattice is cut into kSlabs slabs of
+// kLayers z-layers; workgroup (slab, cloud) scans the WHOLE cloud (480 KB from L2, coalesced),
+// keeps the points whose z-layer falls in its slab, ranks them with LDS atomics (its
+// kLayers*1024 counters live in LDS) and writes their slots; finally it writes every counter of
+// its slab, so all 32768 counters of the cloud are (re)written on every call.
+// (Returning device-scope atomics execute at the memory side on this multi-XCD part:
+// one per point cost 20 us for 320 000 points; this formulation costs a few us.)
+constexpr int kSlabs = 16;                     // (grid_cnt_bytes reserves 16 flags per cloud)
+constexpr int kLayers = kG / kSlabs;           // 2 z-layers per slab
+constexpr int kSlabCells = kLayers * kG * kG;  // 2048 cells
+constexpr int kBuildThreads = 1024;
+
+__global__ void __launch_bounds__(kBuildThreads)
 grid_build_kernel(int n, float inv_side, const float *__restrict__ xyz, int *__restrict__ cnt,
                   int *__restrict__ flags, float4 *__restrict__ slots) {
-  const int b = blockIdx.y;
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= n) return;
-  const float *p = xyz + ((size_t)b * n + k) * 3;
-  const float x = p[0], y = p[1], z = p[2];
-  const int c = cell_index(cell_coord(x, inv_side), cell_coord(y, inv_side),
-                           cell_coord(z, inv_side));
-  const size_t cell = (size_t)b * kCellsPerCloud + c;
-  const int slot = atomicAdd(cnt + cell, 1);
-  if (slot < kCap)
-    slots[cell * kCap + slot] = make_float4(x, y, z, __builtin_bit_cast(float, k));
-  else
-    flags[b] = 1;
+  __shared__ int lcnt[kSlabCells];
+  const int slab = blockIdx.x, b = blockIdx.y;
+  for (int t = threadIdx.x; t < kSlabCells; t += kBuildThreads) lcnt[t] = 0;
+  __syncthreads();
+  const float *pts = xyz + (size_t)b * n * 3;
+  const size_t cell0 = (size_t)b * kCellsPerCloud + (size_t)slab * kSlabCells;
+  bool overflow = false;
+  constexpr int kUnroll = 8;  // z of 8 points in flight per lane before the first use
+  for (int k0 = threadIdx.x; k0 < n; k0 += kBuildThreads * kUnroll) {
+    float zs[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int k = k0 + u * kBuildThreads;
+      zs[u] = k < n ? pts[k * 3 + 2] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int k = k0 + u * kBuildThreads;
+      const int cz = cell_coord(zs[u], inv_side) & (kG - 1);
+      if (k < n && cz / kLayers == slab) {
+        const float x = pts[k * 3 + 0], y = pts[k * 3 + 1];
+        const int local = ((cz % kLayers) * kG + (cell_coord(y, inv_side) & (kG - 1))) * kG +
+                          (cell_coord(x, inv_side) & (kG - 1));
+        const int slot = atomicAdd(&lcnt[local], 1);
+        if (slot < kCap)
+          slots[(cell0 + local) * kCap + slot] =
+              make_float4(x, y, zs[u], __builtin_bit_cast(float, k));
+        else
+          overflow = true;
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < kSlabCells; t += kBuildThreads) cnt[cell0 + t] = lcnt[t];
+  // one flag per (cloud, slab), always written: no clearing pass is needed
+  const int any = __syncthreads_or(overflow ? 1 : 0);
+  if (threadIdx.x == 0) flags[b * kSlabs + slab] = any;
 }
 
 // ---- 64-lane bitonic network on unsigned keys, entirely in registers ---------------------
@@ -140,7 +177,8 @@ grid_query_kernel(int n, int m, float radius2, float inv_side, int nsample,
   const float *pts = xyz + (size_t)b * n * 3;
   const float *ctr = new_xyz + ((size_t)b * m + j) * 3;
   int *row = idx + ((size_t)b * m + j) * nsample;
-  if (flags[b] != 0) {  // a cell of this cloud overflowed: exact brute-force scan instead
+  const bool flagged = __ballot(lane < kSlabs && flags[b * kSlabs + lane] != 0) != 0ull;
+  if (flagged) {  // a cell of this cloud overflowed: exact brute-force scan instead
     ball_query_wave_scan<1>(pts, n, ctr, 1, radius2, nsample, row);
     return;
   }
@@ -240,10 +278,8 @@ int pn2_ball_query_grid_try(int b, int n, int m, float radius, int nsample, cons
   int *cnt = reinterpret_cast<int *>(ws);
   int *flags = cnt + (size_t)b * kCellsPerCloud;
   float4 *slots = reinterpret_cast<float4 *>(ws + grid_cnt_bytes(b));
-  hipError_t e = hipMemsetAsync(cnt, 0, grid_cnt_bytes(b), stream);
-  if (e != hipSuccess) return (int)e;
   const float inv_side = 1.0f / (radius * 1.001f);
-  hipLaunchKernelGGL(grid_build_kernel, dim3(pn2_ceil_div(n, 256), b), dim3(256), 0, stream, n,
+  hipLaunchKernelGGL(grid_build_kernel, dim3(kSlabs, b), dim3(kBuildThreads), 0, stream, n,
                      inv_side, xyz, cnt, flags, slots);
   const float radius2 = radius * radius;  // fp32 product, as ball_query_gpu.cu:27
   hipLaunchKernelGGL(grid_query_kernel, dim3(pn2_ceil_div(m, 256 / kWave), b), dim3(256), 0,

@@ -60,14 +60,30 @@ def build_step(V, cfg, device, world, local_rank):
 
 
 def time_op(fn, iters=20, warm=3):
+    """Average device time of fn() in us.  The calls are captured into one HIP graph and the
+    replay is timed with events on the launch stream, so host launch overhead (ctypes + torch
+    allocations, ~10-20 us per call) does not leak into kernels that only run for a few us;
+    dependent kernel boundaries inside the op are of course included."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
-        fn()
-    e.record()
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(iters):
+                fn()
+        graph.replay()
+        torch.cuda.synchronize()
+        s.record()
+        graph.replay()
+        e.record()
+    except Exception:  # capture not possible: time the eager loop instead
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
     torch.cuda.synchronize()
     return s.elapsed_time(e) * 1e3 / iters  # us
 
