@@ -39,6 +39,14 @@ _SIGNATURES = {
                              _vp, _vp, _vp, _vp, _vp],
     "mlp_bn_relu_pool_backward": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mlp_bn_relu_backward_stats": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _vp, _vp, _vp, _vp, _vp, _vp],
+    "mlp_gemm_forward": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp, _vp, _vp],
+    "mlp_gemm_dgrad": [_c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp,
+                       _vp, _vp, _vp, _vp],
+    "mlp_gemm_wgrad": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                       _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mlp_gemm_wgrad_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
     "iou3d_boxes_overlap_bev": [_c_int, _vp, _c_int, _vp, _vp, _vp],
     "iou3d_boxes_iou_bev": [_c_int, _vp, _c_int, _vp, _vp, _vp],
     "iou3d_boxes_iou3d": [_c_int, _vp, _c_int, _vp, _vp, _vp],
@@ -47,7 +55,7 @@ _SIGNATURES = {
     "iou3d_nms": [_vp, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp],
     "iou3d_boxes_iou_bev_cpu": [_c_int, _vp, _c_int, _vp, _vp],
 }
-_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_fps_workspace_bytes": _sz, "mlp_bn_workspace_floats": _sz, "pn2_error_string": ctypes.c_char_p}
+_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_fps_workspace_bytes": _sz, "mlp_bn_workspace_floats": _sz, "mlp_gemm_wgrad_workspace_floats": _sz, "pn2_error_string": ctypes.c_char_p}
 
 EXPORTS = tuple(_SIGNATURES)
 

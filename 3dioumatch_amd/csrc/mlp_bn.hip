@@ -434,6 +434,23 @@ MLP_API int mlp_bn_relu_backward(int b, int c, int r, int training, const float 
   return pn2_launch_status();
 }
 
+// sums + coefficients only (the dy tensor is formed inside the GEMM operand loads instead)
+MLP_API int mlp_bn_relu_backward_stats(int b, int c, int r, int training, const float *y,
+                                       const float *dz, const float *gamma, const float *scale,
+                                       const float *shift, const float *mean, const float *invstd,
+                                       float *dgamma, float *dbeta, float *coef, float *workspace,
+                                       void *stream_) {
+  if (b <= 0 || c <= 0 || r <= 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int slices = slices_for(r);
+  hipLaunchKernelGGL(bn_relu_bwd_partial_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream,
+                     c, r, slices, y, dz, scale, shift, mean, invstd, workspace);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn2_ceil_div(c, 256)), dim3(256), 0, stream, c,
+                     b * slices, (double)b * (double)r, training, workspace, gamma, invstd, dgamma,
+                     dbeta, coef);
+  return pn2_launch_status();
+}
+
 // pooled layer backward: dpooled (b,c,m) -> dy (b,c,m,ns)
 MLP_API int mlp_bn_relu_pool_backward(int b, int c, int m, int ns, int training, const float *y,
                                       const float *dpooled, const int *argmax, const float *ymax,

@@ -1,0 +1,369 @@
+// 3dioumatch_amd/csrc/mlp_gemm.hip -- the grouped shared-MLP contraction on the matrix cores
+// (gfx950, v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation), with the BatchNorm /
+// ReLU algebra folded into the operand loads.
+//
+// What it replaces: nn.Conv2d(1x1) of a shared-MLP layer (pointnet2/pytorch_utils.py:70-124)
+// and its autograd backward, i.e. for activations X (B, K, R) and a weight W (M, K):
+//     forward : Y[b]  = W * X[b]                                   (M x R)
+//     dgrad   : dX[b] = W^T * dY[b]                                (K x R)
+//     wgrad   : dW    = sum_b dY[b] * X[b]^T                       (M x K)
+// R = npoint*nsample is the contiguous axis of every tensor, so all three are "R-contiguous"
+// GEMMs.  The twist is in what the operands ARE.  A layer's input is relu(bn(Y_prev)) and the
+// gradient that enters its convolution is the BatchNorm/ReLU backward of dZ; instead of
+// materialising those tensors (one write + one read of a GB-scale activation each), the
+// operand tiles are transformed on their way from HBM into LDS:
+//     OP_DIRECT  : x
+//     OP_BNRELU  : max(x*scale[k] + shift[k], 0)                    (input of the next layer)
+//     OP_DY      : a[k]*(([y*sc+sh > 0] ? dz : 0) - c1[k] - ((y-mu[k])*is[k])*c2[k])
+//                  from the pair (y, dz)                            (BN+ReLU backward)
+//
+// Kernel shape: 256 lanes = 4 waves; a workgroup owns TM x TN of the output for one cloud;
+// K is walked in chunks of 16 through LDS ([k][m] and [k][n], both unit-stride for the MFMA
+// fragment reads); each wave accumulates (TM/WM) x (TN/WN) in 32x32 MFMA blocks.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KC = 16;  // K chunk staged in LDS
+
+enum OperandMode { OP_DIRECT = 0, OP_BNRELU = 1, OP_DY = 2 };
+
+struct OperandB {
+  const float *x;        // OP_DIRECT / OP_BNRELU: the tensor; OP_DY: y
+  const float *dz;       // OP_DY only
+  const float *scale;    // per row k
+  const float *shift;
+  const float *mean;     // OP_DY
+  const float *invstd;   // OP_DY
+  const float *coef;     // OP_DY: [k][3] = a, c1, c2
+};
+
+// Per-row constants of an operand (loaded once per row, kept in registers)
+struct RowCoef { float sc, sh, mu, is, a, c1, c2; };
+
+template <int MODE>
+__device__ __forceinline__ RowCoef load_row_coef(const OperandB &op, int k, bool valid) {
+  RowCoef c = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (MODE == OP_DIRECT || !valid) return c;
+  c.sc = op.scale[k]; c.sh = op.shift[k];
+  if (MODE == OP_DY) {
+    c.mu = op.mean[k]; c.is = op.invstd[k];
+    c.a = op.coef[k * 3]; c.c1 = op.coef[k * 3 + 1]; c.c2 = op.coef[k * 3 + 2];
+  }
+  return c;
+}
+
+template <int MODE>
+__device__ __forceinline__ float transform(float x, float dz, const RowCoef &c) {
+  if (MODE == OP_DIRECT) return x;
+  if (MODE == OP_BNRELU) return fmaxf(x * c.sc + c.sh, 0.f);
+  const float g = (x * c.sc + c.sh > 0.f) ? dz : 0.f;
+  return c.a * (g - c.c1 - ((x - c.mu) * c.is) * c.c2);
+}
+
+// N consecutive elements of one operand row starting at element offset `off` (column gr of
+// r): 16-byte loads when the row length allows, scalars (with tail guard) otherwise
+template <int MODE, int N>
+__device__ __forceinline__ void load_row_segment(const OperandB &op, size_t off, int gr, int r,
+                                                 bool vec_ok, bool row_ok, const RowCoef &c,
+                                                 float *out) {
+  float x[N], dz[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { x[i] = 0.f; dz[i] = 0.f; }
+  if (row_ok) {
+    if (vec_ok) {  // row stride and limit are multiples of 4; gr is one by construction
+#pragma unroll
+      for (int i = 0; i < N; i += 4) {
+        if (gr + i < r) {
+          const float4 v = *reinterpret_cast<const float4 *>(op.x + off + i);
+          x[i] = v.x; x[i + 1] = v.y; x[i + 2] = v.z; x[i + 3] = v.w;
+          if (MODE == OP_DY) {
+            const float4 d = *reinterpret_cast<const float4 *>(op.dz + off + i);
+            dz[i] = d.x; dz[i + 1] = d.y; dz[i + 2] = d.z; dz[i + 3] = d.w;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        if (gr + i < r) {
+          x[i] = op.x[off + i];
+          if (MODE == OP_DY) dz[i] = op.dz[off + i];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    out[i] = (row_ok && gr + i < r) ? transform<MODE>(x[i], dz[i], c) : 0.f;
+}
+
+// C[b] (M x R, ldc = R) = A (M x K, row-major, lda) * op(B[b]) (K x R)
+template <int TM, int TN, int WM, int WN, int MODE>
+__global__ void __launch_bounds__(256)
+gemm_nn_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int lda, OperandB opb,
+               float *__restrict__ c, size_t b_stride_in, size_t b_stride_out) {
+  constexpr int MB = TM / WM / 32, NB = TN / WN / 32;
+  constexpr int LDA = TM + 1;  // [k][m], padded: conflict-free transposing stores
+  __shared__ float As[KC * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[KC * TN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r0 = blockIdx.x * TN, m0 = blockIdx.y * TM, b = blockIdx.z;
+  OperandB op = opb;
+  const size_t in_off = (size_t)b * b_stride_in;
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  for (int k0 = 0; k0 < k_total; k0 += KC) {
+    __syncthreads();
+    // A chunk: TM x KC, consecutive lanes along k (contiguous in memory)
+    for (int t = tid; t < TM * KC; t += 256) {
+      const int kk = t % KC, mm = t / KC;
+      const int gm = m0 + mm, gk = k0 + kk;
+      As[kk * LDA + mm] = (gm < m_total && gk < k_total) ? a[(size_t)gm * lda + gk] : 0.f;
+    }
+    // B chunk: KC x TN; a lane owns TN/16 consecutive columns of ONE row (row constants in
+    // registers, 16-byte loads and LDS stores)
+    {
+      constexpr int SEG = TN / 16;
+      const int kk = tid >> 4, nn = (tid & 15) * SEG;
+      const int gk = k0 + kk, gr = r0 + nn;
+      const bool row_ok = gk < k_total;
+      const RowCoef rc = load_row_coef<MODE>(op, gk, row_ok);
+      float v[SEG];
+      load_row_segment<MODE, SEG>(op, in_off + (size_t)gk * r + gr, gr, r, (r & 3) == 0, row_ok,
+                                  rc, v);
+#pragma unroll
+      for (int i = 0; i < SEG; i += 4)
+        *reinterpret_cast<float4 *>(&Bs[kk * TN + nn + i]) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 2) {
+      const int krow = kk + (lane >> 5);
+      float af[MB], bf[NB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) af[i] = As[krow * LDA + (wm * MB + i) * 32 + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bf[j] = Bs[krow * TN + (wn * NB + j) * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // C/D layout of the 32x32 block: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
+  float *cb = c + (size_t)b * b_stride_out;
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int col = r0 + (wn * NB + j) * 32 + (lane & 31);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = m0 + (wm * MB + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (row < m_total && col < r) cb[(size_t)row * r + col] = acc[i][j][q];
+      }
+    }
+}
+
+// Partial wgrad: for one cloud b and one slice of R,
+//   part[slice][m][k] = sum_{r in slice} P[b][m][r] * Q[b][k][r]
+// P = op_p (mode PMODE, rows m), Q = op_q (mode QMODE, rows k).  Tile 128(m) x 64(k) per
+// workgroup, waves 2x2, each 64x32; the R axis is staged [r][m] / [r][k] in LDS.
+constexpr int RC = 32;  // r chunk (128-byte row segments per load)
+
+template <int PMODE, int QMODE>
+__global__ void __launch_bounds__(256)
+gemm_wgrad_kernel(int m_total, int k_total, int r, int r_per_slice, OperandB opp, OperandB opq,
+                  float *__restrict__ part, size_t p_stride, size_t q_stride) {
+  constexpr int TM = 128, TK = 64;
+  constexpr int LDP = TM + 1, LDQ = TK + 1;
+  __shared__ float Ps[RC * LDP];
+  __shared__ float Qs[RC * LDQ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wk = wave & 1;
+  const int k0 = blockIdx.x * TK, m0 = blockIdx.y * TM;
+  const int slices = (r + r_per_slice - 1) / r_per_slice;
+  const int b = blockIdx.z / slices, slice = blockIdx.z % slices;
+  const int r_lo = slice * r_per_slice;
+  const int r_hi = r_lo + r_per_slice < r ? r_lo + r_per_slice : r;
+  OperandB P = opp, Q = opq;
+  const size_t p_off = (size_t)b * p_stride, q_off = (size_t)b * q_stride;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+
+  // fixed ownership: lane t loads row (t/2) of P, 16 consecutive r; row (t/4) of Q, 8
+  // consecutive r -- so the per-row constants live in registers for the whole kernel
+  const int pm = tid >> 1, pr = (tid & 1) * 16;
+  const int qk = tid >> 2, qr = (tid & 3) * 8;
+  const bool p_ok = m0 + pm < m_total, q_ok = k0 + qk < k_total;
+  const RowCoef pc = load_row_coef<PMODE>(P, m0 + pm, p_ok);
+  const RowCoef qc = load_row_coef<QMODE>(Q, k0 + qk, q_ok);
+  const size_t p_row = p_off + (size_t)(m0 + pm) * r, q_row = q_off + (size_t)(k0 + qk) * r;
+  for (int rr = r_lo; rr < r_hi; rr += RC) {
+    float pv[16], qv[8];
+    const bool vec_ok = ((r | r_hi) & 3) == 0;
+    load_row_segment<PMODE, 16>(P, p_row + rr + pr, rr + pr, r_hi, vec_ok, p_ok, pc, pv);
+    load_row_segment<QMODE, 8>(Q, q_row + rr + qr, rr + qr, r_hi, vec_ok, q_ok, qc, qv);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Ps[(pr + i) * LDP + pm] = pv[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) Qs[(qr + i) * LDQ + qk] = qv[i];
+    __syncthreads();
+#pragma unroll
+    for (int ri = 0; ri < RC; ri += 2) {
+      const int row = ri + (lane >> 5);
+      const float bq = Qs[row * LDQ + wk * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float ap = Ps[row * LDP + (wm * 2 + i) * 32 + (lane & 31)];
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap, bq, acc[i], 0, 0, 0);
+      }
+    }
+  }
+  float *out = part + (size_t)blockIdx.z * m_total * k_total;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int col = k0 + wk * 32 + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = m0 + (wm * 2 + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+      if (row < m_total && col < k_total) out[(size_t)row * k_total + col] = acc[i][q];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+reduce_partials_kernel(int count, int parts, const float *__restrict__ part,
+                       float *__restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four loads in flight per lane
+  int p = 0;
+  for (; p + 3 < parts; p += 4) {
+    s0 += part[(size_t)p * count + i];
+    s1 += part[(size_t)(p + 1) * count + i];
+    s2 += part[(size_t)(p + 2) * count + i];
+    s3 += part[(size_t)(p + 3) * count + i];
+  }
+  for (; p < parts; ++p) s0 += part[(size_t)p * count + i];
+  out[i] = (s0 + s1) + (s2 + s3);
+}
+
+template <int MODE>
+int launch_nn(int b, int m, int k, int r, const float *a, int lda, const OperandB &op, float *c,
+              size_t in_stride, size_t out_stride, hipStream_t stream) {
+  // rows are covered by 256-row tiles, then one smaller tile for the remainder
+  int done = 0;
+  while (done < m) {
+    const int left = m - done;
+    const float *a_t = a + (size_t)done * lda;
+    float *c_t = c + (size_t)done * r;
+#define NN(TM, TN, WM, WN)                                                                      \
+  hipLaunchKernelGGL((gemm_nn_kernel<TM, TN, WM, WN, MODE>),                                    \
+                     dim3(pn2_ceil_div(r, TN), 1, b), dim3(256), 0, stream, rows, k, r, a_t, lda, \
+                     op, c_t, in_stride, out_stride)
+    int rows;
+    if (left >= 256) { rows = 256; NN(256, 64, 4, 1); }
+    else if (left > 64) { rows = left < 128 ? left : 128; NN(128, 128, 2, 2); }
+    else if (left > 32) { rows = left; NN(64, 128, 2, 2); }
+    else { rows = left; NN(32, 256, 1, 4); }
+#undef NN
+    done += rows;
+  }
+  return pn2_launch_status();
+}
+
+}  // namespace
+
+#define MLP_API extern "C" __attribute__((visibility("default")))
+
+// mode: 0 = X given directly, 1 = X = relu(bn(Yprev)) via (scale, shift)
+MLP_API int mlp_gemm_forward(int b, int m, int k, int r, const float *w, const float *x, int mode,
+                             const float *scale, const float *shift, float *y, void *stream_) {
+  if (b <= 0 || m <= 0 || k <= 0 || r <= 0) return 0;
+  OperandB op = {x, nullptr, scale, shift, nullptr, nullptr, nullptr};
+  const size_t in_stride = (size_t)k * r, out_stride = (size_t)m * r;
+  if (mode == OP_DIRECT)
+    return launch_nn<OP_DIRECT>(b, m, k, r, w, k, op, y, in_stride, out_stride, (hipStream_t)stream_);
+  return launch_nn<OP_BNRELU>(b, m, k, r, w, k, op, y, in_stride, out_stride, (hipStream_t)stream_);
+}
+
+// dX (b,k,r) = W^T (k x m, given as wt row-major) * dY, with dY either given (mode 0: dy) or
+// formed on the fly from (y, dz) and the per-channel vectors of the BN+ReLU backward (mode 2)
+MLP_API int mlp_gemm_dgrad(int b, int m, int k, int r, const float *wt, int mode, const float *dy,
+                           const float *y, const float *dz, const float *scale,
+                           const float *shift, const float *mean, const float *invstd,
+                           const float *coef, float *dx, void *stream_) {
+  if (b <= 0 || m <= 0 || k <= 0 || r <= 0) return 0;
+  const size_t in_stride = (size_t)m * r, out_stride = (size_t)k * r;
+  if (mode == OP_DIRECT) {
+    OperandB op = {dy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return launch_nn<OP_DIRECT>(b, k, m, r, wt, m, op, dx, in_stride, out_stride, (hipStream_t)stream_);
+  }
+  OperandB op = {y, dz, scale, shift, mean, invstd, coef};
+  return launch_nn<OP_DY>(b, k, m, r, wt, m, op, dx, in_stride, out_stride, (hipStream_t)stream_);
+}
+
+// R is cut into slices so that about 512 workgroups are in flight (tiles x clouds x slices);
+// every slice writes its own partial dW, reduced afterwards (deterministic, no atomics).
+static int wgrad_r_per_slice(int b, int m, int k, int r) {
+  const long long tiles = (long long)pn2_ceil_div(k, 64) * pn2_ceil_div(m, 128) * b;
+  long long slices = (512 + tiles - 1) / tiles;
+  if (slices < 1) slices = 1;
+  long long per = (r + slices - 1) / slices;
+  per = (per + RC - 1) / RC * RC;
+  if (per < 256) per = 256;
+  return (int)per;
+}
+
+MLP_API size_t mlp_gemm_wgrad_workspace_floats(int b, int m, int k, int r) {
+  const int per = wgrad_r_per_slice(b, m, k, r);
+  const int slices = (r + per - 1) / per;
+  return (size_t)b * slices * m * k;
+}
+
+// dW (m x k) = sum_b dY[b] * X[b]^T; dY given (pmode 0) or on the fly (pmode 2, from y/dz);
+// X given (qmode 0) or relu(bn(Yprev)) (qmode 1, via xscale/xshift).
+MLP_API int mlp_gemm_wgrad(int b, int m, int k, int r, int pmode, const float *dy, const float *y,
+                           const float *dz, const float *scale, const float *shift,
+                           const float *mean, const float *invstd, const float *coef, int qmode,
+                           const float *x, const float *xscale, const float *xshift, float *dw,
+                           float *workspace, void *stream_) {
+  if (b <= 0 || m <= 0 || k <= 0 || r <= 0) return 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int per = wgrad_r_per_slice(b, m, k, r);
+  const int slices = (r + per - 1) / per;
+  OperandB P = pmode == OP_DIRECT ? OperandB{dy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
+                                  : OperandB{y, dz, scale, shift, mean, invstd, coef};
+  OperandB Q = {x, nullptr, xscale, xshift, nullptr, nullptr, nullptr};
+  dim3 grid(pn2_ceil_div(k, 64), pn2_ceil_div(m, 128), b * slices);
+  const size_t ps = (size_t)m * r, qs = (size_t)k * r;
+#define WG(PM, QM)                                                                            \
+  hipLaunchKernelGGL((gemm_wgrad_kernel<PM, QM>), grid, dim3(256), 0, stream, m, k, r, per, P, Q, \
+                     workspace, ps, qs)
+  if (pmode == OP_DIRECT && qmode == OP_DIRECT) WG(OP_DIRECT, OP_DIRECT);
+  else if (pmode == OP_DIRECT) WG(OP_DIRECT, OP_BNRELU);
+  else if (qmode == OP_DIRECT) WG(OP_DY, OP_DIRECT);
+  else WG(OP_DY, OP_BNRELU);
+#undef WG
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(pn2_ceil_div((long long)m * k, 256)), dim3(256),
+                     0, stream, m * k, b * slices, workspace, dw);
+  return pn2_launch_status();
+}

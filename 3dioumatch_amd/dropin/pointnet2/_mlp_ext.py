@@ -101,3 +101,91 @@ def bn_relu_pool_backward(y, dpooled, argmax, ymax, gamma, scale, shift, mean, i
                                                 small[2:].data_ptr(), ws.data_ptr(), _stream(y)),
                  "mlp_bn_relu_pool_backward")
     return dy, small[0], small[1]
+
+
+# ---- the 1x1 convolution on the matrix cores (include/mlp_hip.h: mlp_gemm_*) -------------------
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def gemm_forward(w, x, coeff=None):
+    """y (B,M,R) = w (M,K) @ x (B,K,R); with coeff=(scale, shift) the operand is
+    relu(x*scale[k] + shift[k]) formed on the fly (x is then the previous layer's conv output)."""
+    _f32c(x, "x"); _f32c(w, "w")
+    b, k = x.shape[0], x.shape[1]
+    r = x.numel() // (b * k)
+    m = w.shape[0]
+    y = torch.empty((b, m) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    scale, shift = coeff if coeff is not None else (None, None)
+    with torch.cuda.device(x.device):
+        _L.check(_lib.mlp_gemm_forward(b, m, k, r, w.data_ptr(), x.data_ptr(),
+                                       0 if coeff is None else 1, _ptr(scale), _ptr(shift),
+                                       y.data_ptr(), _stream(x)), "mlp_gemm_forward")
+    return y
+
+
+def bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, training):
+    """-> dgamma, dbeta, coef (C,3): everything the on-the-fly dy needs."""
+    _f32c(dz, "dz")
+    b, c = y.shape[0], y.shape[1]
+    r = y.numel() // (b * c)
+    small = torch.empty((5, c), dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        ws = _ws(y, b, c, r)
+        _L.check(_lib.mlp_bn_relu_backward_stats(b, c, r, 1 if training else 0, y.data_ptr(),
+                                                 dz.data_ptr(), gamma.data_ptr(), scale.data_ptr(),
+                                                 shift.data_ptr(), mean.data_ptr(),
+                                                 invstd.data_ptr(), small[0].data_ptr(),
+                                                 small[1].data_ptr(), small[2:].data_ptr(),
+                                                 ws.data_ptr(), _stream(y)),
+                 "mlp_bn_relu_backward_stats")
+    return small[0], small[1], small[2:]
+
+
+def gemm_dgrad(w, dy=None, fly=None, like=None):
+    """dx (B,K,R) = w^T @ dy.  Either dy is a tensor, or fly = (y, dz, scale, shift, mean,
+    invstd, coef) and dy is formed on the fly.  `like`: tensor whose trailing shape dx takes."""
+    m, k = w.shape
+    wt = w.t().contiguous()
+    src = dy if dy is not None else fly[0]
+    b = src.shape[0]
+    r = src.numel() // (b * m)
+    dx = torch.empty((b, k) + tuple(src.shape[2:]), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        if dy is not None:
+            _f32c(dy, "dy")
+            rc = _lib.mlp_gemm_dgrad(b, m, k, r, wt.data_ptr(), 0, dy.data_ptr(), None, None, None,
+                                     None, None, None, None, dx.data_ptr(), _stream(src))
+        else:
+            y, dz, scale, shift, mean, invstd, coef = fly
+            rc = _lib.mlp_gemm_dgrad(b, m, k, r, wt.data_ptr(), 2, None, y.data_ptr(),
+                                     dz.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                     mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(),
+                                     dx.data_ptr(), _stream(src))
+        _L.check(rc, "mlp_gemm_dgrad")
+    return dx
+
+
+def gemm_wgrad(m, k, x, xcoeff=None, dy=None, fly=None):
+    """dw (M,K) = sum_b dy[b] @ x[b]^T; x direct or relu(bn(.)) via xcoeff=(scale, shift);
+    dy direct or on the fly (fly as in gemm_dgrad)."""
+    b = x.shape[0]
+    r = x.numel() // (b * k)
+    dw = torch.empty((m, k), dtype=torch.float32, device=x.device)
+    xs, xh = xcoeff if xcoeff is not None else (None, None)
+    with torch.cuda.device(x.device):
+        ws = torch.empty(max(int(_lib.mlp_gemm_wgrad_workspace_floats(b, m, k, r)), 1),
+                         dtype=torch.float32, device=x.device)
+        if dy is not None:
+            rc = _lib.mlp_gemm_wgrad(b, m, k, r, 0, dy.data_ptr(), None, None, None, None, None,
+                                     None, None, 0 if xcoeff is None else 1, x.data_ptr(),
+                                     _ptr(xs), _ptr(xh), dw.data_ptr(), ws.data_ptr(), _stream(x))
+        else:
+            y, dz, scale, shift, mean, invstd, coef = fly
+            rc = _lib.mlp_gemm_wgrad(b, m, k, r, 2, None, y.data_ptr(), dz.data_ptr(),
+                                     scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                     invstd.data_ptr(), coef.data_ptr(),
+                                     0 if xcoeff is None else 1, x.data_ptr(), _ptr(xs), _ptr(xh),
+                                     dw.data_ptr(), ws.data_ptr(), _stream(x))
+        _L.check(rc, "mlp_gemm_wgrad")
+    return dw

@@ -134,8 +134,90 @@ class _BNReLUMaxPool(Function):
         return dy, dgamma, dbeta, None, None, None, None, None
 
 
+class _FusedMLPChain(Function):
+    """The whole conv(1x1)+BN+ReLU stack (and optionally the final max over nsample) as ONE
+    autograd node on the gfx950 kernels: MFMA GEMMs whose operand loads apply the previous
+    layer's BatchNorm+ReLU (forward) or form the BatchNorm/ReLU backward of the incoming
+    gradient (backward) on the fly.  Per layer only the raw GEMM output y_i is kept; no
+    normalised / rectified activation and no mask is ever written to memory.
+
+    apply(x, pool, training, momenta, epss, w_0, g_0, b_0, rm_0, rv_0, w_1, ...)"""
+
+    @staticmethod
+    def forward(ctx, x, pool, training, momenta, epss, *params):
+        from pointnet2 import _mlp_ext as K
+        n_layers = len(params) // 5
+        x = x.contiguous()
+        ys, coefs = [], []
+        cur, cur_coeff = x, None
+        for i in range(n_layers):
+            w, gamma, beta, rm, rv = params[5 * i:5 * i + 5]
+            w2 = w.reshape(w.shape[0], -1)
+            y = K.gemm_forward(w2, cur, cur_coeff)
+            mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, momenta[i],
+                                                           epss[i], training)
+            ys.append(y)
+            coefs.append((mean, invstd, scale, shift))
+            cur, cur_coeff = y, (scale, shift)
+        extra = []
+        if pool:
+            out, argmax, ymax = K.bn_relu_pool(cur, cur_coeff[0], cur_coeff[1])
+            extra = [argmax, ymax]
+        else:
+            out = K.bn_relu_apply(cur, cur_coeff[0], cur_coeff[1])
+        flat = [t for c in coefs for t in c]
+        ctx.save_for_backward(x, *ys, *flat, *extra, *params)
+        ctx.n_layers, ctx.pool, ctx.training = n_layers, pool, training
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from pointnet2 import _mlp_ext as K
+        n, pool, training = ctx.n_layers, ctx.pool, ctx.training
+        saved = ctx.saved_tensors
+        x, ys = saved[0], saved[1:1 + n]
+        flat = saved[1 + n:1 + 5 * n]
+        coefs = [flat[4 * i:4 * i + 4] for i in range(n)]  # mean, invstd, scale, shift
+        pos = 1 + 5 * n
+        extra = saved[pos:pos + (2 if pool else 0)]
+        params = saved[pos + (2 if pool else 0):]
+        dout = dout.contiguous()
+        grads = [None] * (5 * n)
+        need_dx = ctx.needs_input_grad[0]
+        dy_tensor, fly = None, None
+        dz = dout
+        for i in range(n - 1, -1, -1):
+            w, gamma = params[5 * i], params[5 * i + 1]
+            w2 = w.reshape(w.shape[0], -1)
+            mean, invstd, scale, shift = coefs[i]
+            if i == n - 1 and pool:
+                # the gradient of the pooled layer is dense in dy but sparse in dz: materialise dy
+                dy_tensor, dgamma, dbeta = K.bn_relu_pool_backward(
+                    ys[i], dz, extra[0], extra[1], gamma, scale, shift, mean, invstd, training)
+                fly = None
+            else:
+                dgamma, dbeta, coef = K.bn_relu_backward_stats(ys[i], dz, gamma, scale, shift, mean,
+                                                               invstd, training)
+                dy_tensor, fly = None, (ys[i], dz, scale, shift, mean, invstd, coef)
+            grads[5 * i + 1], grads[5 * i + 2] = dgamma, dbeta
+            m, k = w2.shape
+            if i == 0:
+                grads[0 + 5 * i] = K.gemm_wgrad(m, k, x, None, dy_tensor, fly).view_as(w)
+                dx = K.gemm_dgrad(w2, dy_tensor, fly).view_as(x) if need_dx else None
+            else:
+                pscale, pshift = coefs[i - 1][2], coefs[i - 1][3]
+                grads[5 * i] = K.gemm_wgrad(m, k, ys[i - 1], (pscale, pshift), dy_tensor,
+                                            fly).view_as(w)
+                dz = K.gemm_dgrad(w2, dy_tensor, fly)  # gradient w.r.t. relu(bn(y_{i-1}))
+        return (dx if need_dx else None, None, None, None, None, *grads)
+
+
 def _fused_enabled():
     return os.environ.get("PN2_FUSED_MLP", "1") != "0"
+
+
+def _mfma_enabled():
+    return os.environ.get("PN2_MFMA_MLP", "1") != "0"
 
 
 class SharedMLP(nn.Sequential):
@@ -177,6 +259,18 @@ class SharedMLP(nn.Sequential):
 
     def _run(self, x, pool):
         layers = list(self)
+        if _mfma_enabled():
+            bns = [next(layer.bn.children()) for layer in layers]
+            training = bns[0].training
+            if all(bn.training == training for bn in bns):
+                params = []
+                for layer, bn in zip(layers, bns):
+                    if training:
+                        bn.num_batches_tracked.add_(1)
+                    params += [layer.conv.weight, bn.weight, bn.bias, bn.running_mean,
+                               bn.running_var]
+                return _FusedMLPChain.apply(x, pool, training, [bn.momentum for bn in bns],
+                                            [bn.eps for bn in bns], *params)
         for i, layer in enumerate(layers):
             bn = next(layer.bn.children())
             y = layer.conv(x)

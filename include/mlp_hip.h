@@ -68,6 +68,43 @@ int mlp_bn_relu_pool_backward(int b, int c, int m, int ns, int training, const f
                               const float *mean, const float *invstd, float *dy, float *dgamma,
                               float *dbeta, float *coef, float *workspace, void *stream);
 
+/* as mlp_bn_relu_backward but only the per-channel results (dgamma, dbeta, coef = a, c1, c2);
+ * the dy tensor itself is then formed inside the operand loads of mlp_gemm_dgrad / _wgrad
+ * (replaces the same autograd nodes, pytorch_utils.py:108-124) */
+int mlp_bn_relu_backward_stats(int b, int c, int r, int training, const float *y, const float *dz,
+                               const float *gamma, const float *scale, const float *shift,
+                               const float *mean, const float *invstd, float *dgamma, float *dbeta,
+                               float *coef, float *workspace, void *stream);
+
+/* ---- the 1x1 convolution itself, on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32) ----
+ * X (b,k,r), W (m,k) row-major, Y (b,m,r).  Replaces nn.Conv2d(kernel 1x1, no bias) of a
+ * shared-MLP layer (pytorch_utils.py:70-124, built at :14-39) and its autograd backward. */
+
+/* forward: y = W * x, where x is the given tensor (mode 0) or relu(x*scale[k] + shift[k])
+ * (mode 1: the previous layer's BatchNorm+ReLU applied on the fly, pytorch_utils.py:108-124) */
+int mlp_gemm_forward(int b, int m, int k, int r, const float *w, const float *x, int mode,
+                     const float *scale, const float *shift, float *y, void *stream);
+
+/* input gradient: dx (b,k,r) = W^T * dy; wt is W^T (k,m) row-major.  mode 0: dy is given;
+ * mode 2: dy is formed on the fly from (y, dz) and the vectors of mlp_bn_relu_backward_stats
+ * (replaces conv2d backward-data + the BatchNorm/ReLU backward, pytorch_utils.py:70-124) */
+int mlp_gemm_dgrad(int b, int m, int k, int r, const float *wt, int mode, const float *dy,
+                   const float *y, const float *dz, const float *scale, const float *shift,
+                   const float *mean, const float *invstd, const float *coef, float *dx,
+                   void *stream);
+
+/* weight gradient: dw (m,k) = sum_b dy[b] * x[b]^T; dy given (pmode 0) or on the fly (pmode 2);
+ * x given (qmode 0) or relu(bn(.)) of the previous layer's output (qmode 1).  workspace:
+ * mlp_gemm_wgrad_workspace_floats floats (replaces conv2d backward-weight, pytorch_utils.py:70-124) */
+int mlp_gemm_wgrad(int b, int m, int k, int r, int pmode, const float *dy, const float *y,
+                   const float *dz, const float *scale, const float *shift, const float *mean,
+                   const float *invstd, const float *coef, int qmode, const float *x,
+                   const float *xscale, const float *xshift, float *dw, float *workspace,
+                   void *stream);
+/* scratch (floats) for mlp_gemm_wgrad: per-slice partial dW tiles (replaces cuDNN's
+ * workspace of conv2d backward-weight, pytorch_utils.py:70-124) */
+size_t mlp_gemm_wgrad_workspace_floats(int b, int m, int k, int r);
+
 #ifdef __cplusplus
 }
 #endif

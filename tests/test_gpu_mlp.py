@@ -88,3 +88,83 @@ def test_shared_mlp_fused_matches_sequential():
     mlp.eval(); ref.eval()
     with torch.no_grad():
         close(mlp(x1), torch.nn.Sequential.forward(ref, x2))
+
+
+@pytest.mark.parametrize("b,m,k,r", [(2, 64, 4, 640), (1, 128, 64, 1000), (2, 256, 131, 512),
+                                     (3, 259, 128, 96), (1, 3, 7, 33), (2, 131, 259, 1024),
+                                     (1, 512, 256, 64), (2, 32, 512, 200)])
+def test_mfma_gemm_primitives_vs_torch(b, m, k, r):
+    """forward / dgrad / wgrad of the 1x1 convolution on the matrix cores, every operand mode,
+    ragged M, K, R -- against torch matmul of explicitly materialised operands (fp32)."""
+    load_pkg()
+    K = importlib.import_module("pointnet2._mlp_ext")
+    g = torch.Generator().manual_seed(b * 1000 + m + k + r)
+    w = (torch.randn(m, k, generator=g) / k ** 0.5).to(DEV)
+    x = torch.randn(b, k, r, generator=g).to(DEV)
+    scale_k = (torch.rand(k, generator=g) + 0.5).to(DEV)
+    shift_k = (torch.randn(k, generator=g) * 0.3).to(DEV)
+    # forward, direct and with the BN+ReLU prologue
+    close(K.gemm_forward(w, x), torch.matmul(w, x), 2e-5)
+    xz = torch.relu(x * scale_k[None, :, None] + shift_k[None, :, None])
+    close(K.gemm_forward(w, x, (scale_k, shift_k)), torch.matmul(w, xz), 2e-5)
+    # the on-the-fly dy operand
+    y = torch.randn(b, m, r, generator=g).to(DEV)
+    dz = torch.randn(b, m, r, generator=g).to(DEV)
+    sc = (torch.rand(m, generator=g) + 0.5).to(DEV)
+    sh = (torch.randn(m, generator=g) * 0.3).to(DEV)
+    mu = (torch.randn(m, generator=g) * 0.2).to(DEV)
+    istd = (torch.rand(m, generator=g) + 0.5).to(DEV)
+    coef = torch.stack([torch.rand(m, generator=g) + 0.5, torch.randn(m, generator=g) * 0.1,
+                        torch.randn(m, generator=g) * 0.1], dim=1).contiguous().to(DEV)
+    bc = lambda v: v[None, :, None]  # noqa: E731
+    mask = (y * bc(sc) + bc(sh) > 0).float()
+    dy = bc(coef[:, 0]) * (dz * mask - bc(coef[:, 1]) - (y - bc(mu)) * bc(istd) * bc(coef[:, 2]))
+    fly = (y, dz, sc, sh, mu, istd, coef)
+    want_dx = torch.matmul(w.t(), dy)
+    close(K.gemm_dgrad(w, dy=dy.contiguous()), want_dx, 3e-5)
+    close(K.gemm_dgrad(w, fly=fly), want_dx, 3e-5)
+    want_dw_direct = torch.einsum("bmr,bkr->mk", dy, x)
+    want_dw_bn = torch.einsum("bmr,bkr->mk", dy, xz)
+    tol = 1e-4
+    close(K.gemm_wgrad(m, k, x, None, dy=dy.contiguous()), want_dw_direct, tol)
+    close(K.gemm_wgrad(m, k, x, (scale_k, shift_k), dy=dy.contiguous()), want_dw_bn, tol)
+    close(K.gemm_wgrad(m, k, x, None, fly=fly), want_dw_direct, tol)
+    close(K.gemm_wgrad(m, k, x, (scale_k, shift_k), fly=fly), want_dw_bn, tol)
+
+
+@pytest.mark.parametrize("widths,shape", [([4, 64, 64, 128], (2, 4, 64, 64)),
+                                          ([131, 128, 128, 256], (2, 131, 50, 32)),
+                                          ([259, 128, 128], (3, 259, 20, 16)),
+                                          ([20, 8], (2, 20, 300, 1))])
+@pytest.mark.parametrize("training", [True, False])
+def test_fused_chain_vs_sequential(widths, shape, training):
+    """The one-node MFMA chain (SharedMLP on the GPU) == nn.Sequential of the same modules:
+    pooled and unpooled forward, input / weight / BN gradients, running statistics."""
+    P = _mods()
+    torch.manual_seed(1)
+    mlp = P.SharedMLP(list(widths), bn=True).to(DEV)
+    ref = P.SharedMLP(list(widths), bn=True).to(DEV)
+    ref.load_state_dict(mlp.state_dict())
+    mlp.train(training); ref.train(training)
+    for pool in (True, False):
+        x1 = torch.randn(shape, device=DEV, requires_grad=True)
+        x2 = x1.detach().clone().requires_grad_(True)
+        out = mlp.forward_pooled(x1) if pool else mlp(x1)
+        z = torch.nn.Sequential.forward(ref, x2)
+        want = torch.max(z, dim=3)[0] if pool else z
+        close(out, want, 2e-4)
+        wgt = torch.randn_like(want)
+        mlp.zero_grad(); ref.zero_grad()
+        (out * wgt).sum().backward()
+        (want * wgt).sum().backward()
+        # The two forwards differ in the last ulp (different summation order), so a pre-activation
+        # within rounding of 0 can flip its ReLU mask, and a max over nsample can pick another
+        # near-tied sample: either moves the gradient of ONE column.  Compare robustly: almost
+        # every element agrees tightly, and the dense sums agree in relative L2.
+        d = (x1.grad - x2.grad).abs()
+        assert float((d > 5e-4 * max(1.0, float(x2.grad.abs().max()))).float().mean()) < 2e-3
+        for (n1, p1), (n2, p2) in zip(mlp.named_parameters(), ref.named_parameters()):
+            rel = float((p1.grad - p2.grad).norm() / (p2.grad.norm() + 1e-12))
+            assert rel < 3e-2, (n1, rel)
+        for (n1, b1), (n2, b2) in zip(mlp.named_buffers(), ref.named_buffers()):
+            close(b1.float(), b2.float(), 2e-4)
