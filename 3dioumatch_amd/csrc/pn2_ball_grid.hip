@@ -10,9 +10,10 @@
 //   build  : every point goes into a cell of side 1.001*r of a 32^3 PERIODIC lattice
 //            (cell = floor(p / side) mod 32 per axis -- no bounding box pass, far-apart cells
 //            may alias, which only adds candidates that the exact distance test rejects).
-//            Cells are fixed-capacity slot arrays of (x, y, z, index); each workgroup owns a
-//            slab of z-layers and ranks its points with LDS atomics (no global atomics, no
-//            counter memset); an overflowing cell flags the cloud.
+//            Cells are fixed-capacity slot arrays of (x, y, z, index); each workgroup owns one
+//            z-layer and ranks its points with LDS atomics (no global atomics, no counter
+//            memset); points beyond a cell's capacity go to a per-layer overflow list that the
+//            queries of the neighbouring layers also scan (dense clumps stay exact and fast).
 //   query  : one wavefront per centroid.  Lanes 0..26 fetch the 27 neighbour cell counts;
 //            the nine x-rows of three cells are streamed 64 candidates at a time (all loads
 //            issued before the first use), hits are compacted into an LDS list by ballot
@@ -36,14 +37,11 @@ constexpr int kMaxHits = 256;           // LDS hit list per wave
 constexpr int kRowSlots = 3 * kCap;     // candidates in one x-row of cells (<= 192)
 constexpr int kRowPasses = kRowSlots / kWave;  // 3
 
-struct GridWs {
-  int *cnt;        // [b][kCellsPerCloud]
-  int *flags;      // [b] overflow
-  float4 *slots;   // [b][kCellsPerCloud][kCap]
-};
+constexpr int kOvfCap = 2048;           // overflow points kept per (cloud, z-layer)
 
+// ints: cell counters, then per (cloud, slab): overflow flag and overflow-list length
 __host__ __device__ inline size_t grid_cnt_bytes(int b) {
-  return sizeof(int) * ((size_t)b * kCellsPerCloud + (size_t)((b * 16 + 63) / 64) * 64);
+  return sizeof(int) * ((size_t)b * kCellsPerCloud + (size_t)((b * 64 + 63) / 64) * 64);
 }
 
 __device__ __forceinline__ int cell_coord(float v, float inv_side) {
@@ -61,51 +59,74 @@ __device__ __forceinline__ int cell_index(int cx, int cy, int cz) {
 // its slab, so all 32768 counters of the cloud are (re)written on every call.
 // (Returning device-scope atomics execute at the memory side on this multi-XCD part:
 // one per point cost 20 us for 320 000 points; this formulation costs a few us.)
-constexpr int kSlabs = 16;                     // (grid_cnt_bytes reserves 16 flags per cloud)
-constexpr int kLayers = kG / kSlabs;           // 2 z-layers per slab
-constexpr int kSlabCells = kLayers * kG * kG;  // 2048 cells
+constexpr int kSlabs = 32;                     // (grid_cnt_bytes reserves 32 flags per cloud)
+constexpr int kLayers = kG / kSlabs;           // 1 z-layer per slab
+constexpr int kSlabCells = kLayers * kG * kG;  // 1024 cells
 constexpr int kBuildThreads = 1024;
 
 __global__ void __launch_bounds__(kBuildThreads)
 grid_build_kernel(int n, float inv_side, const float *__restrict__ xyz, int *__restrict__ cnt,
-                  int *__restrict__ flags, float4 *__restrict__ slots) {
+                  int *__restrict__ flags, float4 *__restrict__ slots,
+                  float4 *__restrict__ ovf) {
   __shared__ int lcnt[kSlabCells];
+  __shared__ int l_ovf;
   const int slab = blockIdx.x, b = blockIdx.y;
   for (int t = threadIdx.x; t < kSlabCells; t += kBuildThreads) lcnt[t] = 0;
+  if (threadIdx.x == 0) l_ovf = 0;
   __syncthreads();
+  float4 *my_ovf = ovf + ((size_t)b * kSlabs + slab) * kOvfCap;
   const float *pts = xyz + (size_t)b * n * 3;
   const size_t cell0 = (size_t)b * kCellsPerCloud + (size_t)slab * kSlabCells;
   bool overflow = false;
-  constexpr int kUnroll = 8;  // z of 8 points in flight per lane before the first use
-  for (int k0 = threadIdx.x; k0 < n; k0 += kBuildThreads * kUnroll) {
-    float zs[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const int k = k0 + u * kBuildThreads;
-      zs[u] = k < n ? pts[k * 3 + 2] : 0.f;
+  auto place = [&](float x, float y, float z, int k) {
+    const int cz = cell_coord(z, inv_side) & (kG - 1);
+    if (cz / kLayers != slab) return;
+    const int local = ((cz % kLayers) * kG + (cell_coord(y, inv_side) & (kG - 1))) * kG +
+                      (cell_coord(x, inv_side) & (kG - 1));
+    const int slot = atomicAdd(&lcnt[local], 1);
+    const float4 rec = make_float4(x, y, z, __builtin_bit_cast(float, k));
+    if (slot < kCap) {
+      slots[(cell0 + local) * kCap + slot] = rec;
+    } else {  // dense cell: the point goes to this z-layer's overflow list
+      const int o = atomicAdd(&l_ovf, 1);
+      if (o < kOvfCap) my_ovf[o] = rec; else overflow = true;
     }
+  };
+  if ((n & 3) == 0) {
+    // 4 points = 48 contiguous bytes = three 16-byte loads per lane, fully coalesced and with
+    // no dependent second load; two groups in flight per lane
+    const float4 *v = reinterpret_cast<const float4 *>(pts);
+    const int groups = n / 4;
+    for (int g0 = threadIdx.x; g0 < groups; g0 += 2 * kBuildThreads) {
+      float4 a[2][3];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const int k = k0 + u * kBuildThreads;
-      const int cz = cell_coord(zs[u], inv_side) & (kG - 1);
-      if (k < n && cz / kLayers == slab) {
-        const float x = pts[k * 3 + 0], y = pts[k * 3 + 1];
-        const int local = ((cz % kLayers) * kG + (cell_coord(y, inv_side) & (kG - 1))) * kG +
-                          (cell_coord(x, inv_side) & (kG - 1));
-        const int slot = atomicAdd(&lcnt[local], 1);
-        if (slot < kCap)
-          slots[(cell0 + local) * kCap + slot] =
-              make_float4(x, y, zs[u], __builtin_bit_cast(float, k));
-        else
-          overflow = true;
+      for (int u = 0; u < 2; ++u) {
+        const int g = g0 + u * kBuildThreads;
+        if (g < groups) { a[u][0] = v[g * 3]; a[u][1] = v[g * 3 + 1]; a[u][2] = v[g * 3 + 2]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int g = g0 + u * kBuildThreads;
+        if (g < groups) {
+          place(a[u][0].x, a[u][0].y, a[u][0].z, g * 4 + 0);
+          place(a[u][0].w, a[u][1].x, a[u][1].y, g * 4 + 1);
+          place(a[u][1].z, a[u][1].w, a[u][2].x, g * 4 + 2);
+          place(a[u][2].y, a[u][2].z, a[u][2].w, g * 4 + 3);
+        }
       }
     }
+  } else {
+    for (int k = threadIdx.x; k < n; k += kBuildThreads)
+      place(pts[k * 3 + 0], pts[k * 3 + 1], pts[k * 3 + 2], k);
   }
   __syncthreads();
   for (int t = threadIdx.x; t < kSlabCells; t += kBuildThreads) cnt[cell0 + t] = lcnt[t];
-  // one flag per (cloud, slab), always written: no clearing pass is needed
+  // flag + overflow length per (cloud, slab), always written: no clearing pass is needed
   const int any = __syncthreads_or(overflow ? 1 : 0);
-  if (threadIdx.x == 0) flags[b * kSlabs + slab] = any;
+  if (threadIdx.x == 0) {
+    flags[(b * kSlabs + slab) * 2] = any;
+    flags[(b * kSlabs + slab) * 2 + 1] = l_ovf < kOvfCap ? l_ovf : kOvfCap;
+  }
 }
 
 // ---- 64-lane bitonic network on unsigned keys, entirely in registers ---------------------
@@ -167,7 +188,8 @@ __global__ void __launch_bounds__(256)
 grid_query_kernel(int n, int m, float radius2, float inv_side, int nsample,
                   const float *__restrict__ new_xyz, const float *__restrict__ xyz,
                   const int *__restrict__ cnt, const int *__restrict__ flags,
-                  const float4 *__restrict__ slots, int *__restrict__ idx) {
+                  const float4 *__restrict__ slots, const float4 *__restrict__ ovf,
+                  int *__restrict__ idx) {
   __shared__ unsigned hits[256 / kWave][kMaxHits];
   const int b = blockIdx.y;
   const int lane = lane_id();
@@ -177,8 +199,8 @@ grid_query_kernel(int n, int m, float radius2, float inv_side, int nsample,
   const float *pts = xyz + (size_t)b * n * 3;
   const float *ctr = new_xyz + ((size_t)b * m + j) * 3;
   int *row = idx + ((size_t)b * m + j) * nsample;
-  const bool flagged = __ballot(lane < kSlabs && flags[b * kSlabs + lane] != 0) != 0ull;
-  if (flagged) {  // a cell of this cloud overflowed: exact brute-force scan instead
+  const bool flagged = __ballot(lane < kSlabs && flags[(b * kSlabs + lane) * 2] != 0) != 0ull;
+  if (flagged) {  // an overflow list of this cloud overflowed: exact brute-force scan instead
     ball_query_wave_scan<1>(pts, n, ctr, 1, radius2, nsample, row);
     return;
   }
@@ -233,6 +255,25 @@ grid_query_kernel(int n, int m, float radius2, float inv_side, int nsample,
       }
     }
   }
+  // points that did not fit their cell sit in the overflow list of their z-layer: scan the
+  // lists of the three layers around the centroid (empty unless the cloud has dense clumps)
+#pragma unroll 1
+  for (int dz = -1; dz <= 1; ++dz) {
+    const int layer = (gz + dz) & (kG - 1);
+    const int no = flags[(b * kSlabs + layer) * 2 + 1];
+    const float4 *src = ovf + ((size_t)b * kSlabs + layer) * kOvfCap;
+    for (int base = 0; base < no && total <= kMaxHits; base += kWave) {
+      const bool live = base + lane < no;
+      const float4 q = live ? src[base + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool hit = live && sqdist3(cx, cy, cz, q.x, q.y, q.z) < radius2;
+      const unsigned long long mask = __ballot(hit);
+      if (mask) {
+        const int pos = total + mask_rank(mask);
+        if (hit && pos < kMaxHits) list[pos] = __builtin_bit_cast(unsigned, q.w);
+        total += __popcll(mask);
+      }
+    }
+  }
   if (total > kMaxHits) {  // very dense ball: exact brute-force scan for this centroid
     ball_query_wave_scan<1>(pts, n, ctr, 1, radius2, nsample, row);
     return;
@@ -264,7 +305,8 @@ grid_query_kernel(int n, int m, float radius2, float inv_side, int nsample,
 size_t pn2_ball_query_grid_workspace(int b, int n, int m, int nsample) {
   (void)m;
   if (n < 4096 || nsample > kWave) return 0;
-  return grid_cnt_bytes(b) + sizeof(float4) * (size_t)b * kCellsPerCloud * kCap;
+  return grid_cnt_bytes(b) + sizeof(float4) * (size_t)b * kCellsPerCloud * kCap +
+         sizeof(float4) * (size_t)b * kSlabs * kOvfCap;
 }
 
 int pn2_ball_query_grid_try(int b, int n, int m, float radius, int nsample, const float *new_xyz,
@@ -278,13 +320,14 @@ int pn2_ball_query_grid_try(int b, int n, int m, float radius, int nsample, cons
   int *cnt = reinterpret_cast<int *>(ws);
   int *flags = cnt + (size_t)b * kCellsPerCloud;
   float4 *slots = reinterpret_cast<float4 *>(ws + grid_cnt_bytes(b));
+  float4 *ovf = slots + (size_t)b * kCellsPerCloud * kCap;
   const float inv_side = 1.0f / (radius * 1.001f);
   hipLaunchKernelGGL(grid_build_kernel, dim3(kSlabs, b), dim3(kBuildThreads), 0, stream, n,
-                     inv_side, xyz, cnt, flags, slots);
+                     inv_side, xyz, cnt, flags, slots, ovf);
   const float radius2 = radius * radius;  // fp32 product, as ball_query_gpu.cu:27
   hipLaunchKernelGGL(grid_query_kernel, dim3(pn2_ceil_div(m, 256 / kWave), b), dim3(256), 0,
                      stream, n, m, radius2, inv_side, nsample, new_xyz, xyz, cnt, flags, slots,
-                     idx);
+                     ovf, idx);
   *handled = 1;
   return pn2_launch_status();
 }

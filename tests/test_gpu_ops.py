@@ -386,8 +386,9 @@ print("BUCKET_TIER_OK", len(cases))
     assert r.returncode == 0 and "BUCKET_TIER_OK" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("case", ["aliasing", "overflow", "dense_hits", "negative", "ns_small",
-                                  "ns_over_64", "tiny_radius"])
+@pytest.mark.parametrize("case", ["aliasing", "overflow", "overflow_list_full", "clumps",
+                                  "dense_hits", "negative", "ns_small", "ns_over_64",
+                                  "tiny_radius"])
 def test_ballquery_cell_list_tier_edge_cases(ext, oracle_omp, synth, case):
     """The cell-list tier (n >= 4096, nsample <= 64) against the oracle where its special
     paths trigger: lattice aliasing (cloud wider than 32 cells), cell overflow (> 64 points
@@ -402,6 +403,13 @@ def test_ballquery_cell_list_tier_edge_cases(ext, oracle_omp, synth, case):
         xyz[:, ::2] *= 0.1                                      # plus a dense core
     elif case == "overflow":
         xyz[0, :500] = 0.5 + g.random((500, 3), dtype=np.float32) * 0.05   # 500 points in one cell
+    elif case == "overflow_list_full":
+        xyz[1, :3000] = 0.7 + g.random((3000, 3), dtype=np.float32) * 0.05  # > cell + list capacity
+    elif case == "clumps":
+        for q in range(6):                                      # object-like dense clumps
+            lo = 400 * q
+            xyz[:, lo:lo + 400] = g.random(3, dtype=np.float32) * 1.5 + \
+                g.random((b, 400, 3), dtype=np.float32) * 0.25
     elif case == "dense_hits":
         r, ns = 0.6, 64                                        # ~ 680 hits per ball
     elif case == "negative":
