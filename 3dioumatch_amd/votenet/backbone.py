@@ -4,6 +4,7 @@ Host-side mirror of the reference models/backbone_module.py (hyper-parameters :3
 :105-133): same attribute names (sa1..sa4, fp1, fp2 -> same state_dict keys), same end_points
 keys, int32 index tensors.  Every custom operator underneath is a gfx950 HIP kernel.
 """
+import torch
 import torch.nn as nn
 
 from pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
@@ -38,11 +39,31 @@ class Pointnet2Backbone(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
-    def forward(self, pointcloud, end_points=None):
+    @torch.no_grad()
+    def compute_geometry(self, pointcloud):
+        """Everything in the backbone that depends on the point COORDINATES only (not on any
+        learned weight): the four furthest-point samplings.  Being data-only, it can be computed
+        for the NEXT batch on a side stream while the current step trains (votenet/step.py),
+        which takes the strictly serial FPS rounds (a handful of busy CUs) off the critical
+        path.  Returns {"sa1_inds", ..., "sa4_inds"} (int32)."""
+        from pointnet2 import pointnet2_utils
+        xyz = pointcloud[..., 0:3].contiguous()
+        geometry = {}
+        for i in range(1, 5):
+            npoint = getattr(self, "sa%d" % i).npoint
+            inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
+            geometry["sa%d_inds" % i] = inds
+            xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(),
+                                                   inds).transpose(1, 2).contiguous()
+        geometry["seed_xyz"] = None
+        return geometry
+
+    def forward(self, pointcloud, end_points=None, geometry=None):
         end_points = end_points if end_points else {}
         xyz, features = self._break_up_pc(pointcloud)
         for i in range(1, 5):
-            xyz, features, inds = getattr(self, "sa%d" % i)(xyz, features)
+            given = geometry["sa%d_inds" % i] if geometry is not None else None
+            xyz, features, inds = getattr(self, "sa%d" % i)(xyz, features, given)
             end_points["sa%d_xyz" % i] = xyz
             end_points["sa%d_features" % i] = features
             if i <= 2:

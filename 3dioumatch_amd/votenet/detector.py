@@ -40,7 +40,7 @@ class VoteNet(nn.Module):
                              persistent=False)
 
     def forward_backbone(self, inputs):
-        end_points = self.backbone_net(inputs['point_clouds'], {})
+        end_points = self.backbone_net(inputs['point_clouds'], {}, inputs.get('geometry'))
         xyz, features = end_points['fp2_xyz'], end_points['fp2_features']
         end_points['seed_inds'] = end_points['fp2_inds']
         end_points['seed_xyz'] = xyz
@@ -49,7 +49,26 @@ class VoteNet(nn.Module):
         features = features.div(torch.norm(features, p=2, dim=1).unsqueeze(1))
         end_points['vote_xyz'] = xyz
         end_points['vote_features'] = features
+        geometry = inputs.get('geometry')
+        if geometry is not None and geometry.get('proposal_inds') is not None:
+            end_points['precomputed_proposal_inds'] = geometry['proposal_inds']
         return self.pnet(xyz, features, end_points)
+
+    @torch.no_grad()
+    def compute_geometry(self, inputs):
+        """Coordinate-only index computations of one batch (backbone FPS x4 and, for
+        sampling == 'seed_fps', the proposal FPS on the seeds = SA2 centroids)."""
+        from pointnet2 import pointnet2_utils
+        pc = inputs['point_clouds']
+        geometry = self.backbone_net.compute_geometry(pc)
+        if self.sampling == 'seed_fps':
+            xyz = pc[..., 0:3].contiguous()
+            for key in ("sa1_inds", "sa2_inds"):
+                xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(),
+                                                       geometry[key]).transpose(1, 2).contiguous()
+            geometry['proposal_inds'] = pointnet2_utils.furthest_point_sample(xyz,
+                                                                              self.num_proposal)
+        return geometry
 
     def calculate_bbox(self, end_points):
         """arg-max size/heading class -> (center, HALF size, heading); votenet_iou_branch.py:111-137"""

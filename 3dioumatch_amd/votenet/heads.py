@@ -97,8 +97,10 @@ class ProposalModule(nn.Module):
             xyz, features, sample_inds = self.vote_aggregation(xyz, features)
         elif self.sampling == 'seed_fps':
             # FPS on the seeds, then aggregate the votes of the chosen seeds
-            sample_inds = pointnet2_utils.furthest_point_sample(end_points['seed_xyz'],
-                                                                self.num_proposal)
+            sample_inds = end_points.pop('precomputed_proposal_inds', None)
+            if sample_inds is None:
+                sample_inds = pointnet2_utils.furthest_point_sample(end_points['seed_xyz'],
+                                                                    self.num_proposal)
             xyz, features, _ = self.vote_aggregation(xyz, features, sample_inds)
         elif self.sampling == 'random':
             b, num_seed = end_points['seed_xyz'].shape[:2]

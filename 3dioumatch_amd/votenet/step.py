@@ -73,6 +73,7 @@ class SupervisedStep(object):
         self.net = build_detector(cfg, num_proposal=num_proposal, seed=seed).to(device).train()
         self.model = wrap_ddp(self.net, device, world_size)
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=0)
+        self._side = None
 
     def set_epoch(self, epoch, base_lr=1e-3):
         for group in self.optimizer.param_groups:
@@ -82,10 +83,36 @@ class SupervisedStep(object):
             if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)):
                 m.momentum = momentum
 
+    def prefetch_geometry(self, batch):
+        """Launch the coordinate-only index computations (FPS chain) of `batch` on a side
+        stream; the step that later consumes `batch` waits for them.  Call it for batch i+1
+        right before running the step on batch i: the serial FPS rounds then overlap the
+        dense kernels of step i instead of heading step i+1's critical path."""
+        if self.device.type != "cuda":
+            batch["geometry"] = self.net.compute_geometry(batch)
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(main)  # inputs produced on the main stream are ready
+        with torch.cuda.stream(self._side):
+            geometry = self.net.compute_geometry(batch)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        for t in geometry.values():
+            if torch.is_tensor(t):
+                t.record_stream(main)
+        batch["geometry"] = geometry
+        batch["_geometry_ready"] = done
+
     def __call__(self, batch):
+        ready = batch.pop("_geometry_ready", None)
+        if ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(ready)
         self.optimizer.zero_grad(set_to_none=True)
         end_points = self.model(batch, mode="jitter")
-        end_points.update(batch)
+        batch.pop("geometry", None)  # consumed: every step computes (or prefetches) its own
+        end_points.update({k: v for k, v in batch.items() if torch.is_tensor(v)})
         loss, end_points = get_labeled_loss(end_points, self.cfg, {"dataset_config": self.cfg})
         loss.backward()
         self.optimizer.step()

@@ -127,3 +127,35 @@ def test_state_dict_is_interchangeable_with_reference_layout():
     net2 = V.VoteNet(sun.num_class, sun.num_heading_bin, sun.num_size_cluster, sun.mean_size_arr,
                      sun, input_feature_dim=1, num_proposal=256, sampling="seed_fps")
     assert sum(p.numel() for p in net2.parameters()) == 1060373
+
+
+@pytest.mark.parametrize("use_gpu", [pytest.param(False, id="cpu-hostlogic"),
+                                     pytest.param(True, id="gpu-hip", marks=pytest.mark.gpu)])
+def test_geometry_prefetch_is_equivalent(use_gpu, oracle_omp):
+    """The coordinate-only FPS chain computed ahead of time (side stream on the GPU) yields the
+    same indices, loss and gradients as computing it inline in the forward."""
+    V, dev = _setup(use_gpu, oracle_omp)
+    cfg = V.scannet_config()
+    data = importlib.import_module("3dioumatch_amd.votenet.data")
+    step_mod = importlib.import_module("3dioumatch_amd.votenet.step")
+    base = {k: v.to(dev) for k, v in data.make_batch(B, N, cfg, seed=44, num_objects=5).items()}
+    results = []
+    for prefetch in (False, True):
+        runner = V.SupervisedStep(cfg, dev, world_size=1, num_proposal=K, seed=3)
+        batch = dict(base)
+        if prefetch:
+            runner.prefetch_geometry(batch)
+            assert set(batch["geometry"]) >= {"sa1_inds", "sa2_inds", "sa3_inds", "sa4_inds",
+                                              "proposal_inds"}
+        torch.manual_seed(9)
+        if use_gpu:
+            torch.cuda.manual_seed_all(9)
+        loss, ep = runner(batch)  # forward + backward + Adam; gradients stay in .grad
+        assert "geometry" not in batch  # consumed
+        results.append((float(loss), ep["sa1_inds"].cpu(), ep["aggregated_vote_inds"].cpu(),
+                        step_mod.flat_grads(runner.net).cpu()))
+    assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
+    assert abs(results[0][0] - results[1][0]) <= 1e-5 * max(1.0, abs(results[0][0]))
+    # gradients: equal up to the order of the fp32 atomics in the scatter-add kernels
+    g0, g1 = results[0][3], results[1][3]
+    assert float((g0 - g1).norm() / g0.norm()) < 1e-4
