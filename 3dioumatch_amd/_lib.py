@@ -28,6 +28,8 @@ _SIGNATURES = {
     "pn2_three_interpolate_grad": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "pn2_query_and_group": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _vp, _vp,
                             _vp, _vp, _vp, _vp, _sz, _vp],
+    "pn2_group_concat": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _vp, _vp,
+                         _vp, _vp, _vp, _vp],
     "pn2_error_string": [_c_int],
     "mlp_bn_workspace_floats": [_c_int, _c_int, _c_int],
     "mlp_bn_train_stats": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _c_float, _c_float, _vp, _vp, _vp,

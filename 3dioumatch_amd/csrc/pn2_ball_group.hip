@@ -346,6 +346,10 @@ PN2_API int pn2_group_points_grad(int b, int c, int n, int npoints, int nsample,
   return pn2_launch_status();
 }
 
+PN2_API int pn2_group_concat(int b, int n, int m, int c, float radius, int nsample,
+                             int normalize_xyz, const float *new_xyz, const float *xyz,
+                             const float *features, const int *idx, float *out, void *stream_);
+
 PN2_API int pn2_query_and_group(int b, int n, int m, int c, float radius, int nsample,
                                 int normalize_xyz, const float *new_xyz, const float *xyz,
                                 const float *features, int *idx, float *out, void *workspace,
@@ -355,6 +359,15 @@ PN2_API int pn2_query_and_group(int b, int n, int m, int c, float radius, int ns
   int rc = pn2_ball_query(b, n, m, radius, nsample, new_xyz, xyz, idx, workspace,
                           workspace_bytes, stream_);
   if (rc != 0) return rc;
+  return pn2_group_concat(b, n, m, c, radius, nsample, normalize_xyz, new_xyz, xyz, features, idx,
+                          out, stream_);
+}
+
+PN2_API int pn2_group_concat(int b, int n, int m, int c, float radius, int nsample,
+                             int normalize_xyz, const float *new_xyz, const float *xyz,
+                             const float *features, const int *idx, float *out, void *stream_) {
+  if (b <= 0 || m <= 0 || nsample <= 0) return 0;
+  if (c > 0 && !features) return (int)hipErrorInvalidValue;
   const long long mns = (long long)m * nsample;
   dim3 grid(pn2_ceil_div(mns, 1024), channel_groups(c, 8), b);
   const float inv_radius = 1.0f / radius;  // torch divides by a scalar as x * (1/r)

@@ -200,10 +200,11 @@ def group_points_grad(grad_out, idx, n):
 
 
 # ---- addition (not in the reference's pybind surface) ------------------------------------
-def query_and_group(new_xyz, xyz, features, radius, nsample, normalize_xyz):
+def query_and_group(new_xyz, xyz, features, radius, nsample, normalize_xyz, idx=None):
     """Fused QueryAndGroup front end (pointnet2_utils.py:335-358): returns
     (idx (B,m,ns) i32, grouped (B,3+C,m,ns) f32) with channels 0..2 = relative xyz
-    (optionally / radius) and 3.. = gathered features (features may be None)."""
+    (optionally / radius) and 3.. = gathered features (features may be None).
+    A ball-query result computed earlier may be passed as `idx` (then only the gathers run)."""
     _chk_f32(new_xyz, "new_xyz"); _chk_f32(xyz, "xyz"); _chk_dev(new_xyz, (xyz, "xyz"))
     b, n, _ = xyz.shape
     m = new_xyz.shape[1]
@@ -214,8 +215,18 @@ def query_and_group(new_xyz, xyz, features, radius, nsample, normalize_xyz):
         c = features.shape[1]
         fptr = features.data_ptr()
     nsample = int(nsample)
-    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
     out = torch.empty((b, 3 + c, m, nsample), dtype=torch.float32, device=new_xyz.device)
+    if idx is not None:
+        _chk_i32(idx, "idx"); _chk_dev(new_xyz, (idx, "idx"))
+        if tuple(idx.shape) != (b, m, nsample):
+            raise RuntimeError("idx must have shape (B, npoint, nsample)")
+        with torch.cuda.device(new_xyz.device):
+            _L.check(_lib.pn2_group_concat(b, n, m, c, float(radius), nsample,
+                                           1 if normalize_xyz else 0, new_xyz.data_ptr(),
+                                           xyz.data_ptr(), fptr, idx.data_ptr(), out.data_ptr(),
+                                           _stream(new_xyz)), "group_concat")
+        return idx, out
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
     with torch.cuda.device(new_xyz.device):
         ws, ws_size = _ball_ws(new_xyz, b, n, m, nsample)
         _L.check(_lib.pn2_query_and_group(b, n, m, c, float(radius), nsample,

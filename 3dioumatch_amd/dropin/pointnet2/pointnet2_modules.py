@@ -136,14 +136,19 @@ class PointnetSAModuleVotes(nn.Module):
             return torch.sum(feats * rbf.unsqueeze(1), -1) / float(self.nsample)
         raise ValueError("unknown pooling %r" % (self.pooling,))
 
-    def forward(self, xyz, features=None, inds=None):
+    def forward(self, xyz, features=None, inds=None, ball_idx=None):
+        """ball_idx: optional precomputed ball-query indices (B,npoint,nsample) int32 for the
+        centroids `inds` (both depend on coordinates only; see votenet/step.py)."""
         if inds is not None:
             assert inds.shape[1] == self.npoint
         if self.npoint is not None:
             new_xyz, inds = _sample_centroids(xyz, self.npoint, inds)
         else:
             new_xyz = None
-        grouped = self.grouper(xyz, new_xyz, features)
+        if ball_idx is not None and isinstance(self.grouper, pointnet2_utils.QueryAndGroup):
+            grouped = self.grouper(xyz, new_xyz, features, ball_idx)
+        else:
+            grouped = self.grouper(xyz, new_xyz, features)
         unique_cnt = grouped[2] if self.ret_unique_cnt else None
         if self.pooling == 'max':  # BN + ReLU + max over nsample fused into the last layer
             new_features = self.mlp_module.forward_pooled(grouped[0])

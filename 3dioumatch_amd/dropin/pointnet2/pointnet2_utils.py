@@ -128,9 +128,9 @@ class _FusedQueryAndGroup(Function):
     """
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, features, radius, nsample, normalize_xyz):
+    def forward(ctx, xyz, new_xyz, features, radius, nsample, normalize_xyz, idx=None):
         idx, grouped = _ext.query_and_group(new_xyz, xyz, features, radius, nsample,
-                                            normalize_xyz)
+                                            normalize_xyz, idx)
         ctx.save_for_backward(idx)
         ctx.n_points = xyz.size(1)
         ctx.scale = (1.0 / radius) if normalize_xyz else 1.0
@@ -153,7 +153,7 @@ class _FusedQueryAndGroup(Function):
                 g_xyz = _ext.group_points_grad(gx.contiguous(), idx, ctx.n_points).transpose(1, 2)
             if need_new_xyz:
                 g_new = -gx.sum(dim=3).transpose(1, 2)
-        return g_xyz, g_new, g_feat, None, None, None
+        return g_xyz, g_new, g_feat, None, None, None, None
 
 
 class QueryAndGroup(nn.Module):
@@ -187,13 +187,14 @@ class QueryAndGroup(nn.Module):
                 idx[b, j, :] = torch.cat((members, members[draw]))
         return unique_cnt
 
-    def forward(self, xyz, new_xyz, features=None):
+    def forward(self, xyz, new_xyz, features=None, idx=None):
+        """idx: optional ball-query result for (xyz, new_xyz) computed earlier."""
         if features is None:
             assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
         unique_cnt = None
         if not self.sample_uniformly:
             grouped, _idx = _FusedQueryAndGroup.apply(xyz, new_xyz, features, self.radius,
-                                                      self.nsample, self.normalize_xyz)
+                                                      self.nsample, self.normalize_xyz, idx)
             grouped_xyz = grouped[:, :3]
             new_features = grouped if self.use_xyz else grouped[:, 3:]
         else:

@@ -42,20 +42,22 @@ class Pointnet2Backbone(nn.Module):
     @torch.no_grad()
     def compute_geometry(self, pointcloud):
         """Everything in the backbone that depends on the point COORDINATES only (not on any
-        learned weight): the four furthest-point samplings.  Being data-only, it can be computed
+        learned weight): the four furthest-point samplings and the four ball queries.  Being data-only, it can be computed
         for the NEXT batch on a side stream while the current step trains (votenet/step.py),
         which takes the strictly serial FPS rounds (a handful of busy CUs) off the critical
-        path.  Returns {"sa1_inds", ..., "sa4_inds"} (int32)."""
+        path.  Returns {"sa<i>_inds", "sa<i>_ball_idx"} (int32)."""
         from pointnet2 import pointnet2_utils
         xyz = pointcloud[..., 0:3].contiguous()
         geometry = {}
         for i in range(1, 5):
-            npoint = getattr(self, "sa%d" % i).npoint
-            inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
+            sa = getattr(self, "sa%d" % i)
+            inds = pointnet2_utils.furthest_point_sample(xyz, sa.npoint)
+            new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(),
+                                                       inds).transpose(1, 2).contiguous()
             geometry["sa%d_inds" % i] = inds
-            xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(),
-                                                   inds).transpose(1, 2).contiguous()
-        geometry["seed_xyz"] = None
+            geometry["sa%d_ball_idx" % i] = pointnet2_utils.ball_query(sa.radius, sa.nsample, xyz,
+                                                                       new_xyz)
+            xyz = new_xyz
         return geometry
 
     def forward(self, pointcloud, end_points=None, geometry=None):
@@ -63,7 +65,8 @@ class Pointnet2Backbone(nn.Module):
         xyz, features = self._break_up_pc(pointcloud)
         for i in range(1, 5):
             given = geometry["sa%d_inds" % i] if geometry is not None else None
-            xyz, features, inds = getattr(self, "sa%d" % i)(xyz, features, given)
+            ball = geometry.get("sa%d_ball_idx" % i) if geometry is not None else None
+            xyz, features, inds = getattr(self, "sa%d" % i)(xyz, features, given, ball)
             end_points["sa%d_xyz" % i] = xyz
             end_points["sa%d_features" % i] = features
             if i <= 2:

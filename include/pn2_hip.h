@@ -108,6 +108,12 @@ int pn2_query_and_group(int b, int n, int m, int c, float radius, int nsample, i
                         int *idx, float *out, void *workspace, size_t workspace_bytes,
                         void *stream);
 
+/* Second half of pn2_query_and_group alone, for an idx computed earlier (e.g. one step ahead on a
+ * side stream): the gathers + centroid subtraction + concatenation of pointnet2_utils.py:348-358. */
+int pn2_group_concat(int b, int n, int m, int c, float radius, int nsample, int normalize_xyz,
+                     const float *new_xyz, const float *xyz, const float *features,
+                     const int *idx, float *out, void *stream);
+
 /* Human-readable text for a non-zero return value (hipGetErrorString); stands in for the
  * message the reference prints before exit(-1) in CUDA_CHECK_ERRORS (cuda_utils.h:35-44). */
 const char *pn2_error_string(int code);

@@ -36,9 +36,10 @@ def make(oracle):
     m.group_points = lambda p, i: t(oracle.group_points(n(p), n(i)))
     m.group_points_grad = lambda g, i, nn: t(oracle.group_points_grad(n(g), n(i), nn))
 
-    def query_and_group(new_xyz, xyz, features, radius, nsample, normalize_xyz):
+    def query_and_group(new_xyz, xyz, features, radius, nsample, normalize_xyz, idx=None):
         # the reference composition, pointnet2_utils.py:335-358
-        idx = m.ball_query(new_xyz, xyz, radius, nsample)
+        if idx is None:
+            idx = m.ball_query(new_xyz, xyz, radius, nsample)
         gx = m.group_points(xyz.detach().transpose(1, 2).contiguous(), idx)
         gx = gx - new_xyz.detach().transpose(1, 2).unsqueeze(-1)
         if normalize_xyz:
