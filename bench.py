@@ -236,9 +236,15 @@ def main():
         if not args.no_kernels:
             table, pair_us = kernel_table(device)
             achieved = PAIR_BYTES / (pair_us * 1e-6) / 1e9
+            # HBM bytes per pair from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+            # WRITE_SIZE in separate runs, gfx950 correction applied; profiles/r1_pair_pmc.json)
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r1_pair_pmc.json")
+            if os.path.exists(pmc):
+                traffic = json.load(open(pmc)).get("traffic_bytes_per_pair")
             out["roofline"] = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "ball_query + group_points(xyz,C=3) + group_points(feat,C=1) @ B=8 "
                           "N=40000 m=2048 ns=64", "algorithmic_bytes": PAIR_BYTES,
                 "duration_us": round(pair_us, 2)}
