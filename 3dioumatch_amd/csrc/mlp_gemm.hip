@@ -63,6 +63,36 @@ __device__ __forceinline__ float transform(float x, float dz, const RowCoef &c) 
   return c.a * (g - c.c1 - ((x - c.mu) * c.is) * c.c2);
 }
 
+// raw loads of N consecutive elements (x, and dz for OP_DY); zero outside the row / limit
+template <int MODE, int N>
+__device__ __forceinline__ void load_raw_segment(const OperandB &op, size_t off, int gr, int limit,
+                                                 bool vec_ok, bool row_ok, float *x, float *dz) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) { x[i] = 0.f; dz[i] = 0.f; }
+  if (!row_ok) return;
+  if (vec_ok) {
+#pragma unroll
+    for (int i = 0; i < N; i += 4) {
+      if (gr + i < limit) {
+        const float4 v = *reinterpret_cast<const float4 *>(op.x + off + i);
+        x[i] = v.x; x[i + 1] = v.y; x[i + 2] = v.z; x[i + 3] = v.w;
+        if (MODE == OP_DY) {
+          const float4 d = *reinterpret_cast<const float4 *>(op.dz + off + i);
+          dz[i] = d.x; dz[i + 1] = d.y; dz[i + 2] = d.z; dz[i + 3] = d.w;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (gr + i < limit) {
+        x[i] = op.x[off + i];
+        if (MODE == OP_DY) dz[i] = op.dz[off + i];
+      }
+    }
+  }
+}
+
 // N consecutive elements of one operand row starting at element offset `off` (column gr of
 // r): 16-byte loads when the row length allows, scalars (with tail guard) otherwise
 template <int MODE, int N>
@@ -123,30 +153,52 @@ gemm_nn_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-  for (int k0 = 0; k0 < k_total; k0 += KC) {
-    __syncthreads();
-    // A chunk: TM x KC, consecutive lanes along k (contiguous in memory)
-    for (int t = tid; t < TM * KC; t += 256) {
+  // Software pipeline: the global loads of chunk i+1 are issued before the MFMAs of chunk i and
+  // only waited for (and transformed) when they are stored to LDS, so HBM/L2 latency hides
+  // under the matrix pipe.
+  constexpr int AE = TM * KC / 256;  // A elements per lane
+  constexpr int SEG = TN / 16;       // B elements per lane: 16 lanes share one row
+  const int bkk = tid >> 4, bnn = (tid & 15) * SEG;
+  const bool vec_ok = (r & 3) == 0;
+  float areg[AE], bx[SEG], bdz[SEG];
+  RowCoef rc;
+  bool brow_ok = false;
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < AE; ++e) {
+      const int t = tid + e * 256;
       const int kk = t % KC, mm = t / KC;
       const int gm = m0 + mm, gk = k0 + kk;
-      As[kk * LDA + mm] = (gm < m_total && gk < k_total) ? a[(size_t)gm * lda + gk] : 0.f;
+      areg[e] = (gm < m_total && gk < k_total) ? a[(size_t)gm * lda + gk] : 0.f;
     }
-    // B chunk: KC x TN; a lane owns TN/16 consecutive columns of ONE row (row constants in
-    // registers, 16-byte loads and LDS stores)
-    {
-      constexpr int SEG = TN / 16;
-      const int kk = tid >> 4, nn = (tid & 15) * SEG;
-      const int gk = k0 + kk, gr = r0 + nn;
-      const bool row_ok = gk < k_total;
-      const RowCoef rc = load_row_coef<MODE>(op, gk, row_ok);
-      float v[SEG];
-      load_row_segment<MODE, SEG>(op, in_off + (size_t)gk * r + gr, gr, r, (r & 3) == 0, row_ok,
-                                  rc, v);
+    const int gk = k0 + bkk;
+    brow_ok = gk < k_total;
+    rc = load_row_coef<MODE>(op, gk, brow_ok);
+    load_raw_segment<MODE, SEG>(op, in_off + (size_t)gk * r + r0 + bnn, r0 + bnn, r, vec_ok,
+                                brow_ok, bx, bdz);
+  };
+  auto stash = [&]() {
 #pragma unroll
-      for (int i = 0; i < SEG; i += 4)
-        *reinterpret_cast<float4 *>(&Bs[kk * TN + nn + i]) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+    for (int e = 0; e < AE; ++e) {
+      const int t = tid + e * 256;
+      As[(t % KC) * LDA + t / KC] = areg[e];
     }
+#pragma unroll
+    for (int i = 0; i < SEG; i += 4) {
+      float4 v;
+      v.x = (brow_ok && r0 + bnn + i + 0 < r) ? transform<MODE>(bx[i + 0], bdz[i + 0], rc) : 0.f;
+      v.y = (brow_ok && r0 + bnn + i + 1 < r) ? transform<MODE>(bx[i + 1], bdz[i + 1], rc) : 0.f;
+      v.z = (brow_ok && r0 + bnn + i + 2 < r) ? transform<MODE>(bx[i + 2], bdz[i + 2], rc) : 0.f;
+      v.w = (brow_ok && r0 + bnn + i + 3 < r) ? transform<MODE>(bx[i + 3], bdz[i + 3], rc) : 0.f;
+      *reinterpret_cast<float4 *>(&Bs[bkk * TN + bnn + i]) = v;
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < k_total; k0 += KC) {
+    __syncthreads();  // the MFMAs of the previous chunk are done with LDS
+    stash();
     __syncthreads();
+    if (k0 + KC < k_total) fetch(k0 + KC);
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 2) {
       const int krow = kk + (lane >> 5);
@@ -183,11 +235,14 @@ gemm_nn_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int
 // workgroup, waves 2x2, each 64x32; the R axis is staged [r][m] / [r][k] in LDS.
 constexpr int RC = 32;  // r chunk (128-byte row segments per load)
 
-template <int PMODE, int QMODE>
+template <int PMODE, int QMODE, int TK>
 __global__ void __launch_bounds__(256)
 gemm_wgrad_kernel(int m_total, int k_total, int r, int r_per_slice, OperandB opp, OperandB opq,
                   float *__restrict__ part, size_t p_stride, size_t q_stride) {
-  constexpr int TM = 128, TK = 64;
+  constexpr int TM = 128;
+  constexpr int KBLK = TK / 64;           // 32-wide k blocks per wave (waves 2 x 2)
+  constexpr int QE = TK * RC / 256;       // Q elements per lane (8 or 16)
+  constexpr int QL = 256 / TK;            // lanes per Q row (4 or 2)
   constexpr int LDP = TM + 1, LDQ = TK + 1;
   __shared__ float Ps[RC * LDP];
   __shared__ float Qs[RC * LDQ];
@@ -201,52 +256,69 @@ gemm_wgrad_kernel(int m_total, int k_total, int r, int r_per_slice, OperandB opp
   OperandB P = opp, Q = opq;
   const size_t p_off = (size_t)b * p_stride, q_off = (size_t)b * q_stride;
 
-  f32x16 acc[2];
+  f32x16 acc[2][KBLK];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+    for (int j = 0; j < KBLK; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
   // fixed ownership: lane t loads row (t/2) of P, 16 consecutive r; row (t/4) of Q, 8
-  // consecutive r -- so the per-row constants live in registers for the whole kernel
+  // consecutive r -- so the per-row constants live in registers for the whole kernel.  The raw
+  // loads of chunk i+1 are issued before the MFMAs of chunk i (register prefetch).
   const int pm = tid >> 1, pr = (tid & 1) * 16;
-  const int qk = tid >> 2, qr = (tid & 3) * 8;
+  const int qk = tid / QL, qr = (tid % QL) * QE;
   const bool p_ok = m0 + pm < m_total, q_ok = k0 + qk < k_total;
   const RowCoef pc = load_row_coef<PMODE>(P, m0 + pm, p_ok);
   const RowCoef qc = load_row_coef<QMODE>(Q, k0 + qk, q_ok);
   const size_t p_row = p_off + (size_t)(m0 + pm) * r, q_row = q_off + (size_t)(k0 + qk) * r;
+  const bool vec_ok = ((r | r_hi) & 3) == 0;
+  float px[16], pdz[16], qx[QE], qdz[QE];
+  auto fetch = [&](int rr) {
+    load_raw_segment<PMODE, 16>(P, p_row + rr + pr, rr + pr, r_hi, vec_ok, p_ok, px, pdz);
+    load_raw_segment<QMODE, QE>(Q, q_row + rr + qr, rr + qr, r_hi, vec_ok, q_ok, qx, qdz);
+  };
+  fetch(r_lo);
   for (int rr = r_lo; rr < r_hi; rr += RC) {
-    float pv[16], qv[8];
-    const bool vec_ok = ((r | r_hi) & 3) == 0;
-    load_row_segment<PMODE, 16>(P, p_row + rr + pr, rr + pr, r_hi, vec_ok, p_ok, pc, pv);
-    load_row_segment<QMODE, 8>(Q, q_row + rr + qr, rr + qr, r_hi, vec_ok, q_ok, qc, qv);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) Ps[(pr + i) * LDP + pm] = pv[i];
+    for (int i = 0; i < 16; ++i)
+      Ps[(pr + i) * LDP + pm] =
+          (p_ok && rr + pr + i < r_hi) ? transform<PMODE>(px[i], pdz[i], pc) : 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) Qs[(qr + i) * LDQ + qk] = qv[i];
+    for (int i = 0; i < QE; ++i)
+      Qs[(qr + i) * LDQ + qk] =
+          (q_ok && rr + qr + i < r_hi) ? transform<QMODE>(qx[i], qdz[i], qc) : 0.f;
     __syncthreads();
+    if (rr + RC < r_hi) fetch(rr + RC);
 #pragma unroll
     for (int ri = 0; ri < RC; ri += 2) {
       const int row = ri + (lane >> 5);
-      const float bq = Qs[row * LDQ + wk * 32 + (lane & 31)];
+      float bq[KBLK], ap[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const float ap = Ps[row * LDP + (wm * 2 + i) * 32 + (lane & 31)];
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap, bq, acc[i], 0, 0, 0);
-      }
+      for (int j = 0; j < KBLK; ++j) bq[j] = Qs[row * LDQ + (wk * KBLK + j) * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) ap[i] = Ps[row * LDP + (wm * 2 + i) * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < KBLK; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i], bq[j], acc[i][j], 0, 0, 0);
     }
   }
   float *out = part + (size_t)blockIdx.z * m_total * k_total;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int col = k0 + wk * 32 + (lane & 31);
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int row = m0 + (wm * 2 + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-      if (row < m_total && col < k_total) out[(size_t)row * k_total + col] = acc[i][q];
+    for (int j = 0; j < KBLK; ++j) {
+      const int col = k0 + (wk * KBLK + j) * 32 + (lane & 31);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = m0 + (wm * 2 + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (row < m_total && col < k_total) out[(size_t)row * k_total + col] = acc[i][j][q];
+      }
     }
-  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -323,8 +395,12 @@ MLP_API int mlp_gemm_dgrad(int b, int m, int k, int r, const float *wt, int mode
 
 // R is cut into slices so that about 512 workgroups are in flight (tiles x clouds x slices);
 // every slice writes its own partial dW, reduced afterwards (deterministic, no atomics).
+// 64-wide k tiles measured faster than 128-wide ones on every layer shape (register pressure
+// of four accumulators + the raw operand prefetch outweighs the saved re-reads)
+static int wgrad_tile_k(int k) { (void)k; return 64; }
+
 static int wgrad_r_per_slice(int b, int m, int k, int r) {
-  const long long tiles = (long long)pn2_ceil_div(k, 64) * pn2_ceil_div(m, 128) * b;
+  const long long tiles = (long long)pn2_ceil_div(k, wgrad_tile_k(k)) * pn2_ceil_div(m, 128) * b;
   long long slices = (512 + tiles - 1) / tiles;
   if (slices < 1) slices = 1;
   long long per = (r + slices - 1) / slices;
@@ -353,11 +429,18 @@ MLP_API int mlp_gemm_wgrad(int b, int m, int k, int r, int pmode, const float *d
   OperandB P = pmode == OP_DIRECT ? OperandB{dy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
                                   : OperandB{y, dz, scale, shift, mean, invstd, coef};
   OperandB Q = {x, nullptr, xscale, xshift, nullptr, nullptr, nullptr};
-  dim3 grid(pn2_ceil_div(k, 64), pn2_ceil_div(m, 128), b * slices);
+  const int tk = wgrad_tile_k(k);
+  dim3 grid(pn2_ceil_div(k, tk), pn2_ceil_div(m, 128), b * slices);
   const size_t ps = (size_t)m * r, qs = (size_t)k * r;
-#define WG(PM, QM)                                                                            \
-  hipLaunchKernelGGL((gemm_wgrad_kernel<PM, QM>), grid, dim3(256), 0, stream, m, k, r, per, P, Q, \
-                     workspace, ps, qs)
+#define WG(PM, QM)                                                                              \
+  do {                                                                                          \
+    if (tk == 64)                                                                               \
+      hipLaunchKernelGGL((gemm_wgrad_kernel<PM, QM, 64>), grid, dim3(256), 0, stream, m, k, r,  \
+                         per, P, Q, workspace, ps, qs);                                         \
+    else                                                                                        \
+      hipLaunchKernelGGL((gemm_wgrad_kernel<PM, QM, 128>), grid, dim3(256), 0, stream, m, k, r, \
+                         per, P, Q, workspace, ps, qs);                                         \
+  } while (0)
   if (pmode == OP_DIRECT && qmode == OP_DIRECT) WG(OP_DIRECT, OP_DIRECT);
   else if (pmode == OP_DIRECT) WG(OP_DIRECT, OP_BNRELU);
   else if (qmode == OP_DIRECT) WG(OP_DY, OP_DIRECT);
