@@ -15,6 +15,30 @@ static inline int pn2_launch_status() { return (int)hipGetLastError(); }
 
 static inline int pn2_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Zero `bytes` (a multiple of 4) of device memory with an ordinary kernel.  Used instead of
+// hipMemsetAsync so that, when the caller's stream is being captured into a HIP graph, the
+// clear is a plain kernel node ordered like every other launch.
+static __global__ void __launch_bounds__(256) pn2_zero_words_kernel(unsigned int *p, size_t words) {
+  const size_t stride = (size_t)gridDim.x * 256 * 4;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < words; i += stride) {
+    if (i + 4 <= words && ((size_t)(p + i) & 15) == 0) {
+      *reinterpret_cast<uint4 *>(p + i) = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+      for (size_t j = i; j < words && j < i + 4; ++j) p[j] = 0u;
+    }
+  }
+}
+
+static inline int pn2_zero_async(void *ptr, size_t bytes, hipStream_t stream) {
+  const size_t words = bytes / 4;
+  if (words == 0) return 0;
+  long long blocks = (long long)((words + 1023) / 1024);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pn2_zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                     (unsigned int *)ptr, words);
+  return (int)hipGetLastError();
+}
+
 // (ax-bx)^2 + (ay-by)^2 + (az-bz)^2, left to right, each op rounded to fp32.
 // This is the expression every reference kernel uses for a squared distance
 // (ball_query_gpu.cu:36-37, interpolate_gpu.cu:39, sampling_gpu.cu:108-109).

@@ -239,7 +239,7 @@ IOU3D_API int iou3d_nms(const float *boxes, int boxes_num, float thresh, int nor
                         unsigned long long *mask_ws, long long *keep_dev, int *num_out_dev,
                         void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (boxes_num <= 0) return (int)hipMemsetAsync(num_out_dev, 0, sizeof(int), stream);
+  if (boxes_num <= 0) return pn2_zero_async(num_out_dev, sizeof(int), stream);
   int rc = launch_mask(boxes, mask_ws, boxes_num, thresh, normal != 0, 0, stream);
   if (rc != 0) return rc;
   const int col_blocks = (boxes_num + 63) / 64;

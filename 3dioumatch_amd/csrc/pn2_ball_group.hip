@@ -252,7 +252,7 @@ PN2_API int pn2_ball_query(int b, int n, int m, float radius, int nsample, const
   if (b <= 0 || m <= 0 || nsample <= 0) return 0;
   hipStream_t stream = (hipStream_t)stream_;
   if (n <= 0) {
-    return (int)hipMemsetAsync(idx, 0, sizeof(int) * (size_t)b * m * nsample, stream);
+    return pn2_zero_async(idx, sizeof(int) * (size_t)b * m * nsample, stream);
   }
   int handled = 0;
   const int rc = pn2_ball_query_grid_try(b, n, m, radius, nsample, new_xyz, xyz, idx, workspace,
@@ -333,8 +333,8 @@ PN2_API int pn2_group_points_grad(int b, int c, int n, int npoints, int nsample,
     }
     return pn2_launch_status();
   }
-  hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * n, stream);
-  if (e != hipSuccess) return (int)e;
+  const int e = pn2_zero_async(grad_points, sizeof(float) * (size_t)b * c * n, stream);
+  if (e != 0) return e;
   if (mns <= 0) return 0;
   dim3 grid(pn2_ceil_div(mns, 1024), channel_groups(c, 8), b);
   if (mns % 4 == 0)

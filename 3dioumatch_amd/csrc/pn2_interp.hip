@@ -165,8 +165,8 @@ PN2_API int pn2_three_interpolate_grad(int b, int c, int n, int m, const float *
                                        void *stream_) {
   if (b <= 0 || c <= 0 || m <= 0) return 0;
   hipStream_t stream = (hipStream_t)stream_;
-  hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * m, stream);
-  if (e != hipSuccess) return (int)e;
+  const int e = pn2_zero_async(grad_points, sizeof(float) * (size_t)b * c * m, stream);
+  if (e != 0) return e;
   if (n <= 0) return 0;
   dim3 grid(pn2_ceil_div(n, 256), interp_channel_groups(c), b);
   hipLaunchKernelGGL(three_interpolate_grad_kernel, grid, dim3(256), 0, stream, c, n, m,

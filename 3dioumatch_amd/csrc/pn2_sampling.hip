@@ -230,8 +230,8 @@ PN2_API int pn2_gather_points_grad(int b, int c, int n, int npoints, const float
                                    const int *idx, float *grad_points, void *stream_) {
   if (b <= 0 || c <= 0 || n <= 0) return 0;
   hipStream_t stream = (hipStream_t)stream_;
-  hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * n, stream);
-  if (e != hipSuccess) return (int)e;
+  const int e = pn2_zero_async(grad_points, sizeof(float) * (size_t)b * c * n, stream);
+  if (e != 0) return e;
   if (npoints <= 0) return 0;
   dim3 grid(pn2_ceil_div(npoints, 256), c < 65535 ? c : 65535, b);
   hipLaunchKernelGGL(gather_points_grad_kernel, grid, dim3(256), 0, stream, c, n, npoints,

@@ -154,9 +154,13 @@ def three_interpolate_grad(grad_out, idx, weight, m):
 
 
 def _ball_ws(t, b, n, m, nsample):
+    """Private scratch per call, from torch's stream-aware caching allocator: ball queries run
+    concurrently on the prefetch stream and on the main stream, so a shared buffer would race."""
     need = int(_lib.pn2_ball_query_workspace_bytes(b, n, m, nsample))
-    buf, size = _L.workspace(t.device, need)
-    return (buf.data_ptr() if buf is not None else None), size
+    if need <= 0:
+        return None, None, 0
+    buf = torch.empty(need, dtype=torch.uint8, device=t.device)
+    return buf, buf.data_ptr(), need
 
 
 def ball_query(new_xyz, xyz, radius, nsample):
@@ -168,7 +172,7 @@ def ball_query(new_xyz, xyz, radius, nsample):
     nsample = int(nsample)
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
     with torch.cuda.device(new_xyz.device):
-        ws, ws_size = _ball_ws(new_xyz, b, n, m, nsample)
+        ws_buf, ws, ws_size = _ball_ws(new_xyz, b, n, m, nsample)
         _L.check(_lib.pn2_ball_query(b, n, m, float(radius), nsample, new_xyz.data_ptr(),
                                      xyz.data_ptr(), idx.data_ptr(), ws, ws_size,
                                      _stream(new_xyz)), "ball_query")
@@ -228,7 +232,7 @@ def query_and_group(new_xyz, xyz, features, radius, nsample, normalize_xyz, idx=
         return idx, out
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
     with torch.cuda.device(new_xyz.device):
-        ws, ws_size = _ball_ws(new_xyz, b, n, m, nsample)
+        ws_buf, ws, ws_size = _ball_ws(new_xyz, b, n, m, nsample)
         _L.check(_lib.pn2_query_and_group(b, n, m, c, float(radius), nsample,
                                           1 if normalize_xyz else 0, new_xyz.data_ptr(),
                                           xyz.data_ptr(), fptr, idx.data_ptr(), out.data_ptr(),

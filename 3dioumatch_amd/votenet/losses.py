@@ -50,7 +50,7 @@ def _labels(end_points, inds):
     never be matched (loss_helper_iou.py:56-58)."""
     center = end_points['center_label'][inds, ...].clone()
     empty = (1 - end_points['box_label_mask'][inds, ...]).unsqueeze(-1).expand(-1, -1, 3).bool()
-    center[empty] = -1000
+    center = torch.where(empty, torch.full_like(center, -1000), center)
     return (center, end_points['heading_class_label'][inds, ...],
             end_points['heading_residual_label'][inds, ...],
             end_points['size_class_label'][inds, ...],
@@ -85,9 +85,20 @@ def compute_objectness_loss(end_points, supervised_inds):
     label = (dist < NEAR_THRESHOLD).long()
     mask = ((dist < NEAR_THRESHOLD) | (dist > FAR_THRESHOLD)).float()
     scores = end_points['objectness_scores'][supervised_inds, ...]
-    weights = torch.tensor(OBJECTNESS_CLS_WEIGHTS, device=scores.device)
+    weights = _objectness_weights(scores.device)
     ce = F.cross_entropy(scores.transpose(2, 1), label, weight=weights, reduction='none')
     return _masked_mean(ce, mask), label, mask, ind1
+
+
+_WEIGHTS_ON = {}
+
+
+def _objectness_weights(device):
+    """The class weights, uploaded once per device (a host->device copy per step would also be
+    illegal inside a HIP-graph capture)."""
+    if device not in _WEIGHTS_ON:
+        _WEIGHTS_ON[device] = torch.tensor(OBJECTNESS_CLS_WEIGHTS, device=device)
+    return _WEIGHTS_ON[device]
 
 
 def _block_diagonal_max(iou, b, pred_num):
@@ -236,7 +247,9 @@ def compute_box_and_sem_cls_loss(end_points, supervised_inds, dataset_config, co
 def get_labeled_loss(end_points, dataset_config, config_dict=None):
     """10 * (vote + 0.5*objectness + box + 0.1*sem_cls + iou [+ jitter_iou]) over the samples
     with supervised_mask == 1; fills end_points with every intermediate loss / statistic."""
-    supervised_inds = torch.nonzero(end_points['supervised_mask']).squeeze(1).long()
+    supervised_inds = end_points.get('supervised_inds')  # static under HIP-graph capture
+    if supervised_inds is None:
+        supervised_inds = torch.nonzero(end_points['supervised_mask']).squeeze(1).long()
 
     end_points['vote_loss'] = compute_vote_loss(end_points, supervised_inds)
     objectness_loss, objectness_label, objectness_mask, object_assignment = \

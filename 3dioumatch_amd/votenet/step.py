@@ -9,12 +9,17 @@ data-parallel over one node.
 
 Parallelism (new -- the reference only has a broken nn.DataParallel branch):
 one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm, "gloo" in the
-CPU tests), DistributedDataParallel with ONE gradient bucket (1 063 985 fp32 = 4.26 MB, so a
-single all-reduce per step that overlaps the tail of backward), per-replica BatchNorm buffers
-like the reference's per-GPU BatchNorm (no SyncBN; broadcast_buffers=False).  Each rank draws
-its own scenes (weak scaling).  The custom forward is reached through nn.Module.__call__
-(`model(batch, mode="jitter")`) so that DDP's hooks fire.
+CPU tests), all parameters live in ONE flat buffer (1 063 985 fp32 = 4.26 MB) and so do the gradients, so
+the data-parallel exchange is a single all-reduce per step between the backward graph and the
+Adam graph (a 4 MB ring all-reduce is tens of microseconds on xGMI; there is nothing worth
+overlapping).  BatchNorm buffers stay per replica like the reference's per-GPU BatchNorm (no
+SyncBN).  Each rank draws its own scenes (weak scaling).  `wrap_ddp` remains for callers that
+want torch's DistributedDataParallel around the module (the custom forward is reachable through
+nn.Module.__call__, `model(batch, mode="jitter")`, so that DDP's hooks fire).
 """
+import os
+import sys
+
 import numpy as np
 import torch
 
@@ -64,37 +69,147 @@ def update_ema_variables(model, ema_model, alpha, global_step):
     torch._foreach_add_(ema_params, params, alpha=1 - a)
 
 
-class SupervisedStep(object):
-    """One optimisation step on a labeled batch (dict of tensors already on `device`)."""
+def flatten_parameters(module):
+    """Re-home every parameter of `module` as a view into ONE contiguous fp32 buffer (in
+    parameters() order) and return that buffer as an nn.Parameter.  Gradient exchange, the Adam
+    update and the EMA teacher then each touch a single 4.26 MB tensor instead of 96 small ones.
+    state_dict()/load_state_dict() keep working (they copy in place)."""
+    params = list(module.parameters())
+    total = sum(p.numel() for p in params)
+    flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
+    off = 0
+    for p in params:
+        n = p.numel()
+        flat[off:off + n].copy_(p.data.reshape(-1))
+        p.data = flat[off:off + n].view(p.shape)
+        off += n
+    return torch.nn.Parameter(flat, requires_grad=True)
 
-    def __init__(self, cfg, device, world_size=1, num_proposal=256, lr=1e-3, seed=0):
+
+def _tensor_items(batch):
+    return {k: v for k, v in batch.items() if torch.is_tensor(v)}
+
+
+class SupervisedStep(object):
+    """One optimisation step on a labeled batch (dict of tensors already on `device`).
+
+    On the GPU the step is three HIP graphs, captured on the first call and replayed afterwards
+    (about 1100 kernel launches per step, three quarters of them shorter than 10 us: replaying
+    them removes the host from the critical path):
+
+        G0  coordinate-only index chain (FPS x5, ball queries) of the NEXT batch, replayed on a
+            side stream by prefetch_geometry() so it overlaps the dense kernels of this step
+        G1  forward_with_pred_jitter -> get_labeled_loss -> backward -> gradients packed into
+            one flat buffer
+        --  world_size > 1: ONE all-reduce of the flat gradient (RCCL / gloo), between graphs
+        G2  Adam on the flat parameter buffer
+
+    Inputs are staged into static buffers (`next` while G0 runs, copied to `cur` for G1).  The
+    graphs bake in tensor shapes, the set of supervised samples and the BatchNorm momentum; a
+    change of any of them re-captures.  On the CPU (tests, gloo) the same functions run eagerly.
+    """
+
+    def __init__(self, cfg, device, world_size=1, num_proposal=256, lr=1e-3, seed=0, graphs=None):
         self.cfg = cfg
         self.device = device
+        self.world = world_size
         self.net = build_detector(cfg, num_proposal=num_proposal, seed=seed).to(device).train()
-        self.model = wrap_ddp(self.net, device, world_size)
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=0)
+        self.model = self.net  # callers reach the custom forward through model(batch, mode=...)
+        self._params = list(self.net.parameters())
+        self.flat_params = flatten_parameters(self.net)
+        self.flat_grad = torch.zeros_like(self.flat_params.data)
+        self.flat_params.grad = self.flat_grad
+        on_gpu = device.type == "cuda"
+        self.graphs = on_gpu if graphs is None else (bool(graphs) and on_gpu)
+        if os.environ.get("VOTENET_HIP_GRAPHS", "1") == "0":
+            self.graphs = False
+        lr_value = torch.tensor(float(lr), device=device) if on_gpu else lr
+        self.optimizer = torch.optim.Adam([self.flat_params], lr=lr_value, weight_decay=0,
+                                          capturable=on_gpu)
         self._side = None
+        self._captured = None  # signature the graphs were captured for
+        self._token = 0
 
+    # ---------------------------------------------------------------- schedules
     def set_epoch(self, epoch, base_lr=1e-3):
         for group in self.optimizer.param_groups:
-            group["lr"] = lr_at(epoch, base_lr)
+            if torch.is_tensor(group["lr"]):
+                group["lr"].fill_(lr_at(epoch, base_lr))
+            else:
+                group["lr"] = lr_at(epoch, base_lr)
         momentum = bn_momentum_at(epoch)
         for m in self.net.modules():
             if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)):
+                if m.momentum != momentum:
+                    self._captured = None  # the momentum is a kernel argument baked into G1
                 m.momentum = momentum
 
+    # ---------------------------------------------------------------- the step, eagerly
+    def _forward_backward(self, batch):
+        for p in self._params:
+            p.grad = None
+        end_points = self.model(batch, mode="jitter")
+        end_points.update({k: v for k, v in batch.items() if torch.is_tensor(v)})
+        loss, end_points = get_labeled_loss(end_points, self.cfg, {"dataset_config": self.cfg})
+        loss.backward()
+        self._pack_gradients()
+        return loss, end_points
+
+    def _pack_gradients(self):
+        """p.grad (fresh tensors from autograd) -> flat_grad, one concatenation kernel."""
+        if all(p.grad is not None for p in self._params):
+            torch.cat([p.grad.reshape(-1) for p in self._params], out=self.flat_grad)
+            return
+        self.flat_grad.zero_()
+        off = 0
+        for p in self._params:
+            if p.grad is not None:
+                self.flat_grad[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            off += p.numel()
+
+    def _exchange_gradients(self):
+        """Data parallelism: the mean of the per-rank gradients, one collective per step."""
+        if self.world > 1:
+            torch.distributed.all_reduce(self.flat_grad)
+
+    def _apply(self):
+        if self.world > 1:
+            self.flat_grad.mul_(1.0 / self.world)
+        self.optimizer.step()
+
+    def _expose_gradients(self):
+        """Point every p.grad at its slice of the (averaged) flat gradient."""
+        off = 0
+        for p in self._params:
+            p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+
+    # ---------------------------------------------------------------- geometry prefetch
     def prefetch_geometry(self, batch):
-        """Launch the coordinate-only index computations (FPS chain) of `batch` on a side
-        stream; the step that later consumes `batch` waits for them.  Call it for batch i+1
-        right before running the step on batch i: the serial FPS rounds then overlap the
-        dense kernels of step i instead of heading step i+1's critical path."""
+        """Launch the coordinate-only index computations (FPS chain, ball queries) of `batch`
+        on a side stream; the step that later consumes `batch` waits for them.  Call it for
+        batch i+1 right before running the step on batch i: the serial FPS rounds then overlap
+        the dense kernels of step i instead of heading step i+1's critical path."""
         if self.device.type != "cuda":
             batch["geometry"] = self.net.compute_geometry(batch)
             return
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream(self.device)
-        self._side.wait_stream(main)  # inputs produced on the main stream are ready
+        if self.graphs and self._ensure_captured(batch):
+            slot = self._slots[self._turn]
+            self._turn ^= 1
+            self._side.wait_stream(main)  # inputs are ready; the slot's last consumer is done
+            with torch.cuda.stream(self._side):
+                self._stage(slot, batch)
+                slot["graph"].replay()
+                slot["ready"].record(self._side)
+            self._token += 1
+            slot["token"] = self._token
+            batch["geometry"] = slot["geometry"]
+            batch["_staged"] = (slot, self._token)
+            return
+        self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             geometry = self.net.compute_geometry(batch)
             done = torch.cuda.Event()
@@ -105,17 +220,141 @@ class SupervisedStep(object):
         batch["geometry"] = geometry
         batch["_geometry_ready"] = done
 
+    # ---------------------------------------------------------------- HIP graphs
+    def _signature(self, batch):
+        return tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in _tensor_items(batch).items()))
+
+    def _stage(self, slot, batch):
+        src = _tensor_items(batch)
+        torch._foreach_copy_([slot["inputs"][k] for k in self._keys], [src[k] for k in self._keys])
+
+    def _ensure_captured(self, batch):
+        """Capture G0/G1/G2 for the shapes of `batch` (once).  Returns False -- and switches to
+        the eager path for good -- if the capture is not possible on this stack."""
+        sig = self._signature(batch)
+        if self._captured == sig:
+            return True
+        try:
+            self._capture(batch, sig)
+            return True
+        except Exception as err:  # noqa: BLE001 -- keep training, but say so loudly
+            sys.stderr.write("SupervisedStep: HIP graph capture failed (%s: %s); running the "
+                             "step eagerly\n" % (type(err).__name__, err))
+            torch.cuda.synchronize(self.device)
+            self.graphs = False
+            self._captured = None
+            return False
+
+    def _capture(self, batch, sig):
+        dev = self.device
+        torch.cuda.synchronize(dev)
+        src = _tensor_items(batch)
+        src.pop("supervised_inds", None)
+        self._keys = sorted(src)
+        # two staging slots (inputs + index chain of a prefetched batch) and the buffers G1 reads
+        self._slots = [{"inputs": {k: src[k].clone() for k in self._keys}, "token": -1,
+                        "ready": torch.cuda.Event()} for _ in range(2)]
+        self._turn = 0
+        self._cur = {k: src[k].clone() for k in self._keys}
+        # which samples are supervised is part of the captured control flow (host-side nonzero)
+        # (kept on self: everything a graph reads must outlive the capture)
+        self._supervised_inds = torch.nonzero(src["supervised_mask"]).squeeze(1).long()
+
+        # state touched by the warm-up iterations and by the capture itself
+        buffers = [b for b in self.net.buffers()]
+        saved_buffers = [b.clone() for b in buffers]
+        saved_params = self.flat_params.data.clone()
+        saved_rng = torch.cuda.get_rng_state(dev)
+        had_state = len(self.optimizer.state) > 0
+        saved_opt = {k: v.clone() for k, v in self.optimizer.state.get(self.flat_params, {}).items()
+                     if torch.is_tensor(v)}
+
+        def body_geometry(slot):
+            return self.net.compute_geometry(slot["inputs"])
+
+        def body_step():
+            inputs = dict(self._cur)
+            inputs["geometry"] = self._cur_geometry
+            inputs["supervised_inds"] = self._supervised_inds
+            return self._forward_backward(inputs)
+
+        warm = torch.cuda.Stream(device=dev)
+        warm.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(warm):
+            for _ in range(2):  # lazy initialisations (MIOpen/hipBLASLt handles, autograd)
+                geometry = body_geometry(self._slots[0])
+                self._cur_geometry = {k: v.clone() for k, v in geometry.items()}
+                body_step()
+                self.flat_grad.zero_()
+                self._apply()  # creates the Adam state; a zero gradient leaves the weights alone
+        torch.cuda.current_stream(dev).wait_stream(warm)
+        torch.cuda.synchronize(dev)
+
+        mode = dict(capture_error_mode="thread_local")
+        for slot in self._slots:
+            slot["graph"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(slot["graph"], **mode):
+                slot["geometry"] = body_geometry(slot)
+        self._geo_keys = sorted(k for k, v in self._slots[0]["geometry"].items() if torch.is_tensor(v))
+        self._cur_geometry = {k: self._slots[0]["geometry"][k].clone() for k in self._geo_keys}
+        self._g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g1, **mode):
+            self._loss, self._end_points = body_step()
+        self._g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g2, **mode):
+            self._apply()
+        torch.cuda.synchronize(dev)
+
+        # undo every side effect of warm-up and capture
+        for b, s in zip(buffers, saved_buffers):
+            b.copy_(s)
+        self.flat_params.data.copy_(saved_params)
+        for k, v in self.optimizer.state[self.flat_params].items():
+            if torch.is_tensor(v):
+                v.copy_(saved_opt[k]) if had_state else v.zero_()
+        torch.cuda.set_rng_state(saved_rng, dev)
+        self._expose_gradients()
+        self._copy_dst = [self._cur[k] for k in self._keys] + \
+            [self._cur_geometry[k] for k in self._geo_keys]
+        for slot in self._slots:
+            slot["copy_src"] = [slot["inputs"][k] for k in self._keys] + \
+                [slot["geometry"][k] for k in self._geo_keys]
+        torch.cuda.synchronize(dev)
+        self._captured = sig
+
+    def _replay(self, batch):
+        main = torch.cuda.current_stream(self.device)
+        slot, token = batch.pop("_staged", (None, None))
+        if slot is not None and slot["token"] == token:
+            main.wait_event(slot["ready"])
+        else:  # not prefetched: stage and run the index chain inline
+            slot = self._slots[self._turn]
+            self._turn ^= 1
+            if self._side is not None:
+                main.wait_stream(self._side)  # a prefetch in flight may own the slot
+            self._stage(slot, batch)
+            slot["graph"].replay()
+        slot["token"] = -1
+        torch._foreach_copy_(self._copy_dst, slot["copy_src"])
+        self._g1.replay()
+        self._exchange_gradients()
+        self._g2.replay()
+        batch.pop("geometry", None)
+        return self._loss, self._end_points
+
+    # ---------------------------------------------------------------- entry point
     def __call__(self, batch):
+        if self.graphs and self._ensure_captured(batch):
+            return self._replay(batch)
+        batch.pop("_staged", None)
         ready = batch.pop("_geometry_ready", None)
         if ready is not None:
             torch.cuda.current_stream(self.device).wait_event(ready)
-        self.optimizer.zero_grad(set_to_none=True)
-        end_points = self.model(batch, mode="jitter")
+        loss, end_points = self._forward_backward(batch)
         batch.pop("geometry", None)  # consumed: every step computes (or prefetches) its own
-        end_points.update({k: v for k, v in batch.items() if torch.is_tensor(v)})
-        loss, end_points = get_labeled_loss(end_points, self.cfg, {"dataset_config": self.cfg})
-        loss.backward()
-        self.optimizer.step()
+        self._exchange_gradients()
+        self._apply()
+        self._expose_gradients()
         return loss, end_points
 
 

@@ -59,6 +59,7 @@ def build_step(V, cfg, device, world, local_rank):
         return runner(batch)[0]
 
     step.prefetch = runner.prefetch_geometry
+    step.runner = runner
     return step
 
 
@@ -201,23 +202,25 @@ def main():
     views = [dict(batch), dict(batch)]  # two views of the resident batch: current / next
     if pipelined:
         step.prefetch(views[0])
+    history = torch.zeros(args.warmup + args.steps, device=device)  # loss per step (diagnostics)
     for i in range(args.warmup):
         if pipelined:
             step.prefetch(views[(i + 1) % 2])
-        step(views[i % 2])
+        history[i].copy_(step(views[i % 2]).detach())
     fence()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         if pipelined:
             step.prefetch(views[(i + 1) % 2])
         loss = step(views[i % 2])
+        history[i].copy_(loss.detach())
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert torch.isfinite(loss).item(), "loss diverged"
+    assert torch.isfinite(history).all().item(), "loss diverged: %s" % history.tolist()
 
     if rank == 0:
         ms = elapsed * 1e3 / args.steps
@@ -231,7 +234,8 @@ def main():
                                    "forward_with_pred_jitter + labeled loss + backward + Adam",
                        "per_gpu_batch": B, "global_batch": B * world, "num_points": NPTS,
                        "num_proposals": KPROP, "parallelism": "dp%d" % world,
-                       "fps_prefetch_one_step_ahead": pipelined},
+                       "fps_prefetch_one_step_ahead": pipelined,
+                       "hip_graphs": bool(step.runner.graphs)},
         }
         if not args.no_kernels:
             table, pair_us = kernel_table(device)

@@ -159,3 +159,65 @@ def test_geometry_prefetch_is_equivalent(use_gpu, oracle_omp):
     # gradients: equal up to the order of the fp32 atomics in the scatter-add kernels
     g0, g1 = results[0][3], results[1][3]
     assert float((g0 - g1).norm() / g0.norm()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_graph_replay_matches_eager(oracle_omp):
+    """The three HIP graphs of SupervisedStep (index chain / forward+loss+backward / Adam)
+    replay exactly the eager step: same indices and loss, same parameters after two steps on
+    two different batches (the second one prefetched), same BatchNorm statistics."""
+    V, dev = _setup(True, oracle_omp)
+    cfg = V.scannet_config()
+    data = importlib.import_module("3dioumatch_amd.votenet.data")
+    step_mod = importlib.import_module("3dioumatch_amd.votenet.step")
+    batches = [{k: v.to(dev) for k, v in data.make_batch(B, N, cfg, seed=s, num_objects=5).items()}
+               for s in (44, 45)]
+    results = []
+    for graphs in (False, True):
+        runner = V.SupervisedStep(cfg, dev, world_size=1, num_proposal=K, seed=3, graphs=graphs)
+        assert runner.graphs == graphs
+        torch.manual_seed(9)
+        torch.cuda.manual_seed_all(9)
+        first, second = dict(batches[0]), dict(batches[1])
+        runner.prefetch_geometry(first)
+        runner.prefetch_geometry(second)
+        loss0, ep0 = runner(first)
+        loss0, inds0 = float(loss0), ep0["aggregated_vote_inds"].cpu().clone()
+        loss1, ep1 = runner(second)
+        assert runner.graphs == graphs  # the capture did not fall back
+        results.append((loss0, float(loss1), inds0, ep1["aggregated_vote_inds"].cpu().clone(),
+                        step_mod.flat_params(runner.net).cpu(), step_mod.flat_grads(runner.net).cpu(),
+                        runner.net.backbone_net.sa1.mlp_module.layer0.bn.bn.running_mean.cpu().clone(),
+                        int(runner.net.pnet.bn1.num_batches_tracked)))
+    eager, graph = results
+    assert torch.equal(eager[2], graph[2]) and torch.equal(eager[3], graph[3])
+    assert abs(eager[0] - graph[0]) <= 1e-5 * max(1.0, abs(eager[0]))
+    assert abs(eager[1] - graph[1]) <= 1e-3 * max(1.0, abs(eager[1]))
+    assert float((eager[5] - graph[5]).norm() / eager[5].norm()) < 5e-2  # grads after an Adam step
+    # Adam turns the sign of a near-zero gradient into a full +-lr step: bounded, not tiny
+    assert float((eager[4] - graph[4]).abs().max()) <= 6e-3  # two Adam steps of lr 1e-3
+    assert float((eager[4] - graph[4]).norm() / eager[4].norm()) < 1e-3
+    assert torch.allclose(eager[6], graph[6], rtol=1e-4, atol=1e-6)
+    assert eager[7] == graph[7] == 2
+
+
+@pytest.mark.gpu
+def test_graph_replay_survives_host_syncs(oracle_omp):
+    """Replays separated by device-wide syncs and eager allocations (the pattern that exposed
+    mis-ordered memset nodes: the scatter-add kernels now clear their outputs with a kernel
+    node, csrc/common.h pn2_zero_async) keep every gradient finite."""
+    V, dev = _setup(True, oracle_omp)
+    cfg = V.scannet_config()
+    data = importlib.import_module("3dioumatch_amd.votenet.data")
+    batch = {k: v.to(dev) for k, v in data.make_batch(B, N, cfg, seed=46, num_objects=5).items()}
+    runner = V.SupervisedStep(cfg, dev, world_size=1, num_proposal=K, seed=3, graphs=True)
+    views = [dict(batch), dict(batch)]
+    runner.prefetch_geometry(views[0])
+    for i in range(8):
+        runner.prefetch_geometry(views[(i + 1) % 2])
+        loss, _ = runner(views[i % 2])
+        torch.cuda.synchronize()
+        junk = [torch.isfinite(runner.flat_grad[j::97]).all() for j in range(64)]  # eager allocations
+        assert all(bool(t) for t in junk), i
+        assert bool(torch.isfinite(loss)) and bool(torch.isfinite(runner.flat_params).all()), i
+    assert runner.graphs
