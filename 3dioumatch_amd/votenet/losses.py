@@ -41,6 +41,13 @@ def nn_distance(pc1, pc2, l1smooth=False, delta=1.0, l1=False):
     return dist1, idx1, dist2, idx2
 
 
+def _sel(t, inds):
+    """t[inds, ...]; `inds is None` means every sample is supervised (stage-1 pretraining, and
+    what SupervisedStep passes when supervised_mask is all ones): no gather, no scatter-add in
+    the backward."""
+    return t if inds is None else t[inds, ...]
+
+
 def _masked_mean(values, mask):
     return torch.sum(values * mask) / (torch.sum(mask) + 1e-6)
 
@@ -48,23 +55,22 @@ def _masked_mean(values, mask):
 def _labels(end_points, inds):
     """GT tensors of the supervised samples; empty GT slots get centre -1000 so that they can
     never be matched (loss_helper_iou.py:56-58)."""
-    center = end_points['center_label'][inds, ...].clone()
-    empty = (1 - end_points['box_label_mask'][inds, ...]).unsqueeze(-1).expand(-1, -1, 3).bool()
+    center = _sel(end_points['center_label'], inds)
+    empty = (1 - _sel(end_points['box_label_mask'], inds)).unsqueeze(-1).expand(-1, -1, 3).bool()
     center = torch.where(empty, torch.full_like(center, -1000), center)
-    return (center, end_points['heading_class_label'][inds, ...],
-            end_points['heading_residual_label'][inds, ...],
-            end_points['size_class_label'][inds, ...],
-            end_points['size_residual_label'][inds, ...])
+    return (center, _sel(end_points['heading_class_label'], inds),
+            _sel(end_points['heading_residual_label'], inds),
+            _sel(end_points['size_class_label'], inds),
+            _sel(end_points['size_residual_label'], inds))
 
 
 def compute_vote_loss(end_points, supervised_inds):
     """A seed inside an object must vote for (one of) its object centre(s): min L1 distance
     between the predicted votes and the 3 stored GT votes, averaged over object seeds."""
-    b = supervised_inds.shape[0]
-    seed_xyz = end_points['seed_xyz'][supervised_inds, ...]
-    num_seed = seed_xyz.shape[1]
-    vote_xyz = end_points['vote_xyz'][supervised_inds, ...]
-    seed_inds = end_points['seed_inds'][supervised_inds, ...].long()
+    seed_xyz = _sel(end_points['seed_xyz'], supervised_inds)
+    b, num_seed = seed_xyz.shape[:2]
+    vote_xyz = _sel(end_points['vote_xyz'], supervised_inds)
+    seed_inds = _sel(end_points['seed_inds'], supervised_inds).long()
     mask = torch.gather(end_points['vote_label_mask'], 1, seed_inds)
     gt_votes = torch.gather(end_points['vote_label'], 1,
                             seed_inds.view(b, num_seed, 1).expand(-1, -1, 3 * GT_VOTE_FACTOR))
@@ -78,13 +84,13 @@ def compute_vote_loss(end_points, supervised_inds):
 def compute_objectness_loss(end_points, supervised_inds):
     """Proposals within 0.3 m of a GT centre are positives, beyond 0.6 m negatives, the rest
     ignored; weighted cross-entropy.  Also returns the nearest-GT assignment."""
-    agg = end_points['aggregated_vote_xyz'][supervised_inds, ...]
+    agg = _sel(end_points['aggregated_vote_xyz'], supervised_inds)
     gt_center = _labels(end_points, supervised_inds)[0]
     dist1, ind1, _, _ = nn_distance(agg, gt_center)
     dist = torch.sqrt(dist1 + 1e-6)
     label = (dist < NEAR_THRESHOLD).long()
     mask = ((dist < NEAR_THRESHOLD) | (dist > FAR_THRESHOLD)).float()
-    scores = end_points['objectness_scores'][supervised_inds, ...]
+    scores = _sel(end_points['objectness_scores'], supervised_inds)
     weights = _objectness_weights(scores.device)
     ce = F.cross_entropy(scores.transpose(2, 1), label, weight=weights, reduction='none')
     return _masked_mean(ce, mask), label, mask, ind1
@@ -161,33 +167,33 @@ def compute_box_and_sem_cls_loss(end_points, supervised_inds, dataset_config, co
     sup = supervised_inds
 
     def pick(key):
-        return torch.gather(end_points[key][sup, ...], 1, assign)
+        return torch.gather(_sel(end_points[key], sup), 1, assign)
 
     # centre: chamfer between predicted centres (positives) and GT centres (real boxes)
-    dist1, _, dist2, _ = nn_distance(end_points['center'][sup, ...],
-                                     end_points['center_label'][sup, ...][:, :, 0:3])
-    box_label_mask = end_points['box_label_mask'][sup, ...]
+    dist1, _, dist2, _ = nn_distance(_sel(end_points['center'], sup),
+                                     _sel(end_points['center_label'], sup)[:, :, 0:3])
+    box_label_mask = _sel(end_points['box_label_mask'], sup)
     center_loss = _masked_mean(dist1, obj) + _masked_mean(dist2, box_label_mask)
 
     # heading: class + residual of the assigned GT
     h_cls_label = pick('heading_class_label')
     heading_class_loss = _masked_mean(
-        F.cross_entropy(end_points['heading_scores'][sup, ...].transpose(2, 1), h_cls_label,
+        F.cross_entropy(_sel(end_points['heading_scores'], sup).transpose(2, 1), h_cls_label,
                         reduction='none'), obj)
     h_res_label = pick('heading_residual_label') / (np.pi / nh)
     h_onehot = F.one_hot(h_cls_label, nh).float()
-    h_res_pred = torch.sum(end_points['heading_residuals_normalized'][sup, ...] * h_onehot, -1)
+    h_res_pred = torch.sum(_sel(end_points['heading_residuals_normalized'], sup) * h_onehot, -1)
     heading_reg_loss = _masked_mean(huber_loss(h_res_pred - h_res_label, delta=1.0), obj)
 
     # size: class + normalised residual
     s_cls_label = pick('size_class_label')
     size_class_loss = _masked_mean(
-        F.cross_entropy(end_points['size_scores'][sup, ...].transpose(2, 1), s_cls_label,
+        F.cross_entropy(_sel(end_points['size_scores'], sup).transpose(2, 1), s_cls_label,
                         reduction='none'), obj)
-    s_res_label = torch.gather(end_points['size_residual_label'][sup, ...], 1,
+    s_res_label = torch.gather(_sel(end_points['size_residual_label'], sup), 1,
                                assign.unsqueeze(-1).repeat(1, 1, 3))
     s_onehot = F.one_hot(s_cls_label, ns).float().unsqueeze(-1).repeat(1, 1, 1, 3)
-    s_res_pred = torch.sum(end_points['size_residuals_normalized'][sup, ...] * s_onehot, 2)
+    s_res_pred = torch.sum(_sel(end_points['size_residuals_normalized'], sup) * s_onehot, 2)
     mean_size = dataset_config.mean_size(s_res_pred.device).unsqueeze(0).unsqueeze(0)
     mean_size_label = torch.sum(s_onehot * mean_size, 2)
     size_reg_loss = _masked_mean(
@@ -195,31 +201,31 @@ def compute_box_and_sem_cls_loss(end_points, supervised_inds, dataset_config, co
 
     # semantic class
     sem_label = pick('sem_cls_label')
-    sem_scores = end_points['sem_cls_scores'][sup, ...]
+    sem_scores = _sel(end_points['sem_cls_scores'], sup)
     sem_cls_loss = _masked_mean(
         F.cross_entropy(sem_scores.transpose(2, 1), sem_label, reduction='none'), obj)
     end_points['cls_acc'] = _masked_mean((sem_label == sem_scores.argmax(dim=-1)).float(), obj)
 
     # IoU labels of the decoded predictions, and the IoU-estimation losses
     iou_labels, _, iou_assignment = compute_iou_labels(
-        end_points, sup, end_points['aggregated_vote_xyz'][sup, ...],
-        end_points['center'][sup, ...], None, None, end_points['heading_scores'][sup, ...],
-        end_points['heading_residuals'][sup, ...], end_points['size_scores'][sup, ...],
-        end_points['size_residuals'][sup, ...], config_dict={'dataset_config': dataset_config})
+        end_points, sup, _sel(end_points['aggregated_vote_xyz'], sup),
+        _sel(end_points['center'], sup), None, None, _sel(end_points['heading_scores'], sup),
+        _sel(end_points['heading_residuals'], sup), _sel(end_points['size_scores'], sup),
+        _sel(end_points['size_residuals'], sup), config_dict={'dataset_config': dataset_config})
     end_points['pred_iou_value'] = iou_labels.mean()
     end_points['pred_iou_obj_value'] = _masked_mean(iou_labels, obj)
     end_points['obj_count'] = torch.sum(obj)
 
     if 'jitter_center' in end_points:
         gt_bbox = _gt_boxes(end_points, sup, dataset_config)
-        pred_bbox = torch.cat([end_points['jitter_center'][sup, ...],
-                               end_points['jitter_size'][sup, ...],
-                               -end_points['jitter_heading'][sup, ...][:, :, None]], dim=2)
+        pred_bbox = torch.cat([_sel(end_points['jitter_center'], sup),
+                               _sel(end_points['jitter_size'], sup),
+                               -_sel(end_points['jitter_heading'], sup)[:, :, None]], dim=2)
         pred_num = pred_bbox.shape[1]
         jitter_iou = boxes_iou3d_gpu(pred_bbox.view(-1, 7), gt_bbox.view(-1, 7))
         jitter_iou_labels, jitter_assign = _block_diagonal_max(jitter_iou, b, pred_num)
-        jitter_sem = torch.gather(end_points['sem_cls_label'][sup, ...], 1, jitter_assign)
-        jitter_pred = torch.sigmoid(end_points['iou_scores_jitter'][sup, ...])
+        jitter_sem = torch.gather(_sel(end_points['sem_cls_label'], sup), 1, jitter_assign)
+        jitter_pred = torch.sigmoid(_sel(end_points['iou_scores_jitter'], sup))
         jitter_pred = torch.gather(jitter_pred, 2, jitter_sem.unsqueeze(-1)).squeeze(-1) \
             if jitter_pred.shape[2] > 1 else jitter_pred.squeeze(-1)
         jitter_acc = torch.abs(jitter_pred - jitter_iou_labels)
@@ -229,9 +235,9 @@ def compute_box_and_sem_cls_loss(end_points, supervised_inds, dataset_config, co
             huber_loss(jitter_pred - jitter_iou_labels, delta=1.0).sum() / (jitter_acc.numel() + 1e-6)
 
     if 'iou_scores' in end_points:
-        iou_pred = torch.sigmoid(end_points['iou_scores'][sup, ...])
+        iou_pred = torch.sigmoid(_sel(end_points['iou_scores'], sup))
         if iou_pred.shape[2] > 1:
-            iou_sem = torch.gather(end_points['sem_cls_label'][sup, ...], 1, iou_assignment)
+            iou_sem = torch.gather(_sel(end_points['sem_cls_label'], sup), 1, iou_assignment)
             iou_pred = torch.gather(iou_pred, 2, iou_sem.unsqueeze(-1)).squeeze(-1)
         else:
             iou_pred = iou_pred.squeeze(-1)
@@ -247,9 +253,12 @@ def compute_box_and_sem_cls_loss(end_points, supervised_inds, dataset_config, co
 def get_labeled_loss(end_points, dataset_config, config_dict=None):
     """10 * (vote + 0.5*objectness + box + 0.1*sem_cls + iou [+ jitter_iou]) over the samples
     with supervised_mask == 1; fills end_points with every intermediate loss / statistic."""
-    supervised_inds = end_points.get('supervised_inds')  # static under HIP-graph capture
-    if supervised_inds is None:
-        supervised_inds = torch.nonzero(end_points['supervised_mask']).squeeze(1).long()
+    if end_points.get('all_supervised', False):  # host-side knowledge: skip every gather
+        supervised_inds = None
+    else:
+        supervised_inds = end_points.get('supervised_inds')  # static under HIP-graph capture
+        if supervised_inds is None:
+            supervised_inds = torch.nonzero(end_points['supervised_mask']).squeeze(1).long()
 
     end_points['vote_loss'] = compute_vote_loss(end_points, supervised_inds)
     objectness_loss, objectness_label, objectness_mask, object_assignment = \
@@ -283,7 +292,7 @@ def get_labeled_loss(end_points, dataset_config, config_dict=None):
     end_points['detection_loss'] = loss
     end_points['loss'] = loss
 
-    obj_pred = torch.argmax(end_points['objectness_scores'][supervised_inds, ...], 2)
+    obj_pred = torch.argmax(_sel(end_points['objectness_scores'], supervised_inds), 2)
     end_points['obj_acc'] = _masked_mean((obj_pred == objectness_label.long()).float(),
                                          objectness_mask)
     return loss, end_points

@@ -149,7 +149,8 @@ class SupervisedStep(object):
         for p in self._params:
             p.grad = None
         end_points = self.model(batch, mode="jitter")
-        end_points.update({k: v for k, v in batch.items() if torch.is_tensor(v)})
+        end_points.update({k: v for k, v in batch.items()
+                           if torch.is_tensor(v) or k == "all_supervised"})
         loss, end_points = get_labeled_loss(end_points, self.cfg, {"dataset_config": self.cfg})
         loss.backward()
         self._pack_gradients()
@@ -259,6 +260,7 @@ class SupervisedStep(object):
         # which samples are supervised is part of the captured control flow (host-side nonzero)
         # (kept on self: everything a graph reads must outlive the capture)
         self._supervised_inds = torch.nonzero(src["supervised_mask"]).squeeze(1).long()
+        self._all_supervised = self._supervised_inds.numel() == src["supervised_mask"].numel()
 
         # state touched by the warm-up iterations and by the capture itself
         buffers = [b for b in self.net.buffers()]
@@ -276,6 +278,7 @@ class SupervisedStep(object):
             inputs = dict(self._cur)
             inputs["geometry"] = self._cur_geometry
             inputs["supervised_inds"] = self._supervised_inds
+            inputs["all_supervised"] = self._all_supervised
             return self._forward_backward(inputs)
 
         warm = torch.cuda.Stream(device=dev)

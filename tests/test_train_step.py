@@ -221,3 +221,28 @@ def test_graph_replay_survives_host_syncs(oracle_omp):
         assert all(bool(t) for t in junk), i
         assert bool(torch.isfinite(loss)) and bool(torch.isfinite(runner.flat_params).all()), i
     assert runner.graphs
+
+
+def test_all_supervised_shortcut_is_identity(oracle_omp):
+    """get_labeled_loss with the host-side `all_supervised` flag (no per-tensor gathers) equals
+    the reference formulation that indexes every tensor with nonzero(supervised_mask)."""
+    V, dev = _setup(False, oracle_omp)
+    cfg = V.scannet_config()
+    data = importlib.import_module("3dioumatch_amd.votenet.data")
+    step_mod = importlib.import_module("3dioumatch_amd.votenet.step")
+    batch = data.make_batch(B, N, cfg, seed=47, num_objects=5)
+    out = []
+    for flag in (False, True):
+        net = step_mod.build_detector(cfg, num_proposal=K, seed=5).train()
+        torch.manual_seed(11)
+        ep = net(dict(batch), mode="jitter")
+        ep.update(batch)
+        if flag:
+            ep["all_supervised"] = True
+        loss, ep = V.get_labeled_loss(ep, cfg, {"dataset_config": cfg})
+        loss.backward()
+        out.append((float(loss), step_mod.flat_grads(net), {k: float(ep[k]) for k in STAT_KEYS
+                                                            if k in ep}))
+    assert out[0][0] == out[1][0]
+    assert torch.allclose(out[0][1], out[1][1], rtol=0, atol=1e-7)
+    assert out[0][2] == out[1][2]

@@ -19,7 +19,7 @@ config = import_module("3dioumatch_amd.votenet.config")
 
 dev = torch.device("cuda:0")
 cfg = config.scannet_config()
-st = step_mod.SupervisedStep(cfg, dev)
+st = step_mod.SupervisedStep(cfg, dev, graphs=False)
 batch = data_mod.make_batch(8, 40000, cfg, seed=1, device=dev)
 
 
@@ -71,6 +71,10 @@ for name, p in results.items():
           % (name, len(ev), tot / 1e3, len(small), sum(e.device_time for e in small) / 1e3))
     ka = p.key_averages()
     rows = sorted(ka, key=lambda k: -k.self_device_time_total)
-    for k in rows[:14]:
+    for k in rows[:10]:
         if k.self_device_time_total > 0:
             print("   %-60s n=%4d  %.3f ms" % (k.key[:60], k.count, k.self_device_time_total / 1e3))
+    print("   -- host ops by launch count")
+    ops = [k for k in ka if k.key.startswith("aten::") and k.self_device_time_total > 0]
+    for k in sorted(ops, key=lambda k: -k.count)[:22]:
+        print("   %-40s n=%4d  %.3f ms" % (k.key[:40], k.count, k.self_device_time_total / 1e3))
