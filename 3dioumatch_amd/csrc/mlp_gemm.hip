@@ -21,6 +21,7 @@
 // K is walked in chunks of 16 through LDS ([k][m] and [k][n], both unit-stride for the MFMA
 // fragment reads); each wave accumulates (TM/WM) x (TN/WN) in 32x32 MFMA blocks.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -231,24 +232,30 @@ gemm_nn_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int
 
 // Partial wgrad: for one cloud b and one slice of R,
 //   part[slice][m][k] = sum_{r in slice} P[b][m][r] * Q[b][k][r]
-// P = op_p (mode PMODE, rows m), Q = op_q (mode QMODE, rows k).  Tile 128(m) x 64(k) per
-// workgroup, waves 2x2, each 64x32; the R axis is staged [r][m] / [r][k] in LDS.
+// P = op_p (mode PMODE, rows m: the gradient operand, the expensive transform), Q = op_q (mode
+// QMODE, rows k).  A workgroup owns 64 rows of M and TK = 32*KBW*WK columns of K, so the
+// costly P tile is staged once for up to 256 columns of K.  The four waves are arranged as WK
+// column groups x RS shares of the r-chunk: every wave accumulates a 64 x (32*KBW) block
+// (2 x KBW MFMA tiles, 2 + KBW LDS reads per 2*KBW MFMAs) over its share of the chunk's
+// r-steps; shares are summed through LDS at the end.  The R axis is staged [r][m] / [r][k].
 constexpr int RC = 32;  // r chunk (128-byte row segments per load)
 
-template <int PMODE, int QMODE, int TK>
+template <int PMODE, int QMODE, int KBW, int WK, int RS>
 __global__ void __launch_bounds__(256)
-gemm_wgrad_kernel(int m_total, int k_total, int r, int r_per_slice, OperandB opp, OperandB opq,
-                  float *__restrict__ part, size_t p_stride, size_t q_stride) {
-  constexpr int TM = 128;
-  constexpr int KBLK = TK / 64;           // 32-wide k blocks per wave (waves 2 x 2)
-  constexpr int QE = TK * RC / 256;       // Q elements per lane (8 or 16)
-  constexpr int QL = 256 / TK;            // lanes per Q row (4 or 2)
+gemm_wgrad_kernel(int m_total, int k_begin, int k_end, int k_total, int r, int r_per_slice,
+                  OperandB opp, OperandB opq, float *__restrict__ part, size_t p_stride,
+                  size_t q_stride) {
+  static_assert(WK * RS == 4, "four waves");
+  constexpr int TM = 64, TK = 32 * KBW * WK;
+  constexpr int QSEG = TK / 64;            // 8-float row segments of Q per lane
   constexpr int LDP = TM + 1, LDQ = TK + 1;
-  __shared__ float Ps[RC * LDP];
-  __shared__ float Qs[RC * LDQ];
+  constexpr int STAGE = RC * (LDP + LDQ);
+  constexpr int REDUCE = RS > 1 ? WK * 2 * KBW * 16 * 64 : 0;  // one accumulator set per group
+  __shared__ float lds[STAGE > REDUCE ? STAGE : REDUCE];
+  float *Ps = lds, *Qs = lds + RC * LDP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wk = wave & 1;
-  const int k0 = blockIdx.x * TK, m0 = blockIdx.y * TM;
+  const int wk = wave % WK, wr = wave / WK;
+  const int k0 = k_begin + blockIdx.x * TK, m0 = blockIdx.y * TM;
   const int slices = (r + r_per_slice - 1) / r_per_slice;
   const int b = blockIdx.z / slices, slice = blockIdx.z % slices;
   const int r_lo = slice * r_per_slice;
@@ -256,67 +263,104 @@ gemm_wgrad_kernel(int m_total, int k_total, int r, int r_per_slice, OperandB opp
   OperandB P = opp, Q = opq;
   const size_t p_off = (size_t)b * p_stride, q_off = (size_t)b * q_stride;
 
-  f32x16 acc[2][KBLK];
+  f32x16 acc[2][KBW];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < KBLK; ++j)
+    for (int j = 0; j < KBW; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-  // fixed ownership: lane t loads row (t/2) of P, 16 consecutive r; row (t/4) of Q, 8
-  // consecutive r -- so the per-row constants live in registers for the whole kernel.  The raw
-  // loads of chunk i+1 are issued before the MFMAs of chunk i (register prefetch).
-  const int pm = tid >> 1, pr = (tid & 1) * 16;
-  const int qk = tid / QL, qr = (tid % QL) * QE;
-  const bool p_ok = m0 + pm < m_total, q_ok = k0 + qk < k_total;
-  const RowCoef pc = load_row_coef<PMODE>(P, m0 + pm, p_ok);
-  const RowCoef qc = load_row_coef<QMODE>(Q, k0 + qk, q_ok);
-  const size_t p_row = p_off + (size_t)(m0 + pm) * r, q_row = q_off + (size_t)(k0 + qk) * r;
+  // fixed ownership: lane t loads 8 consecutive r of P row t/4 and of Q rows t/4 + 64*s, so the
+  // per-row constants live in registers for the whole kernel.  The raw loads of chunk i+1 are
+  // issued before the MFMAs of chunk i (register prefetch).
+  const int seg_row = tid >> 2, seg_r = (tid & 3) * 8;
+  const bool p_ok = m0 + seg_row < m_total;
+  const RowCoef pc = load_row_coef<PMODE>(P, m0 + seg_row, p_ok);
+  const size_t p_row = p_off + (size_t)(m0 + seg_row) * r;
+  bool q_ok[QSEG];
+  RowCoef qc[QSEG];
+  size_t q_row[QSEG];
+#pragma unroll
+  for (int s = 0; s < QSEG; ++s) {
+    const int gk = k0 + seg_row + 64 * s;
+    q_ok[s] = gk < k_end;
+    qc[s] = load_row_coef<QMODE>(Q, gk, q_ok[s]);
+    q_row[s] = q_off + (size_t)gk * r;
+  }
   const bool vec_ok = ((r | r_hi) & 3) == 0;
-  float px[16], pdz[16], qx[QE], qdz[QE];
+  float px[8], pdz[8], qx[QSEG][8], qdz[QSEG][8];
   auto fetch = [&](int rr) {
-    load_raw_segment<PMODE, 16>(P, p_row + rr + pr, rr + pr, r_hi, vec_ok, p_ok, px, pdz);
-    load_raw_segment<QMODE, QE>(Q, q_row + rr + qr, rr + qr, r_hi, vec_ok, q_ok, qx, qdz);
+    load_raw_segment<PMODE, 8>(P, p_row + rr + seg_r, rr + seg_r, r_hi, vec_ok, p_ok, px, pdz);
+#pragma unroll
+    for (int s = 0; s < QSEG; ++s)
+      load_raw_segment<QMODE, 8>(Q, q_row[s] + rr + seg_r, rr + seg_r, r_hi, vec_ok, q_ok[s],
+                                 qx[s], qdz[s]);
   };
   fetch(r_lo);
   for (int rr = r_lo; rr < r_hi; rr += RC) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-      Ps[(pr + i) * LDP + pm] =
-          (p_ok && rr + pr + i < r_hi) ? transform<PMODE>(px[i], pdz[i], pc) : 0.f;
+    for (int i = 0; i < 8; ++i)
+      Ps[(seg_r + i) * LDP + seg_row] =
+          (p_ok && rr + seg_r + i < r_hi) ? transform<PMODE>(px[i], pdz[i], pc) : 0.f;
 #pragma unroll
-    for (int i = 0; i < QE; ++i)
-      Qs[(qr + i) * LDQ + qk] =
-          (q_ok && rr + qr + i < r_hi) ? transform<QMODE>(qx[i], qdz[i], qc) : 0.f;
+    for (int s = 0; s < QSEG; ++s)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        Qs[(seg_r + i) * LDQ + seg_row + 64 * s] =
+            (q_ok[s] && rr + seg_r + i < r_hi) ? transform<QMODE>(qx[s][i], qdz[s][i], qc[s]) : 0.f;
     __syncthreads();
     if (rr + RC < r_hi) fetch(rr + RC);
 #pragma unroll
-    for (int ri = 0; ri < RC; ri += 2) {
-      const int row = ri + (lane >> 5);
-      float bq[KBLK], ap[2];
+    for (int st = 0; st < RC / 2 / RS; ++st) {
+      const int row = wr * (RC / RS) + 2 * st + (lane >> 5);
+      float bq[KBW], ap[2];
 #pragma unroll
-      for (int j = 0; j < KBLK; ++j) bq[j] = Qs[row * LDQ + (wk * KBLK + j) * 32 + (lane & 31)];
+      for (int j = 0; j < KBW; ++j) bq[j] = Qs[row * LDQ + (wk * KBW + j) * 32 + (lane & 31)];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) ap[i] = Ps[row * LDP + (wm * 2 + i) * 32 + (lane & 31)];
+      for (int i = 0; i < 2; ++i) ap[i] = Ps[row * LDP + i * 32 + (lane & 31)];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < KBLK; ++j)
+        for (int j = 0; j < KBW; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i], bq[j], acc[i][j], 0, 0, 0);
     }
+  }
+  if (RS > 1) {  // sum the r-shares of each column group: share s -> LDS -> share 0
+    float *red = lds + (size_t)wk * (2 * KBW * 16 * 64);
+    for (int s = 1; s < RS; ++s) {
+      __syncthreads();
+      if (wr == s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < KBW; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) red[((i * KBW + j) * 16 + q) * 64 + lane] = acc[i][j][q];
+      }
+      __syncthreads();
+      if (wr == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < KBW; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] += red[((i * KBW + j) * 16 + q) * 64 + lane];
+      }
+    }
+    if (wr != 0) return;
   }
   float *out = part + (size_t)blockIdx.z * m_total * k_total;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < KBLK; ++j) {
-      const int col = k0 + (wk * KBLK + j) * 32 + (lane & 31);
+    for (int j = 0; j < KBW; ++j) {
+      const int col = k0 + (wk * KBW + j) * 32 + (lane & 31);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int row = m0 + (wm * 2 + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        if (row < m_total && col < k_total) out[(size_t)row * k_total + col] = acc[i][j][q];
+        const int row = m0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (row < m_total && col < k_end) out[(size_t)row * k_total + col] = acc[i][j][q];
       }
     }
 }
@@ -393,19 +437,29 @@ MLP_API int mlp_gemm_dgrad(int b, int m, int k, int r, const float *wt, int mode
   return launch_nn<OP_DY>(b, k, m, r, wt, m, op, dx, in_stride, out_stride, (hipStream_t)stream_);
 }
 
-// R is cut into slices so that about 512 workgroups are in flight (tiles x clouds x slices);
+// K is covered by column tiles of 256 / 192 / 128 / 64 (largest first), M by 64-row tiles, and
+// R is cut into slices so that about 1024 workgroups are in flight (tiles x clouds x slices);
 // every slice writes its own partial dW, reduced afterwards (deterministic, no atomics).
-// 64-wide k tiles measured faster than 128-wide ones on every layer shape (register pressure
-// of four accumulators + the raw operand prefetch outweighs the saved re-reads)
-static int wgrad_tile_k(int k) { (void)k; return 64; }
+static int wgrad_next_tile(int k_left) {
+  if (k_left > 192) return 256;
+  if (k_left > 128) return 192;
+  if (k_left > 64) return 128;
+  return 64;
+}
 
 static int wgrad_r_per_slice(int b, int m, int k, int r) {
-  const long long tiles = (long long)pn2_ceil_div(k, wgrad_tile_k(k)) * pn2_ceil_div(m, 128) * b;
-  long long slices = (512 + tiles - 1) / tiles;
+  // one launch per column tile, every launch with the same slicing: size it so that a launch
+  // is exactly one resident round of workgroups (3 per CU, 2 for the 192-wide tile whose
+  // six accumulators cost a wave of occupancy), minus 16 CUs of slack for the index-chain
+  // kernels of the next batch that run beside it -- a partial second round is pure tail
+  static const long long forced = getenv("MLP_WGRAD_WGS") ? atoll(getenv("MLP_WGRAD_WGS")) : 0;
+  const long long target = forced > 0 ? forced : (wgrad_next_tile(k) == 192 ? 480 : 720);
+  const long long tiles = (long long)pn2_ceil_div(m, 64) * b;
+  long long slices = (target + tiles / 2) / tiles;
   if (slices < 1) slices = 1;
   long long per = (r + slices - 1) / slices;
   per = (per + RC - 1) / RC * RC;
-  if (per < 256) per = 256;
+  if (per < 64) per = 64;
   return (int)per;
 }
 
@@ -429,17 +483,27 @@ MLP_API int mlp_gemm_wgrad(int b, int m, int k, int r, int pmode, const float *d
   OperandB P = pmode == OP_DIRECT ? OperandB{dy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
                                   : OperandB{y, dz, scale, shift, mean, invstd, coef};
   OperandB Q = {x, nullptr, xscale, xshift, nullptr, nullptr, nullptr};
-  const int tk = wgrad_tile_k(k);
-  dim3 grid(pn2_ceil_div(k, tk), pn2_ceil_div(m, 128), b * slices);
   const size_t ps = (size_t)m * r, qs = (size_t)k * r;
 #define WG(PM, QM)                                                                              \
   do {                                                                                          \
-    if (tk == 64)                                                                               \
-      hipLaunchKernelGGL((gemm_wgrad_kernel<PM, QM, 64>), grid, dim3(256), 0, stream, m, k, r,  \
-                         per, P, Q, workspace, ps, qs);                                         \
-    else                                                                                        \
-      hipLaunchKernelGGL((gemm_wgrad_kernel<PM, QM, 128>), grid, dim3(256), 0, stream, m, k, r, \
-                         per, P, Q, workspace, ps, qs);                                         \
+    for (int kb = 0; kb < k;) {                                                                 \
+      const int tk = wgrad_next_tile(k - kb);                                                   \
+      const int ke = kb + tk < k ? kb + tk : k;                                                 \
+      dim3 grid(1, pn2_ceil_div(m, 64), b * slices);                                            \
+      if (tk == 256)                                                                            \
+        hipLaunchKernelGGL((gemm_wgrad_kernel<PM, QM, 2, 4, 1>), grid, dim3(256), 0, stream, m, \
+                           kb, ke, k, r, per, P, Q, workspace, ps, qs);                         \
+      else if (tk == 192)                                                                       \
+        hipLaunchKernelGGL((gemm_wgrad_kernel<PM, QM, 3, 2, 2>), grid, dim3(256), 0, stream, m, \
+                           kb, ke, k, r, per, P, Q, workspace, ps, qs);                         \
+      else if (tk == 128)                                                                       \
+        hipLaunchKernelGGL((gemm_wgrad_kernel<PM, QM, 2, 2, 2>), grid, dim3(256), 0, stream, m, \
+                           kb, ke, k, r, per, P, Q, workspace, ps, qs);                         \
+      else                                                                                      \
+        hipLaunchKernelGGL((gemm_wgrad_kernel<PM, QM, 2, 1, 4>), grid, dim3(256), 0, stream, m, \
+                           kb, ke, k, r, per, P, Q, workspace, ps, qs);                         \
+      kb = ke;                                                                                  \
+    }                                                                                           \
   } while (0)
   if (pmode == OP_DIRECT && qmode == OP_DIRECT) WG(OP_DIRECT, OP_DIRECT);
   else if (pmode == OP_DIRECT) WG(OP_DIRECT, OP_BNRELU);

@@ -92,7 +92,8 @@ def test_shared_mlp_fused_matches_sequential():
 
 @pytest.mark.parametrize("b,m,k,r", [(2, 64, 4, 640), (1, 128, 64, 1000), (2, 256, 131, 512),
                                      (3, 259, 128, 96), (1, 3, 7, 33), (2, 131, 259, 1024),
-                                     (1, 512, 256, 64), (2, 32, 512, 200)])
+                                     (1, 512, 256, 64), (2, 32, 512, 200), (2, 64, 64, 3001),
+                                     (1, 100, 100, 2050), (2, 70, 160, 1537), (1, 65, 300, 777)])
 def test_mfma_gemm_primitives_vs_torch(b, m, k, r):
     """forward / dgrad / wgrad of the 1x1 convolution on the matrix cores, every operand mode,
     ragged M, K, R -- against torch matmul of explicitly materialised operands (fp32)."""
