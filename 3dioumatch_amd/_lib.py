@@ -48,6 +48,10 @@ _SIGNATURES = {
                        _vp, _vp, _vp, _vp],
     "mlp_gemm_wgrad": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                        _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mlp_gemm_dgrad_pooled": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp,
+                              _vp, _vp, _vp, _vp, _vp],
+    "mlp_gemm_wgrad_pooled": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp,
+                              _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_gemm_wgrad_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
     "iou3d_boxes_overlap_bev": [_c_int, _vp, _c_int, _vp, _vp, _vp],
     "iou3d_boxes_iou_bev": [_c_int, _vp, _c_int, _vp, _vp, _vp],

@@ -465,6 +465,7 @@ MLP_API int mlp_bn_relu_pool_backward(int b, int c, int m, int ns, int training,
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn2_ceil_div(c, 256)), dim3(256), 0, stream, c,
                      b, (double)b * (double)m * (double)ns, training, workspace, gamma, invstd,
                      dgamma, dbeta, coef);
+  if (dy == nullptr) return pn2_launch_status();  // statistics only (mlp_gemm_*_pooled form dy)
   const long long r = (long long)m * ns;
   if (r % 4 == 0)
     hipLaunchKernelGGL(pool_bwd_apply_kernel<true>, dim3(pn2_ceil_div(r, 1024), c, b), dim3(256), 0,

@@ -16,6 +16,9 @@
 //     OP_BNRELU  : max(x*scale[k] + shift[k], 0)                    (input of the next layer)
 //     OP_DY      : a[k]*(([y*sc+sh > 0] ? dz : 0) - c1[k] - ((y-mu[k])*is[k])*c2[k])
 //                  from the pair (y, dz)                            (BN+ReLU backward)
+//     OP_POOLDY  : the same with dz[k][g*ns+s] = [s == argmax[k][g]] * dpooled[k][g]: the
+//                  backward of max-over-nsample + ReLU + BN of an SA module's last layer,
+//                  from y and the two small (B,C,m) tensors -- dz/dy are never materialised
 //
 // Kernel shape: 256 lanes = 4 waves; a workgroup owns TM x TN of the output for one cloud;
 // K is walked in chunks of 16 through LDS ([k][m] and [k][n], both unit-stride for the MFMA
@@ -29,7 +32,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KC = 16;  // K chunk staged in LDS
 
-enum OperandMode { OP_DIRECT = 0, OP_BNRELU = 1, OP_DY = 2 };
+enum OperandMode { OP_DIRECT = 0, OP_BNRELU = 1, OP_DY = 2, OP_POOLDY = 3 };
 
 struct OperandB {
   const float *x;        // OP_DIRECT / OP_BNRELU: the tensor; OP_DY: y
@@ -39,7 +42,11 @@ struct OperandB {
   const float *mean;     // OP_DY
   const float *invstd;   // OP_DY
   const float *coef;     // OP_DY: [k][3] = a, c1, c2
+  const int *argmax;     // OP_POOLDY: (rows, r/ns) winning sample per group; dz holds dpooled
+  int ns;                // OP_POOLDY: samples per group
 };
+
+constexpr bool is_dy(int mode) { return mode == OP_DY || mode == OP_POOLDY; }
 
 // Per-row constants of an operand (loaded once per row, kept in registers)
 struct RowCoef { float sc, sh, mu, is, a, c1, c2; };
@@ -49,7 +56,7 @@ __device__ __forceinline__ RowCoef load_row_coef(const OperandB &op, int k, bool
   RowCoef c = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (MODE == OP_DIRECT || !valid) return c;
   c.sc = op.scale[k]; c.sh = op.shift[k];
-  if (MODE == OP_DY) {
+  if (is_dy(MODE)) {
     c.mu = op.mean[k]; c.is = op.invstd[k];
     c.a = op.coef[k * 3]; c.c1 = op.coef[k * 3 + 1]; c.c2 = op.coef[k * 3 + 2];
   }
@@ -71,6 +78,27 @@ __device__ __forceinline__ void load_raw_segment(const OperandB &op, size_t off,
 #pragma unroll
   for (int i = 0; i < N; ++i) { x[i] = 0.f; dz[i] = 0.f; }
   if (!row_ok) return;
+  if (MODE == OP_POOLDY) {
+    // dz of the segment from the pooled tensors: (off - gr) / ns is the row's group base
+    const size_t gbase = (off - (size_t)gr) / (size_t)op.ns;
+    if (op.ns % N == 0 && gr % N == 0) {  // the whole segment lies in one group
+      if (gr < limit) {
+        const int g = gr / op.ns, s0 = gr - g * op.ns;
+        const int win = op.argmax[gbase + g] - s0;
+        const float dp = op.dz[gbase + g];
+#pragma unroll
+        for (int i = 0; i < N; ++i) dz[i] = (i == win) ? dp : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        if (gr + i < limit) {
+          const int g = (gr + i) / op.ns;
+          dz[i] = (op.argmax[gbase + g] == gr + i - g * op.ns) ? op.dz[gbase + g] : 0.f;
+        }
+      }
+    }
+  }
   if (vec_ok) {
 #pragma unroll
     for (int i = 0; i < N; i += 4) {
@@ -92,43 +120,6 @@ __device__ __forceinline__ void load_raw_segment(const OperandB &op, size_t off,
       }
     }
   }
-}
-
-// N consecutive elements of one operand row starting at element offset `off` (column gr of
-// r): 16-byte loads when the row length allows, scalars (with tail guard) otherwise
-template <int MODE, int N>
-__device__ __forceinline__ void load_row_segment(const OperandB &op, size_t off, int gr, int r,
-                                                 bool vec_ok, bool row_ok, const RowCoef &c,
-                                                 float *out) {
-  float x[N], dz[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) { x[i] = 0.f; dz[i] = 0.f; }
-  if (row_ok) {
-    if (vec_ok) {  // row stride and limit are multiples of 4; gr is one by construction
-#pragma unroll
-      for (int i = 0; i < N; i += 4) {
-        if (gr + i < r) {
-          const float4 v = *reinterpret_cast<const float4 *>(op.x + off + i);
-          x[i] = v.x; x[i + 1] = v.y; x[i + 2] = v.z; x[i + 3] = v.w;
-          if (MODE == OP_DY) {
-            const float4 d = *reinterpret_cast<const float4 *>(op.dz + off + i);
-            dz[i] = d.x; dz[i + 1] = d.y; dz[i + 2] = d.z; dz[i + 3] = d.w;
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        if (gr + i < r) {
-          x[i] = op.x[off + i];
-          if (MODE == OP_DY) dz[i] = op.dz[off + i];
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i)
-    out[i] = (row_ok && gr + i < r) ? transform<MODE>(x[i], dz[i], c) : 0.f;
 }
 
 // C[b] (M x R, ldc = R) = A (M x K, row-major, lda) * op(B[b]) (K x R)
@@ -437,6 +428,20 @@ MLP_API int mlp_gemm_dgrad(int b, int m, int k, int r, const float *wt, int mode
   return launch_nn<OP_DY>(b, k, m, r, wt, m, op, dx, in_stride, out_stride, (hipStream_t)stream_);
 }
 
+// the same for the pooled last layer of an SA module: dy from (y, dpooled, argmax) on the fly
+MLP_API int mlp_gemm_dgrad_pooled(int b, int m, int k, int groups, int ns, const float *wt,
+                                  const float *y, const float *dpooled, const int *argmax,
+                                  const float *scale, const float *shift, const float *mean,
+                                  const float *invstd, const float *coef, float *dx,
+                                  void *stream_) {
+  if (b <= 0 || m <= 0 || k <= 0 || groups <= 0 || ns <= 0) return 0;
+  const int r = groups * ns;
+  const size_t in_stride = (size_t)m * r, out_stride = (size_t)k * r;
+  OperandB op = {y, dpooled, scale, shift, mean, invstd, coef, argmax, ns};
+  return launch_nn<OP_POOLDY>(b, k, m, r, wt, m, op, dx, in_stride, out_stride,
+                              (hipStream_t)stream_);
+}
+
 // K is covered by column tiles of 256 / 192 / 128 / 64 (largest first), M by 64-row tiles, and
 // R is cut into slices so that about 1024 workgroups are in flight (tiles x clouds x slices);
 // every slice writes its own partial dW, reduced afterwards (deterministic, no atomics).
@@ -469,19 +474,11 @@ MLP_API size_t mlp_gemm_wgrad_workspace_floats(int b, int m, int k, int r) {
   return (size_t)b * slices * m * k;
 }
 
-// dW (m x k) = sum_b dY[b] * X[b]^T; dY given (pmode 0) or on the fly (pmode 2, from y/dz);
-// X given (qmode 0) or relu(bn(Yprev)) (qmode 1, via xscale/xshift).
-MLP_API int mlp_gemm_wgrad(int b, int m, int k, int r, int pmode, const float *dy, const float *y,
-                           const float *dz, const float *scale, const float *shift,
-                           const float *mean, const float *invstd, const float *coef, int qmode,
-                           const float *x, const float *xscale, const float *xshift, float *dw,
-                           float *workspace, void *stream_) {
-  if (b <= 0 || m <= 0 || k <= 0 || r <= 0) return 0;
-  hipStream_t stream = (hipStream_t)stream_;
+static int wgrad_run(int b, int m, int k, int r, int pmode, const OperandB &P, int qmode,
+                     const float *x, const float *xscale, const float *xshift, float *dw,
+                     float *workspace, hipStream_t stream) {
   const int per = wgrad_r_per_slice(b, m, k, r);
   const int slices = (r + per - 1) / per;
-  OperandB P = pmode == OP_DIRECT ? OperandB{dy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
-                                  : OperandB{y, dz, scale, shift, mean, invstd, coef};
   OperandB Q = {x, nullptr, xscale, xshift, nullptr, nullptr, nullptr};
   const size_t ps = (size_t)m * r, qs = (size_t)k * r;
 #define WG(PM, QM)                                                                              \
@@ -507,10 +504,39 @@ MLP_API int mlp_gemm_wgrad(int b, int m, int k, int r, int pmode, const float *d
   } while (0)
   if (pmode == OP_DIRECT && qmode == OP_DIRECT) WG(OP_DIRECT, OP_DIRECT);
   else if (pmode == OP_DIRECT) WG(OP_DIRECT, OP_BNRELU);
-  else if (qmode == OP_DIRECT) WG(OP_DY, OP_DIRECT);
-  else WG(OP_DY, OP_BNRELU);
+  else if (pmode == OP_DY && qmode == OP_DIRECT) WG(OP_DY, OP_DIRECT);
+  else if (pmode == OP_DY) WG(OP_DY, OP_BNRELU);
+  else if (qmode == OP_DIRECT) WG(OP_POOLDY, OP_DIRECT);
+  else WG(OP_POOLDY, OP_BNRELU);
 #undef WG
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(pn2_ceil_div((long long)m * k, 256)), dim3(256),
                      0, stream, m * k, b * slices, workspace, dw);
   return pn2_launch_status();
+}
+
+// dW (m x k) = sum_b dY[b] * X[b]^T; dY given (pmode 0) or on the fly (pmode 2, from y/dz);
+// X given (qmode 0) or relu(bn(Yprev)) (qmode 1, via xscale/xshift).
+MLP_API int mlp_gemm_wgrad(int b, int m, int k, int r, int pmode, const float *dy, const float *y,
+                           const float *dz, const float *scale, const float *shift,
+                           const float *mean, const float *invstd, const float *coef, int qmode,
+                           const float *x, const float *xscale, const float *xshift, float *dw,
+                           float *workspace, void *stream_) {
+  if (b <= 0 || m <= 0 || k <= 0 || r <= 0) return 0;
+  OperandB P = pmode == OP_DIRECT ? OperandB{dy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
+                                  : OperandB{y, dz, scale, shift, mean, invstd, coef};
+  return wgrad_run(b, m, k, r, pmode == OP_DIRECT ? OP_DIRECT : OP_DY, P, qmode, x, xscale, xshift,
+                   dw, workspace, (hipStream_t)stream_);
+}
+
+// the same for the pooled last layer: dY from (y, dpooled, argmax) on the fly
+MLP_API int mlp_gemm_wgrad_pooled(int b, int m, int k, int groups, int ns, const float *y,
+                                  const float *dpooled, const int *argmax, const float *scale,
+                                  const float *shift, const float *mean, const float *invstd,
+                                  const float *coef, int qmode, const float *x,
+                                  const float *xscale, const float *xshift, float *dw,
+                                  float *workspace, void *stream_) {
+  if (b <= 0 || m <= 0 || k <= 0 || groups <= 0 || ns <= 0) return 0;
+  OperandB P = {y, dpooled, scale, shift, mean, invstd, coef, argmax, ns};
+  return wgrad_run(b, m, k, groups * ns, OP_POOLDY, P, qmode, x, xscale, xshift, dw, workspace,
+                   (hipStream_t)stream_);
 }

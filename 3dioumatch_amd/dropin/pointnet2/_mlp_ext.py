@@ -103,6 +103,26 @@ def bn_relu_pool_backward(y, dpooled, argmax, ymax, gamma, scale, shift, mean, i
     return dy, small[0], small[1]
 
 
+def bn_relu_pool_backward_stats(y, dpooled, argmax, ymax, gamma, scale, shift, mean, invstd,
+                                training):
+    """-> dgamma, dbeta, coef (C,3) of the pooled last layer; dy itself is formed inside
+    gemm_dgrad / gemm_wgrad (pooled=...)."""
+    _f32c(dpooled, "dpooled")
+    b, c, m, ns = y.shape
+    small = torch.empty((5, c), dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        ws = _ws(y, b, c, m)
+        _L.check(_lib.mlp_bn_relu_pool_backward(b, c, m, ns, 1 if training else 0, y.data_ptr(),
+                                                dpooled.data_ptr(), argmax.data_ptr(),
+                                                ymax.data_ptr(), gamma.data_ptr(),
+                                                scale.data_ptr(), shift.data_ptr(),
+                                                mean.data_ptr(), invstd.data_ptr(), None,
+                                                small[0].data_ptr(), small[1].data_ptr(),
+                                                small[2:].data_ptr(), ws.data_ptr(), _stream(y)),
+                 "mlp_bn_relu_pool_backward(stats)")
+    return small[0], small[1], small[2:]
+
+
 # ---- the 1x1 convolution on the matrix cores (include/mlp_hip.h: mlp_gemm_*) -------------------
 def _ptr(t):
     return t.data_ptr() if t is not None else None
@@ -142,12 +162,13 @@ def bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, training):
     return small[0], small[1], small[2:]
 
 
-def gemm_dgrad(w, dy=None, fly=None, like=None):
+def gemm_dgrad(w, dy=None, fly=None, pooled=None):
     """dx (B,K,R) = w^T @ dy.  Either dy is a tensor, or fly = (y, dz, scale, shift, mean,
-    invstd, coef) and dy is formed on the fly.  `like`: tensor whose trailing shape dx takes."""
+    invstd, coef), or pooled = (y (B,M,m,ns), dpooled, argmax, scale, shift, mean, invstd, coef)
+    and dy is formed on the fly."""
     m, k = w.shape
     wt = w.t().contiguous()
-    src = dy if dy is not None else fly[0]
+    src = dy if dy is not None else (fly[0] if fly is not None else pooled[0])
     b = src.shape[0]
     r = src.numel() // (b * m)
     dx = torch.empty((b, k) + tuple(src.shape[2:]), dtype=torch.float32, device=src.device)
@@ -156,6 +177,13 @@ def gemm_dgrad(w, dy=None, fly=None, like=None):
             _f32c(dy, "dy")
             rc = _lib.mlp_gemm_dgrad(b, m, k, r, wt.data_ptr(), 0, dy.data_ptr(), None, None, None,
                                      None, None, None, None, dx.data_ptr(), _stream(src))
+        elif pooled is not None:
+            y, dpooled, argmax, scale, shift, mean, invstd, coef = pooled
+            rc = _lib.mlp_gemm_dgrad_pooled(b, m, k, y.shape[2], y.shape[3], wt.data_ptr(),
+                                            y.data_ptr(), dpooled.data_ptr(), argmax.data_ptr(),
+                                            scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                            invstd.data_ptr(), coef.data_ptr(), dx.data_ptr(),
+                                            _stream(src))
         else:
             y, dz, scale, shift, mean, invstd, coef = fly
             rc = _lib.mlp_gemm_dgrad(b, m, k, r, wt.data_ptr(), 2, None, y.data_ptr(),
@@ -166,7 +194,7 @@ def gemm_dgrad(w, dy=None, fly=None, like=None):
     return dx
 
 
-def gemm_wgrad(m, k, x, xcoeff=None, dy=None, fly=None):
+def gemm_wgrad(m, k, x, xcoeff=None, dy=None, fly=None, pooled=None):
     """dw (M,K) = sum_b dy[b] @ x[b]^T; x direct or relu(bn(.)) via xcoeff=(scale, shift);
     dy direct or on the fly (fly as in gemm_dgrad)."""
     b = x.shape[0]
@@ -180,6 +208,14 @@ def gemm_wgrad(m, k, x, xcoeff=None, dy=None, fly=None):
             rc = _lib.mlp_gemm_wgrad(b, m, k, r, 0, dy.data_ptr(), None, None, None, None, None,
                                      None, None, 0 if xcoeff is None else 1, x.data_ptr(),
                                      _ptr(xs), _ptr(xh), dw.data_ptr(), ws.data_ptr(), _stream(x))
+        elif pooled is not None:
+            y, dpooled, argmax, scale, shift, mean, invstd, coef = pooled
+            rc = _lib.mlp_gemm_wgrad_pooled(b, m, k, y.shape[2], y.shape[3], y.data_ptr(),
+                                            dpooled.data_ptr(), argmax.data_ptr(),
+                                            scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                            invstd.data_ptr(), coef.data_ptr(),
+                                            0 if xcoeff is None else 1, x.data_ptr(), _ptr(xs),
+                                            _ptr(xh), dw.data_ptr(), ws.data_ptr(), _stream(x))
         else:
             y, dz, scale, shift, mean, invstd, coef = fly
             rc = _lib.mlp_gemm_wgrad(b, m, k, r, 2, None, y.data_ptr(), dz.data_ptr(),

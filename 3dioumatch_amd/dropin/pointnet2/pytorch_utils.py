@@ -184,31 +184,34 @@ class _FusedMLPChain(Function):
         dout = dout.contiguous()
         grads = [None] * (5 * n)
         need_dx = ctx.needs_input_grad[0]
-        dy_tensor, fly = None, None
+        dy_tensor, fly, pooled = None, None, None
         dz = dout
         for i in range(n - 1, -1, -1):
             w, gamma = params[5 * i], params[5 * i + 1]
             w2 = w.reshape(w.shape[0], -1)
             mean, invstd, scale, shift = coefs[i]
             if i == n - 1 and pool:
-                # the gradient of the pooled layer is dense in dy but sparse in dz: materialise dy
-                dy_tensor, dgamma, dbeta = K.bn_relu_pool_backward(
+                # dz of the pooled layer is one value per (channel, group): the GEMM operand
+                # loads rebuild dy from y, dpooled and the arg-max, nothing dense is written
+                dgamma, dbeta, coef = K.bn_relu_pool_backward_stats(
                     ys[i], dz, extra[0], extra[1], gamma, scale, shift, mean, invstd, training)
-                fly = None
+                dy_tensor, fly = None, None
+                pooled = (ys[i], dz, extra[0], scale, shift, mean, invstd, coef)
             else:
+                pooled = None
                 dgamma, dbeta, coef = K.bn_relu_backward_stats(ys[i], dz, gamma, scale, shift, mean,
                                                                invstd, training)
                 dy_tensor, fly = None, (ys[i], dz, scale, shift, mean, invstd, coef)
             grads[5 * i + 1], grads[5 * i + 2] = dgamma, dbeta
             m, k = w2.shape
             if i == 0:
-                grads[0 + 5 * i] = K.gemm_wgrad(m, k, x, None, dy_tensor, fly).view_as(w)
-                dx = K.gemm_dgrad(w2, dy_tensor, fly).view_as(x) if need_dx else None
+                grads[0 + 5 * i] = K.gemm_wgrad(m, k, x, None, dy_tensor, fly, pooled).view_as(w)
+                dx = K.gemm_dgrad(w2, dy_tensor, fly, pooled).view_as(x) if need_dx else None
             else:
                 pscale, pshift = coefs[i - 1][2], coefs[i - 1][3]
                 grads[5 * i] = K.gemm_wgrad(m, k, ys[i - 1], (pscale, pshift), dy_tensor,
-                                            fly).view_as(w)
-                dz = K.gemm_dgrad(w2, dy_tensor, fly)  # gradient w.r.t. relu(bn(y_{i-1}))
+                                            fly, pooled).view_as(w)
+                dz = K.gemm_dgrad(w2, dy_tensor, fly, pooled)  # gradient w.r.t. relu(bn(y_{i-1}))
         return (dx if need_dx else None, None, None, None, None, *grads)
 
 

@@ -61,7 +61,8 @@ int mlp_bn_relu_backward(int b, int c, int r, int training, const float *y, cons
                          float *dbeta, float *coef, float *workspace, void *stream);
 
 /* replaces the autograd backward of max_pool2d + ReLU + BatchNorm2d of the last layer
- * (pointnet2_modules.py:256-262): dpooled (b,c,m) -> dy (b,c,m,ns), dgamma, dbeta. */
+ * (pointnet2_modules.py:256-262): dpooled (b,c,m) -> dy (b,c,m,ns), dgamma, dbeta.  dy == NULL:
+ * only dgamma, dbeta and coef are produced (dy is then formed inside mlp_gemm_*_pooled). */
 int mlp_bn_relu_pool_backward(int b, int c, int m, int ns, int training, const float *y,
                               const float *dpooled, const int *argmax, const float *ymax,
                               const float *gamma, const float *scale, const float *shift,
@@ -93,6 +94,16 @@ int mlp_gemm_dgrad(int b, int m, int k, int r, const float *wt, int mode, const 
                    const float *mean, const float *invstd, const float *coef, float *dx,
                    void *stream);
 
+/* mlp_gemm_dgrad for the pooled last layer of a set-abstraction MLP: dy (b,m,groups,ns) is formed
+ * on the fly from y, dpooled (b,m,groups), argmax (b,m,groups) and the vectors of
+ * mlp_bn_relu_pool_backward(dy = NULL) -- neither dz nor dy is written to memory (replaces
+ * F.max_pool2d backward + ReLU/BatchNorm2d backward + conv2d backward-data,
+ * pointnet2_modules.py:256-262 and pytorch_utils.py:70-124) */
+int mlp_gemm_dgrad_pooled(int b, int m, int k, int groups, int ns, const float *wt, const float *y,
+                          const float *dpooled, const int *argmax, const float *scale,
+                          const float *shift, const float *mean, const float *invstd,
+                          const float *coef, float *dx, void *stream);
+
 /* weight gradient: dw (m,k) = sum_b dy[b] * x[b]^T; dy given (pmode 0) or on the fly (pmode 2);
  * x given (qmode 0) or relu(bn(.)) of the previous layer's output (qmode 1).  workspace:
  * mlp_gemm_wgrad_workspace_floats floats (replaces conv2d backward-weight, pytorch_utils.py:70-124) */
@@ -101,6 +112,15 @@ int mlp_gemm_wgrad(int b, int m, int k, int r, int pmode, const float *dy, const
                    const float *invstd, const float *coef, int qmode, const float *x,
                    const float *xscale, const float *xshift, float *dw, float *workspace,
                    void *stream);
+/* mlp_gemm_wgrad for the pooled last layer (dy formed on the fly as in mlp_gemm_dgrad_pooled;
+ * replaces F.max_pool2d backward + ReLU/BatchNorm2d backward + conv2d backward-weight,
+ * pointnet2_modules.py:256-262 and pytorch_utils.py:70-124); workspace as for r = groups*ns */
+int mlp_gemm_wgrad_pooled(int b, int m, int k, int groups, int ns, const float *y,
+                          const float *dpooled, const int *argmax, const float *scale,
+                          const float *shift, const float *mean, const float *invstd,
+                          const float *coef, int qmode, const float *x, const float *xscale,
+                          const float *xshift, float *dw, float *workspace, void *stream);
+
 /* scratch (floats) for mlp_gemm_wgrad: per-slice partial dW tiles (replaces cuDNN's
  * workspace of conv2d backward-weight, pytorch_utils.py:70-124) */
 size_t mlp_gemm_wgrad_workspace_floats(int b, int m, int k, int r);

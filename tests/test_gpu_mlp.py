@@ -133,6 +133,38 @@ def test_mfma_gemm_primitives_vs_torch(b, m, k, r):
     close(K.gemm_wgrad(m, k, x, (scale_k, shift_k), fly=fly), want_dw_bn, tol)
 
 
+@pytest.mark.parametrize("b,m,k,groups,ns", [(2, 128, 64, 50, 64), (1, 256, 131, 33, 32),
+                                             (2, 70, 259, 17, 16), (1, 64, 20, 40, 6),
+                                             (2, 33, 7, 9, 3)])
+def test_pooled_operand_mode_vs_materialised(b, m, k, groups, ns):
+    """dgrad / wgrad of a pooled last layer with dy rebuilt inside the operand loads from
+    (y, dpooled, argmax) == the same GEMMs on the dy tensor written out by the BN/pool backward."""
+    load_pkg()
+    K = importlib.import_module("pointnet2._mlp_ext")
+    g = torch.Generator().manual_seed(m * 7 + k + groups + ns)
+    w = (torch.randn(m, k, generator=g) / k ** 0.5).to(DEV)
+    x = torch.randn(b, k, groups, ns, generator=g).to(DEV)
+    y = torch.randn(b, m, groups, ns, generator=g).to(DEV)
+    gamma = (torch.rand(m, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(m, generator=g) * 0.3).to(DEV)
+    rm, rv = torch.zeros(m, device=DEV), torch.ones(m, device=DEV)
+    mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, 0.1, 1e-5, True)
+    pooled, argmax, ymax = K.bn_relu_pool(y, scale, shift)
+    dpooled = torch.randn(b, m, groups, generator=g).to(DEV)
+    dy, dgamma, dbeta = K.bn_relu_pool_backward(y, dpooled, argmax, ymax, gamma, scale, shift, mean,
+                                                invstd, True)
+    dgamma2, dbeta2, coef = K.bn_relu_pool_backward_stats(y, dpooled, argmax, ymax, gamma, scale,
+                                                          shift, mean, invstd, True)
+    close(dgamma2, dgamma, 1e-6); close(dbeta2, dbeta, 1e-6)
+    op = (y, dpooled, argmax, scale, shift, mean, invstd, coef)
+    close(K.gemm_dgrad(w, pooled=op), K.gemm_dgrad(w, dy=dy), 1e-5)
+    scale_k = (torch.rand(k, generator=g) + 0.5).to(DEV)
+    shift_k = (torch.randn(k, generator=g) * 0.3).to(DEV)
+    close(K.gemm_wgrad(m, k, x, None, pooled=op), K.gemm_wgrad(m, k, x, None, dy=dy), 1e-5)
+    close(K.gemm_wgrad(m, k, x, (scale_k, shift_k), pooled=op),
+          K.gemm_wgrad(m, k, x, (scale_k, shift_k), dy=dy), 1e-5)
+
+
 @pytest.mark.parametrize("widths,shape", [([4, 64, 64, 128], (2, 4, 64, 64)),
                                           ([131, 128, 128, 256], (2, 131, 50, 32)),
                                           ([259, 128, 128], (3, 259, 20, 16)),
