@@ -70,6 +70,27 @@ bn_partial_stats_kernel(int c, int r, int slices, const float *__restrict__ y,
 }
 
 // ---- finalize: Chan combination, running statistics, affine coefficients ------------------
+// One wave per channel: lanes combine every 64th partial, then a butterfly merges the lanes.
+struct Moments { double n, mean, m2; };
+
+__device__ __forceinline__ Moments chan_merge(const Moments &a, const Moments &b) {
+  if (b.n <= 0.0) return a;
+  if (a.n <= 0.0) return b;
+  Moments o;
+  const double delta = b.mean - a.mean;
+  o.n = a.n + b.n;
+  o.mean = a.mean + delta * b.n / o.n;
+  o.m2 = a.m2 + b.m2 + delta * delta * a.n * b.n / o.n;
+  return o;
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, mask, kWave);
+  hi = __shfl_xor(hi, mask, kWave);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ void __launch_bounds__(256)
 bn_finalize_kernel(int c, int parts, const float *__restrict__ partial,
                    const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
@@ -77,19 +98,24 @@ bn_finalize_kernel(int c, int parts, const float *__restrict__ partial,
                    float *__restrict__ running_var, float *__restrict__ mean_out,
                    float *__restrict__ invstd_out, float *__restrict__ scale_out,
                    float *__restrict__ shift_out) {
-  const int ch = blockIdx.x * 256 + threadIdx.x;
+  const int ch = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
   if (ch >= c) return;
-  double n = 0.0, mean = 0.0, m2 = 0.0;
+  const int lane = lane_id();
+  Moments acc = {0.0, 0.0, 0.0};
   const float *p = partial + (size_t)ch * parts * 3;
-  for (int q = 0; q < parts; ++q) {
-    const double nb = p[q * 3], mb = p[q * 3 + 1], m2b = p[q * 3 + 2];
-    if (nb > 0.0) {
-      const double tot = n + nb, delta = mb - mean;
-      mean += delta * nb / tot;
-      m2 += m2b + delta * delta * n * nb / tot;
-      n = tot;
-    }
+  for (int q = lane; q < parts; q += kWave) {
+    const Moments part = {(double)p[q * 3], (double)p[q * 3 + 1], (double)p[q * 3 + 2]};
+    acc = chan_merge(acc, part);
   }
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    Moments other = {shfl_xor_f64(acc.n, off), shfl_xor_f64(acc.mean, off),
+                     shfl_xor_f64(acc.m2, off)};
+    // merge in a lane-independent order so that every lane ends with the same bits
+    acc = (lane & off) ? chan_merge(other, acc) : chan_merge(acc, other);
+  }
+  if (lane != 0) return;
+  const double n = acc.n, mean = acc.mean, m2 = acc.m2;
   const double var = n > 0.0 ? m2 / n : 0.0;  // biased, used for normalisation
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float fmean = (float)mean;
@@ -254,17 +280,25 @@ pool_bwd_partial_kernel(int c, int m, const float *__restrict__ dpooled,
   }
 }
 
-// dgamma = s2, dbeta = s1, and the per-channel coefficients of dy (training mode)
+// dgamma = s2, dbeta = s1, and the per-channel coefficients of dy (training mode); one wave
+// per channel
 __global__ void __launch_bounds__(256)
 bn_bwd_finalize_kernel(int c, int parts, double count, int training,
                        const float *__restrict__ partial, const float *__restrict__ gamma,
                        const float *__restrict__ invstd, float *__restrict__ dgamma,
                        float *__restrict__ dbeta, float *__restrict__ coef) {
-  const int ch = blockIdx.x * 256 + threadIdx.x;
+  const int ch = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
   if (ch >= c) return;
+  const int lane = lane_id();
   double s1 = 0.0, s2 = 0.0;
   const float *p = partial + (size_t)ch * parts * 2;
-  for (int q = 0; q < parts; ++q) { s1 += p[q * 2]; s2 += p[q * 2 + 1]; }
+  for (int q = lane; q < parts; q += kWave) { s1 += p[q * 2]; s2 += p[q * 2 + 1]; }
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    s1 += shfl_xor_f64(s1, off);
+    s2 += shfl_xor_f64(s2, off);
+  }
+  if (lane != 0) return;
   dbeta[ch] = (float)s1;
   dgamma[ch] = (float)s2;
   coef[ch * 3 + 0] = gamma[ch] * invstd[ch];
@@ -360,7 +394,7 @@ MLP_API int mlp_bn_train_stats(int b, int c, int r, const float *y, const float 
   const int slices = slices_for(r);
   hipLaunchKernelGGL(bn_partial_stats_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream, c,
                      r, slices, y, workspace);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(pn2_ceil_div(c, 256)), dim3(256), 0, stream, c,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(pn2_ceil_div(c, 256 / kWave)), dim3(256), 0, stream, c,
                      b * slices, workspace, gamma, beta, eps, momentum, running_mean,
                      running_var, mean, invstd, scale, shift);
   return pn2_launch_status();
@@ -422,7 +456,7 @@ MLP_API int mlp_bn_relu_backward(int b, int c, int r, int training, const float 
   const int slices = slices_for(r);
   hipLaunchKernelGGL(bn_relu_bwd_partial_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream,
                      c, r, slices, y, dz, scale, shift, mean, invstd, workspace);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn2_ceil_div(c, 256)), dim3(256), 0, stream, c,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn2_ceil_div(c, 256 / kWave)), dim3(256), 0, stream, c,
                      b * slices, (double)b * (double)r, training, workspace, gamma, invstd, dgamma,
                      dbeta, coef);
   if (r % 4 == 0)
@@ -445,7 +479,7 @@ MLP_API int mlp_bn_relu_backward_stats(int b, int c, int r, int training, const 
   const int slices = slices_for(r);
   hipLaunchKernelGGL(bn_relu_bwd_partial_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream,
                      c, r, slices, y, dz, scale, shift, mean, invstd, workspace);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn2_ceil_div(c, 256)), dim3(256), 0, stream, c,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn2_ceil_div(c, 256 / kWave)), dim3(256), 0, stream, c,
                      b * slices, (double)b * (double)r, training, workspace, gamma, invstd, dgamma,
                      dbeta, coef);
   return pn2_launch_status();
@@ -462,7 +496,7 @@ MLP_API int mlp_bn_relu_pool_backward(int b, int c, int m, int ns, int training,
   hipStream_t stream = (hipStream_t)stream_;
   hipLaunchKernelGGL(pool_bwd_partial_kernel, dim3(1, c, b), dim3(kBnThreads), 0, stream, c, m,
                      dpooled, ymax, scale, shift, mean, invstd, workspace);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn2_ceil_div(c, 256)), dim3(256), 0, stream, c,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn2_ceil_div(c, 256 / kWave)), dim3(256), 0, stream, c,
                      b, (double)b * (double)m * (double)ns, training, workspace, gamma, invstd,
                      dgamma, dbeta, coef);
   if (dy == nullptr) return pn2_launch_status();  // statistics only (mlp_gemm_*_pooled form dy)

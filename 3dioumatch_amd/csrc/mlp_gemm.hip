@@ -356,21 +356,34 @@ gemm_wgrad_kernel(int m_total, int k_begin, int k_end, int k_total, int r, int r
     }
 }
 
+// dw[i] = sum_p part[p][i]: a workgroup owns 32 consecutive elements, its 8 lane groups each sum
+// every 8th partial (128-byte rows, four loads in flight per lane), LDS adds the groups in a
+// fixed order -- deterministic, and a few hundred partials finish in a few microseconds
 __global__ void __launch_bounds__(256)
 reduce_partials_kernel(int count, int parts, const float *__restrict__ part,
                        float *__restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= count) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four loads in flight per lane
-  int p = 0;
-  for (; p + 3 < parts; p += 4) {
-    s0 += part[(size_t)p * count + i];
-    s1 += part[(size_t)(p + 1) * count + i];
-    s2 += part[(size_t)(p + 2) * count + i];
-    s3 += part[(size_t)(p + 3) * count + i];
+  __shared__ float sums[8][32];
+  const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < count) {
+    int p = grp;
+    for (; p + 24 < parts; p += 32) {
+      s0 += part[(size_t)p * count + i];
+      s1 += part[(size_t)(p + 8) * count + i];
+      s2 += part[(size_t)(p + 16) * count + i];
+      s3 += part[(size_t)(p + 24) * count + i];
+    }
+    for (; p < parts; p += 8) s0 += part[(size_t)p * count + i];
   }
-  for (; p < parts; ++p) s0 += part[(size_t)p * count + i];
-  out[i] = (s0 + s1) + (s2 + s3);
+  sums[grp][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && i < count) {
+    float t = sums[0][e];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t += sums[q][e];
+    out[i] = t;
+  }
 }
 
 template <int MODE>
@@ -509,7 +522,7 @@ static int wgrad_run(int b, int m, int k, int r, int pmode, const OperandB &P, i
   else if (qmode == OP_DIRECT) WG(OP_POOLDY, OP_DIRECT);
   else WG(OP_POOLDY, OP_BNRELU);
 #undef WG
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(pn2_ceil_div((long long)m * k, 256)), dim3(256),
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(pn2_ceil_div((long long)m * k, 32)), dim3(256),
                      0, stream, m * k, b * slices, workspace, dw);
   return pn2_launch_status();
 }
