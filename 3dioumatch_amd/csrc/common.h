@@ -15,6 +15,32 @@ static inline int pn2_launch_status() { return (int)hipGetLastError(); }
 
 static inline int pn2_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// XCD-aware block ids.  The dispatcher hands workgroup i (x fastest, then y, z) to XCD i % 8,
+// and every XCD has a private 4 MB L2.  With the cloud index in the slowest grid dimension the
+// default placement makes every XCD touch every cloud (each L2 re-fetches all of them); this
+// remap gives each XCD a CONTIGUOUS range of logical block ids instead -- for B = 8 clouds
+// exactly one cloud per XCD -- so a cloud's points / cell lists are fetched from HBM once and
+// then hit in that XCD's L2.  Bijective for any grid size (cdna_hip_programming.md T1); purely
+// a placement choice, no kernel depends on it for correctness.
+struct BlockId { int x, y, z; };
+
+__device__ __forceinline__ int xcd_contiguous_block(int hw, int nwg) {
+  const int xcd = hw & 7, slot = hw >> 3, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+__device__ __forceinline__ BlockId xcd_block_id() {
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int nwg = gx * gy * gridDim.z;
+  int l = xcd_contiguous_block(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), nwg);
+  BlockId o;
+  o.x = l % gx;
+  l /= gx;
+  o.y = l % gy;
+  o.z = l / gy;
+  return o;
+}
+
 // Zero `bytes` (a multiple of 4) of device memory with an ordinary kernel.  Used instead of
 // hipMemsetAsync so that, when the caller's stream is being captured into a HIP graph, the
 // clear is a plain kernel node ordered like every other launch.

@@ -246,9 +246,11 @@ gemm_wgrad_kernel(int m_total, int k_begin, int k_end, int k_total, int r, int r
   float *Ps = lds, *Qs = lds + RC * LDP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave % WK, wr = wave / WK;
-  const int k0 = k_begin + blockIdx.x * TK, m0 = blockIdx.y * TM;
+  // XCD-contiguous ids: the 64-row tiles of one (cloud, slice) share their Q rows through one L2
+  const BlockId blk = xcd_block_id();
+  const int k0 = k_begin + blk.x * TK, m0 = blk.y * TM;
   const int slices = (r + r_per_slice - 1) / r_per_slice;
-  const int b = blockIdx.z / slices, slice = blockIdx.z % slices;
+  const int b = blk.z / slices, slice = blk.z % slices;
   const int r_lo = slice * r_per_slice;
   const int r_hi = r_lo + r_per_slice < r ? r_lo + r_per_slice : r;
   OperandB P = opp, Q = opq;
@@ -342,7 +344,7 @@ gemm_wgrad_kernel(int m_total, int k_begin, int k_end, int k_total, int r, int r
     }
     if (wr != 0) return;
   }
-  float *out = part + (size_t)blockIdx.z * m_total * k_total;
+  float *out = part + (size_t)blk.z * m_total * k_total;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll

@@ -70,7 +70,8 @@ grid_build_kernel(int n, float inv_side, const float *__restrict__ xyz, int *__r
                   float4 *__restrict__ ovf) {
   __shared__ int lcnt[kSlabCells];
   __shared__ int l_ovf;
-  const int slab = blockIdx.x, b = blockIdx.y;
+  const BlockId blk = xcd_block_id();  // all 32 slabs of a cloud on one XCD: one HBM read
+  const int slab = blk.x, b = blk.y;
   for (int t = threadIdx.x; t < kSlabCells; t += kBuildThreads) lcnt[t] = 0;
   if (threadIdx.x == 0) l_ovf = 0;
   __syncthreads();
@@ -191,10 +192,11 @@ grid_query_kernel(int n, int m, float radius2, float inv_side, int nsample,
                   const float4 *__restrict__ slots, const float4 *__restrict__ ovf,
                   int *__restrict__ idx) {
   __shared__ unsigned hits[256 / kWave][kMaxHits];
-  const int b = blockIdx.y;
+  const BlockId blk = xcd_block_id();
+  const int b = blk.y;
   const int lane = lane_id();
   const int wave = threadIdx.x / kWave;
-  const int j = blockIdx.x * (256 / kWave) + wave;
+  const int j = blk.x * (256 / kWave) + wave;
   if (j >= m) return;  // whole wave
   const float *pts = xyz + (size_t)b * n * 3;
   const float *ctr = new_xyz + ((size_t)b * m + j) * 3;

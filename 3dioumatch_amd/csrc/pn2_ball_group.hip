@@ -24,9 +24,10 @@ __global__ void __launch_bounds__(256)
 ball_query_bf_kernel(int n, int m, float radius2, int nsample,
                      const float *__restrict__ new_xyz, const float *__restrict__ xyz,
                      int *__restrict__ idx) {
-  const int b = blockIdx.y;
+  const BlockId blk = xcd_block_id();
+  const int b = blk.y;
   const int wave = threadIdx.x / kWave;
-  const int j0 = (blockIdx.x * (256 / kWave) + wave) * QW;
+  const int j0 = (blk.x * (256 / kWave) + wave) * QW;
   if (j0 >= m) return;
   ball_query_wave_scan<QW>(xyz + (size_t)b * n * 3, n, new_xyz + ((size_t)b * m + j0) * 3,
                            m - j0 < QW ? m - j0 : QW, radius2, nsample,
@@ -40,8 +41,9 @@ template <bool VEC>
 __global__ void __launch_bounds__(256)
 group_points_kernel(int c, int n, int mns, const float *__restrict__ points,
                     const int *__restrict__ idx, float *__restrict__ out) {
-  const int b = blockIdx.z;
-  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const BlockId blk = xcd_block_id();
+  const int b = blk.z;
+  const int e = (blk.x * 256 + threadIdx.x) * 4;
   if (e >= mns) return;
   const int *ib = idx + (size_t)b * mns + e;
   int i0, i1 = 0, i2 = 0, i3 = 0;
@@ -55,7 +57,7 @@ group_points_kernel(int c, int n, int mns, const float *__restrict__ points,
     if (live > 2) i2 = ib[2];
     if (live > 3) i3 = ib[3];
   }
-  for (int l = blockIdx.y; l < c; l += gridDim.y) {
+  for (int l = blk.y; l < c; l += gridDim.y) {
     const float *src = points + ((size_t)b * c + l) * n;
     float *dst = out + ((size_t)b * c + l) * mns + e;
     if (VEC) {
@@ -76,8 +78,9 @@ template <bool VEC>
 __global__ void __launch_bounds__(256)
 group_points_grad_kernel(int c, int n, int mns, const float *__restrict__ grad_out,
                          const int *__restrict__ idx, float *__restrict__ grad_points) {
-  const int b = blockIdx.z;
-  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const BlockId blk = xcd_block_id();
+  const int b = blk.z;
+  const int e = (blk.x * 256 + threadIdx.x) * 4;
   if (e >= mns) return;
   const int *ib = idx + (size_t)b * mns + e;
   int i0, i1 = 0, i2 = 0, i3 = 0;
@@ -91,7 +94,7 @@ group_points_grad_kernel(int c, int n, int mns, const float *__restrict__ grad_o
     if (live > 2) i2 = ib[2];
     if (live > 3) i3 = ib[3];
   }
-  for (int l = blockIdx.y; l < c; l += gridDim.y) {
+  for (int l = blk.y; l < c; l += gridDim.y) {
     float *dst = grad_points + ((size_t)b * c + l) * n;
     const float *src = grad_out + ((size_t)b * c + l) * mns + e;
     if (VEC) {
@@ -125,8 +128,9 @@ __global__ void __launch_bounds__(1024)
 group_points_grad_lds_kernel(int c, int n, int mns, const float *__restrict__ grad_out,
                              const int *__restrict__ idx, float *__restrict__ grad_points) {
   extern __shared__ __attribute__((aligned(16))) float acc[];
-  const int b = blockIdx.y;
-  const int l0 = blockIdx.x * CPW;
+  const BlockId blk = xcd_block_id();
+  const int b = blk.y;
+  const int l0 = blk.x * CPW;
   const int nc = c - l0 < CPW ? c - l0 : CPW;
   for (int t = threadIdx.x; t < nc * n; t += 1024) acc[t] = 0.f;
   __syncthreads();
@@ -179,9 +183,10 @@ group_concat_kernel(int c, int n, int m, int ns, float inv_radius, int normalize
                     const float *__restrict__ new_xyz, const float *__restrict__ xyz,
                     const float *__restrict__ features, const int *__restrict__ idx,
                     float *__restrict__ out) {
-  const int b = blockIdx.z;
+  const BlockId blk = xcd_block_id();
+  const int b = blk.z;
   const int mns = m * ns;
-  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int e = (blk.x * 256 + threadIdx.x) * 4;
   if (e >= mns) return;
   const int live = mns - e < 4 ? mns - e : 4;
   const int *ib = idx + (size_t)b * mns + e;
@@ -193,7 +198,7 @@ group_concat_kernel(int c, int n, int m, int ns, float inv_radius, int normalize
     for (int t = 0; t < live; ++t) ii[t] = ib[t];
   }
   const int ctot = 3 + c;
-  if (blockIdx.y == 0) {
+  if (blk.y == 0) {
     const float *pts = xyz + (size_t)b * n * 3;
     const float *ctr = new_xyz + (size_t)b * m * 3;
     float r[3][4];
@@ -217,7 +222,7 @@ group_concat_kernel(int c, int n, int m, int ns, float inv_radius, int normalize
       }
     }
   }
-  for (int l = blockIdx.y; l < c; l += gridDim.y) {
+  for (int l = blk.y; l < c; l += gridDim.y) {
     const float *src = features + ((size_t)b * c + l) * n;
     float *dst = out + ((size_t)b * ctot + 3 + l) * mns + e;
     if (VEC) {

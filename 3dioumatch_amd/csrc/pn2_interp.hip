@@ -19,8 +19,9 @@ three_nn_kernel(int n, int m, const float *__restrict__ unknown,
                 const float *__restrict__ known, float *__restrict__ dist2,
                 int *__restrict__ idx) {
   __shared__ float4 tile[kNNTile];
-  const int b = blockIdx.y;
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const BlockId blk = xcd_block_id();
+  const int b = blk.y;
+  const int j = blk.x * 256 + threadIdx.x;
   const bool live = j < n;
   const float *kn = known + (size_t)b * m * 3;
   float ux = 0.f, uy = 0.f, uz = 0.f;
@@ -75,8 +76,9 @@ __global__ void __launch_bounds__(256)
 three_interpolate_kernel(int c, int m, int n, const float *__restrict__ points,
                          const int *__restrict__ idx, const float *__restrict__ weight,
                          float *__restrict__ out) {
-  const int b = blockIdx.z;
-  const int j0 = (blockIdx.x * 256 + threadIdx.x) * JP;
+  const BlockId blk = xcd_block_id();
+  const int b = blk.z;
+  const int j0 = (blk.x * 256 + threadIdx.x) * JP;
   if (j0 >= n) return;
   int ii[JP][3];
   float ww[JP][3];
@@ -88,7 +90,7 @@ three_interpolate_kernel(int c, int m, int n, const float *__restrict__ points,
 #pragma unroll
     for (int q = 0; q < 3; ++q) { ii[t][q] = ib[q]; ww[t][q] = wb[q]; }
   }
-  for (int l = blockIdx.y; l < c; l += gridDim.y) {
+  for (int l = blk.y; l < c; l += gridDim.y) {
     const float *src = points + ((size_t)b * c + l) * m;
     float r[JP];
 #pragma unroll
@@ -110,14 +112,15 @@ __global__ void __launch_bounds__(256)
 three_interpolate_grad_kernel(int c, int n, int m, const float *__restrict__ grad_out,
                               const int *__restrict__ idx, const float *__restrict__ weight,
                               float *__restrict__ grad_points) {
-  const int b = blockIdx.z;
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const BlockId blk = xcd_block_id();
+  const int b = blk.z;
+  const int j = blk.x * 256 + threadIdx.x;
   if (j >= n) return;
   const int *ib = idx + ((size_t)b * n + j) * 3;
   const float *wb = weight + ((size_t)b * n + j) * 3;
   const int i1 = ib[0], i2 = ib[1], i3 = ib[2];
   const float w1 = wb[0], w2 = wb[1], w3 = wb[2];
-  for (int l = blockIdx.y; l < c; l += gridDim.y) {
+  for (int l = blk.y; l < c; l += gridDim.y) {
     const float g = grad_out[((size_t)b * c + l) * n + j];
     float *dst = grad_points + ((size_t)b * c + l) * m;
     atomicAdd(dst + i1, __fmul_rn(g, w1));
