@@ -15,6 +15,7 @@
 //    a tail fill after the scan; rows without a hit are written as zeros, so the output
 //    needs no pre-zeroing.
 #include "common.h"
+#include <stdlib.h>
 #include "ball_common.h"
 
 namespace {
