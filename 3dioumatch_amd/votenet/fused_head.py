@@ -1,0 +1,123 @@
+"""conv1d(1) -> BN -> ReLU -> conv1d(1) -> BN -> ReLU -> conv1d(1): the three identical heads of
+VoteNet-IoU (voting_module.py:34-60, proposal_module.py:78-125, grid_conv_module.py:60-116) as
+ONE autograd node on the gfx950 MFMA / BatchNorm kernels of pointnet2._mlp_ext.
+
+Same parameters (nn.Conv1d with bias, nn.BatchNorm1d) and the same results as
+F.relu(bn(conv(x))) x2 + conv; what changes is how they are computed:
+  * the 1x1 convolutions are the R-contiguous GEMMs of the shared MLP (no NCHW<->NHWC transposes,
+    no MIOpen in the train step);
+  * BatchNorm+ReLU of layer i are applied inside the operand loads of layer i+1, their backward
+    inside the operand loads of dgrad / wgrad;
+  * a bias in front of a training-mode BatchNorm cancels in the output; it only shifts the
+    running mean (accounted for) and its gradient is sum(dy) == 0 (returned as exact zeros; the
+    reference accumulates rounding noise there).  In eval mode the bias is folded into the shift.
+"""
+import os
+
+import torch
+from torch.autograd import Function
+
+
+def _enabled():
+    """Off by default: at the head sizes (R = 256..1024 columns per cloud) the K-loop of the GEMM
+    kernels is a chain of 8..16 exposed load latencies with one workgroup per CU, and the step
+    measured 0.2 ms slower than with MIOpen's kernels (13.4 vs 13.2 ms).  VOTENET_FUSED_HEADS=1
+    gives a train step without any MIOpen / rocBLAS kernel."""
+    return os.environ.get("VOTENET_FUSED_HEADS", "0") == "1"
+
+
+class _HeadChain(Function):
+    """apply(x, training, mom1, eps1, mom2, eps2,
+             w1, b1, g1, be1, rm1, rv1,  w2, b2, g2, be2, rm2, rv2,  w3, b3)"""
+
+    @staticmethod
+    def forward(ctx, x, training, mom1, eps1, mom2, eps2, w1, b1, g1, be1, rm1, rv1, w2, b2, g2,
+                be2, rm2, rv2, w3, b3):
+        from pointnet2 import _mlp_ext as K
+        x = x.contiguous()
+        w1m, w2m, w3m = (w.reshape(w.shape[0], -1) for w in (w1, w2, w3))
+
+        def bn(y, bias, gamma, beta, rm, rv, momentum, eps):
+            mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, momentum, eps,
+                                                           training)
+            if bias is not None:
+                if training:
+                    rm.add_(bias.detach(), alpha=momentum)  # running mean of (W x + b)
+                else:
+                    shift = shift + scale * bias.detach()    # scale*(y + b - rm) + beta
+                    mean = mean - bias.detach()              # x-hat of the biased pre-activation
+            return mean, invstd, scale, shift
+
+        y1 = K.gemm_forward(w1m, x)
+        c1 = bn(y1, b1, g1, be1, rm1, rv1, mom1, eps1)
+        y2 = K.gemm_forward(w2m, y1, (c1[2], c1[3]))
+        c2 = bn(y2, b2, g2, be2, rm2, rv2, mom2, eps2)
+        y3 = K.gemm_forward(w3m, y2, (c2[2], c2[3]))
+        if b3 is not None:
+            y3 += b3.detach().view(1, -1, 1)
+        ctx.save_for_backward(x, y1, y2, *c1, *c2, w1, w2, w3, g1, g2)
+        ctx.training = training
+        ctx.has_bias = (b1 is not None, b2 is not None, b3 is not None)
+        return y3
+
+    @staticmethod
+    def backward(ctx, dy3):
+        from pointnet2 import _mlp_ext as K
+        (x, y1, y2, mean1, invstd1, scale1, shift1, mean2, invstd2, scale2, shift2, w1, w2, w3, g1,
+         g2) = ctx.saved_tensors
+        training = ctx.training
+        dy3 = dy3.contiguous()
+        w1m, w2m, w3m = (w.reshape(w.shape[0], -1) for w in (w1, w2, w3))
+        db3 = dy3.sum(dim=(0, 2)) if ctx.has_bias[2] else None
+        dw3 = K.gemm_wgrad(w3m.shape[0], w3m.shape[1], y2, (scale2, shift2), dy=dy3).view_as(w3)
+        dz2 = K.gemm_dgrad(w3m, dy=dy3)
+        dg2, dbe2, coef2 = K.bn_relu_backward_stats(y2, dz2, g2, scale2, shift2, mean2, invstd2,
+                                                    training)
+        fly2 = (y2, dz2, scale2, shift2, mean2, invstd2, coef2)
+        dw2 = K.gemm_wgrad(w2m.shape[0], w2m.shape[1], y1, (scale1, shift1), fly=fly2).view_as(w2)
+        dz1 = K.gemm_dgrad(w2m, fly=fly2)
+        dg1, dbe1, coef1 = K.bn_relu_backward_stats(y1, dz1, g1, scale1, shift1, mean1, invstd1,
+                                                    training)
+        fly1 = (y1, dz1, scale1, shift1, mean1, invstd1, coef1)
+        dw1 = K.gemm_wgrad(w1m.shape[0], w1m.shape[1], x, None, fly=fly1).view_as(w1)
+        dx = K.gemm_dgrad(w1m, fly=fly1).view_as(x) if ctx.needs_input_grad[0] else None
+
+        def dbias(present, coef, dbeta):
+            if not present:
+                return None
+            # training: sum(dy) vanishes identically; eval: dy = gamma*invstd*dz_masked
+            return torch.zeros_like(dbeta) if training else coef.reshape(-1)[0::3] * dbeta  # coef is [C][3]
+
+        db2 = dbias(ctx.has_bias[1], coef2, dbe2)
+        db1 = dbias(ctx.has_bias[0], coef1, dbe1)
+        return (dx, None, None, None, None, None, dw1, db1, dg1, dbe1, None, None, dw2, db2, dg2,
+                dbe2, None, None, dw3, db3)
+
+
+def _plain_conv(conv):
+    return (isinstance(conv, torch.nn.Conv1d) and conv.kernel_size == (1,) and conv.stride == (1,)
+            and conv.padding == (0,) and conv.dilation == (1,) and conv.groups == 1)
+
+
+def _plain_bn(bn):
+    return (isinstance(bn, torch.nn.BatchNorm1d) and bn.affine and bn.track_running_stats
+            and bn.momentum is not None)
+
+
+def head_chain(x, conv1, bn1, conv2, bn2, conv3):
+    """relu(bn1(conv1(x))) -> relu(bn2(conv2(.))) -> conv3(.) for x of shape (B, C, R)."""
+    fused = (_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3
+             and all(_plain_conv(c) for c in (conv1, conv2, conv3)) and _plain_bn(bn1)
+             and _plain_bn(bn2) and bn1.training == bn2.training)
+    if not fused:
+        net = torch.nn.functional.relu(bn1(conv1(x)))
+        net = torch.nn.functional.relu(bn2(conv2(net)))
+        return conv3(net)
+    training = bn1.training
+    if training:
+        bn1.num_batches_tracked.add_(1)
+        bn2.num_batches_tracked.add_(1)
+    return _HeadChain.apply(x, training, bn1.momentum, bn1.eps, bn2.momentum, bn2.eps,
+                            conv1.weight, conv1.bias, bn1.weight, bn1.bias, bn1.running_mean,
+                            bn1.running_var, conv2.weight, conv2.bias, bn2.weight, bn2.bias,
+                            bn2.running_mean, bn2.running_var, conv3.weight, conv3.bias)

@@ -19,6 +19,8 @@ from pointnet2 import pointnet2_utils
 from pointnet2 import pytorch_utils as pt_utils
 from pointnet2.pointnet2_modules import PointnetSAModuleVotes
 
+from .fused_head import head_chain
+
 
 class VotingModule(nn.Module):
     """seed (xyz, features) -> votes: xyz + offset, features + residual (vote_factor per seed)."""
@@ -36,9 +38,8 @@ class VotingModule(nn.Module):
 
     def forward(self, seed_xyz, seed_features):
         b, num_seed = seed_xyz.shape[:2]
-        net = F.relu(self.bn1(self.conv1(seed_features)))
-        net = F.relu(self.bn2(self.conv2(net)))
-        net = self.conv3(net).transpose(2, 1).view(b, num_seed, self.vote_factor, 3 + self.out_dim)
+        net = head_chain(seed_features, self.conv1, self.bn1, self.conv2, self.bn2, self.conv3)
+        net = net.transpose(2, 1).view(b, num_seed, self.vote_factor, 3 + self.out_dim)
         vote_xyz = (seed_xyz.unsqueeze(2) + net[..., 0:3]).reshape(b, num_seed * self.vote_factor, 3)
         vote_features = seed_features.transpose(2, 1).unsqueeze(2) + net[..., 3:]
         vote_features = vote_features.reshape(b, num_seed * self.vote_factor, self.out_dim)
@@ -111,9 +112,7 @@ class ProposalModule(nn.Module):
             raise ValueError('Unknown sampling strategy: %s' % (self.sampling,))
         end_points['aggregated_vote_xyz'] = xyz
         end_points['aggregated_vote_inds'] = sample_inds
-        net = F.relu(self.bn1(self.conv1(features)))
-        net = F.relu(self.bn2(self.conv2(net)))
-        net = self.conv3(net)
+        net = head_chain(features, self.conv1, self.bn1, self.conv2, self.bn2, self.conv3)
         return decode_scores(net, end_points, self.num_class, self.num_heading_bin,
                              self.num_size_cluster, self._mean_size)
 
@@ -184,8 +183,7 @@ class GridConv(nn.Module):
         feats = torch.cat([relative.transpose(1, 2).reshape(b, 3, k, g3),
                            interp.view(b, -1, k, g3)], dim=1)
         iou_features = self.mlp_before_iou.forward_pooled(feats)
-        net = F.relu(self.bn1_iou(self.conv1_iou(iou_features)))
-        net = F.relu(self.bn2_iou(self.conv2_iou(net)))
-        net = self.conv3_iou(net)
+        net = head_chain(iou_features, self.conv1_iou, self.bn1_iou, self.conv2_iou, self.bn2_iou,
+                         self.conv3_iou)
         end_points['iou_scores'] = net.transpose(2, 1)[:, :, -self.iou_size:]
         return end_points

@@ -3,6 +3,7 @@ torch ops on the same device (fp32 reference of the same op): forward values, ru
 statistics, and gradients w.r.t. input, gamma, beta -- training and eval mode, vector and
 ragged shapes.  Tolerance 1e-4 (relative to the tensor scale)."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -201,3 +202,51 @@ def test_fused_chain_vs_sequential(widths, shape, training):
             assert rel < 3e-2, (n1, rel)
         for (n1, b1), (n2, b2) in zip(mlp.named_buffers(), ref.named_buffers()):
             close(b1.float(), b2.float(), 2e-4)
+
+
+@pytest.mark.parametrize("cin,mid,cout,shape", [(256, 256, 259, (2, 1024)), (128, 128, 79, (3, 256)),
+                                                (20, 12, 7, (2, 33))])
+@pytest.mark.parametrize("training", [True, False])
+def test_fused_head_chain_vs_torch(cin, mid, cout, shape, training):
+    """conv1d-BN-ReLU x2 + conv1d of the vote / proposal / IoU heads on the MFMA + BN kernels ==
+    the torch modules: output, every gradient, running statistics (bias folded correctly)."""
+    load_pkg()
+    fh = importlib.import_module("3dioumatch_amd.votenet.fused_head")
+    nn = torch.nn
+    torch.manual_seed(cin + cout)
+    mods = [nn.Conv1d(cin, mid, 1), nn.BatchNorm1d(mid), nn.Conv1d(mid, mid, 1), nn.BatchNorm1d(mid),
+            nn.Conv1d(mid, cout, 1)]
+    for m in mods:
+        if isinstance(m, nn.BatchNorm1d):
+            m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.3)
+            m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+        else:
+            m.bias.data.normal_(0, 0.5)
+    import copy
+    ref = [copy.deepcopy(m).to(DEV) for m in mods]
+    mods = [m.to(DEV) for m in mods]
+    for m in mods + ref:
+        m.train(training)
+    b, r = shape
+    x1 = torch.randn(b, cin, r, device=DEV, requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    os.environ["VOTENET_FUSED_HEADS"] = "1"
+    try:
+        out = fh.head_chain(x1, *mods)
+    finally:
+        os.environ["VOTENET_FUSED_HEADS"] = "0"
+    want = fh.head_chain(x2, *ref)
+    close(out, want, 2e-4)
+    gout = torch.randn_like(want)
+    out.backward(gout)
+    want.backward(gout)
+    close(x1.grad, x2.grad, 5e-4)
+    for m, q in zip(mods, ref):
+        for (n1, p1), (n2, p2) in zip(m.named_parameters(), q.named_parameters()):
+            if training and n1 == "bias" and isinstance(m, torch.nn.Conv1d) and m is not mods[4]:
+                assert float(p1.grad.abs().max()) == 0.0  # cancels in front of a batch-stat BN
+                assert float(p2.grad.abs().max()) < 1e-3  # ... where torch accumulates noise
+                continue
+            close(p1.grad, p2.grad, 5e-4)
+        for (n1, b1), (n2, b2) in zip(m.named_buffers(), q.named_buffers()):
+            close(b1.float(), b2.float(), 1e-5)
