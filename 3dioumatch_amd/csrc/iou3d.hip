@@ -95,6 +95,61 @@ pair_matrix_kernel(int na, const float *__restrict__ boxes_a, int nb,
   ans[(size_t)gi * nb + gj] = pair_value<MODE>(raw + r * 7, raw + (16 + cidx) * 7, A, B, st);
 }
 
+// Per-scene best match: for prediction i of scene s, max_j iou3d(a[s][i], b[s][j]) and the first j
+// attaining it -- the block-diagonal of the all-pairs matrix and the max/gather the reference
+// applies to it (loss_helper_iou.py:106-111), without the (S-1)/S cross-scene pairs.
+// Workgroup = 16 predictions of one scene; lane (row, col) walks the scene's boxes 16 at a time.
+__global__ void __launch_bounds__(256)
+scene_max_kernel(int na, int nb, const float *__restrict__ boxes_a,
+                 const float *__restrict__ boxes_b, float *__restrict__ best_iou,
+                 int *__restrict__ best_idx) {
+  __shared__ float poly[kPolySlots * 256];
+  __shared__ BoxPre pre[32];
+  __shared__ float raw[32 * 7];
+  const int tid = threadIdx.x;
+  const int scene = blockIdx.y, row0 = blockIdx.x * 16;
+  const float *sa = boxes_a + (size_t)scene * na * 7;
+  const float *sb = boxes_b + (size_t)scene * nb * 7;
+  const int r = tid >> 4, cidx = tid & 15;
+  const int gi = row0 + r;
+  float best = -1.f;  // every IoU is >= 0, so column 0 wins an all-zero row
+  int arg = 0;
+  LdsPoly st{poly + tid};
+  for (int col0 = 0; col0 < nb; col0 += 16) {
+    __syncthreads();
+    if (tid < 32) {
+      const bool is_a = tid < 16;
+      const int g = is_a ? row0 + tid : col0 + (tid - 16);
+      const bool ok = is_a ? g < na : g < nb;
+      const float *src = (is_a ? sa : sb) + (size_t)(ok ? g : 0) * 7;
+      if (!is_a || col0 == 0) {
+        float bx[7];
+#pragma unroll
+        for (int d = 0; d < 7; ++d) { bx[d] = src[d]; raw[tid * 7 + d] = bx[d]; }
+        boxgeom::box_prepare(bx, pre[tid]);
+      }
+    }
+    __syncthreads();
+    const int gj = col0 + cidx;
+    if (gi < na && gj < nb) {
+      const float v = pair_value<kIou3d>(raw + r * 7, raw + (16 + cidx) * 7, pre[r],
+                                         pre[16 + cidx], st);
+      if (v > best) { best = v; arg = gj; }  // strict: the earlier column keeps a tie
+    }
+  }
+  // the 16 lanes of a row are consecutive: butterfly over them, (value desc, index asc)
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) {
+    const float ov = __shfl_xor(best, off, 16);
+    const int oa = __shfl_xor(arg, off, 16);
+    if (ov > best || (ov == best && oa < arg)) { best = ov; arg = oa; }
+  }
+  if (cidx == 0 && gi < na) {
+    best_iou[(size_t)scene * na + gi] = best < 0.f ? 0.f : best;
+    best_idx[(size_t)scene * na + gi] = arg;
+  }
+}
+
 // iou_bev_3D (:237-247) / iou_normal (:327-338) as used by the NMS kernels
 template <bool NORMAL>
 __device__ __forceinline__ float nms_iou(const float *a, const float *b, const BoxPre &A,
@@ -210,6 +265,20 @@ IOU3D_API int iou3d_boxes_iou_bev(int num_a, const float *boxes_a, int num_b,
 IOU3D_API int iou3d_boxes_iou3d(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
                                 float *ans, void *stream) {
   return launch_pairs<kIou3d>(num_a, boxes_a, num_b, boxes_b, ans, stream);
+}
+
+IOU3D_API int iou3d_scene_best_iou3d(int scenes, int num_a, const float *boxes_a, int num_b,
+                                     const float *boxes_b, float *best_iou, int *best_idx,
+                                     void *stream) {
+  if (scenes <= 0 || num_a <= 0) return 0;
+  if (num_b <= 0) {
+    int rc = pn2_zero_async(best_iou, sizeof(float) * (size_t)scenes * num_a, (hipStream_t)stream);
+    if (rc == 0) rc = pn2_zero_async(best_idx, sizeof(int) * (size_t)scenes * num_a, (hipStream_t)stream);
+    return rc;
+  }
+  hipLaunchKernelGGL(scene_max_kernel, dim3(pn2_ceil_div(num_a, 16), scenes), dim3(256), 0,
+                     (hipStream_t)stream, num_a, num_b, boxes_a, boxes_b, best_iou, best_idx);
+  return pn2_launch_status();
 }
 
 static int launch_mask(const float *boxes, unsigned long long *mask, int n, float thresh,

@@ -75,6 +75,27 @@ def boxes_iou3d_fused_gpu(boxes_a, boxes_b, ans_iou3d):
     return _pairs(_lib.iou3d_boxes_iou3d, "boxes_iou3d_fused_gpu", boxes_a, boxes_b, ans_iou3d)
 
 
+def scene_best_iou3d_gpu(boxes_a, boxes_b, best_iou, best_idx):
+    """Addition: boxes_a (S,P,7), boxes_b (S,G,7) -> best_iou (S,P) f32, best_idx (S,P) i32 in
+    place: per prediction the largest 3-D IoU with a box of the SAME scene and the first index
+    attaining it (boxes_iou3d_gpu over all pairs + the block-diagonal max/gather of
+    loss_helper_iou.py:98-111 in one kernel)."""
+    _chk_gpu(boxes_a, "boxes_a"); _chk_gpu(boxes_b, "boxes_b"); _chk_gpu(best_iou, "best_iou")
+    if boxes_a.dim() != 3 or boxes_b.dim() != 3 or boxes_a.shape[0] != boxes_b.shape[0] \
+            or boxes_a.shape[2] != 7 or boxes_b.shape[2] != 7:
+        raise RuntimeError("boxes must be (S,P,7) and (S,G,7)")
+    s, p, g = boxes_a.shape[0], boxes_a.shape[1], boxes_b.shape[1]
+    if best_iou.numel() != s * p or best_idx.numel() != s * p or best_idx.dtype != torch.int32 \
+            or not best_idx.is_cuda or not best_idx.is_contiguous():
+        raise RuntimeError("best_iou / best_idx must be contiguous (S,P) float32 / int32 GPU tensors")
+    with torch.cuda.device(boxes_a.device):
+        _L.check(_lib.iou3d_scene_best_iou3d(s, p, boxes_a.data_ptr(), g, boxes_b.data_ptr(),
+                                             best_iou.data_ptr(), best_idx.data_ptr(),
+                                             _L.current_stream_ptr(boxes_a.device)),
+                 "scene_best_iou3d_gpu")
+    return 1
+
+
 def _nms(boxes, keep, thresh, normal):
     _chk_gpu(boxes, "boxes")
     if keep.is_cuda or not keep.is_contiguous():

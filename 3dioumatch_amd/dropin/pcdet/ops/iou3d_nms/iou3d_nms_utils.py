@@ -47,6 +47,17 @@ def boxes_iou3d_gpu(boxes_a, boxes_b):
     return iou3d
 
 
+def boxes_iou3d_scene_max_gpu(boxes_a, boxes_b):
+    """(S,P,7),(S,G,7) device tensors -> (best IoU (S,P) f32, index of the best same-scene box
+    (S,P) i64): what compute_iou_labels (loss_helper_iou.py:98-111) derives from the all-pairs
+    matrix, computed for the same-scene pairs only."""
+    assert boxes_a.shape[2] == boxes_b.shape[2] == 7
+    best = torch.empty(boxes_a.shape[:2], dtype=torch.float32, device=boxes_a.device)
+    idx = torch.empty(boxes_a.shape[:2], dtype=torch.int32, device=boxes_a.device)
+    iou3d_nms_cuda.scene_best_iou3d_gpu(boxes_a.contiguous(), boxes_b.contiguous(), best, idx)
+    return best, idx.long()
+
+
 def _nms_common(fn, boxes, scores, thresh, pre_maxsize=None):
     assert boxes.shape[1] == 7
     order = scores.sort(0, descending=True)[1]

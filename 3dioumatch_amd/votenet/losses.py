@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from pcdet.ops.iou3d_nms.iou3d_nms_utils import boxes_iou3d_gpu
+from pcdet.ops.iou3d_nms.iou3d_nms_utils import boxes_iou3d_gpu, boxes_iou3d_scene_max_gpu
 
 FAR_THRESHOLD = 0.6
 NEAR_THRESHOLD = 0.3
@@ -116,6 +116,18 @@ def _block_diagonal_max(iou, b, pred_num):
             assignment.gather(dim=1, index=scene).view(b, -1))
 
 
+def _scene_best_iou(pred_bbox, gt_bbox):
+    """(B,P,7),(B,G,7) -> (IoU with the best GT box of the same scene (B,P), its index (B,P)).
+    On the GPU one kernel over the same-scene pairs; elsewhere the reference's formulation
+    (all pairs through boxes_iou3d_gpu, then the block diagonal)."""
+    b, pred_num = pred_bbox.shape[:2]
+    if pred_bbox.is_cuda:
+        best, assignment = boxes_iou3d_scene_max_gpu(pred_bbox.detach(), gt_bbox.detach())
+        return best, assignment
+    iou = boxes_iou3d_gpu(pred_bbox.view(-1, 7), gt_bbox.view(-1, 7))
+    return _block_diagonal_max(iou, b, pred_num)
+
+
 def _gt_boxes(end_points, inds, config):
     center, h_cls, h_res, s_cls, s_res = _labels(end_points, inds)
     gt_size = config.class2size_gpu(s_cls, s_res)
@@ -154,8 +166,7 @@ def compute_iou_labels(end_points, unsupervised_inds, pred_votes, pred_center, p
         scene = torch.arange(b, device=iou.device).unsqueeze(1).expand(-1, gt_num * pred_num)
         scene = scene.reshape(-1, 1, pred_num)
         return iou.gather(dim=1, index=scene).view(b, -1, pred_num).detach()
-    iou = boxes_iou3d_gpu(pred_bbox.view(-1, 7), gt_bbox.view(-1, 7))
-    iou_labels, object_assignment = _block_diagonal_max(iou, b, pred_num)
+    iou_labels, object_assignment = _scene_best_iou(pred_bbox, gt_bbox)
     return iou_labels, objectness_label, object_assignment
 
 
@@ -222,8 +233,7 @@ def compute_box_and_sem_cls_loss(end_points, supervised_inds, dataset_config, co
                                _sel(end_points['jitter_size'], sup),
                                -_sel(end_points['jitter_heading'], sup)[:, :, None]], dim=2)
         pred_num = pred_bbox.shape[1]
-        jitter_iou = boxes_iou3d_gpu(pred_bbox.view(-1, 7), gt_bbox.view(-1, 7))
-        jitter_iou_labels, jitter_assign = _block_diagonal_max(jitter_iou, b, pred_num)
+        jitter_iou_labels, jitter_assign = _scene_best_iou(pred_bbox, gt_bbox)
         jitter_sem = torch.gather(_sel(end_points['sem_cls_label'], sup), 1, jitter_assign)
         jitter_pred = torch.sigmoid(_sel(end_points['iou_scores_jitter'], sup))
         jitter_pred = torch.gather(jitter_pred, 2, jitter_sem.unsqueeze(-1)).squeeze(-1) \

@@ -59,6 +59,13 @@ int iou3d_boxes_iou_bev_cpu(int num_a, const float *boxes_a_host, int num_b,
 int iou3d_boxes_iou3d(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
                       float *ans_iou3d, void *stream);
 
+/* replaces boxes_iou3d_gpu over ALL (scene, scene') pairs followed by the block-diagonal
+ * max / gather of compute_iou_labels (loss_helper_iou.py:98-111): boxes_a (scenes, num_a, 7),
+ * boxes_b (scenes, num_b, 7) -> best_iou (scenes, num_a) f32 and best_idx (scenes, num_a) i32 =
+ * the first box of the SAME scene with the largest 3-D IoU (index 0 when every IoU is 0). */
+int iou3d_scene_best_iou3d(int scenes, int num_a, const float *boxes_a, int num_b,
+                           const float *boxes_b, float *best_iou, int *best_idx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -282,6 +282,32 @@ def test_train_step_iou_shape_properties(synth):
     assert float((self_iou - 1).abs().max()) < 5e-2
 
 
+@pytest.mark.parametrize("scenes,p,g,seed", [(8, 256, 64, 0), (3, 33, 7, 1), (2, 16, 100, 2),
+                                             (1, 1, 1, 3), (4, 50, 0, 4)])
+def test_scene_best_iou3d_vs_oracle(oracle, synth, scenes, p, g, seed):
+    """Per-scene best IoU + first arg-max == block diagonal of the oracle's all-pairs matrix, bit
+    for bit the same kernel arithmetic as boxes_iou3d_gpu; empty GT sets give zeros."""
+    import importlib
+    ut = importlib.import_module("pcdet.ops.iou3d_nms.iou3d_nms_utils")
+    a, b = synth.boxes_pair(max(scenes * p, scenes * max(g, 1)), seed=seed)
+    a = a[:scenes * p].reshape(scenes, p, 7)
+    b = b[:scenes * g].reshape(scenes, g, 7)
+    a[:, p // 2:] += 50.0  # half of the predictions overlap nothing: all-zero rows -> index 0
+    best, idx = ut.boxes_iou3d_scene_max_gpu(dev(a), dev(b))
+    assert best.shape == (scenes, p) and idx.dtype == torch.int64
+    if g == 0:
+        assert float(best.abs().max()) == 0.0 and int(idx.abs().max()) == 0
+        return
+    full = ut.boxes_iou3d_gpu(dev(a.reshape(-1, 7)), dev(b.reshape(-1, 7))).cpu().numpy()
+    want = oracle.boxes_iou3d(a.reshape(-1, 7), b.reshape(-1, 7))
+    for s in range(scenes):
+        blk_gpu = full[s * p:(s + 1) * p, s * g:(s + 1) * g]
+        blk = want[s * p:(s + 1) * p, s * g:(s + 1) * g]
+        np.testing.assert_array_equal(best[s].cpu().numpy(), blk_gpu.max(axis=1))
+        np.testing.assert_array_equal(idx[s].cpu().numpy(), blk_gpu.argmax(axis=1))
+        np.testing.assert_allclose(best[s].cpu().numpy(), blk.max(axis=1), rtol=0, atol=1e-4)
+
+
 def _mask_words(t):
     return t.cpu().numpy().view(np.uint64)
 
