@@ -1,0 +1,35 @@
+"""Device-side NMS of the pseudo-label filter (binding of include/lhs_hip.h).
+
+The reference copies the 64 best teacher predictions of every unlabeled scene to the host, builds
+their 3-D boxes one by one in numpy and runs utils/nms.py:lhs_3d_faster_samecls
+(models/loss_helper_unlabeled.py:447-487); here the same computation is one kernel launch with no
+host round trip, so the semi-supervised step stays capturable in a HIP graph.
+"""
+import importlib
+
+import torch
+
+_L = importlib.import_module("3dioumatch_amd._lib")
+_lib = _L.lib
+
+
+def lhs_nms_samecls_gpu(center, size, heading, score, cls, thresh, old_type=False):
+    """center (S,n,3) f32, size (S,n,3) f64, heading (S,n) f64, score (S,n) f32, cls (S,n) i64 ->
+    picked (S,n) bool: True for the boxes lhs_3d_faster_samecls keeps (n <= 64)."""
+    for t, dt, name in ((center, torch.float32, "center"), (size, torch.float64, "size"),
+                        (heading, torch.float64, "heading"), (score, torch.float32, "score"),
+                        (cls, torch.int64, "cls")):
+        if not t.is_cuda or t.dtype != dt:
+            raise RuntimeError("%s must be a %s GPU tensor" % (name, dt))
+    s, n = score.shape
+    if n > 64:
+        raise RuntimeError("lhs_nms_samecls: at most 64 boxes per scene (MAX_NUM_OBJ)")
+    picked = torch.zeros((s, n), dtype=torch.int32, device=score.device)
+    with torch.cuda.device(score.device):
+        _L.check(_lib.lhs_nms_samecls(s, n, center.contiguous().data_ptr(),
+                                      size.contiguous().data_ptr(),
+                                      heading.contiguous().data_ptr(),
+                                      score.contiguous().data_ptr(), cls.contiguous().data_ptr(),
+                                      float(thresh), 1 if old_type else 0, picked.data_ptr(),
+                                      _L.current_stream_ptr(score.device)), "lhs_nms_samecls")
+    return picked.bool()

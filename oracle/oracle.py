@@ -195,6 +195,32 @@ class Oracle:
     def nms_normal(self, boxes_sorted, thresh):
         return self._nms(self.lib.iou3do_nms_normal, boxes_sorted, thresh)
 
+    # ---- pseudo-label filter (utils/nms.py:168-214, loss_helper_unlabeled.py:447-487) -------
+    def camera_aabb(self, center, size, heading):
+        """center (n,3) f32, size (n,3) f64, heading (n,) f64 -> (n,6) float32 axis-aligned bounds of
+        get_3d_box in the camera frame."""
+        center, cp = _f(center)
+        size = np.ascontiguousarray(size, np.float64)
+        heading = np.ascontiguousarray(heading, np.float64)
+        n = center.shape[0]
+        out = np.zeros((n, 6), np.float32)
+        dp = ctypes.POINTER(ctypes.c_double)
+        self.lib.lhso_camera_aabb(n, cp, size.ctypes.data_as(dp), heading.ctypes.data_as(dp),
+                                  out.ctypes.data_as(_f32p))
+        return out
+
+    def lhs_nms_samecls(self, aabb, score, cls, thresh, old_type=False):
+        """-> picked (n,) int32 mask: the indices lhs_3d_faster_samecls returns."""
+        aabb, ap = _f(aabb)
+        score, sp = _f(score)
+        cls = np.ascontiguousarray(cls, np.int64)
+        n = aabb.shape[0]
+        out = np.zeros(n, np.int32)
+        self.lib.lhso_nms_samecls(n, ap, sp, cls.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)),
+                                  ctypes.c_double(float(thresh)), int(bool(old_type)),
+                                  out.ctypes.data_as(_i32p))
+        return out
+
 
 class Reference:
     """The reference's own compiled CPU code (oracle/_ref). Raises if it was not built."""

@@ -453,3 +453,37 @@ def test_ballquery_cell_list_tier_edge_cases(ext, oracle_omp, synth, case):
     got = ext.ball_query(dev(cen), dev(xyz), r, ns).cpu().numpy()
     assert np.array_equal(got, want), np.argwhere(got != want)[:5]
     assert np.all(got[:, -1] == 0)
+
+
+def test_lhs_nms_vs_reference_golden_and_oracle(oracle, synth):
+    """Device pseudo-label NMS == the reference's numpy lhs_3d_faster_samecls (committed vectors)
+    and == the oracle on a batch of crowded random scenes."""
+    import importlib
+    nms = importlib.import_module("3dioumatch_amd.votenet.pseudo_nms")
+    g = golden("lhs_nms_ref.npz")
+    for k in range(int(g["num_cases"])):
+        get = lambda name: g["c%d_%s" % (k, name)]  # noqa: E731
+        picked = nms.lhs_nms_samecls_gpu(
+            dev(get("center")[None]), torch.from_numpy(get("size").astype(np.float64)[None]).cuda(),
+            torch.from_numpy(get("heading").astype(np.float64)[None]).cuda(), dev(get("score")[None]),
+            torch.from_numpy(get("cls")[None]).cuda(), float(get("thresh")), bool(get("old")))
+        np.testing.assert_array_equal(picked[0].cpu().numpy().astype(np.int32), get("pick"))
+    rng = np.random.default_rng(5)
+    s, n = 12, 64
+    clump = rng.uniform(-2, 2, (s, 4, 3))
+    center = (clump[np.arange(s)[:, None], rng.integers(0, 4, (s, n))] +
+              rng.normal(0, 0.2, (s, n, 3))).astype(np.float32)
+    size = rng.uniform(0.3, 1.5, (s, n, 3)).astype(np.float32).astype(np.float64)
+    heading = np.zeros((s, n))
+    heading[s // 2:] = rng.uniform(-3, 3, (s - s // 2, n))
+    score = rng.uniform(0, 1, (s, n)).astype(np.float32)
+    score[:, 10:14] = score[:, 9:10]  # ties
+    cls = rng.integers(0, 2, (s, n)).astype(np.int64)
+    got = nms.lhs_nms_samecls_gpu(dev(center), torch.from_numpy(size).cuda(),
+                                  torch.from_numpy(heading).cuda(), dev(score),
+                                  torch.from_numpy(cls).cuda(), 0.25).cpu().numpy()
+    for i in range(s):
+        aabb = oracle.camera_aabb(center[i], size[i], heading[i])
+        want = oracle.lhs_nms_samecls(aabb, score[i], cls[i], 0.25)
+        np.testing.assert_array_equal(got[i].astype(np.int32), want)
+    assert 0 < got.sum() < s * n
