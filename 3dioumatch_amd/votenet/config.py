@@ -38,6 +38,37 @@ class DatasetConfig(object):
             angle = angle - (angle > np.pi).float() * (2 * np.pi)
         return angle
 
+    def class2angle_f64(self, pred_cls, residual):
+        """The numpy decoding used by the pseudo-label filter (class2angle in
+        model_util_scannet.py:60-64 / model_util_sunrgbd.py:110-120): float64."""
+        if self.num_heading_bin == 1:
+            return torch.zeros(pred_cls.shape, dtype=torch.float64, device=pred_cls.device)
+        angle = pred_cls.double() * (2 * np.pi / float(self.num_heading_bin)) + residual.double()
+        return angle - 2 * np.pi * (angle > np.pi).double()
+
+    def angle2class_gpu(self, angle):
+        """angle -> (heading class, residual) with class*(2pi/N) + residual == angle
+        (model_util_sunrgbd.py:62-78)."""
+        if self.num_heading_bin == 1:
+            return torch.zeros_like(angle, dtype=torch.int32), angle
+        angle = angle % (2 * np.pi)
+        per = 2 * np.pi / float(self.num_heading_bin)
+        shifted = (angle + per / 2) % (2 * np.pi)
+        class_id = (shifted / per).int()
+        return class_id, shifted - (class_id * per + per / 2)
+
+    # numpy forms, as the reference's dataset configs offer them (used by its host-side filter)
+    def class2angle(self, pred_cls, residual, to_label_format=True):
+        if self.num_heading_bin == 1:
+            return np.zeros(np.shape(pred_cls))
+        angle = pred_cls * (2 * np.pi / float(self.num_heading_bin)) + residual
+        if to_label_format:
+            angle = angle - 2 * np.pi * (angle > np.pi)
+        return angle
+
+    def class2size(self, pred_cls, residual):
+        return self.mean_size_arr[pred_cls, :] + residual
+
     def class2size_gpu(self, pred_cls, residual):
         """size class + residual -> box size (model_util_scannet.py:56-58)."""
         return self.mean_size(residual.device)[pred_cls, :] + residual

@@ -41,6 +41,7 @@ def main():
     iou_stub = types.ModuleType("pcdet.ops.iou3d_nms.iou3d_nms_utils")
     iou_stub.boxes_iou3d_gpu = lambda a, b: torch.from_numpy(
         o.boxes_iou3d(a.detach().numpy(), b.detach().numpy()))
+    iou_stub.boxes_iou3d_scene_max_gpu = None  # GPU-only entry point of the mirror, unused here
     for name in ("pcdet", "pcdet.ops", "pcdet.ops.iou3d_nms"):
         sys.modules[name] = types.ModuleType(name)
     sys.modules["pcdet.ops.iou3d_nms.iou3d_nms_utils"] = iou_stub
