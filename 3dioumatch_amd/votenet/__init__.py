@@ -6,4 +6,6 @@ from .config import DatasetConfig, scannet_config, sunrgbd_config  # noqa: F401
 from .detector import VoteNet  # noqa: F401
 from .heads import GridConv, ProposalModule, VotingModule  # noqa: F401
 from .losses import get_labeled_loss  # noqa: F401
-from .step import SupervisedStep, update_ema_variables, lr_at, bn_momentum_at  # noqa: F401
+from .data import make_batch, make_semi_batch  # noqa: F401
+from .step import (SemiSupervisedStep, SupervisedStep, update_ema_variables, lr_at,  # noqa: F401
+                   bn_momentum_at)

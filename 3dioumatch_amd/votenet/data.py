@@ -63,3 +63,66 @@ def make_batch(batch_size, num_points, config, seed=0, num_objects=12, device="c
         'supervised_mask': torch.ones(batch_size, dtype=torch.int64, device=device),
         'scan_idx': torch.arange(batch_size, dtype=torch.int64, device=device),
     }
+
+
+def make_semi_batch(labeled, unlabeled, num_points, config, seed=0, num_objects=12, device="cpu"):
+    """A stage-2 batch as train.py:321-325 collates it: `labeled` + `unlabeled` scenes.
+    point_clouds / ema_point_clouds / the augmentation keys / supervised_mask / scan_idx have
+    batch labeled+unlabeled (labeled first), the label tensors batch `labeled`.  The student sees
+    the flipped / rotated / scaled cloud (and, for labeled scenes, labels in that frame), the EMA
+    teacher an independent, un-augmented subsample of the same scene
+    (scannet_ssl_dataset.py:90-128,177)."""
+    total = labeled + unlabeled
+    base = make_batch(total, num_points, config, seed=seed, num_objects=num_objects)
+    g = np.random.default_rng(seed + 7919)
+    pc = base['point_clouds'].numpy()
+    ema_pc = np.stack([pc[b][g.permutation(num_points)] for b in range(total)])
+    flip_x = g.integers(0, 2, total).astype(np.int64)
+    flip_y = g.integers(0, 2, total).astype(np.int64)
+    rot_angle = ((g.random(total) - 0.5) * (np.pi / 18)).astype(np.float32)  # +-5 degrees
+    scale = (g.random((total, 1, 3)) * 0.3 + 0.85).astype(np.float32)
+    c, s = np.cos(rot_angle), np.sin(rot_angle)
+    rot_mat = np.zeros((total, 3, 3), np.float32)
+    rot_mat[:, 0, 0], rot_mat[:, 0, 1], rot_mat[:, 1, 0], rot_mat[:, 1, 1], rot_mat[:, 2, 2] = \
+        c, -s, s, c, 1.0
+
+    def to_student(xyz, b):  # (n,3) teacher frame -> student frame
+        out = xyz.copy()
+        if flip_x[b]:
+            out[:, 0] = -out[:, 0]
+        if flip_y[b]:
+            out[:, 1] = -out[:, 1]
+        return (out @ rot_mat[b].T) * scale[b]
+
+    student_pc = pc.copy()
+    center = base['center_label'].numpy().copy()
+    size_res = base['size_residual_label'].numpy().copy()
+    vote = base['vote_label'].numpy().copy()
+    for b in range(total):
+        student_pc[b, :, :3] = to_student(pc[b, :, :3], b)
+        if student_pc.shape[2] > 3:
+            student_pc[b, :, 3] = student_pc[b, :, 2] - np.percentile(student_pc[b, :, 2], 0.99)
+        if b < labeled:
+            k = int(base['box_label_mask'][b].sum())
+            center[b, :k] = to_student(center[b, :k], b)
+            cls = base['size_class_label'][b, :k].numpy()
+            size_res[b, :k] = (config.mean_size_arr[cls] + size_res[b, :k]) * scale[b] \
+                - config.mean_size_arr[cls]
+            target = pc[b, :, :3] + vote[b, :, :3]          # voted centre, teacher frame
+            moved = to_student(target, b) - student_pc[b, :, :3]
+            vote[b] = np.tile(moved * base['vote_label_mask'][b].numpy()[:, None], (1, 3))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+    lab = slice(0, labeled)
+    out = {
+        'point_clouds': t(student_pc), 'ema_point_clouds': t(ema_pc),
+        'flip_x_axis': t(flip_x), 'flip_y_axis': t(flip_y), 'rot_mat': t(rot_mat),
+        'rot_angle': t(rot_angle), 'scale': t(scale),
+        'supervised_mask': t(np.array([1] * labeled + [0] * unlabeled, np.int64)),
+        'scan_idx': torch.arange(total, dtype=torch.int64, device=device),
+        'center_label': t(center[lab]), 'size_residual_label': t(size_res[lab]),
+        'vote_label': t(vote[lab]),
+    }
+    for k in ('heading_class_label', 'heading_residual_label', 'size_class_label', 'sem_cls_label',
+              'box_label_mask', 'vote_label_mask'):
+        out[k] = base[k][lab].to(device)
+    return out

@@ -44,8 +44,13 @@ def nn_distance(pc1, pc2, l1smooth=False, delta=1.0, l1=False):
 def _sel(t, inds):
     """t[inds, ...]; `inds is None` means every sample is supervised (stage-1 pretraining, and
     what SupervisedStep passes when supervised_mask is all ones): no gather, no scatter-add in
-    the backward."""
-    return t if inds is None else t[inds, ...]
+    the backward.  A slice(0, n) selects the first n samples (stage-2 batches put the labeled
+    scenes first, train.py:321-325); label tensors that already have batch n pass through."""
+    if inds is None:
+        return t
+    if isinstance(inds, slice):  # labeled-first batch layout: a view, no gather
+        return t if t.shape[0] == inds.stop else t[inds]
+    return t[inds, ...]
 
 
 def _masked_mean(values, mask):
@@ -265,6 +270,8 @@ def get_labeled_loss(end_points, dataset_config, config_dict=None):
     with supervised_mask == 1; fills end_points with every intermediate loss / statistic."""
     if end_points.get('all_supervised', False):  # host-side knowledge: skip every gather
         supervised_inds = None
+    elif end_points.get('labeled_num') is not None:  # labeled scenes first, count known on the host
+        supervised_inds = slice(0, int(end_points['labeled_num']))
     else:
         supervised_inds = end_points.get('supervised_inds')  # static under HIP-graph capture
         if supervised_inds is None:

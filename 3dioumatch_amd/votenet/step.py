@@ -129,6 +129,7 @@ class SupervisedStep(object):
         self._side = None
         self._captured = None  # signature the graphs were captured for
         self._token = 0
+        self.global_step = 0
 
     # ---------------------------------------------------------------- schedules
     def set_epoch(self, epoch, base_lr=1e-3):
@@ -150,7 +151,7 @@ class SupervisedStep(object):
             p.grad = None
         end_points = self.model(batch, mode="jitter")
         end_points.update({k: v for k, v in batch.items()
-                           if torch.is_tensor(v) or k == "all_supervised"})
+                           if torch.is_tensor(v) or k in ("all_supervised", "labeled_num")})
         loss, end_points = get_labeled_loss(end_points, self.cfg, {"dataset_config": self.cfg})
         loss.backward()
         self._pack_gradients()
@@ -185,6 +186,26 @@ class SupervisedStep(object):
             p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
             off += p.numel()
 
+    # ---------------------------------------------------------------- hooks for subclasses
+    def _compute_geometry(self, inputs):
+        """Coordinate-only index chain of one batch (dict of tensors)."""
+        return self.net.compute_geometry(inputs)
+
+    def _host_info(self, src):
+        """Host-side facts about the batch layout that the captured graphs bake in."""
+        sup = torch.nonzero(src["supervised_mask"]).squeeze(1).long()
+        self._supervised_inds = sup  # (kept on self: a graph input must outlive the capture)
+        return {"supervised_inds": sup,
+                "all_supervised": sup.numel() == src["supervised_mask"].numel()}
+
+    def _state(self):
+        """Every tensor a step mutates besides the optimizer state (restored after capture)."""
+        return [b for b in self.net.buffers()] + [self.flat_params.data]
+
+    def _before_apply(self):
+        """Eager host-side work between the backward graph and the update graph."""
+        self.global_step += 1
+
     # ---------------------------------------------------------------- geometry prefetch
     def prefetch_geometry(self, batch):
         """Launch the coordinate-only index computations (FPS chain, ball queries) of `batch`
@@ -192,7 +213,7 @@ class SupervisedStep(object):
         batch i+1 right before running the step on batch i: the serial FPS rounds then overlap
         the dense kernels of step i instead of heading step i+1's critical path."""
         if self.device.type != "cuda":
-            batch["geometry"] = self.net.compute_geometry(batch)
+            batch["geometry"] = self._compute_geometry(batch)
             return
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
@@ -212,7 +233,7 @@ class SupervisedStep(object):
             return
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
-            geometry = self.net.compute_geometry(batch)
+            geometry = self._compute_geometry(batch)
             done = torch.cuda.Event()
             done.record(self._side)
         for t in geometry.values():
@@ -258,27 +279,23 @@ class SupervisedStep(object):
         self._turn = 0
         self._cur = {k: src[k].clone() for k in self._keys}
         # which samples are supervised is part of the captured control flow (host-side nonzero)
-        # (kept on self: everything a graph reads must outlive the capture)
-        self._supervised_inds = torch.nonzero(src["supervised_mask"]).squeeze(1).long()
-        self._all_supervised = self._supervised_inds.numel() == src["supervised_mask"].numel()
+        host_info = self._host_info(src)
 
         # state touched by the warm-up iterations and by the capture itself
-        buffers = [b for b in self.net.buffers()]
-        saved_buffers = [b.clone() for b in buffers]
-        saved_params = self.flat_params.data.clone()
+        state = self._state()
+        saved_state = [t.clone() for t in state]
         saved_rng = torch.cuda.get_rng_state(dev)
         had_state = len(self.optimizer.state) > 0
         saved_opt = {k: v.clone() for k, v in self.optimizer.state.get(self.flat_params, {}).items()
                      if torch.is_tensor(v)}
 
         def body_geometry(slot):
-            return self.net.compute_geometry(slot["inputs"])
+            return self._compute_geometry(slot["inputs"])
 
         def body_step():
             inputs = dict(self._cur)
             inputs["geometry"] = self._cur_geometry
-            inputs["supervised_inds"] = self._supervised_inds
-            inputs["all_supervised"] = self._all_supervised
+            inputs.update(host_info)
             return self._forward_backward(inputs)
 
         warm = torch.cuda.Stream(device=dev)
@@ -309,9 +326,8 @@ class SupervisedStep(object):
         torch.cuda.synchronize(dev)
 
         # undo every side effect of warm-up and capture
-        for b, s in zip(buffers, saved_buffers):
-            b.copy_(s)
-        self.flat_params.data.copy_(saved_params)
+        for t, saved in zip(state, saved_state):
+            t.copy_(saved)
         for k, v in self.optimizer.state[self.flat_params].items():
             if torch.is_tensor(v):
                 v.copy_(saved_opt[k]) if had_state else v.zero_()
@@ -341,6 +357,7 @@ class SupervisedStep(object):
         torch._foreach_copy_(self._copy_dst, slot["copy_src"])
         self._g1.replay()
         self._exchange_gradients()
+        self._before_apply()
         self._g2.replay()
         batch.pop("geometry", None)
         return self._loss, self._end_points
@@ -356,9 +373,99 @@ class SupervisedStep(object):
         loss, end_points = self._forward_backward(batch)
         batch.pop("geometry", None)  # consumed: every step computes (or prefetches) its own
         self._exchange_gradients()
+        self._before_apply()
         self._apply()
         self._expose_gradients()
         return loss, end_points
+
+
+class SemiSupervisedStep(SupervisedStep):
+    """One stage-2 (3DIoUMatch) step on a labeled+unlabeled batch (train.py:305-371):
+
+        teacher (EMA) forward_with_pred_jitter on `ema_point_clouds`, no grad, train-mode BN
+        student forward_with_pred_jitter on `point_clouds`
+        loss = get_labeled_loss (labeled scenes) + 2.0 * get_unlabeled_loss (pseudo labels of the
+               teacher, filtered by objectness / class / predicted IoU and the device-side LHS-NMS)
+        backward -> [one all-reduce] -> Adam -> teacher <- a*teacher + (1-a)*student
+
+    Same launch structure as SupervisedStep: the coordinate-only index chains of BOTH clouds of the
+    next batch run one step ahead on a side stream (G0), forward/backward of both networks and all
+    losses replay as one HIP graph (G1), Adam and the EMA update as another (G2).  The EMA weight
+    a = min(1 - 1/(step+1), ema_decay) lives in a device scalar that is refreshed before G2.
+    The teacher's parameters are a second flat buffer, so the EMA update is a single lerp."""
+
+    def __init__(self, cfg, device, world_size=1, num_proposal=256, lr=2e-3, seed=0, graphs=None,
+                 unlabeled_loss_weight=2.0, ema_decay=0.999, dataset="scannet", config_dict=None):
+        super().__init__(cfg, device, world_size=world_size, num_proposal=num_proposal, lr=lr,
+                         seed=seed, graphs=graphs)
+        from .losses_unlabeled import default_config_dict
+        self.teacher = build_detector(cfg, num_proposal=num_proposal, seed=seed).to(device).train()
+        for p in self.teacher.parameters():
+            p.requires_grad_(False)  # train.py:176-178 (detach_)
+        self.flat_teacher = flatten_parameters(self.teacher).data
+        self.flat_teacher.copy_(self.flat_params.data)  # both start from the same checkpoint
+        self.unlabeled_loss_weight = unlabeled_loss_weight
+        self.ema_decay = ema_decay
+        self.config_dict = config_dict or default_config_dict(cfg, dataset=dataset)
+        self._ema_weight = torch.zeros((), device=device)  # 1 - a, read by the update graph
+
+    # the BN-momentum schedule touches the student only (train.py:234-237): inherited set_epoch
+    # walks self.net
+
+    def _compute_geometry(self, inputs):
+        geometry = dict(self.net.compute_geometry(inputs))
+        teacher = self.teacher.compute_geometry({"point_clouds": inputs["ema_point_clouds"]})
+        geometry.update({"ema_" + k: v for k, v in teacher.items()})
+        return geometry
+
+    def _host_info(self, src):
+        mask = src["supervised_mask"]
+        labeled = int(torch.count_nonzero(mask))
+        if not bool((mask[:labeled] != 0).all()):
+            raise ValueError("labeled scenes must come first in the batch (train.py:321-325)")
+        return {"labeled_num": labeled}
+
+    def _state(self):
+        return super()._state() + [b for b in self.teacher.buffers()] + [self.flat_teacher]
+
+    def _forward_backward(self, batch):
+        from .losses_unlabeled import get_unlabeled_loss
+        for p in self._params:
+            p.grad = None
+        geometry = batch.get("geometry")
+        student_geo = teacher_geo = None
+        if geometry is not None:
+            student_geo = {k: v for k, v in geometry.items() if not k.startswith("ema_")}
+            teacher_geo = {k[4:]: v for k, v in geometry.items() if k.startswith("ema_")}
+        with torch.no_grad():
+            ema_end_points = self.teacher({"point_clouds": batch["ema_point_clouds"],
+                                           "geometry": teacher_geo}, mode="jitter")
+        end_points = self.model({"point_clouds": batch["point_clouds"], "geometry": student_geo},
+                                mode="jitter")
+        end_points.update({k: v for k, v in batch.items()
+                           if torch.is_tensor(v) and k not in ("point_clouds", "ema_point_clouds")})
+        labeled = batch.get("labeled_num")
+        if labeled is None:
+            labeled = self._host_info(batch)["labeled_num"]
+        end_points["labeled_num"] = labeled
+        detection_loss, end_points = get_labeled_loss(end_points, self.cfg,
+                                                      {"dataset_config": self.cfg})
+        unlabeled_loss, end_points = get_unlabeled_loss(end_points, ema_end_points, self.cfg,
+                                                        self.config_dict)
+        loss = detection_loss + unlabeled_loss * self.unlabeled_loss_weight
+        end_points["loss"] = loss
+        loss.backward()
+        self._pack_gradients()
+        return loss, end_points
+
+    def _before_apply(self):
+        self.global_step += 1
+        a = min(1 - 1 / (self.global_step + 1), self.ema_decay)  # train.py:285-289
+        self._ema_weight.fill_(1 - a)
+
+    def _apply(self):
+        super()._apply()
+        self.flat_teacher.lerp_(self.flat_params.data, self._ema_weight)
 
 
 def flat_grads(module):

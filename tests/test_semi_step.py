@@ -1,0 +1,112 @@
+"""The stage-2 (semi-supervised) step of votenet/step.py: EMA teacher forward + labeled loss +
+pseudo-label consistency loss + backward + Adam + EMA update (reference train.py:305-371).
+CPU: host logic on the oracle stand-ins.  GPU: HIP kernels, graph replay == eager."""
+import importlib
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_pkg
+from test_unlabeled_loss import _oracle_nms
+
+LAB, UNL, N, K = 2, 3, 3000, 64
+
+
+def _setup(use_gpu, oracle, monkeypatch):
+    load_pkg()
+    utils = importlib.import_module("pointnet2.pointnet2_utils")
+    V = importlib.import_module("3dioumatch_amd.votenet")
+    losses = importlib.import_module("3dioumatch_amd.votenet.losses")
+    U = importlib.import_module("3dioumatch_amd.votenet.losses_unlabeled")
+    if use_gpu:
+        return V, torch.device("cuda:0")
+    from oracle import standin as oracle_ext
+    monkeypatch.setattr(utils, "_ext", oracle_ext.make(oracle))
+    monkeypatch.setattr(losses, "boxes_iou3d_gpu", lambda a, b: torch.from_numpy(
+        oracle.boxes_iou3d(a.detach().numpy(), b.detach().numpy())))
+    monkeypatch.setattr(U, "_lhs_nms", _oracle_nms(oracle))
+    return V, torch.device("cpu")
+
+
+def _loose_filter(V, cfg):
+    """Random-weight networks pass no 0.9 thresholds: loosen them so pseudo labels exist."""
+    U = importlib.import_module("3dioumatch_amd.votenet.losses_unlabeled")
+    d = U.default_config_dict(cfg, unlabeled_batch_size=UNL)
+    d.update(obj_threshold=0.3, cls_threshold=0.03, iou_threshold=0.2)
+    return d
+
+
+@pytest.mark.parametrize("use_gpu", [pytest.param(False, id="cpu-hostlogic"),
+                                     pytest.param(True, id="gpu-hip", marks=pytest.mark.gpu)])
+def test_semi_supervised_step(use_gpu, oracle_omp, monkeypatch):
+    V, dev = _setup(use_gpu, oracle_omp, monkeypatch)
+    cfg = V.scannet_config()
+    step_mod = importlib.import_module("3dioumatch_amd.votenet.step")
+    batch = {k: v.to(dev) for k, v in V.make_semi_batch(LAB, UNL, N, cfg, seed=3, num_objects=5).items()}
+    runner = V.SemiSupervisedStep(cfg, dev, num_proposal=K, seed=4, graphs=False,
+                                  config_dict=_loose_filter(V, cfg))
+    student0 = step_mod.flat_params(runner.net).clone()
+    assert torch.equal(step_mod.flat_params(runner.teacher), student0)
+    bn_t0 = runner.teacher.pnet.bn1.running_mean.clone()
+    torch.manual_seed(1)
+    loss, ep = runner(dict(batch))
+    assert bool(torch.isfinite(loss))
+    # loss composition (train.py:348) and the pieces that feed it
+    want = ep["detection_loss"] + 2.0 * ep["unlabeled_detection_loss"]
+    assert abs(float(loss) - float(want)) <= 1e-5 * abs(float(want))
+    assert ep["unlabeled_box_label_mask"].shape == (UNL, 64) and int(ep["unlabeled_box_label_mask"].sum()) > 0
+    assert ep["objectness_label"].shape[0] == LAB and ep["unlabeled_objectness_label"].shape[0] == UNL
+    # Adam moved the student; the teacher is the EMA with a = min(1 - 1/2, 0.999) = 0.5
+    student1 = step_mod.flat_params(runner.net)
+    assert float((student1 - student0).abs().max()) > 0
+    teacher1 = step_mod.flat_params(runner.teacher)
+    assert torch.allclose(teacher1, 0.5 * student0 + 0.5 * student1, rtol=0, atol=2e-6)
+    assert all(p.grad is None for p in runner.teacher.parameters())
+    # the teacher ran in train mode: its BatchNorm statistics moved, independently of the student's
+    assert not torch.equal(runner.teacher.pnet.bn1.running_mean, bn_t0)
+    assert not torch.equal(runner.teacher.pnet.bn1.running_mean, runner.net.pnet.bn1.running_mean)
+    # second step: a = min(1 - 1/3, 0.999)
+    student1 = student1.clone(); teacher1 = teacher1.clone()
+    runner(dict(batch))
+    student2 = step_mod.flat_params(runner.net)
+    a = 1 - 1 / 3
+    assert torch.allclose(step_mod.flat_params(runner.teacher), a * teacher1 + (1 - a) * student2,
+                          rtol=0, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_semi_graph_replay_matches_eager(oracle_omp, monkeypatch):
+    """Captured stage-2 step (two index chains prefetched, both networks, all losses, device NMS,
+    Adam + EMA) == the eager step: same pseudo labels and loss, same student and teacher weights."""
+    V, dev = _setup(True, oracle_omp, monkeypatch)
+    cfg = V.scannet_config()
+    step_mod = importlib.import_module("3dioumatch_amd.votenet.step")
+    batches = [{k: v.to(dev) for k, v in V.make_semi_batch(LAB, UNL, N, cfg, seed=s, num_objects=5).items()}
+               for s in (5, 6)]
+    results = []
+    for graphs in (False, True):
+        runner = V.SemiSupervisedStep(cfg, dev, num_proposal=K, seed=4, graphs=graphs,
+                                      config_dict=_loose_filter(V, cfg))
+        torch.manual_seed(9)
+        torch.cuda.manual_seed_all(9)
+        first, second = dict(batches[0]), dict(batches[1])
+        runner.prefetch_geometry(first)
+        runner.prefetch_geometry(second)
+        loss0, ep0 = runner(first)
+        loss0, mask0 = float(loss0), ep0["unlabeled_box_label_mask"].cpu().clone()
+        torch.cuda.synchronize()
+        loss1, ep1 = runner(second)
+        assert runner.graphs == graphs
+        results.append((loss0, float(loss1), mask0, step_mod.flat_params(runner.net).cpu(),
+                        step_mod.flat_params(runner.teacher).cpu(),
+                        runner.teacher.pnet.bn1.running_mean.cpu().clone()))
+    eager, graph = results
+    assert torch.equal(eager[2], graph[2])
+    assert abs(eager[0] - graph[0]) <= 1e-5 * max(1.0, abs(eager[0]))
+    assert abs(eager[1] - graph[1]) <= 2e-2 * max(1.0, abs(eager[1]))
+    assert float((eager[3] - graph[3]).abs().max()) <= 1.2e-2  # two Adam steps of lr 2e-3
+    assert float((eager[3] - graph[3]).norm() / eager[3].norm()) < 2e-3
+    assert float((eager[4] - graph[4]).norm() / eager[4].norm()) < 2e-3
+    assert torch.allclose(eager[5], graph[5], rtol=1e-3, atol=1e-5)
