@@ -40,6 +40,16 @@ B, NPTS, KPROP = 8, 40000, 256
 PAIR_BYTES = 38516736  # ball_query 8 230 912 + group(xyz) 20 617 216 + group(feat) 9 668 608
 
 
+SEMI_LABELED, SEMI_UNLABELED = 4, 8  # train.py default batch_size "4,8"
+WORKLOADS = {
+    "pretrain": "ScanNet pretrain step (BASELINE configs[1]): VoteNet-IoU "
+                "forward_with_pred_jitter + labeled loss + backward + Adam",
+    "semi": "ScanNet semi-supervised step (BASELINE configs[3]): EMA teacher + student "
+            "forward_with_pred_jitter on 4 labeled + 8 unlabeled scenes, labeled loss + "
+            "pseudo-label consistency loss (device-side filter + LHS-NMS), backward, Adam, EMA",
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -47,13 +57,19 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--workload", choices=("pretrain", "semi"), default="pretrain",
+                    help="pretrain = BASELINE configs[1] (the headline metric); semi = configs[3]: "
+                         "stage-2 step, 4 labeled + 8 unlabeled scenes per GPU, EMA teacher")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="compute the FPS chain inline instead of one step ahead on a side stream")
     return ap.parse_args()
 
 
-def build_step(V, cfg, device, world, local_rank):
-    runner = V.SupervisedStep(cfg, device, world_size=world, num_proposal=KPROP, lr=1e-3)
+def build_step(V, cfg, device, world, local_rank, workload="pretrain"):
+    if workload == "semi":
+        runner = V.SemiSupervisedStep(cfg, device, world_size=world, num_proposal=KPROP, lr=2e-3)
+    else:
+        runner = V.SupervisedStep(cfg, device, world_size=world, num_proposal=KPROP, lr=1e-3)
 
     def step(batch):
         return runner(batch)[0]
@@ -185,8 +201,14 @@ def main():
     data = importlib.import_module("3dioumatch_amd.votenet.data")
     cfg = V.scannet_config()
 
-    step = build_step(V, cfg, device, world, local_rank)
-    batch = data.make_batch(B, NPTS, cfg, seed=100 + rank, device=device)  # resident in HBM
+    step = build_step(V, cfg, device, world, local_rank, args.workload)
+    if args.workload == "semi":
+        scenes = SEMI_LABELED + SEMI_UNLABELED
+        batch = data.make_semi_batch(SEMI_LABELED, SEMI_UNLABELED, NPTS, cfg, seed=100 + rank,
+                                     device=device)
+    else:
+        scenes = B
+        batch = data.make_batch(B, NPTS, cfg, seed=100 + rank, device=device)  # resident in HBM
 
     def fence():
         if world > 1:
@@ -226,13 +248,12 @@ def main():
         ms = elapsed * 1e3 / args.steps
         out = {
             "metric": "scenes/sec train-step (ScanNet 40k pts, 256 proposals)",
-            "value": round(B * world * args.steps / elapsed, 3), "unit": "scenes/s",
+            "value": round(scenes * world * args.steps / elapsed, 3), "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ScanNet pretrain step (BASELINE configs[1]): VoteNet-IoU "
-                                   "forward_with_pred_jitter + labeled loss + backward + Adam",
-                       "per_gpu_batch": B, "global_batch": B * world, "num_points": NPTS,
+            "config": {"workload": WORKLOADS[args.workload],
+                       "per_gpu_batch": scenes, "global_batch": scenes * world, "num_points": NPTS,
                        "num_proposals": KPROP, "parallelism": "dp%d" % world,
                        "fps_prefetch_one_step_ahead": pipelined,
                        "hip_graphs": bool(step.runner.graphs)},
@@ -253,7 +274,7 @@ def main():
                           "N=40000 m=2048 ns=64", "algorithmic_bytes": PAIR_BYTES,
                 "duration_us": round(pair_us, 2)}
             out["kernels_us"] = table
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "pretrain":
             out["cpu_baseline"] = cpu_baseline(V, cfg)
         print(json.dumps(out), flush=True)
     if world > 1:
