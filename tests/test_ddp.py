@@ -31,6 +31,9 @@ def _install_standins():
     utils._ext = standin.make(o)
     losses.boxes_iou3d_gpu = lambda a, b: torch.from_numpy(
         o.boxes_iou3d(a.detach().numpy(), b.detach().numpy()))
+    unl = importlib.import_module("3dioumatch_amd.votenet.losses_unlabeled")
+    from test_unlabeled_loss import _oracle_nms
+    unl._lhs_nms = _oracle_nms(o)
 
 
 def _batch(V, cfg, seed):
@@ -114,3 +117,45 @@ def test_ema_update_and_schedules():
     assert V.lr_at(0) == 1e-3 and abs(V.lr_at(450) - 1e-4) < 1e-12 and abs(V.lr_at(900) - 1e-6) < 1e-15
     assert V.bn_momentum_at(0) == 0.5 and V.bn_momentum_at(20) == 0.25
     assert V.bn_momentum_at(10000) == 0.001
+
+
+def _semi_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_standins()
+    V = importlib.import_module("3dioumatch_amd.votenet")
+    step_mod = importlib.import_module("3dioumatch_amd.votenet.step")
+    unl = importlib.import_module("3dioumatch_amd.votenet.losses_unlabeled")
+    cfg = V.scannet_config()
+    filt = unl.default_config_dict(cfg, unlabeled_batch_size=2)
+    filt.update(obj_threshold=0.3, cls_threshold=0.03, iou_threshold=0.2)
+    runner = V.SemiSupervisedStep(cfg, torch.device("cpu"), world_size=world, num_proposal=K,
+                                  config_dict=filt)
+    torch.manual_seed(100 + rank)
+    loss, ep = runner(V.make_semi_batch(1, 2, N, cfg, seed=300 + rank, num_objects=5))
+    np.savez(os.path.join(out_dir, "semi%d.npz" % rank),
+             grad=step_mod.flat_grads(runner.net).numpy(),
+             params=step_mod.flat_params(runner.net).numpy(),
+             teacher=step_mod.flat_params(runner.teacher).numpy(),
+             loss=float(loss), pseudo=int(ep["unlabeled_box_label_mask"].sum()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_semi_supervised_ddp_two_ranks_gloo(tmp_path):
+    """Stage-2 step data-parallel over 2 ranks: after the single gradient all-reduce both ranks
+    hold the same gradient, hence identical student AND teacher (EMA) weights, from different data."""
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_semi_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "semi0.npz")
+    r1 = np.load(tmp_path / "semi1.npz")
+    assert np.array_equal(r0["grad"], r1["grad"])
+    assert np.array_equal(r0["params"], r1["params"])
+    assert np.array_equal(r0["teacher"], r1["teacher"])
+    assert np.isfinite(r0["loss"]) and np.isfinite(r1["loss"]) and r0["loss"] != r1["loss"]
+    assert r0["pseudo"] > 0 and r1["pseudo"] > 0
