@@ -68,11 +68,13 @@ GT_VOTE_FACTOR = 3  # GT votes stored per point
 OBJECTNESS_CLS_WEIGHTS = [0.2, 0.8]
 
 
-def huber_loss(error, delta=1.0):
-    """0.5*x^2 for |x| <= delta, delta*(|x| - 0.5*delta) beyond."""
-    abs_error = torch.abs(error)
-    quadratic = torch.clamp(abs_error, max=delta)
-    return 0.5 * quadratic ** 2 + delta * (abs_error - quadratic)
+def huber_loss(error, delta=1.0, target=None):
+    """0.5*x^2 for |x| <= delta, delta*(|x| - 0.5*delta) beyond, x = error (- target)
+    (utils/nn_distance.py:16-33; the reference spells it with clamp/pow: 0.5*q^2 + delta*(|x| - q),
+    q = min(|x|, delta) -- the same function; one kernel here)."""
+    if target is None:
+        target = torch.zeros((), dtype=error.dtype, device=error.device).expand_as(error)
+    return F.huber_loss(error, target, reduction='none', delta=delta)
 
 
 def nn_distance(pc1, pc2, l1smooth=False, delta=1.0, l1=False):
@@ -224,66 +226,67 @@ def compute_iou_labels(end_points, unsupervised_inds, pred_votes, pred_center, p
     return iou_labels, objectness_label, object_assignment
 
 
+def _select(values, cls):
+    """values (B,K,C[,3]) at class cls (B,K): what `sum(values * one_hot(cls))` evaluates to
+    (x*1 + zeros == x exactly), as one gather instead of one_hot / repeat / mul / sum."""
+    index = cls.view(*cls.shape, *([1] * (values.dim() - 2)))
+    index = index.expand(*cls.shape, 1, *values.shape[3:])
+    return torch.gather(values, 2, index).squeeze(2)
+
+
 def compute_box_and_sem_cls_loss(end_points, supervised_inds, dataset_config, config_dict):
-    nh, ns = dataset_config.num_heading_bin, dataset_config.num_size_cluster
+    """Centre / heading / size / class / IoU-estimation losses of the supervised samples
+    (loss_helper_labeled.py:126-297).  Same arithmetic per term as the reference; organised so
+    that the nine averages over positive proposals share ONE masked reduction (the reference
+    spends five small kernels on each) and class-selected residuals are gathers."""
+    nh = dataset_config.num_heading_bin
     assign = end_points['object_assignment']
     obj = end_points['objectness_label'].float()
     sup = supervised_inds
-    out = {}
+    fork = _Branches(assign, 6)
+    terms = {}  # per-proposal (B,K) quantities averaged over the positive proposals
 
     def pick(key):
         return torch.gather(_sel(end_points[key], sup), 1, assign)
 
-    def center_term():
-        # chamfer between predicted centres (positives) and GT centres (real boxes)
-        dist1, _, dist2, _ = nn_distance(_sel(end_points['center'], sup),
-                                         _sel(end_points['center_label'], sup)[:, :, 0:3])
-        box_label_mask = _sel(end_points['box_label_mask'], sup)
-        out['center'] = _masked_mean(dist1, obj) + _masked_mean(dist2, box_label_mask)
+    with fork.branch(0):  # centre: chamfer between predicted centres and GT centres
+        terms['center1'], _, dist2, _ = nn_distance(
+            _sel(end_points['center'], sup), _sel(end_points['center_label'], sup)[:, :, 0:3])
+        center_back = _masked_mean(dist2, _sel(end_points['box_label_mask'], sup))
 
-    def heading_terms():
-        # class + residual of the assigned GT
+    with fork.branch(1):  # heading: class + residual of the assigned GT
         h_cls_label = pick('heading_class_label')
-        out['heading_cls'] = _masked_mean(
-            F.cross_entropy(_sel(end_points['heading_scores'], sup).transpose(2, 1), h_cls_label,
-                            reduction='none'), obj)
+        terms['heading_cls'] = F.cross_entropy(
+            _sel(end_points['heading_scores'], sup).transpose(2, 1), h_cls_label, reduction='none')
         h_res_label = pick('heading_residual_label') / (np.pi / nh)
-        h_onehot = F.one_hot(h_cls_label, nh).float()
-        h_res_pred = torch.sum(_sel(end_points['heading_residuals_normalized'], sup) * h_onehot, -1)
-        out['heading_reg'] = _masked_mean(huber_loss(h_res_pred - h_res_label, delta=1.0), obj)
+        h_res_pred = _select(_sel(end_points['heading_residuals_normalized'], sup), h_cls_label)
+        terms['heading_reg'] = huber_loss(h_res_pred, delta=1.0, target=h_res_label)
 
-    def size_terms():
-        # class + normalised residual
+    with fork.branch(2):  # size: class + normalised residual
         s_cls_label = pick('size_class_label')
-        out['size_cls'] = _masked_mean(
-            F.cross_entropy(_sel(end_points['size_scores'], sup).transpose(2, 1), s_cls_label,
-                            reduction='none'), obj)
+        terms['size_cls'] = F.cross_entropy(
+            _sel(end_points['size_scores'], sup).transpose(2, 1), s_cls_label, reduction='none')
         s_res_label = torch.gather(_sel(end_points['size_residual_label'], sup), 1,
-                                   assign.unsqueeze(-1).repeat(1, 1, 3))
-        s_onehot = F.one_hot(s_cls_label, ns).float().unsqueeze(-1).repeat(1, 1, 1, 3)
-        s_res_pred = torch.sum(_sel(end_points['size_residuals_normalized'], sup) * s_onehot, 2)
-        mean_size = dataset_config.mean_size(s_res_pred.device).unsqueeze(0).unsqueeze(0)
-        mean_size_label = torch.sum(s_onehot * mean_size, 2)
-        out['size_reg'] = _masked_mean(
-            torch.mean(huber_loss(s_res_pred - s_res_label / mean_size_label, delta=1.0), -1), obj)
+                                   assign.unsqueeze(-1).expand(-1, -1, 3))
+        s_res_pred = _select(_sel(end_points['size_residuals_normalized'], sup), s_cls_label)
+        mean_size_label = dataset_config.mean_size(s_res_pred.device)[s_cls_label]
+        terms['size_reg'] = torch.mean(
+            huber_loss(s_res_pred, delta=1.0, target=s_res_label / mean_size_label), -1)
 
-    def class_term():
+    with fork.branch(3):  # semantic class
         sem_label = pick('sem_cls_label')
         sem_scores = _sel(end_points['sem_cls_scores'], sup)
-        out['sem_cls'] = _masked_mean(
-            F.cross_entropy(sem_scores.transpose(2, 1), sem_label, reduction='none'), obj)
-        end_points['cls_acc'] = _masked_mean((sem_label == sem_scores.argmax(dim=-1)).float(), obj)
+        terms['sem_cls'] = F.cross_entropy(sem_scores.transpose(2, 1), sem_label, reduction='none')
+        terms['cls_acc'] = (sem_label == sem_scores.argmax(dim=-1)).float()
 
-    def iou_terms():
-        # IoU labels of the decoded predictions, and the IoU-estimation loss
+    with fork.branch(4):  # IoU labels of the decoded predictions, IoU-estimation loss
         iou_labels, _, iou_assignment = compute_iou_labels(
             end_points, sup, _sel(end_points['aggregated_vote_xyz'], sup),
             _sel(end_points['center'], sup), None, None, _sel(end_points['heading_scores'], sup),
             _sel(end_points['heading_residuals'], sup), _sel(end_points['size_scores'], sup),
             _sel(end_points['size_residuals'], sup), config_dict={'dataset_config': dataset_config})
         end_points['pred_iou_value'] = iou_labels.mean()
-        end_points['pred_iou_obj_value'] = _masked_mean(iou_labels, obj)
-        end_points['obj_count'] = torch.sum(obj)
+        terms['pred_iou_obj'] = iou_labels
         if 'iou_scores' in end_points:
             iou_pred = torch.sigmoid(_sel(end_points['iou_scores'], sup))
             if iou_pred.shape[2] > 1:
@@ -293,36 +296,39 @@ def compute_box_and_sem_cls_loss(end_points, supervised_inds, dataset_config, co
                 iou_pred = iou_pred.squeeze(-1)
             iou_acc = torch.abs(iou_pred - iou_labels)
             end_points['iou_acc'] = iou_acc.mean()
-            end_points['iou_acc_obj'] = _masked_mean(iou_acc, obj)
-            end_points['iou_loss'] = huber_loss(iou_pred - iou_labels, delta=1.0).mean()
+            terms['iou_acc_obj'] = iou_acc
+            end_points['iou_loss'] = huber_loss(iou_pred, delta=1.0, target=iou_labels).mean()
 
-    def jitter_terms():
-        if 'jitter_center' not in end_points:
-            return
-        gt_bbox = _gt_boxes(end_points, sup, dataset_config)
-        pred_bbox = torch.cat([_sel(end_points['jitter_center'], sup),
-                               _sel(end_points['jitter_size'], sup),
-                               -_sel(end_points['jitter_heading'], sup)[:, :, None]], dim=2)
-        jitter_iou_labels, jitter_assign = _scene_best_iou(pred_bbox, gt_bbox)
-        jitter_sem = torch.gather(_sel(end_points['sem_cls_label'], sup), 1, jitter_assign)
-        jitter_pred = torch.sigmoid(_sel(end_points['iou_scores_jitter'], sup))
-        jitter_pred = torch.gather(jitter_pred, 2, jitter_sem.unsqueeze(-1)).squeeze(-1) \
-            if jitter_pred.shape[2] > 1 else jitter_pred.squeeze(-1)
-        jitter_acc = torch.abs(jitter_pred - jitter_iou_labels)
-        end_points['jitter_iou_acc'] = jitter_acc.mean()
-        end_points['jitter_iou_acc_obj'] = jitter_acc.sum() / (jitter_acc.numel() + 1e-6)
-        end_points['jitter_iou_loss'] = \
-            huber_loss(jitter_pred - jitter_iou_labels, delta=1.0).sum() / (jitter_acc.numel() + 1e-6)
-
-    # six independent chains: forked over streams inside a graph capture, sequential otherwise
-    fork = _Branches(assign, 6)
-    for i, term in enumerate((center_term, heading_terms, size_terms, class_term, iou_terms,
-                              jitter_terms)):
-        with fork.branch(i):
-            term()
+    with fork.branch(5):
+        if 'jitter_center' in end_points:
+            gt_bbox = _gt_boxes(end_points, sup, dataset_config)
+            pred_bbox = torch.cat([_sel(end_points['jitter_center'], sup),
+                                   _sel(end_points['jitter_size'], sup),
+                                   -_sel(end_points['jitter_heading'], sup)[:, :, None]], dim=2)
+            jitter_iou_labels, jitter_assign = _scene_best_iou(pred_bbox, gt_bbox)
+            jitter_sem = torch.gather(_sel(end_points['sem_cls_label'], sup), 1, jitter_assign)
+            jitter_pred = torch.sigmoid(_sel(end_points['iou_scores_jitter'], sup))
+            jitter_pred = torch.gather(jitter_pred, 2, jitter_sem.unsqueeze(-1)).squeeze(-1) \
+                if jitter_pred.shape[2] > 1 else jitter_pred.squeeze(-1)
+            jitter_acc = torch.abs(jitter_pred - jitter_iou_labels)
+            end_points['jitter_iou_acc'] = jitter_acc.mean()
+            end_points['jitter_iou_acc_obj'] = jitter_acc.sum() / (jitter_acc.numel() + 1e-6)
+            end_points['jitter_iou_loss'] = huber_loss(
+                jitter_pred, delta=1.0, target=jitter_iou_labels).sum() / (jitter_acc.numel() + 1e-6)
     fork.join()
-    return (out['center'], out['heading_cls'], out['heading_reg'], out['size_cls'], out['size_reg'],
-            out['sem_cls'])
+
+    # sum(term * obj) / (sum(obj) + 1e-6) for every term, in one reduction
+    names = list(terms)
+    count = torch.sum(obj)
+    means = torch.sum(torch.stack([terms[n] for n in names]) * obj, dim=(1, 2)) / (count + 1e-6)
+    mean = dict(zip(names, means.unbind(0)))
+    end_points['obj_count'] = count
+    end_points['cls_acc'] = mean['cls_acc']
+    end_points['pred_iou_obj_value'] = mean['pred_iou_obj']
+    if 'iou_acc_obj' in mean:
+        end_points['iou_acc_obj'] = mean['iou_acc_obj']
+    return (mean['center1'] + center_back, mean['heading_cls'], mean['heading_reg'],
+            mean['size_cls'], mean['size_reg'], mean['sem_cls'])
 
 
 def get_labeled_loss(end_points, dataset_config, config_dict=None):

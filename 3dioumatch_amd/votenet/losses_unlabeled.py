@@ -159,7 +159,7 @@ def compute_box_and_sem_cls_loss(end_points, labeled_num, config):
     h_res_label = pick('unlabeled_heading_residual_label') / (np.pi / nh)
     h_onehot = F.one_hot(h_cls_label, nh).float()
     h_res_pred = torch.sum(end_points['heading_residuals_normalized'][labeled_num:] * h_onehot, -1)
-    heading_reg_loss = _masked_mean(huber_loss(h_res_pred - h_res_label, delta=1.0), obj)
+    heading_reg_loss = _masked_mean(huber_loss(h_res_pred, delta=1.0, target=h_res_label), obj)
 
     s_cls_label = pick('unlabeled_size_class_label')
     size_class_loss = _masked_mean(
@@ -172,7 +172,7 @@ def compute_box_and_sem_cls_loss(end_points, labeled_num, config):
     mean_size = config.mean_size(s_res_pred.device).unsqueeze(0).unsqueeze(0)
     mean_size_label = torch.sum(s_onehot * mean_size, 2)
     size_reg_loss = _masked_mean(
-        torch.mean(huber_loss(s_res_pred - s_res_label / mean_size_label, delta=1.0), -1), obj)
+        torch.mean(huber_loss(s_res_pred, delta=1.0, target=s_res_label / mean_size_label), -1), obj)
 
     sem_label = pick('unlabeled_sem_cls_label')
     sem_cls_loss = _masked_mean(
