@@ -130,10 +130,12 @@ def compute_vote_loss(end_points, supervised_inds):
     mask = torch.gather(end_points['vote_label_mask'], 1, seed_inds)
     gt_votes = torch.gather(end_points['vote_label'], 1,
                             seed_inds.view(b, num_seed, 1).expand(-1, -1, 3 * GT_VOTE_FACTOR))
-    gt_votes = gt_votes + seed_xyz.repeat(1, 1, 3)
-    _, _, dist2, _ = nn_distance(vote_xyz.view(b * num_seed, -1, 3),
-                                 gt_votes.view(b * num_seed, GT_VOTE_FACTOR, 3), l1=True)
-    votes_dist = torch.min(dist2, dim=1)[0].view(b, num_seed)
+    # L1 distance of the vote to each of the 3 stored GT votes, the smallest one counts
+    # (nn_distance(..., l1=True) on (B*S,1,3) x (B*S,3,3) followed by min over the votes)
+    gt_votes = gt_votes.view(b, num_seed, 1, GT_VOTE_FACTOR, 3) + seed_xyz.view(b, num_seed, 1, 1, 3)
+    votes = vote_xyz.view(b, num_seed, -1, 1, 3)  # vote_factor predictions per seed
+    votes_dist = torch.sum(torch.abs(votes - gt_votes), dim=-1)  # (B, S, vote_factor, 3)
+    votes_dist = torch.min(votes_dist.flatten(2), dim=2)[0]
     return _masked_mean(votes_dist, mask.float())
 
 
@@ -193,20 +195,24 @@ def _gt_boxes(end_points, inds, config):
 
 def compute_iou_labels(end_points, unsupervised_inds, pred_votes, pred_center, pred_sem_cls,
                        pred_objectness, pred_heading_scores, pred_heading_residuals,
-                       pred_size_scores, pred_size_residuals, config_dict, reverse=False):
+                       pred_size_scores, pred_size_residuals, config_dict, reverse=False,
+                       with_objectness=True, gt_bbox=None):
     """3-D IoU between every decoded prediction and every GT box of its scene."""
     config = config_dict['dataset_config']
-    gt_center = _labels(end_points, unsupervised_inds)[0]
+    gt_center = _labels(end_points, unsupervised_inds)[0] if with_objectness else None
     h_cls = torch.argmax(pred_heading_scores, -1)
     h_res = torch.gather(pred_heading_residuals, 2, h_cls.unsqueeze(-1)).squeeze(2)
     s_cls = torch.argmax(pred_size_scores, -1)
     s_res = torch.gather(pred_size_residuals, 2,
                          s_cls.unsqueeze(-1).unsqueeze(-1).repeat(1, 1, 1, 3)).squeeze(2)
-    dist1, object_assignment, _, _ = nn_distance(pred_votes, gt_center)
-    objectness_label = (torch.sqrt(dist1 + 1e-6) < NEAR_THRESHOLD).long()
-    b = dist1.shape[0]
+    objectness_label = None
+    if with_objectness:  # (the labeled loss has these from compute_objectness_loss already)
+        dist1, _, _, _ = nn_distance(pred_votes, gt_center)
+        objectness_label = (torch.sqrt(dist1 + 1e-6) < NEAR_THRESHOLD).long()
+    b = pred_center.shape[0]
 
-    gt_bbox = _gt_boxes(end_points, unsupervised_inds, config)
+    if gt_bbox is None:
+        gt_bbox = _gt_boxes(end_points, unsupervised_inds, config)
     pred_size = config.class2size_gpu(s_cls.detach(), s_res)
     pred_size = torch.where(pred_size <= 0, torch.full_like(pred_size, 1e-6), pred_size)
     if config.num_heading_bin == 1:
@@ -279,12 +285,14 @@ def compute_box_and_sem_cls_loss(end_points, supervised_inds, dataset_config, co
         terms['sem_cls'] = F.cross_entropy(sem_scores.transpose(2, 1), sem_label, reduction='none')
         terms['cls_acc'] = (sem_label == sem_scores.argmax(dim=-1)).float()
 
+    gt_bbox = _gt_boxes(end_points, sup, dataset_config)  # shared by the two IoU terms
     with fork.branch(4):  # IoU labels of the decoded predictions, IoU-estimation loss
         iou_labels, _, iou_assignment = compute_iou_labels(
             end_points, sup, _sel(end_points['aggregated_vote_xyz'], sup),
             _sel(end_points['center'], sup), None, None, _sel(end_points['heading_scores'], sup),
             _sel(end_points['heading_residuals'], sup), _sel(end_points['size_scores'], sup),
-            _sel(end_points['size_residuals'], sup), config_dict={'dataset_config': dataset_config})
+            _sel(end_points['size_residuals'], sup), config_dict={'dataset_config': dataset_config},
+            with_objectness=False, gt_bbox=gt_bbox)
         end_points['pred_iou_value'] = iou_labels.mean()
         terms['pred_iou_obj'] = iou_labels
         if 'iou_scores' in end_points:
@@ -301,7 +309,6 @@ def compute_box_and_sem_cls_loss(end_points, supervised_inds, dataset_config, co
 
     with fork.branch(5):
         if 'jitter_center' in end_points:
-            gt_bbox = _gt_boxes(end_points, sup, dataset_config)
             pred_bbox = torch.cat([_sel(end_points['jitter_center'], sup),
                                    _sel(end_points['jitter_size'], sup),
                                    -_sel(end_points['jitter_heading'], sup)[:, :, None]], dim=2)
