@@ -95,9 +95,12 @@ def test_shared_mlp_fused_matches_sequential():
                                      (3, 259, 128, 96), (1, 3, 7, 33), (2, 131, 259, 1024),
                                      (1, 512, 256, 64), (2, 32, 512, 200), (2, 64, 64, 3001),
                                      (1, 100, 100, 2050), (2, 70, 160, 1537), (1, 65, 300, 777)])
-def test_mfma_gemm_primitives_vs_torch(b, m, k, r):
+@pytest.mark.parametrize("small", [True, False], ids=["small-tile", "big-tile"])
+def test_mfma_gemm_primitives_vs_torch(b, m, k, r, small, monkeypatch):
     """forward / dgrad / wgrad of the 1x1 convolution on the matrix cores, every operand mode,
-    ragged M, K, R -- against torch matmul of explicitly materialised operands (fp32)."""
+    ragged M, K, R -- against torch matmul of explicitly materialised operands (fp32); both the
+    64x64 latency-oriented kernel and the large-tile kernels."""
+    monkeypatch.setenv("MLP_SMALL_GEMM_COLS", "1000000000" if small else "0")
     load_pkg()
     K = importlib.import_module("pointnet2._mlp_ext")
     g = torch.Generator().manual_seed(b * 1000 + m + k + r)
@@ -230,12 +233,12 @@ def test_fused_head_chain_vs_torch(cin, mid, cout, shape, training):
     b, r = shape
     x1 = torch.randn(b, cin, r, device=DEV, requires_grad=True)
     x2 = x1.detach().clone().requires_grad_(True)
-    os.environ["VOTENET_FUSED_HEADS"] = "1"
+    out = fh.head_chain(x1, *mods)
+    os.environ["VOTENET_FUSED_HEADS"] = "0"
     try:
-        out = fh.head_chain(x1, *mods)
+        want = fh.head_chain(x2, *ref)
     finally:
-        os.environ["VOTENET_FUSED_HEADS"] = "0"
-    want = fh.head_chain(x2, *ref)
+        os.environ.pop("VOTENET_FUSED_HEADS")
     close(out, want, 2e-4)
     gout = torch.randn_like(want)
     out.backward(gout)
