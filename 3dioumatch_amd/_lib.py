@@ -48,6 +48,10 @@ _SIGNATURES = {
                        _vp, _vp, _vp, _vp],
     "mlp_gemm_wgrad": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                        _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mlp_gemm_dgrad_nt": [_c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp,
+                          _vp, _vp, _vp, _vp],
+    "mlp_gemm_dgrad_pooled_nt": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp,
+                                 _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_gemm_dgrad_pooled": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp, _vp, _vp, _vp],
     "mlp_gemm_wgrad_pooled": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp,

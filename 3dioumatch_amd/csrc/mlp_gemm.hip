@@ -123,7 +123,10 @@ __device__ __forceinline__ void load_raw_segment(const OperandB &op, size_t off,
 }
 
 // C[b] (M x R, ldc = R) = A (M x K, row-major, lda) * op(B[b]) (K x R)
-template <int TM, int TN, int WM, int WN, int MODE>
+// A_TRANS: the A operand is given transposed in memory (A[gm][gk] = a[gk*lda + gm]) -- dgrad reads
+// the weight as stored instead of a transposed copy; the lane<->element mapping of the A loads is
+// swapped so that they stay coalesced.
+template <int TM, int TN, int WM, int WN, int MODE, bool A_TRANS>
 __global__ void __launch_bounds__(256)
 gemm_nn_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int lda, OperandB opb,
                float *__restrict__ c, size_t b_stride_in, size_t b_stride_out) {
@@ -159,9 +162,10 @@ gemm_nn_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int
 #pragma unroll
     for (int e = 0; e < AE; ++e) {
       const int t = tid + e * 256;
-      const int kk = t % KC, mm = t / KC;
+      const int kk = A_TRANS ? t / TM : t % KC, mm = A_TRANS ? t % TM : t / KC;
       const int gm = m0 + mm, gk = k0 + kk;
-      areg[e] = (gm < m_total && gk < k_total) ? a[(size_t)gm * lda + gk] : 0.f;
+      const size_t at = A_TRANS ? (size_t)gk * lda + gm : (size_t)gm * lda + gk;
+      areg[e] = (gm < m_total && gk < k_total) ? a[at] : 0.f;
     }
     const int gk = k0 + bkk;
     brow_ok = gk < k_total;
@@ -173,7 +177,7 @@ gemm_nn_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int
 #pragma unroll
     for (int e = 0; e < AE; ++e) {
       const int t = tid + e * 256;
-      As[(t % KC) * LDA + t / KC] = areg[e];
+      As[(A_TRANS ? t / TM : t % KC) * LDA + (A_TRANS ? t % TM : t / KC)] = areg[e];
     }
 #pragma unroll
     for (int i = 0; i < SEG; i += 4) {
@@ -229,7 +233,7 @@ gemm_nn_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int
 // their accumulators through LDS at the end.
 constexpr int KS = 64;  // K chunk of the small variant
 
-template <int MODE>
+template <int MODE, bool A_TRANS>
 __global__ void __launch_bounds__(256)
 gemm_nn_small_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int lda,
                      OperandB opb, float *__restrict__ c, size_t b_stride_in,
@@ -259,9 +263,10 @@ gemm_nn_small_kernel(int m_total, int k_total, int r, const float *__restrict__ 
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int t = tid + e * 256;
-      const int kk = t % KS, mm = t / KS;
+      const int kk = A_TRANS ? t / TM : t % KS, mm = A_TRANS ? t % TM : t / KS;
       const int gm = m0 + mm, gk = k0 + kk;
-      areg[e] = (gm < m_total && gk < k_total) ? a[(size_t)gm * lda + gk] : 0.f;
+      const size_t at = A_TRANS ? (size_t)gk * lda + gm : (size_t)gm * lda + gk;
+      areg[e] = (gm < m_total && gk < k_total) ? a[at] : 0.f;
     }
     const int gk = k0 + bkk;
     brow_ok = gk < k_total;
@@ -275,7 +280,7 @@ gemm_nn_small_kernel(int m_total, int k_total, int r, const float *__restrict__ 
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int t = tid + e * 256;
-      As[(t % KS) * LDA + t / KS] = areg[e];
+      As[(A_TRANS ? t / TM : t % KS) * LDA + (A_TRANS ? t % TM : t / KS)] = areg[e];
     }
 #pragma unroll
     for (int i = 0; i < 16; i += 4) {
@@ -505,14 +510,14 @@ reduce_partials_kernel(int count, int parts, const float *__restrict__ part,
   }
 }
 
-template <int MODE>
+template <int MODE, bool A_TRANS = false>
 int launch_nn(int b, int m, int k, int r, const float *a, int lda, const OperandB &op, float *c,
               size_t in_stride, size_t out_stride, hipStream_t stream) {
   // (read per call so that the tests can steer both kernels; a getenv costs nothing next to a launch)
   const char *env = getenv("MLP_SMALL_GEMM_COLS");
   const long long small_cols = env ? atoll(env) : 16384;
   if ((long long)b * r <= small_cols) {  // a few hundred columns per cloud: latency-bound regime
-    hipLaunchKernelGGL((gemm_nn_small_kernel<MODE>),
+    hipLaunchKernelGGL((gemm_nn_small_kernel<MODE, A_TRANS>),
                        dim3(pn2_ceil_div(r, 64), pn2_ceil_div(m, 64), b), dim3(256), 0, stream, m,
                        k, r, a, lda, op, c, in_stride, out_stride);
     return pn2_launch_status();
@@ -521,10 +526,10 @@ int launch_nn(int b, int m, int k, int r, const float *a, int lda, const Operand
   int done = 0;
   while (done < m) {
     const int left = m - done;
-    const float *a_t = a + (size_t)done * lda;
+    const float *a_t = A_TRANS ? a + done : a + (size_t)done * lda;
     float *c_t = c + (size_t)done * r;
 #define NN(TM, TN, WM, WN)                                                                      \
-  hipLaunchKernelGGL((gemm_nn_kernel<TM, TN, WM, WN, MODE>),                                    \
+  hipLaunchKernelGGL((gemm_nn_kernel<TM, TN, WM, WN, MODE, A_TRANS>),                                    \
                      dim3(pn2_ceil_div(r, TN), 1, b), dim3(256), 0, stream, rows, k, r, a_t, lda, \
                      op, c_t, in_stride, out_stride)
     int rows;
@@ -567,6 +572,36 @@ MLP_API int mlp_gemm_dgrad(int b, int m, int k, int r, const float *wt, int mode
   }
   OperandB op = {y, dz, scale, shift, mean, invstd, coef};
   return launch_nn<OP_DY>(b, k, m, r, wt, m, op, dx, in_stride, out_stride, (hipStream_t)stream_);
+}
+
+// mlp_gemm_dgrad with the weight as stored, w (m,k) row-major: no transposed copy is needed
+MLP_API int mlp_gemm_dgrad_nt(int b, int m, int k, int r, const float *w, int mode,
+                              const float *dy, const float *y, const float *dz,
+                              const float *scale, const float *shift, const float *mean,
+                              const float *invstd, const float *coef, float *dx, void *stream_) {
+  if (b <= 0 || m <= 0 || k <= 0 || r <= 0) return 0;
+  const size_t in_stride = (size_t)m * r, out_stride = (size_t)k * r;
+  if (mode == OP_DIRECT) {
+    OperandB op = {dy, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return launch_nn<OP_DIRECT, true>(b, k, m, r, w, k, op, dx, in_stride, out_stride,
+                                      (hipStream_t)stream_);
+  }
+  OperandB op = {y, dz, scale, shift, mean, invstd, coef};
+  return launch_nn<OP_DY, true>(b, k, m, r, w, k, op, dx, in_stride, out_stride,
+                                (hipStream_t)stream_);
+}
+
+MLP_API int mlp_gemm_dgrad_pooled_nt(int b, int m, int k, int groups, int ns, const float *w,
+                                     const float *y, const float *dpooled, const int *argmax,
+                                     const float *scale, const float *shift, const float *mean,
+                                     const float *invstd, const float *coef, float *dx,
+                                     void *stream_) {
+  if (b <= 0 || m <= 0 || k <= 0 || groups <= 0 || ns <= 0) return 0;
+  const int r = groups * ns;
+  const size_t in_stride = (size_t)m * r, out_stride = (size_t)k * r;
+  OperandB op = {y, dpooled, scale, shift, mean, invstd, coef, argmax, ns};
+  return launch_nn<OP_POOLDY, true>(b, k, m, r, w, k, op, dx, in_stride, out_stride,
+                                    (hipStream_t)stream_);
 }
 
 // the same for the pooled last layer of an SA module: dy from (y, dpooled, argmax) on the fly

@@ -167,7 +167,7 @@ def gemm_dgrad(w, dy=None, fly=None, pooled=None):
     invstd, coef), or pooled = (y (B,M,m,ns), dpooled, argmax, scale, shift, mean, invstd, coef)
     and dy is formed on the fly."""
     m, k = w.shape
-    wt = w.t().contiguous()
+    _f32c(w, "w")  # read as stored: the kernels take A transposed (no w.t().contiguous() copy)
     src = dy if dy is not None else (fly[0] if fly is not None else pooled[0])
     b = src.shape[0]
     r = src.numel() // (b * m)
@@ -175,18 +175,18 @@ def gemm_dgrad(w, dy=None, fly=None, pooled=None):
     with torch.cuda.device(src.device):
         if dy is not None:
             _f32c(dy, "dy")
-            rc = _lib.mlp_gemm_dgrad(b, m, k, r, wt.data_ptr(), 0, dy.data_ptr(), None, None, None,
+            rc = _lib.mlp_gemm_dgrad_nt(b, m, k, r, w.data_ptr(), 0, dy.data_ptr(), None, None, None,
                                      None, None, None, None, dx.data_ptr(), _stream(src))
         elif pooled is not None:
             y, dpooled, argmax, scale, shift, mean, invstd, coef = pooled
-            rc = _lib.mlp_gemm_dgrad_pooled(b, m, k, y.shape[2], y.shape[3], wt.data_ptr(),
+            rc = _lib.mlp_gemm_dgrad_pooled_nt(b, m, k, y.shape[2], y.shape[3], w.data_ptr(),
                                             y.data_ptr(), dpooled.data_ptr(), argmax.data_ptr(),
                                             scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
                                             invstd.data_ptr(), coef.data_ptr(), dx.data_ptr(),
                                             _stream(src))
         else:
             y, dz, scale, shift, mean, invstd, coef = fly
-            rc = _lib.mlp_gemm_dgrad(b, m, k, r, wt.data_ptr(), 2, None, y.data_ptr(),
+            rc = _lib.mlp_gemm_dgrad_nt(b, m, k, r, w.data_ptr(), 2, None, y.data_ptr(),
                                      dz.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                                      mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(),
                                      dx.data_ptr(), _stream(src))

@@ -116,8 +116,8 @@ class VoteNet(nn.Module):
         all_heading = torch.cat([heading, heading_jitter], dim=1)
         end_points = self.grid_conv(all_center.detach(), all_size.detach(), all_heading.detach(),
                                     end_points)
-        end_points['iou_scores_jitter'] = end_points['iou_scores'][:, k:]
-        end_points['iou_scores'] = end_points['iou_scores'][:, :k]
+        end_points['iou_scores'], end_points['iou_scores_jitter'] = torch.split(
+            end_points['iou_scores'], [k, end_points['iou_scores'].shape[1] - k], dim=1)
         end_points['jitter_center'] = center_jitter
         end_points['jitter_size'] = size_jitter * 2
         end_points['jitter_heading'] = heading_jitter

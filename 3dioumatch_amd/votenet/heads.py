@@ -40,8 +40,9 @@ class VotingModule(nn.Module):
         b, num_seed = seed_xyz.shape[:2]
         net = head_chain(seed_features, self.conv1, self.bn1, self.conv2, self.bn2, self.conv3)
         net = net.transpose(2, 1).view(b, num_seed, self.vote_factor, 3 + self.out_dim)
-        vote_xyz = (seed_xyz.unsqueeze(2) + net[..., 0:3]).reshape(b, num_seed * self.vote_factor, 3)
-        vote_features = seed_features.transpose(2, 1).unsqueeze(2) + net[..., 3:]
+        offset, residual = torch.split(net, [3, self.out_dim], dim=-1)
+        vote_xyz = (seed_xyz.unsqueeze(2) + offset).reshape(b, num_seed * self.vote_factor, 3)
+        vote_features = seed_features.transpose(2, 1).unsqueeze(2) + residual
         vote_features = vote_features.reshape(b, num_seed * self.vote_factor, self.out_dim)
         return vote_xyz, vote_features.transpose(2, 1).contiguous()
 
@@ -52,18 +53,20 @@ def decode_scores(net, end_points, num_class, num_heading_bin, num_size_cluster,
     t = net.transpose(2, 1)
     b, k = t.shape[:2]
     nh, ns = num_heading_bin, num_size_cluster
-    end_points['objectness_scores'] = t[:, :, 0:2]
-    end_points['center'] = end_points['aggregated_vote_xyz'] + t[:, :, 2:5]
-    end_points['heading_scores'] = t[:, :, 5:5 + nh]
-    hrn = t[:, :, 5 + nh:5 + nh * 2]
+    # one split instead of seven slices: its backward is a single concatenation (each slice
+    # would cost a zero-fill, a copy and an accumulation)
+    objectness, offset, heading_scores, hrn, size_scores, srn, sem = torch.split(
+        t, [2, 3, nh, nh, ns, ns * 3, t.shape[2] - (5 + nh * 2 + ns * 4)], dim=2)
+    end_points['objectness_scores'] = objectness
+    end_points['center'] = end_points['aggregated_vote_xyz'] + offset
+    end_points['heading_scores'] = heading_scores
     end_points['heading_residuals_normalized'] = hrn  # in [-1, 1]
     end_points['heading_residuals'] = hrn * (np.pi / nh)
-    end_points['size_scores'] = t[:, :, 5 + nh * 2:5 + nh * 2 + ns]
-    srn = t[:, :, 5 + nh * 2 + ns:5 + nh * 2 + ns * 4].reshape(b, k, ns, 3)
-    srn = F.softplus(srn) - 1
+    end_points['size_scores'] = size_scores
+    srn = F.softplus(srn.reshape(b, k, ns, 3)) - 1
     end_points['size_residuals_normalized'] = srn
     end_points['size_residuals'] = srn * mean_size.unsqueeze(0).unsqueeze(0)
-    end_points['sem_cls_scores'] = t[:, :, 5 + nh * 2 + ns * 4:]
+    end_points['sem_cls_scores'] = sem
     return end_points
 
 

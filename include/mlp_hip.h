@@ -94,6 +94,22 @@ int mlp_gemm_dgrad(int b, int m, int k, int r, const float *wt, int mode, const 
                    const float *mean, const float *invstd, const float *coef, float *dx,
                    void *stream);
 
+/* mlp_gemm_dgrad with the weight as stored (w (m,k) row-major) instead of its transposed copy:
+ * the kernel reads A transposed with a swapped lane mapping (replaces conv2d backward-data,
+ * pytorch_utils.py:70-124, without the per-call transpose of the weight) */
+int mlp_gemm_dgrad_nt(int b, int m, int k, int r, const float *w, int mode, const float *dy,
+                      const float *y, const float *dz, const float *scale, const float *shift,
+                      const float *mean, const float *invstd, const float *coef, float *dx,
+                      void *stream);
+
+/* mlp_gemm_dgrad_pooled with the weight as stored (replaces F.max_pool2d backward + ReLU /
+ * BatchNorm2d backward + conv2d backward-data, pointnet2_modules.py:256-262,
+ * pytorch_utils.py:70-124) */
+int mlp_gemm_dgrad_pooled_nt(int b, int m, int k, int groups, int ns, const float *w, const float *y,
+                             const float *dpooled, const int *argmax, const float *scale,
+                             const float *shift, const float *mean, const float *invstd,
+                             const float *coef, float *dx, void *stream);
+
 /* mlp_gemm_dgrad for the pooled last layer of a set-abstraction MLP: dy (b,m,groups,ns) is formed
  * on the fly from y, dpooled (b,m,groups), argmax (b,m,groups) and the vectors of
  * mlp_bn_relu_pool_backward(dy = NULL) -- neither dz nor dy is written to memory (replaces
