@@ -44,6 +44,8 @@ SEMI_LABELED, SEMI_UNLABELED = 4, 8  # train.py default batch_size "4,8"
 WORKLOADS = {
     "pretrain": "ScanNet pretrain step (BASELINE configs[1]): VoteNet-IoU "
                 "forward_with_pred_jitter + labeled loss + backward + Adam",
+    "sunrgbd": "SUN RGB-D pretrain step (BASELINE configs[2]): 20000 pts, batch 16, 12 heading "
+               "bins (oriented-box IoU), forward_with_pred_jitter + labeled loss + backward + Adam",
     "semi": "ScanNet semi-supervised step (BASELINE configs[3]): EMA teacher + student "
             "forward_with_pred_jitter on 4 labeled + 8 unlabeled scenes, labeled loss + "
             "pseudo-label consistency loss (device-side filter + LHS-NMS), backward, Adam, EMA",
@@ -57,9 +59,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
-    ap.add_argument("--workload", choices=("pretrain", "semi"), default="pretrain",
+    ap.add_argument("--workload", choices=("pretrain", "semi", "sunrgbd"), default="pretrain",
                     help="pretrain = BASELINE configs[1] (the headline metric); semi = configs[3]: "
-                         "stage-2 step, 4 labeled + 8 unlabeled scenes per GPU, EMA teacher")
+                         "stage-2 step, 4 labeled + 8 unlabeled scenes per GPU, EMA teacher; "
+                         "sunrgbd = configs[2]: SUN RGB-D pretrain, 20000 pts, batch 16, oriented boxes")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="compute the FPS chain inline instead of one step ahead on a side stream")
     return ap.parse_args()
@@ -199,13 +202,17 @@ def main():
     importlib.import_module("3dioumatch_amd")
     V = importlib.import_module("3dioumatch_amd.votenet")
     data = importlib.import_module("3dioumatch_amd.votenet.data")
-    cfg = V.scannet_config()
+    cfg = V.sunrgbd_config() if args.workload == "sunrgbd" else V.scannet_config()
+    npts = 20000 if args.workload == "sunrgbd" else NPTS
 
     step = build_step(V, cfg, device, world, local_rank, args.workload)
     if args.workload == "semi":
         scenes = SEMI_LABELED + SEMI_UNLABELED
         batch = data.make_semi_batch(SEMI_LABELED, SEMI_UNLABELED, NPTS, cfg, seed=100 + rank,
                                      device=device)
+    elif args.workload == "sunrgbd":
+        scenes = 16
+        batch = data.make_batch(scenes, npts, cfg, seed=100 + rank, device=device)
     else:
         scenes = B
         batch = data.make_batch(B, NPTS, cfg, seed=100 + rank, device=device)  # resident in HBM
@@ -247,13 +254,14 @@ def main():
     if rank == 0:
         ms = elapsed * 1e3 / args.steps
         out = {
-            "metric": "scenes/sec train-step (ScanNet 40k pts, 256 proposals)",
+            "metric": "scenes/sec train-step (ScanNet 40k pts, 256 proposals)" if args.workload != "sunrgbd"
+            else "scenes/sec train-step (SUN RGB-D 20k pts, 256 proposals)",
             "value": round(scenes * world * args.steps / elapsed, 3), "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload],
-                       "per_gpu_batch": scenes, "global_batch": scenes * world, "num_points": NPTS,
+                       "per_gpu_batch": scenes, "global_batch": scenes * world, "num_points": npts,
                        "num_proposals": KPROP, "parallelism": "dp%d" % world,
                        "fps_prefetch_one_step_ahead": pipelined,
                        "hip_graphs": bool(step.runner.graphs)},
