@@ -21,7 +21,8 @@
 //            64-lane bitonic network built from DPP row moves and permlane swaps (no LDS, no
 //            scratch): chunk 0 is sorted ascending, every further chunk descending and folded
 //            in with one min + a 6-stage bitonic merge.  Lane s then writes slot s of the row.
-//            Flagged clouds, rows with more than kMaxHits hits and nsample > 64 fall back to
+//            For 64 < nsample <= 128 a second pass collects the next 64 the same way.  Flagged
+//            clouds, rows with more than kMaxHits hits and nsample > 128 fall back to
 //            the brute-force scan of ball_common.h inside the same launch.
 //
 // The order in which atomics fill a cell is irrelevant: selection and ordering are by index.
@@ -33,7 +34,7 @@ namespace {
 constexpr int kG = 32;                  // lattice cells per axis (periodic)
 constexpr int kCellsPerCloud = kG * kG * kG;
 constexpr int kCap = 64;                // slots per cell
-constexpr int kMaxHits = 256;           // LDS hit list per wave
+constexpr int kMaxHits = 384;           // LDS hit list per wave
 constexpr int kRowSlots = 3 * kCap;     // candidates in one x-row of cells (<= 192)
 constexpr int kRowPasses = kRowSlots / kWave;  // 3
 
@@ -185,6 +186,8 @@ __device__ __forceinline__ unsigned bitonic_sort64(unsigned v, int lane, bool as
   return bitonic_merge64(v, lane, asc);
 }
 
+// WIDE: nsample in (64, 128] -- two result registers per lane (the 64 smallest and the next 64)
+template <bool WIDE>
 __global__ void __launch_bounds__(256)
 grid_query_kernel(int n, int m, float radius2, float inv_side, int nsample,
                   const float *__restrict__ new_xyz, const float *__restrict__ xyz,
@@ -308,15 +311,41 @@ grid_query_kernel(int n, int m, float radius2, float inv_side, int nsample,
     a = bitonic_merge64(a, lane, true);
   }
   const unsigned first = (unsigned)__builtin_amdgcn_readlane((int)a, 0);
-  const int have = total < kWave ? total : kWave;
+  if (!WIDE) {
+    const int have = total < kWave ? total : kWave;
+    if (lane < nsample) row[lane] = (int)(lane < have ? a : first);
+    return;
+  }
+  // WIDE: `a` holds the 64 smallest; a second pass over the list collects the next 64 -- the 64
+  // smallest among the hits LARGER than a's maximum (indices are distinct, so "larger than the
+  // 64th smallest" is exactly "not among the first 64")
+  const unsigned cut = (unsigned)__builtin_amdgcn_readlane((int)a, 63);
+  unsigned a1 = kNone;
+  if (total > kWave) {
+    bool started = false;
+    for (int base = 0; base < total; base += kWave) {
+      unsigned c = base + lane < total ? list[base + lane] : kNone;
+      if (c <= cut) c = kNone;
+      if (!started) {
+        a1 = bitonic_sort64(c, lane, true);
+        started = true;
+      } else {
+        c = bitonic_sort64(c, lane, false);
+        a1 = a1 < c ? a1 : c;
+        a1 = bitonic_merge64(a1, lane, true);
+      }
+    }
+  }
+  const int have = total < 2 * kWave ? total : 2 * kWave;
   if (lane < nsample) row[lane] = (int)(lane < have ? a : first);
+  if (kWave + lane < nsample) row[kWave + lane] = (int)(kWave + lane < have ? a1 : first);
 }
 
 }  // namespace
 
 size_t pn2_ball_query_grid_workspace(int b, int n, int m, int nsample) {
   (void)m;
-  if (n < 4096 || nsample > kWave) return 0;
+  if (n < 4096 || nsample > 2 * kWave) return 0;
   return grid_cnt_bytes(b) + sizeof(float4) * (size_t)b * kCellsPerCloud * kCap +
          sizeof(float4) * (size_t)b * kSlabs * kOvfCap;
 }
@@ -337,9 +366,14 @@ int pn2_ball_query_grid_try(int b, int n, int m, float radius, int nsample, cons
   hipLaunchKernelGGL(grid_build_kernel, dim3(kSlabs, b), dim3(kBuildThreads), 0, stream, n,
                      inv_side, xyz, cnt, flags, slots, ovf);
   const float radius2 = radius * radius;  // fp32 product, as ball_query_gpu.cu:27
-  hipLaunchKernelGGL(grid_query_kernel, dim3(pn2_ceil_div(m, 256 / kWave), b), dim3(256), 0,
-                     stream, n, m, radius2, inv_side, nsample, new_xyz, xyz, cnt, flags, slots,
-                     ovf, idx);
+  if (nsample > kWave)
+    hipLaunchKernelGGL(grid_query_kernel<true>, dim3(pn2_ceil_div(m, 256 / kWave), b), dim3(256),
+                       0, stream, n, m, radius2, inv_side, nsample, new_xyz, xyz, cnt, flags,
+                       slots, ovf, idx);
+  else
+    hipLaunchKernelGGL(grid_query_kernel<false>, dim3(pn2_ceil_div(m, 256 / kWave), b), dim3(256),
+                       0, stream, n, m, radius2, inv_side, nsample, new_xyz, xyz, cnt, flags,
+                       slots, ovf, idx);
   *handled = 1;
   return pn2_launch_status();
 }

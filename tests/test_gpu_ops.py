@@ -414,13 +414,14 @@ print("BUCKET_TIER_OK", len(cases))
 
 @pytest.mark.parametrize("case", ["aliasing", "overflow", "overflow_list_full", "clumps",
                                   "dense_hits", "negative", "ns_small", "ns_over_64",
-                                  "tiny_radius"])
+                                  "ns_128_dense", "ns_128_sparse", "ns_over_128", "tiny_radius"])
 def test_ballquery_cell_list_tier_edge_cases(ext, oracle_omp, synth, case):
-    """The cell-list tier (n >= 4096, nsample <= 64) against the oracle where its special
+    """The cell-list tier (n >= 4096, nsample <= 128) against the oracle where its special
     paths trigger: lattice aliasing (cloud wider than 32 cells), cell overflow (> 64 points
-    in one cell -> flagged cloud -> in-launch brute force), > 256 hits in a ball, negative
-    coordinates, small nsample, nsample > 64 (tier declines), radius so small that balls hold
-    only their own centroid."""
+    in one cell -> flagged cloud -> in-launch brute force), > 384 hits in a ball, negative
+    coordinates, small nsample, 64 < nsample <= 128 (second selection pass; balls with fewer /
+    more than 128 hits), nsample > 128 (tier declines), radius so small that balls hold only
+    their own centroid."""
     g = np.random.default_rng(11)
     b, n, m, r, ns = 2, 6000, 300, 0.2, 64
     xyz = synth.cloud_uniform(b, n, 2.0, seed=21)
@@ -445,6 +446,12 @@ def test_ballquery_cell_list_tier_edge_cases(ext, oracle_omp, synth, case):
         ns = 5
     elif case == "ns_over_64":
         ns = 100
+    elif case == "ns_128_dense":
+        r, ns = 0.45, 128                                      # ~ 290 hits per ball
+    elif case == "ns_128_sparse":
+        r, ns = 0.25, 128                                      # ~ 50 hits: mostly padding
+    elif case == "ns_over_128":
+        r, ns = 0.45, 200
     elif case == "tiny_radius":
         r = 1e-4
     cen = xyz[:, g.permutation(n)[:m]].copy()
