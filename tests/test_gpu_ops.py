@@ -35,10 +35,11 @@ def test_fps_golden(ext, key):
 
 @pytest.mark.parametrize("n,m", [(1, 1), (2, 2), (63, 10), (64, 64), (511, 60), (512, 100),
                                  (513, 100), (1024, 128), (2048, 256), (3000, 200),
-                                 (5000, 128), (9000, 96), (16384, 64), (20000, 48)])
+                                 (5000, 128), (9000, 96), (16384, 64), (20000, 48),
+                                 (40000, 40), (65536, 32), (66000, 32), (80000, 24)])
 def test_fps_sizes_vs_oracle(ext, oracle, synth, n, m):
-    # exercises every kernel instantiation (register tiers and the streaming tier) with
-    # duplicates (ties) and near-origin (skipped) points present
+    # exercises every kernel instantiation (register tiers, the bucketed tiers up to 65536 points
+    # and the streaming tier beyond) with duplicates (ties) and near-origin (skipped) points present
     xyz = synth.cloud_edge_cases(2, n, 1.0, seed=100 + n, near_origin=min(4, n // 8),
                                  duplicates=min(32, n // 8)) if n >= 16 else \
         synth.cloud_uniform(2, n, 1.0, seed=n)
