@@ -44,6 +44,7 @@ struct OperandB {
   const float *coef;     // OP_DY: [k][3] = a, c1, c2
   const int *argmax;     // OP_POOLDY: (rows, r/ns) winning sample per group; dz holds dpooled
   int ns;                // OP_POOLDY: samples per group
+  int groups;            // OP_POOLDY: r / ns (groups per row)
 };
 
 constexpr bool is_dy(int mode) { return mode == OP_DY || mode == OP_POOLDY; }
@@ -72,15 +73,17 @@ __device__ __forceinline__ float transform(float x, float dz, const RowCoef &c) 
 }
 
 // raw loads of N consecutive elements (x, and dz for OP_DY); zero outside the row / limit
+// (`row` = index of the operand row over the whole batch, b * rows + row: OP_POOLDY only)
 template <int MODE, int N>
 __device__ __forceinline__ void load_raw_segment(const OperandB &op, size_t off, int gr, int limit,
-                                                 bool vec_ok, bool row_ok, float *x, float *dz) {
+                                                 bool vec_ok, bool row_ok, float *x, float *dz,
+                                                 int row = 0) {
 #pragma unroll
   for (int i = 0; i < N; ++i) { x[i] = 0.f; dz[i] = 0.f; }
   if (!row_ok) return;
   if (MODE == OP_POOLDY) {
-    // dz of the segment from the pooled tensors: (off - gr) / ns is the row's group base
-    const size_t gbase = (off - (size_t)gr) / (size_t)op.ns;
+    // dz of the segment from the pooled tensors (B, rows, groups): no 64-bit division here
+    const size_t gbase = (size_t)row * op.groups;
     if (op.ns % N == 0 && gr % N == 0) {  // the whole segment lies in one group
       if (gr < limit) {
         const int g = gr / op.ns, s0 = gr - g * op.ns;
@@ -171,7 +174,7 @@ gemm_nn_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int
     brow_ok = gk < k_total;
     rc = load_row_coef<MODE>(op, gk, brow_ok);
     load_raw_segment<MODE, SEG>(op, in_off + (size_t)gk * r + r0 + bnn, r0 + bnn, r, vec_ok,
-                                brow_ok, bx, bdz);
+                                brow_ok, bx, bdz, b * k_total + gk);
   };
   auto stash = [&]() {
 #pragma unroll
@@ -272,7 +275,7 @@ gemm_nn_small_kernel(int m_total, int k_total, int r, const float *__restrict__ 
     brow_ok = gk < k_total;
     rc = load_row_coef<MODE>(op, gk, brow_ok);
     load_raw_segment<MODE, 16>(op, in_off + (size_t)gk * r + r0 + bnn, r0 + bnn, r, vec_ok,
-                               brow_ok, bx, bdz);
+                               brow_ok, bx, bdz, b * k_total + gk);
   };
   fetch(0);
   for (int k0 = 0; k0 < k_total; k0 += KS) {
@@ -406,7 +409,8 @@ gemm_wgrad_kernel(int m_total, int k_begin, int k_end, int k_total, int r, int r
   const bool vec_ok = ((r | r_hi) & 3) == 0;
   float px[8], pdz[8], qx[QSEG][8], qdz[QSEG][8];
   auto fetch = [&](int rr) {
-    load_raw_segment<PMODE, 8>(P, p_row + rr + seg_r, rr + seg_r, r_hi, vec_ok, p_ok, px, pdz);
+    load_raw_segment<PMODE, 8>(P, p_row + rr + seg_r, rr + seg_r, r_hi, vec_ok, p_ok, px, pdz,
+                               b * m_total + m0 + seg_row);
 #pragma unroll
     for (int s = 0; s < QSEG; ++s)
       load_raw_segment<QMODE, 8>(Q, q_row[s] + rr + seg_r, rr + seg_r, r_hi, vec_ok, q_ok[s],
@@ -599,7 +603,7 @@ MLP_API int mlp_gemm_dgrad_pooled_nt(int b, int m, int k, int groups, int ns, co
   if (b <= 0 || m <= 0 || k <= 0 || groups <= 0 || ns <= 0) return 0;
   const int r = groups * ns;
   const size_t in_stride = (size_t)m * r, out_stride = (size_t)k * r;
-  OperandB op = {y, dpooled, scale, shift, mean, invstd, coef, argmax, ns};
+  OperandB op = {y, dpooled, scale, shift, mean, invstd, coef, argmax, ns, groups};
   return launch_nn<OP_POOLDY, true>(b, k, m, r, w, k, op, dx, in_stride, out_stride,
                                     (hipStream_t)stream_);
 }
@@ -613,7 +617,7 @@ MLP_API int mlp_gemm_dgrad_pooled(int b, int m, int k, int groups, int ns, const
   if (b <= 0 || m <= 0 || k <= 0 || groups <= 0 || ns <= 0) return 0;
   const int r = groups * ns;
   const size_t in_stride = (size_t)m * r, out_stride = (size_t)k * r;
-  OperandB op = {y, dpooled, scale, shift, mean, invstd, coef, argmax, ns};
+  OperandB op = {y, dpooled, scale, shift, mean, invstd, coef, argmax, ns, groups};
   return launch_nn<OP_POOLDY>(b, k, m, r, wt, m, op, dx, in_stride, out_stride,
                               (hipStream_t)stream_);
 }
@@ -712,7 +716,7 @@ MLP_API int mlp_gemm_wgrad_pooled(int b, int m, int k, int groups, int ns, const
                                   const float *xscale, const float *xshift, float *dw,
                                   float *workspace, void *stream_) {
   if (b <= 0 || m <= 0 || k <= 0 || groups <= 0 || ns <= 0) return 0;
-  OperandB P = {y, dpooled, scale, shift, mean, invstd, coef, argmax, ns};
+  OperandB P = {y, dpooled, scale, shift, mean, invstd, coef, argmax, ns, groups};
   return wgrad_run(b, m, k, groups * ns, OP_POOLDY, P, qmode, x, xscale, xshift, dw, workspace,
                    (hipStream_t)stream_);
 }
