@@ -99,19 +99,3 @@ def check(code, what):
 def current_stream_ptr(device):
     import torch
     return torch.cuda.current_stream(device).cuda_stream
-
-
-_workspaces = {}
-
-
-def workspace(device, nbytes):
-    """Per-device scratch buffer (grow-only), allocated through torch's caching allocator."""
-    import torch
-    if nbytes <= 0:
-        return None, 0
-    key = (device.type, device.index)
-    buf = _workspaces.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _workspaces[key] = buf
-    return buf, buf.numel()

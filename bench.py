@@ -158,7 +158,7 @@ def kernel_table(device):
     return {k: round(v, 2) for k, v in t.items()}, pair_us
 
 
-def cpu_baseline(V, cfg, steps=2):
+def cpu_baseline(V, cfg, steps=5):
     """The same supervised step on the host cores: oracle (OpenMP) behind the same modules."""
     from oracle.oracle import Oracle
     from oracle import standin
