@@ -1,0 +1,44 @@
+"""bench.py end to end on the GPU: the JSON contract of the default workload and the two other
+BASELINE workloads (short runs)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+            "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"}
+
+
+def _run(*flags):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup",
+                        "1", *flags], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+def test_bench_default_line_has_roofline_and_cpu_baseline():
+    d = _run()
+    assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["unit"] == "scenes/s" and d["value"] > 0 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert abs(d["value"] - 8 * 1000.0 / d["ms_per_step"]) <= 0.02 * d["value"]
+    assert d["config"]["hip_graphs"] is True and "workload" in d["config"]
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert roof["algorithmic_bytes"] == 38516736 and roof["traffic"] > roof["algorithmic_bytes"]
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and 0 < cpu["value"] < d["value"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,scenes", [("semi", 12), ("sunrgbd", 16)])
+def test_bench_other_workloads(workload, scenes):
+    d = _run("--workload", workload, "--no-kernels", "--no-cpu-baseline")
+    assert REQUIRED <= set(d) and d["config"]["per_gpu_batch"] == scenes
+    assert d["config"]["hip_graphs"] is True and d["value"] > 0
