@@ -246,3 +246,33 @@ def test_all_supervised_shortcut_is_identity(oracle_omp):
     assert out[0][0] == out[1][0]
     assert torch.allclose(out[0][1], out[1][1], rtol=0, atol=1e-7)
     assert out[0][2] == out[1][2]
+
+
+@pytest.mark.gpu
+def test_graph_recapture_on_shape_or_schedule_change(oracle_omp):
+    """A different batch shape, or a new BatchNorm momentum from the epoch schedule, re-captures
+    the graphs; the learning-rate schedule does not (the rate lives in a device tensor)."""
+    V, dev = _setup(True, oracle_omp)
+    cfg = V.scannet_config()
+    data = importlib.import_module("3dioumatch_amd.votenet.data")
+    runner = V.SupervisedStep(cfg, dev, world_size=1, num_proposal=K, seed=3, graphs=True)
+    mk = lambda b, n, s: {k: v.to(dev) for k, v in data.make_batch(b, n, cfg, seed=s, num_objects=5).items()}  # noqa: E731
+    loss, _ = runner(mk(B, N, 50))
+    first = runner._g1
+    assert runner.graphs and bool(torch.isfinite(loss))
+    loss, _ = runner(mk(B, N, 51))
+    assert runner._g1 is first                      # same shapes: replay
+    loss, _ = runner(mk(B + 1, N + 512, 52))
+    assert runner.graphs and runner._g1 is not first and bool(torch.isfinite(loss))  # re-captured
+    second = runner._g1
+    runner.set_epoch(450)                           # lr 1e-3 -> 1e-4, momentum 0.5 -> 0.5^23 -> 1e-3
+    assert abs(float(runner.optimizer.param_groups[0]["lr"]) - 1e-4) < 1e-9
+    before = step_params(runner)
+    loss, _ = runner(mk(B + 1, N + 512, 53))
+    assert runner._g1 is not second and bool(torch.isfinite(loss))
+    moved = float((step_params(runner) - before).abs().max())
+    assert 0 < moved <= 3.5e-4                      # lr 1e-4 now: far below a 1e-3 step (Adam ratio <= ~3.2)
+
+
+def step_params(runner):
+    return importlib.import_module("3dioumatch_amd.votenet.step").flat_params(runner.net).clone()
