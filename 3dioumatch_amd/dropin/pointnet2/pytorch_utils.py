@@ -6,6 +6,7 @@ pointnet2/pytorch_utils.py:14-39 (SharedMLP), :42-67 (BatchNorm wrappers), :70-1
 (_ConvBase), :127-236 (Conv1d/2d/3d), :239-270 (FC), :272-299 (BN momentum scheduler), so
 checkpoints are interchangeable.  The implementation is written fresh around one builder.
 """
+import contextlib
 import os
 
 import torch
@@ -215,6 +216,30 @@ class _FusedMLPChain(Function):
         return (dx if need_dx else None, None, None, None, None, *grads)
 
 
+_deferred_counters = None
+
+
+@contextlib.contextmanager
+def deferred_bn_counters():
+    """Inside this context the fused layers collect their `num_batches_tracked += 1` updates and
+    apply them with ONE multi-tensor add at exit (37 one-element kernels per forward otherwise)."""
+    global _deferred_counters
+    previous, _deferred_counters = _deferred_counters, []
+    try:
+        yield
+    finally:
+        pending, _deferred_counters = _deferred_counters, previous
+        if pending:
+            torch._foreach_add_(pending, 1)
+
+
+def bump_batches_tracked(counter):
+    if _deferred_counters is not None:
+        _deferred_counters.append(counter)
+    else:
+        counter.add_(1)
+
+
 def _fused_enabled():
     return os.environ.get("PN2_FUSED_MLP", "1") != "0"
 
@@ -269,7 +294,7 @@ class SharedMLP(nn.Sequential):
                 params = []
                 for layer, bn in zip(layers, bns):
                     if training:
-                        bn.num_batches_tracked.add_(1)
+                        bump_batches_tracked(bn.num_batches_tracked)
                     params += [layer.conv.weight, bn.weight, bn.bias, bn.running_mean,
                                bn.running_var]
                 return _FusedMLPChain.apply(x, pool, training, [bn.momentum for bn in bns],
@@ -279,7 +304,7 @@ class SharedMLP(nn.Sequential):
             y = layer.conv(x)
             training = bn.training
             if training:
-                bn.num_batches_tracked.add_(1)
+                bump_batches_tracked(bn.num_batches_tracked)
             op = _BNReLUMaxPool if (pool and i == len(layers) - 1) else _BNReLU
             x = op.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum,
                          bn.eps, training)

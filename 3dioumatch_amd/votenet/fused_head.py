@@ -114,8 +114,9 @@ def head_chain(x, conv1, bn1, conv2, bn2, conv3):
         return conv3(net)
     training = bn1.training
     if training:
-        bn1.num_batches_tracked.add_(1)
-        bn2.num_batches_tracked.add_(1)
+        from pointnet2.pytorch_utils import bump_batches_tracked
+        bump_batches_tracked(bn1.num_batches_tracked)
+        bump_batches_tracked(bn2.num_batches_tracked)
     return _HeadChain.apply(x, training, bn1.momentum, bn1.eps, bn2.momentum, bn2.eps,
                             conv1.weight, conv1.bias, bn1.weight, bn1.bias, bn1.running_mean,
                             bn1.running_var, conv2.weight, conv2.bias, bn2.weight, bn2.bias,

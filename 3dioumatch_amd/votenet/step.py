@@ -23,6 +23,8 @@ import sys
 import numpy as np
 import torch
 
+from pointnet2.pytorch_utils import deferred_bn_counters
+
 from .detector import VoteNet
 from .losses import get_labeled_loss
 
@@ -149,7 +151,8 @@ class SupervisedStep(object):
     def _forward_backward(self, batch):
         for p in self._params:
             p.grad = None
-        end_points = self.model(batch, mode="jitter")
+        with deferred_bn_counters():
+            end_points = self.model(batch, mode="jitter")
         end_points.update({k: v for k, v in batch.items()
                            if torch.is_tensor(v) or k in ("all_supervised", "labeled_num")})
         loss, end_points = get_labeled_loss(end_points, self.cfg, {"dataset_config": self.cfg})
@@ -437,11 +440,12 @@ class SemiSupervisedStep(SupervisedStep):
         if geometry is not None:
             student_geo = {k: v for k, v in geometry.items() if not k.startswith("ema_")}
             teacher_geo = {k[4:]: v for k, v in geometry.items() if k.startswith("ema_")}
-        with torch.no_grad():
-            ema_end_points = self.teacher({"point_clouds": batch["ema_point_clouds"],
-                                           "geometry": teacher_geo}, mode="jitter")
-        end_points = self.model({"point_clouds": batch["point_clouds"], "geometry": student_geo},
-                                mode="jitter")
+        with deferred_bn_counters():
+            with torch.no_grad():
+                ema_end_points = self.teacher({"point_clouds": batch["ema_point_clouds"],
+                                               "geometry": teacher_geo}, mode="jitter")
+            end_points = self.model({"point_clouds": batch["point_clouds"],
+                                     "geometry": student_geo}, mode="jitter")
         end_points.update({k: v for k, v in batch.items()
                            if torch.is_tensor(v) and k not in ("point_clouds", "ema_point_clouds")})
         labeled = batch.get("labeled_num")

@@ -29,6 +29,7 @@ def run(phase_out):
     with phase_out("forward"):
         ep = st.model(b, mode="jitter")
     ep.update({k: v for k, v in b.items() if torch.is_tensor(v)})
+    ep["all_supervised"] = True  # what SupervisedStep passes for a fully labeled batch
     with phase_out("loss"):
         loss, ep = losses.get_labeled_loss(ep, cfg, {"dataset_config": cfg})
     with phase_out("backward"):
