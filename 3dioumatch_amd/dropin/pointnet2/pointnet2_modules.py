@@ -136,12 +136,15 @@ class PointnetSAModuleVotes(nn.Module):
             return torch.sum(feats * rbf.unsqueeze(1), -1) / float(self.nsample)
         raise ValueError("unknown pooling %r" % (self.pooling,))
 
-    def forward(self, xyz, features=None, inds=None, ball_idx=None):
-        """ball_idx: optional precomputed ball-query indices (B,npoint,nsample) int32 for the
-        centroids `inds` (both depend on coordinates only; see votenet/step.py)."""
+    def forward(self, xyz, features=None, inds=None, ball_idx=None, new_xyz=None):
+        """ball_idx / new_xyz: optional precomputed ball-query indices (B,npoint,nsample) int32 and
+        centroid coordinates (B,npoint,3) for the centroids `inds` (all three depend on
+        coordinates only; see votenet/step.py)."""
         if inds is not None:
             assert inds.shape[1] == self.npoint
-        if self.npoint is not None:
+        if new_xyz is not None and inds is not None:
+            pass  # the index chain was computed ahead of time
+        elif self.npoint is not None:
             new_xyz, inds = _sample_centroids(xyz, self.npoint, inds)
         else:
             new_xyz = None
@@ -192,13 +195,20 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
 
-    def forward(self, unknown, known, unknow_feats, known_feats):
+    @staticmethod
+    def interpolation(unknown, known):
+        """(idx (B,n,3) int32, weight (B,n,3)): the three nearest known points of every unknown
+        point and their normalised inverse distances -- coordinates only."""
+        dist, idx = pointnet2_utils.three_nn(unknown, known)
+        recip = 1.0 / (dist + 1e-8)
+        return idx, recip / torch.sum(recip, dim=2, keepdim=True)
+
+    def forward(self, unknown, known, unknow_feats, known_feats, interpolation=None):
         if known is None:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         else:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
-            recip = 1.0 / (dist + 1e-8)
-            weight = recip / torch.sum(recip, dim=2, keepdim=True)
+            idx, weight = interpolation if interpolation is not None else \
+                self.interpolation(unknown, known)
             interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
         stacked = interpolated if unknow_feats is None else \
             torch.cat([interpolated, unknow_feats], dim=1)

@@ -45,7 +45,8 @@ class Pointnet2Backbone(nn.Module):
         learned weight): the four furthest-point samplings and the four ball queries.  Being data-only, it can be computed
         for the NEXT batch on a side stream while the current step trains (votenet/step.py),
         which takes the strictly serial FPS rounds (a handful of busy CUs) off the critical
-        path.  Returns {"sa<i>_inds", "sa<i>_ball_idx"} (int32)."""
+        path.  Returns {"sa<i>_inds", "sa<i>_ball_idx"} (int32), the centroid coordinates
+        "sa<i>_new_xyz" and the interpolation ("fp<j>_idx", "fp<j>_weight") of the two FP layers."""
         from pointnet2 import pointnet2_utils
         xyz = pointcloud[..., 0:3].contiguous()
         geometry = {}
@@ -55,9 +56,15 @@ class Pointnet2Backbone(nn.Module):
             new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(),
                                                        inds).transpose(1, 2).contiguous()
             geometry["sa%d_inds" % i] = inds
+            geometry["sa%d_new_xyz" % i] = new_xyz
             geometry["sa%d_ball_idx" % i] = pointnet2_utils.ball_query(sa.radius, sa.nsample, xyz,
                                                                        new_xyz)
             xyz = new_xyz
+        # the two feature-propagation layers interpolate sa4 -> sa3 and sa3 -> sa2
+        for name, unknown, known in (("fp1", "sa3", "sa4"), ("fp2", "sa2", "sa3")):
+            idx, weight = self.fp1.interpolation(geometry[unknown + "_new_xyz"],
+                                                 geometry[known + "_new_xyz"])
+            geometry[name + "_idx"], geometry[name + "_weight"] = idx, weight.contiguous()
         return geometry
 
     def forward(self, pointcloud, end_points=None, geometry=None):
@@ -66,15 +73,19 @@ class Pointnet2Backbone(nn.Module):
         for i in range(1, 5):
             given = geometry["sa%d_inds" % i] if geometry is not None else None
             ball = geometry.get("sa%d_ball_idx" % i) if geometry is not None else None
-            xyz, features, inds = getattr(self, "sa%d" % i)(xyz, features, given, ball)
+            centroids = geometry.get("sa%d_new_xyz" % i) if geometry is not None else None
+            xyz, features, inds = getattr(self, "sa%d" % i)(xyz, features, given, ball, centroids)
             end_points["sa%d_xyz" % i] = xyz
             end_points["sa%d_features" % i] = features
             if i <= 2:
                 end_points["sa%d_inds" % i] = inds
+        interp = [None, None]
+        if geometry is not None and "fp1_idx" in geometry:
+            interp = [(geometry["fp%d_idx" % j], geometry["fp%d_weight" % j]) for j in (1, 2)]
         features = self.fp1(end_points["sa3_xyz"], end_points["sa4_xyz"],
-                            end_points["sa3_features"], end_points["sa4_features"])
+                            end_points["sa3_features"], end_points["sa4_features"], interp[0])
         features = self.fp2(end_points["sa2_xyz"], end_points["sa3_xyz"],
-                            end_points["sa2_features"], features)
+                            end_points["sa2_features"], features, interp[1])
         end_points["fp2_features"] = features
         end_points["fp2_xyz"] = end_points["sa2_xyz"]
         num_seed = end_points["fp2_xyz"].shape[1]
