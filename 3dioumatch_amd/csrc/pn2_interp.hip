@@ -107,6 +107,80 @@ three_interpolate_kernel(int c, int m, int n, const float *__restrict__ points,
   }
 }
 
+// The same with the CPW source rows of the workgroup staged in LDS (m*4 bytes each): the 3 x JP
+// gathers per channel become LDS reads (the global form is bound by the texture-address unit:
+// one 4-byte gather per address), and the kernel is left with its 16-byte output stores.  idx and
+// weight of the lane's queries are read once per channel group (they stay in the XCD's L2).
+template <int CPW>
+__global__ void __launch_bounds__(256)
+three_interpolate_lds_kernel(int c, int m, int n, const float *__restrict__ points,
+                             const int *__restrict__ idx, const float *__restrict__ weight,
+                             float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float rows[];
+  const BlockId blk = xcd_block_id();
+  const int b = blk.z, l0 = blk.y * CPW;
+  const int nc = c - l0 < CPW ? c - l0 : CPW;
+  const float *src = points + ((size_t)b * c + l0) * m;
+  for (int t = threadIdx.x; t < nc * m; t += 256) rows[t] = src[t];
+  __syncthreads();
+  const int j0 = (blk.x * 256 + threadIdx.x) * 4;
+  if (j0 >= n) return;
+  const int4 *ib = reinterpret_cast<const int4 *>(idx + ((size_t)b * n + j0) * 3);
+  const float4 *wb = reinterpret_cast<const float4 *>(weight + ((size_t)b * n + j0) * 3);
+  const int4 i0 = ib[0], i1 = ib[1], i2 = ib[2];
+  const float4 w0 = wb[0], w1 = wb[1], w2 = wb[2];
+  const int ii[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
+  const float ww[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+#pragma unroll
+  for (int cc = 0; cc < CPW; ++cc) {
+    if (cc < nc) {
+      const float *row = rows + cc * m;
+      float r[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        r[t] = __fadd_rn(__fadd_rn(__fmul_rn(row[ii[3 * t]], ww[3 * t]),
+                                   __fmul_rn(row[ii[3 * t + 1]], ww[3 * t + 1])),
+                         __fmul_rn(row[ii[3 * t + 2]], ww[3 * t + 2]));
+      *reinterpret_cast<float4 *>(out + ((size_t)b * c + l0 + cc) * n + j0) =
+          make_float4(r[0], r[1], r[2], r[3]);
+    }
+  }
+}
+
+// Scatter-add with the CPW destination rows privatised in LDS (ds_add_f32), written back once:
+// no global atomics and no pre-zeroing (the global-atomic kernel below remains for large m).
+template <int CPW>
+__global__ void __launch_bounds__(256)
+three_interpolate_grad_lds_kernel(int c, int n, int m, const float *__restrict__ grad_out,
+                                  const int *__restrict__ idx, const float *__restrict__ weight,
+                                  float *__restrict__ grad_points) {
+  extern __shared__ __attribute__((aligned(16))) float rows[];
+  const BlockId blk = xcd_block_id();
+  const int b = blk.y, l0 = blk.x * CPW;
+  const int nc = c - l0 < CPW ? c - l0 : CPW;
+  for (int t = threadIdx.x; t < nc * m; t += 256) rows[t] = 0.f;
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const int *ib = idx + ((size_t)b * n + j) * 3;
+    const float *wb = weight + ((size_t)b * n + j) * 3;
+    const int i1 = ib[0], i2 = ib[1], i3 = ib[2];
+    const float w1 = wb[0], w2 = wb[1], w3 = wb[2];
+#pragma unroll
+    for (int cc = 0; cc < CPW; ++cc) {
+      if (cc < nc) {
+        const float g = grad_out[((size_t)b * c + l0 + cc) * n + j];
+        float *row = rows + cc * m;
+        atomicAdd(row + i1, __fmul_rn(g, w1));
+        atomicAdd(row + i2, __fmul_rn(g, w2));
+        atomicAdd(row + i3, __fmul_rn(g, w3));
+      }
+    }
+  }
+  __syncthreads();
+  float *dst = grad_points + ((size_t)b * c + l0) * m;
+  for (int t = threadIdx.x; t < nc * m; t += 256) dst[t] = rows[t];
+}
+
 // grad_points[b,l,i_t] += grad_out[b,l,j] * w_t   (interpolate_gpu.cu:121-148)
 __global__ void __launch_bounds__(256)
 three_interpolate_grad_kernel(int c, int n, int m, const float *__restrict__ grad_out,
@@ -151,6 +225,14 @@ PN2_API int pn2_three_interpolate(int b, int c, int m, int n, const float *point
                                   const int *idx, const float *weight, float *out,
                                   void *stream_) {
   if (b <= 0 || c <= 0 || n <= 0) return 0;
+  if (n % 4 == 0 && n >= 2048 && m > 0 && m <= 2048) {  // 8 source rows fit 64 KB of LDS
+    constexpr int CPW = 8;
+    dim3 grid(pn2_ceil_div(n, 1024), pn2_ceil_div(c, CPW), b);
+    hipLaunchKernelGGL(three_interpolate_lds_kernel<CPW>, grid, dim3(256),
+                       sizeof(float) * (size_t)CPW * m, (hipStream_t)stream_, c, m, n, points, idx,
+                       weight, out);
+    return pn2_launch_status();
+  }
   if (n % 4 == 0) {
     dim3 grid(pn2_ceil_div(n, 1024), interp_channel_groups(c), b);
     hipLaunchKernelGGL(three_interpolate_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream_, c,
@@ -168,6 +250,13 @@ PN2_API int pn2_three_interpolate_grad(int b, int c, int n, int m, const float *
                                        void *stream_) {
   if (b <= 0 || c <= 0 || m <= 0) return 0;
   hipStream_t stream = (hipStream_t)stream_;
+  if (n > 0 && m <= 1024) {  // 16 destination rows fit 64 KB of LDS
+    constexpr int CPW = 16;
+    hipLaunchKernelGGL(three_interpolate_grad_lds_kernel<CPW>, dim3(pn2_ceil_div(c, CPW), b),
+                       dim3(256), sizeof(float) * (size_t)CPW * m, stream, c, n, m, grad_out, idx,
+                       weight, grad_points);
+    return pn2_launch_status();
+  }
   const int e = pn2_zero_async(grad_points, sizeof(float) * (size_t)b * c * m, stream);
   if (e != 0) return e;
   if (n <= 0) return 0;

@@ -199,6 +199,27 @@ def test_interp_golden(ext):
     np.testing.assert_allclose(grad.cpu().numpy(), g["grad"], rtol=0, atol=1e-4)
 
 
+@pytest.mark.parametrize("b,c,m,n", [(2, 20, 700, 4096), (1, 9, 2048, 2048), (2, 33, 50, 2052),
+                                     (1, 5, 2049, 4096), (2, 17, 1024, 3000), (1, 40, 1500, 900),
+                                     (2, 256, 1024, 8192)])
+def test_three_interpolate_every_kernel_vs_oracle(ext, oracle, b, c, m, n):
+    """Forward (LDS-staged rows for m <= 2048 and n >= 2048, global gathers otherwise) bit-exact
+    against the oracle; backward (LDS-privatised rows for m <= 1024, global atomics otherwise)
+    within the fp32 reordering of the scatter-add."""
+    g = np.random.default_rng(c * 1000 + m + n)
+    feats = g.standard_normal((b, c, m)).astype(np.float32)
+    idx = g.integers(0, m, (b, n, 3)).astype(np.int32)
+    idx[:, ::7, 1] = idx[:, ::7, 0]  # repeated neighbours: same-address accumulation
+    w = g.random((b, n, 3)).astype(np.float32)
+    w = (w / w.sum(axis=2, keepdims=True)).astype(np.float32)
+    out = ext.three_interpolate(dev(feats), dev(idx), dev(w)).cpu().numpy()
+    assert np.array_equal(bits(out), bits(oracle.three_interpolate(feats, idx, w)))
+    go = g.standard_normal((b, c, n)).astype(np.float32)
+    grad = ext.three_interpolate_grad(dev(go), dev(idx), dev(w), m).cpu().numpy()
+    want = oracle.three_interpolate_grad(go, idx, w, m)
+    np.testing.assert_allclose(grad, want, rtol=0, atol=1e-4 * max(1.0, np.abs(want).max()))
+
+
 @pytest.mark.parametrize("b,n,m", [(2, 4096, 1024), (1, 1000, 1500), (3, 37, 5), (1, 2500, 2049)])
 def test_three_nn_vs_oracle(ext, oracle, synth, b, n, m):
     unk = synth.cloud_uniform(b, n, 2.0, seed=n)
