@@ -227,33 +227,36 @@ grid_query_kernel(int n, int m, float radius2, float inv_side, int nsample,
   // pays about five L2 round trips instead of nine.
   int total = 0;
   unsigned *list = hits[wave];
-  struct Row { float4 q[kRowPasses]; int rc, c0, c01; };
-  auto load_row = [&](int r) {
-    Row o;
-    o.c0 = __builtin_amdgcn_readlane(my_cnt, r * 3 + 0);
+  struct Row { float4 q[kRowPasses]; int rc; };
+  auto load_row = [&](int r, Row &o) {
+    const int c0 = __builtin_amdgcn_readlane(my_cnt, r * 3 + 0);
     const int c1 = __builtin_amdgcn_readlane(my_cnt, r * 3 + 1);
     const int c2 = __builtin_amdgcn_readlane(my_cnt, r * 3 + 2);
     const int e0 = __builtin_amdgcn_readlane(my_cell, r * 3 + 0);
     const int e1 = __builtin_amdgcn_readlane(my_cell, r * 3 + 1);
     const int e2 = __builtin_amdgcn_readlane(my_cell, r * 3 + 2);
-    o.c01 = o.c0 + c1;
-    o.rc = o.c01 + c2;
+    const int c01 = c0 + c1;
+    o.rc = c01 + c2;
 #pragma unroll
     for (int p = 0; p < kRowPasses; ++p) {
-      const int t = p * kWave + lane;
-      int cell = e0, s = t;
-      if (t >= o.c0) { cell = e1; s = t - o.c0; }
-      if (t >= o.c01) { cell = e2; s = t - o.c01; }
-      o.q[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t < o.rc) o.q[p] = cloud_slots[(size_t)cell * kCap + s];
+      if (p * kWave < o.rc) {  // wave-uniform: the second / third pass of a row is rare
+        // lanes past the end re-read the row's last candidate (a valid slot: no masked load, no
+        // zero fill); they are excluded by `live` when the row is tested
+        int t = p * kWave + lane;
+        t = t < o.rc ? t : o.rc - 1;
+        int cell = e0, s = t;
+        if (t >= c0) { cell = e1; s = t - c0; }
+        if (t >= c01) { cell = e2; s = t - c01; }
+        o.q[p] = cloud_slots[cell * kCap + s];
+      }
     }
-    return o;
   };
-  Row cur = load_row(0);
+  Row rows[2];
+  load_row(0, rows[0]);
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
-    Row nxt = cur;
-    if (r + 1 < 9) nxt = load_row(r + 1);
+    if (r + 1 < 9) load_row(r + 1, rows[(r + 1) & 1]);
+    const Row &cur = rows[r & 1];
 #pragma unroll
     for (int p = 0; p < kRowPasses; ++p) {
       if (p * kWave < cur.rc) {  // wave-uniform
@@ -268,7 +271,6 @@ grid_query_kernel(int n, int m, float radius2, float inv_side, int nsample,
         }
       }
     }
-    cur = nxt;
   }
   // points that did not fit their cell sit in the overflow list of their z-layer: scan the
   // lists of the three layers around the centroid (empty unless the cloud has dense clumps)
