@@ -134,7 +134,9 @@ __global__ void __launch_bounds__(256)
 gemm_nn_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int lda, OperandB opb,
                float *__restrict__ c, size_t b_stride_in, size_t b_stride_out) {
   constexpr int MB = TM / WM / 32, NB = TN / WN / 32;
-  constexpr int LDA = TM + 1;  // [k][m], padded: conflict-free transposing stores
+  // [k][m]; the transposing stores put lane (kk, mm) at bank (kk*LDA + mm) % 64: with LDA = TM + 4
+  // the 16 x 4 lanes of a wave hit 64 distinct banks (TM + 1 folded them onto 19)
+  constexpr int LDA = TM + 4;
   __shared__ float As[KC * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[KC * TN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
