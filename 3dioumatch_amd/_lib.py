@@ -57,6 +57,8 @@ _SIGNATURES = {
     "mlp_gemm_wgrad_pooled": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_gemm_wgrad_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
+    "lhs_nms3d_aabb": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _c_int, _c_int, _vp,
+                       _vp],
     "lhs_nms_samecls": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _c_int, _vp, _vp],
     "iou3d_boxes_overlap_bev": [_c_int, _vp, _c_int, _vp, _vp, _vp],
     "iou3d_boxes_iou_bev": [_c_int, _vp, _c_int, _vp, _vp, _vp],

@@ -45,8 +45,8 @@ __device__ __forceinline__ Aabb camera_aabb(const float *c, const double *sz, do
 __global__ void __launch_bounds__(64)
 lhs_nms_kernel(int n, const float *__restrict__ center, const double *__restrict__ size,
                const double *__restrict__ heading, const float *__restrict__ score,
-               const long long *__restrict__ cls, double thresh, int old_type,
-               int *__restrict__ picked) {
+               const long long *__restrict__ cls, double thresh, int old_type, int same_class,
+               int readmit, double area_eps, int *__restrict__ picked) {
   __shared__ float s_score[64];
   __shared__ Aabb s_box[64];
   __shared__ double s_area[64];
@@ -74,7 +74,7 @@ lhs_nms_kernel(int n, const float *__restrict__ center, const double *__restrict
     }
     s_box[rank] = mine;
     s_area[rank] = ((double)mine.x2 - mine.x1) * ((double)mine.y2 - mine.y1) *
-                       ((double)mine.z2 - mine.z1) + 1e-8;
+                       ((double)mine.z2 - mine.z1) + area_eps;
     s_cls[rank] = my_cls;
     s_orig[rank] = lane;
   }
@@ -106,11 +106,11 @@ lhs_nms_kernel(int n, const float *__restrict__ center, const double *__restrict
         const double inter = l * w * h;
         o = inter / (area_i + area - inter);
       }
-      o = o * (ci == c ? 1.0 : 0.0);
+      if (same_class) o = o * (ci == c ? 1.0 : 0.0);
       suppressed = o > thresh;
     }
     const unsigned long long sup = __ballot(suppressed);
-    const int keep_n = __popcll(sup) / 2;  // the upper half by score is re-admitted
+    const int keep_n = readmit ? __popcll(sup) / 2 : 0;  // LHS: the upper half by score returns
     const unsigned long long above = lane >= 63 ? 0ull : (sup >> (lane + 1));
     const unsigned long long readmit = __ballot(suppressed && __popcll(above) < keep_n);
     pick |= readmit;
@@ -119,16 +119,136 @@ lhs_nms_kernel(int n, const float *__restrict__ center, const double *__restrict
   if (live) picked[base + s_orig[lane]] = (int)((pick >> lane) & 1ull);
 }
 
+// The same greedy loop for 64 < n <= 256 (evaluation: every proposal of a scene takes part,
+// models/ap_helper.py:101-215): one 256-lane workgroup per scene, lane = box in ascending score
+// order, the alive / suppressed sets are four ballot words in LDS.
+__global__ void __launch_bounds__(256)
+nms_aabb_block_kernel(int n, const float *__restrict__ center, const double *__restrict__ size,
+                      const double *__restrict__ heading, const float *__restrict__ score,
+                      const long long *__restrict__ cls, double thresh, int old_type,
+                      int same_class, int readmit, double area_eps, int *__restrict__ picked) {
+  __shared__ float s_score[256];
+  __shared__ Aabb s_box[256];
+  __shared__ double s_area[256];
+  __shared__ long long s_cls[256];
+  __shared__ int s_orig[256];
+  __shared__ unsigned long long s_alive[4], s_sup[4];
+  const int scene = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const size_t base = (size_t)scene * n;
+  const bool live = tid < n;
+  Aabb mine = {0, 0, 0, 0, 0, 0};
+  float my_score = 0.f;
+  long long my_cls = -1;
+  if (live) {
+    mine = camera_aabb(center + (base + tid) * 3, size + (base + tid) * 3, heading[base + tid]);
+    my_score = score[base + tid];
+    my_cls = cls[base + tid];
+  }
+  s_score[tid] = my_score;
+  __syncthreads();
+  if (live) {
+    int rank = 0;
+    for (int k = 0; k < n; ++k) {
+      const float sk = s_score[k];
+      rank += (sk < my_score || (sk == my_score && k < tid)) ? 1 : 0;
+    }
+    s_box[rank] = mine;
+    s_area[rank] = ((double)mine.x2 - mine.x1) * ((double)mine.y2 - mine.y1) *
+                       ((double)mine.z2 - mine.z1) + area_eps;
+    s_cls[rank] = my_cls;
+    s_orig[rank] = tid;
+  }
+  __syncthreads();
+  const Aabb b = live ? s_box[tid] : mine;   // lane r is now the box of rank r
+  const double area = live ? s_area[tid] : 1.0;
+  const long long c = live ? s_cls[tid] : -1;
+  bool alive = live, pick = false;
+  for (;;) {
+    const unsigned long long am = __ballot(alive);
+    if (lane == 0) s_alive[w] = am;
+    __syncthreads();
+    int i = -1;
+#pragma unroll
+    for (int q = 3; q >= 0; --q)
+      if (i < 0 && s_alive[q]) i = q * 64 + 63 - __builtin_clzll(s_alive[q]);
+    if (i < 0) break;  // uniform: every lane read the same words
+    const Aabb bi = s_box[i];
+    const double area_i = s_area[i];
+    const long long ci = s_cls[i];
+    bool suppressed = false;
+    if (alive && tid != i) {
+      const double xx1 = bi.x1 > b.x1 ? bi.x1 : b.x1, yy1 = bi.y1 > b.y1 ? bi.y1 : b.y1,
+                   zz1 = bi.z1 > b.z1 ? bi.z1 : b.z1;
+      const double xx2 = bi.x2 < b.x2 ? bi.x2 : b.x2, yy2 = bi.y2 < b.y2 ? bi.y2 : b.y2,
+                   zz2 = bi.z2 < b.z2 ? bi.z2 : b.z2;
+      const double l = xx2 - xx1 > 0 ? xx2 - xx1 : 0, wd = yy2 - yy1 > 0 ? yy2 - yy1 : 0,
+                   h = zz2 - zz1 > 0 ? zz2 - zz1 : 0;
+      double o;
+      if (old_type) {
+        o = (l * wd * h) / area;
+      } else {
+        const double inter = l * wd * h;
+        o = inter / (area_i + area - inter);
+      }
+      if (same_class) o = o * (ci == c ? 1.0 : 0.0);
+      suppressed = o > thresh;
+    }
+    const unsigned long long sm = __ballot(suppressed);
+    if (lane == 0) s_sup[w] = sm;
+    __syncthreads();
+    if (tid == i) { pick = true; alive = false; }
+    if (suppressed) {
+      if (readmit) {
+        int total = 0, above = lane >= 63 ? 0 : __popcll(s_sup[w] >> (lane + 1));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          total += __popcll(s_sup[q]);
+          if (q > w) above += __popcll(s_sup[q]);
+        }
+        if (above < total / 2) pick = true;
+      }
+      alive = false;
+    }
+    __syncthreads();  // s_alive / s_sup are rewritten by the next round
+  }
+  if (live) picked[base + s_orig[tid]] = pick ? 1 : 0;
+}
+
 }  // namespace
+
+static int nms_aabb_launch(int scenes, int n, const float *center, const double *size,
+                           const double *heading, const float *score, const long long *cls,
+                           double thresh, int old_type, int same_class, int readmit,
+                           double area_eps, int *picked, hipStream_t stream) {
+  if (scenes <= 0 || n <= 0) return 0;
+  if (n > 256) return (int)hipErrorInvalidValue;
+  if (n <= 64)
+    hipLaunchKernelGGL(lhs_nms_kernel, dim3(scenes), dim3(64), 0, stream, n, center, size, heading,
+                       score, cls, thresh, old_type, same_class, readmit, area_eps, picked);
+  else
+    hipLaunchKernelGGL(nms_aabb_block_kernel, dim3(scenes), dim3(256), 0, stream, n, center, size,
+                       heading, score, cls, thresh, old_type, same_class, readmit, area_eps,
+                       picked);
+  return pn2_launch_status();
+}
+
+// picked (scenes, n) int32 <- 1 for every box the reference's greedy axis-aligned 3-D NMS returns:
+// nms_3d_faster (same_class = 0) / nms_3d_faster_samecls (same_class = 1), utils/nms.py:77-166,
+// n <= 256 (the evaluation path, models/ap_helper.py:170-203)
+extern "C" __attribute__((visibility("default")))
+int lhs_nms3d_aabb(int scenes, int n, const float *center, const double *size,
+                   const double *heading, const float *score, const long long *cls, double thresh,
+                   int old_type, int same_class, int *picked, void *stream) {
+  return nms_aabb_launch(scenes, n, center, size, heading, score, cls, thresh, old_type,
+                         same_class, 0, 0.0, picked, (hipStream_t)stream);
+}
 
 // picked (scenes, n) int32 <- 1 for every box lhs_3d_faster_samecls returns (utils/nms.py:168-214)
 extern "C" __attribute__((visibility("default")))
 int lhs_nms_samecls(int scenes, int n, const float *center, const double *size,
                     const double *heading, const float *score, const long long *cls, double thresh,
                     int old_type, int *picked, void *stream) {
-  if (scenes <= 0 || n <= 0) return 0;
   if (n > 64) return (int)hipErrorInvalidValue;  // MAX_NUM_OBJ = 64 (loss_helper_unlabeled.py:21)
-  hipLaunchKernelGGL(lhs_nms_kernel, dim3(scenes), dim3(64), 0, (hipStream_t)stream, n, center,
-                     size, heading, score, cls, thresh, old_type, picked);
-  return pn2_launch_status();
+  return nms_aabb_launch(scenes, n, center, size, heading, score, cls, thresh, old_type, 1, 1, 1e-8,
+                         picked, (hipStream_t)stream);
 }

@@ -33,3 +33,25 @@ def lhs_nms_samecls_gpu(center, size, heading, score, cls, thresh, old_type=Fals
                                       float(thresh), 1 if old_type else 0, picked.data_ptr(),
                                       _L.current_stream_ptr(score.device)), "lhs_nms_samecls")
     return picked.bool()
+
+
+def nms3d_aabb_gpu(center, size, heading, score, cls, thresh, old_type=False, same_class=True):
+    """The evaluation path's per-scene NMS (utils/nms.py nms_3d_faster / nms_3d_faster_samecls on
+    the camera-frame bounds of every proposal) -> picked (S,n) bool, n <= 256."""
+    for t, dt, name in ((center, torch.float32, "center"), (size, torch.float64, "size"),
+                        (heading, torch.float64, "heading"), (score, torch.float32, "score"),
+                        (cls, torch.int64, "cls")):
+        if not t.is_cuda or t.dtype != dt:
+            raise RuntimeError("%s must be a %s GPU tensor" % (name, dt))
+    s, n = score.shape
+    if n > 256:
+        raise RuntimeError("nms3d_aabb: at most 256 boxes per scene")
+    picked = torch.zeros((s, n), dtype=torch.int32, device=score.device)
+    with torch.cuda.device(score.device):
+        _L.check(_lib.lhs_nms3d_aabb(s, n, center.contiguous().data_ptr(),
+                                     size.contiguous().data_ptr(), heading.contiguous().data_ptr(),
+                                     score.contiguous().data_ptr(), cls.contiguous().data_ptr(),
+                                     float(thresh), 1 if old_type else 0, 1 if same_class else 0,
+                                     picked.data_ptr(), _L.current_stream_ptr(score.device)),
+                 "lhs_nms3d_aabb")
+    return picked.bool()

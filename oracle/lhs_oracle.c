@@ -50,8 +50,25 @@ void lhso_camera_aabb(int n, const float *center, const double *size, const doub
 /* nms.py:168-214 for one scene.  aabb (n,6) float32, score (n) float32 (already the float32
  * product pos_obj*iou), cls (n).  picked[i] = 1 for every index the reference appends to `pick`.
  * Ties in the ascending argsort are broken by index (numpy's quicksort leaves them unspecified). */
+static void nms_core(int n, const float *aabb, const float *score, const long long *cls,
+                     double thresh, int old_type, int same_class, int readmit, double area_eps,
+                     int *picked);
+
 void lhso_nms_samecls(int n, const float *aabb, const float *score, const long long *cls,
                       double thresh, int old_type, int *picked) {
+  nms_core(n, aabb, score, cls, thresh, old_type, 1, 1, 1e-8, picked);
+}
+
+/* utils/nms.py:77-116 nms_3d_faster (same_class = 0) and :118-166 nms_3d_faster_samecls
+ * (same_class = 1): the plain greedy loop (nothing re-admitted, areas without the 1e-8). */
+void lhso_nms3d_aabb(int n, const float *aabb, const float *score, const long long *cls,
+                     double thresh, int old_type, int same_class, int *picked) {
+  nms_core(n, aabb, score, cls, thresh, old_type, same_class, 0, 0.0, picked);
+}
+
+static void nms_core(int n, const float *aabb, const float *score, const long long *cls,
+                     double thresh, int old_type, int same_class, int readmit, double area_eps,
+                     int *picked) {
   int *order = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
   int *sup = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
   double *area = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
@@ -59,7 +76,7 @@ void lhso_nms_samecls(int n, const float *aabb, const float *score, const long l
     picked[i] = 0;
     order[i] = i;
     area[i] = ((double)aabb[i * 6 + 3] - aabb[i * 6 + 0]) * ((double)aabb[i * 6 + 4] - aabb[i * 6 + 1]) *
-                  ((double)aabb[i * 6 + 5] - aabb[i * 6 + 2]) + 1e-8;
+                  ((double)aabb[i * 6 + 5] - aabb[i * 6 + 2]) + area_eps;
   }
   for (int a = 1; a < n; ++a) { /* stable insertion sort, ascending score */
     const int v = order[a];
@@ -89,10 +106,11 @@ void lhso_nms_samecls(int n, const float *aabb, const float *score, const long l
         const double inter = l * w * h;
         o = inter / (area[i] + area[j] - inter);
       }
-      o = o * (cls[i] == cls[j] ? 1.0 : 0.0);
+      if (same_class) o = o * (cls[i] == cls[j] ? 1.0 : 0.0);
       if (o > thresh) sup[ns++] = t;
     }
-    for (int c = 0; c < ns / 2; ++c) picked[order[sup[ns - c - 1]]] = 1;
+    if (readmit)
+      for (int c = 0; c < ns / 2; ++c) picked[order[sup[ns - c - 1]]] = 1;
     /* delete position count-1 and every suppressed position */
     int w = 0, s = 0;
     for (int t = 0; t < count - 1; ++t) {

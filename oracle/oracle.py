@@ -209,6 +209,18 @@ class Oracle:
                                   out.ctypes.data_as(_f32p))
         return out
 
+    def nms3d_aabb(self, aabb, score, cls, thresh, old_type=False, same_class=True):
+        """-> picked (n,) int32 mask of nms_3d_faster[_samecls] (utils/nms.py:77-166)."""
+        aabb, ap = _f(aabb)
+        score, sp = _f(score)
+        cls = np.ascontiguousarray(cls, np.int64)
+        n = aabb.shape[0]
+        out = np.zeros(n, np.int32)
+        self.lib.lhso_nms3d_aabb(n, ap, sp, cls.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)),
+                                 ctypes.c_double(float(thresh)), int(bool(old_type)),
+                                 int(bool(same_class)), out.ctypes.data_as(_i32p))
+        return out
+
     def lhs_nms_samecls(self, aabb, score, cls, thresh, old_type=False):
         """-> picked (n,) int32 mask: the indices lhs_3d_faster_samecls returns."""
         aabb, ap = _f(aabb)

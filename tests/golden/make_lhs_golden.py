@@ -80,6 +80,29 @@ def main():
                           ("aabb", aabb), ("pick", pick),
                           ("thresh", np.float64(thresh)), ("old", np.int32(old))):
             arrays["c%d_%s" % (k, name)] = arr
+    # evaluation-path NMS (nms_3d_faster / nms_3d_faster_samecls) on up to 256 proposals
+    eval_cases = [(256, 8, False, 0.25, False, True), (256, 5, True, 0.25, False, True),
+                  (200, 4, False, 0.25, False, False), (128, 3, False, 0.5, True, True),
+                  (65, 2, True, 0.25, False, False)]
+    for k, (n, clumps, oriented, thresh, old, same) in enumerate(eval_cases):
+        c, s, h, sc, cl = scene(g, n, clumps, oriented)
+        corners = np.zeros((n, 8, 3), dtype=np.float32)
+        cam = flip_axis_to_camera(c)
+        for j in range(n):
+            corners[j] = ref_box.get_3d_box(s[j].astype(np.float64), float(h[j]), cam[j, :])
+        boxes = np.zeros((n, 8))
+        boxes[:, 0:3] = corners.min(axis=1)
+        boxes[:, 3:6] = corners.max(axis=1)
+        boxes[:, 6] = sc
+        boxes[:, 7] = cl
+        fn = ref_nms.nms_3d_faster_samecls if same else ref_nms.nms_3d_faster
+        pick = np.zeros(n, np.int32)
+        pick[np.asarray(fn(boxes if same else boxes[:, :7], thresh, old), dtype=np.int64)] = 1
+        for name, arr in (("center", c), ("size", s), ("heading", h), ("score", sc), ("cls", cl),
+                          ("pick", pick), ("thresh", np.float64(thresh)), ("old", np.int32(old)),
+                          ("same", np.int32(same))):
+            arrays["e%d_%s" % (k, name)] = arr
+    arrays["num_eval_cases"] = np.int32(len(eval_cases))
     arrays["num_cases"] = np.int32(len(cases))
     path = os.path.join(HERE, "lhs_nms_ref.npz")
     np.savez_compressed(path, **arrays)

@@ -516,3 +516,36 @@ def test_lhs_nms_vs_reference_golden_and_oracle(oracle, synth):
         want = oracle.lhs_nms_samecls(aabb, score[i], cls[i], 0.25)
         np.testing.assert_array_equal(got[i].astype(np.int32), want)
     assert 0 < got.sum() < s * n
+
+
+def test_eval_nms_vs_reference_golden(oracle):
+    """Device NMS of the evaluation path (n up to 256, one workgroup per scene) == the reference's
+    numpy nms_3d_faster[_samecls]; batched call == per-scene oracle."""
+    import importlib
+    nms = importlib.import_module("3dioumatch_amd.votenet.pseudo_nms")
+    g = golden("lhs_nms_ref.npz")
+    t64 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float64)).cuda()  # noqa: E731
+    for k in range(int(g["num_eval_cases"])):
+        get = lambda name: g["e%d_%s" % (k, name)]  # noqa: E731
+        picked = nms.nms3d_aabb_gpu(dev(get("center")[None]), t64(get("size")[None]),
+                                    t64(get("heading")[None]), dev(get("score")[None]),
+                                    torch.from_numpy(get("cls")[None]).cuda(), float(get("thresh")),
+                                    bool(get("old")), bool(get("same")))
+        np.testing.assert_array_equal(picked[0].cpu().numpy().astype(np.int32), get("pick"))
+    rng = np.random.default_rng(6)
+    s, n = 5, 256
+    clump = rng.uniform(-2, 2, (s, 6, 3))
+    center = (clump[np.arange(s)[:, None], rng.integers(0, 6, (s, n))] +
+              rng.normal(0, 0.2, (s, n, 3))).astype(np.float32)
+    size = rng.uniform(0.3, 1.5, (s, n, 3)).astype(np.float32).astype(np.float64)
+    heading = rng.uniform(-3, 3, (s, n))
+    score = rng.uniform(0, 1, (s, n)).astype(np.float32)
+    score[:, 100:104] = score[:, 99:100]
+    cls = rng.integers(0, 3, (s, n)).astype(np.int64)
+    for same in (True, False):
+        got = nms.nms3d_aabb_gpu(dev(center), t64(size), t64(heading), dev(score),
+                                 torch.from_numpy(cls).cuda(), 0.25, False, same).cpu().numpy()
+        for i in range(s):
+            aabb = oracle.camera_aabb(center[i], size[i], heading[i])
+            want = oracle.nms3d_aabb(aabb, score[i], cls[i], 0.25, False, same)
+            np.testing.assert_array_equal(got[i].astype(np.int32), want)
