@@ -196,6 +196,8 @@ class SupervisedStep(object):
 
     def _host_info(self, src):
         """Host-side facts about the batch layout that the captured graphs bake in."""
+        if "supervised_mask" not in src:  # a plain labeled batch
+            return {"all_supervised": True}
         sup = torch.nonzero(src["supervised_mask"]).squeeze(1).long()
         self._supervised_inds = sup  # (kept on self: a graph input must outlive the capture)
         return {"supervised_inds": sup,
