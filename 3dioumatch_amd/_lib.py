@@ -64,6 +64,8 @@ _SIGNATURES = {
     "iou3d_boxes_iou_bev": [_c_int, _vp, _c_int, _vp, _vp, _vp],
     "iou3d_boxes_iou3d": [_c_int, _vp, _c_int, _vp, _vp, _vp],
     "iou3d_scene_best_iou3d": [_c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp],
+    "iou3d_corners_iou3d": [_c_int, _vp, _c_int, _vp, _vp, _vp],
+    "iou3d_corners_best_match": [_c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "iou3d_nms_mask": [_vp, _vp, _c_int, _c_float, _vp],
     "iou3d_nms_normal_mask": [_vp, _vp, _c_int, _c_float, _vp],
     "iou3d_nms": [_vp, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp],

@@ -9,3 +9,5 @@ from .losses import get_labeled_loss  # noqa: F401
 from .data import make_batch, make_semi_batch  # noqa: F401
 from .step import (SemiSupervisedStep, SupervisedStep, update_ema_variables, lr_at,  # noqa: F401
                    bn_momentum_at)
+from .eval_helper import APCalculator, parse_groundtruths, parse_predictions  # noqa: F401
+from .eval_det import eval_det, eval_det_cls, voc_ap  # noqa: F401

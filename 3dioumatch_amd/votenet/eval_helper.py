@@ -8,6 +8,10 @@ utils/box_util.py:335-358) and runs utils/nms.py per scene in numpy; here the de
 batched float64 tensor ops, the NMS one kernel launch (votenet/pseudo_nms.py:nms3d_aabb_gpu) and
 only the final, small Python lists are built on the host.
 
+parse_groundtruths (:224-307) and APCalculator (:382-435) complete the evaluation loop of
+train.py:evaluate_one_epoch; the average precision itself is votenet/eval_det.py (oriented-box IoU
+on the device).
+
 Not mirrored (raise NotImplementedError): `remove_empty_box` (off in the reference's configs) and
 the 2-D NMS branch.
 """
@@ -99,3 +103,64 @@ def parse_predictions(end_points, config_dict):
         batch.append(cur)
     end_points['batch_pred_map_cls'] = batch
     return batch
+
+
+@torch.no_grad()
+def parse_groundtruths(end_points, config_dict):
+    """-> batch_gt_map_cls: per scene a list of (class, corners (8,3) float32 ndarray) of the boxes
+    with box_label_mask == 1 (ap_helper.py:224-307: groundtruths2corners3d + parse_groundtruths);
+    the corners of all B x MAX_NUM_OBJ labels are decoded in one batched float64 pass."""
+    config = config_dict['dataset_config']
+    center = end_points['center_label'][:, :, 0:3].float()
+    size64 = config.mean_size(center.device).double()[end_points['size_class_label'].long()] + \
+        end_points['size_residual_label'].double()
+    heading64 = config.class2angle_f64(end_points['heading_class_label'].long(),
+                                       end_points['heading_residual_label'].float())
+    corners = corners_upright_camera(center, size64, heading64).cpu().numpy()
+    mask = (end_points['box_label_mask'] == 1).cpu().numpy()
+    sem = end_points['sem_cls_label'].cpu().numpy()
+    batch = [[(int(sem[i, j]), corners[i, j]) for j in np.nonzero(mask[i])[0]]
+             for i in range(mask.shape[0])]
+    end_points['batch_gt_map_cls'] = batch
+    return batch
+
+
+class APCalculator(object):
+    """ap_helper.py:382-435: accumulates per-scan predictions / ground truths, then one
+    eval_det (votenet/eval_det.py) per compute_metrics with the oriented-box IoU."""
+
+    def __init__(self, ap_iou_thresh=0.25, class2type_map=None, device=None):
+        self.ap_iou_thresh = ap_iou_thresh
+        self.class2type_map = class2type_map
+        self.device = device
+        self.reset()
+
+    def step(self, batch_pred_map_cls, batch_gt_map_cls):
+        bsize = len(batch_pred_map_cls)
+        assert bsize == len(batch_gt_map_cls)
+        for i in range(bsize):
+            self.gt_map_cls[self.scan_cnt] = batch_gt_map_cls[i]
+            self.pred_map_cls[self.scan_cnt] = batch_pred_map_cls[i]
+            self.scan_cnt += 1
+
+    def compute_metrics(self):
+        from .eval_det import eval_det
+        rec, prec, ap = eval_det(self.pred_map_cls, self.gt_map_cls, ovthresh=self.ap_iou_thresh,
+                                 device=self.device)
+        name = lambda key: self.class2type_map[key] if self.class2type_map else str(key)  # noqa: E731
+        ret_dict = {}
+        for key in sorted(ap.keys()):
+            ret_dict['%s Average Precision' % name(key)] = ap[key]
+        ret_dict['mAP'] = np.mean(list(ap.values()))
+        rec_list = []
+        for key in sorted(ap.keys()):
+            last = rec[key][-1] if np.ndim(rec[key]) and len(rec[key]) else 0
+            ret_dict['%s Recall' % name(key)] = last
+            rec_list.append(last)
+        ret_dict['AR'] = np.mean(rec_list)
+        return ret_dict
+
+    def reset(self):
+        self.gt_map_cls = {}    # {scan_id: [(classname, bbox)]}
+        self.pred_map_cls = {}  # {scan_id: [(classname, bbox, score)]}
+        self.scan_cnt = 0

@@ -66,6 +66,23 @@ int iou3d_boxes_iou3d(int num_a, const float *boxes_a, int num_b, const float *b
 int iou3d_scene_best_iou3d(int scenes, int num_a, const float *boxes_a, int num_b,
                            const float *boxes_b, float *best_iou, int *best_idx, void *stream);
 
+/* ---- evaluation path ---- */
+
+/* replaces get_iou_obb = box3d_iou(...)[0] (utils/eval_det.py:74-77, utils/box_util.py:112-137)
+ * for all pairs: a (n,8,3), b (m,8,3) float32 corners in the upright camera frame (vertex order
+ * of get_3d_box, utils/box_util.py:335-358) -> iou (n,m) float64.  Footprint clipping follows
+ * polygon_clip (box_util.py:23-69) in float64 source order; the clipped polygon's area is its
+ * shoelace sum (the reference asks scipy's ConvexHull, box_util.py:77-88; equal to rounding), 0
+ * for fewer than 3 vertices (the reference raises QhullError there). */
+int iou3d_corners_iou3d(int n, const float *a, int m, const float *b, double *iou, void *stream);
+
+/* replaces the per-detection loop of eval_det_cls (utils/eval_det.py:128-141): for detection d
+ * the ground-truth boxes gt[gt_begin[d] .. gt_begin[d]+gt_count[d]) (its scan, its class) ->
+ * ovmax[d] f64 = largest IoU, jmax[d] i32 = first box reaching it (strict `>` update); -inf / -1
+ * when gt_count[d] == 0.  det (nd,8,3), gt (ng,8,3) float32 corners. */
+int iou3d_corners_best_match(int nd, const float *det, const int *gt_begin, const int *gt_count,
+                             const float *gt, double *ovmax, int *jmax, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

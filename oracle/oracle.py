@@ -233,6 +233,30 @@ class Oracle:
                                   out.ctypes.data_as(_i32p))
         return out
 
+    # ---- AP evaluation (utils/box_util.py:112-137, utils/eval_det.py:128-141) ---------------
+    def box3d_iou_matrix(self, a, b):
+        """a (n,8,3), b (m,8,3) float32 corners -> (n,m) float64 box3d_iou(a[i], b[j])[0]."""
+        a, ap = _f(a)
+        b, bp = _f(b)
+        n, m = a.shape[0], b.shape[0]
+        out = np.zeros((n, m), np.float64)
+        self.lib.evo_iou_matrix(n, ap, m, bp, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        return out
+
+    def best_match(self, det, gt_begin, gt_count, gt):
+        """-> (ovmax (nd,) f64, jmax (nd,) i32) of the per-detection loop of eval_det_cls."""
+        det, dp = _f(det)
+        gt, gp = _f(gt if len(gt) else np.zeros((1, 8, 3), np.float32))
+        gt_begin = np.ascontiguousarray(gt_begin, np.int32)
+        gt_count = np.ascontiguousarray(gt_count, np.int32)
+        nd = det.shape[0]
+        ov = np.zeros(nd, np.float64)
+        jm = np.zeros(nd, np.int32)
+        self.lib.evo_best_match(nd, dp, gt_begin.ctypes.data_as(_i32p), gt_count.ctypes.data_as(_i32p),
+                                gp, ov.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                jm.ctypes.data_as(_i32p))
+        return ov, jm
+
 
 class Reference:
     """The reference's own compiled CPU code (oracle/_ref). Raises if it was not built."""
