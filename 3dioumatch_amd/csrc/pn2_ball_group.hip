@@ -74,6 +74,61 @@ group_points_kernel(int c, int n, int mns, const float *__restrict__ points,
   }
 }
 
+// LDS-staged gather.  A 4-byte gather whose 64 lanes fall in 64 different cache lines costs the
+// CU's address unit ~64 cycles, and a ball's indices are scattered over the whole cloud: the
+// kernel above is bound by that (5 us per channel at N = 40000, 2048 x 64 indices, for 8.4 MB of
+// traffic).  Here workgroup (slice, channel, cloud) first copies its channel row -- at most LDSF
+// floats; 40960 = the CU's whole 160 KB LDS -- with coalesced 16-byte loads (an L2 hit on the
+// cloud's XCD), then serves its slice of the index array from LDS, where a scattered 64-lane
+// read is a handful of bank-conflict cycles.
+template <int LDSF, bool VEC>
+__global__ void __launch_bounds__(1024)
+group_points_lds_kernel(int c, int n, int mns, const float *__restrict__ points,
+                        const int *__restrict__ idx, float *__restrict__ out) {
+  __shared__ float row[LDSF];
+  const BlockId blk = xcd_block_id();
+  const int b = blk.z, l = blk.y;
+  const float *src = points + ((size_t)b * c + l) * n;
+  if ((n & 3) == 0 && n > 0) {
+    // all of a lane's 16-byte loads are issued before the first LDS write (one L2 round trip
+    // for the whole row instead of one per 16 KB)
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    float4 *r4 = reinterpret_cast<float4 *>(row);
+    constexpr int kIter = LDSF / 4096;
+    float4 v[kIter];
+    const int n4 = n / 4;  // >= 1 here
+#pragma unroll
+    for (int u = 0; u < kIter; ++u) {  // unconditional (clamped) so that the loads stay batched
+      const int t = threadIdx.x + u * 1024;
+      v[u] = s4[t < n4 ? t : n4 - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < kIter; ++u)  // keeps the compiler from sinking each load to its write
+      asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+#pragma unroll
+    for (int u = 0; u < kIter; ++u)
+      if (threadIdx.x + u * 1024 < n4) r4[threadIdx.x + u * 1024] = v[u];
+  } else {
+    for (int t = threadIdx.x; t < n; t += 1024) row[t] = src[t];
+  }
+  __syncthreads();
+  const int chunks = (mns + 3) / 4;
+  const int per = (chunks + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int q1 = (blk.x + 1) * per < chunks ? (blk.x + 1) * per : chunks;
+  const int *ib = idx + (size_t)b * mns;
+  float *dst = out + ((size_t)b * c + l) * mns;
+  for (int q = blk.x * per + threadIdx.x; q < q1; q += 1024) {
+    if (VEC) {
+      const int4 v = reinterpret_cast<const int4 *>(ib)[q];
+      float4 o;
+      o.x = row[v.x]; o.y = row[v.y]; o.z = row[v.z]; o.w = row[v.w];
+      reinterpret_cast<float4 *>(dst)[q] = o;
+    } else {
+      for (int e = q * 4; e < q * 4 + 4 && e < mns; ++e) dst[e] = row[ib[e]];
+    }
+  }
+}
+
 // grad_points[b,l,idx[b,e]] += grad_out[b,l,e]   (group_points_gpu.cu:48-69)
 template <bool VEC>
 __global__ void __launch_bounds__(256)
@@ -234,6 +289,9 @@ group_concat_kernel(int c, int n, int m, int ns, float inv_radius, int normalize
   }
 }
 
+constexpr int kGroupLdsFloats = 40960;  // 160 KB, all of a CU's LDS: one channel of N <= 40960
+constexpr int kGroupLdsSmall = 16384;   // 64 KB variant: two workgroups per CU
+
 int channel_groups(int c, int per_thread) {
   int g = (c + per_thread - 1) / per_thread;
   if (g < 1) g = 1;
@@ -291,17 +349,42 @@ PN2_API int pn2_ball_query(int b, int n, int m, float radius, int nsample, const
   return pn2_launch_status();
 }
 
+template <int LDSF>
+static void launch_group_lds(dim3 grid, int c, int n, long long mns, const float *points,
+                             const int *idx, float *out, hipStream_t stream) {
+  if (mns % 4 == 0)
+    hipLaunchKernelGGL((group_points_lds_kernel<LDSF, true>), grid, dim3(1024), 0, stream, c, n,
+                       (int)mns, points, idx, out);
+  else
+    hipLaunchKernelGGL((group_points_lds_kernel<LDSF, false>), grid, dim3(1024), 0, stream, c, n,
+                       (int)mns, points, idx, out);
+}
+
 PN2_API int pn2_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
                              const int *idx, float *out, void *stream_) {
   const long long mns = (long long)npoints * nsample;
   if (b <= 0 || c <= 0 || mns <= 0) return 0;
-  (void)n;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n <= kGroupLdsFloats && mns >= 4096 && c <= 65535) {
+    // one resident round: slices so that (slices x channels x clouds) ~ the CU count, but at
+    // least 1024 four-index chunks per workgroup
+    const long long rows = (long long)b * c;
+    long long slices = rows >= 256 ? 1 : 256 / rows;
+    const long long max_slices = (mns / 4 + 1023) / 1024;
+    if (slices > max_slices) slices = max_slices;
+    const dim3 grid((unsigned)slices, c, b);
+    if (n <= kGroupLdsSmall)
+      launch_group_lds<kGroupLdsSmall>(grid, c, n, mns, points, idx, out, stream);
+    else
+      launch_group_lds<kGroupLdsFloats>(grid, c, n, mns, points, idx, out, stream);
+    return pn2_launch_status();
+  }
   dim3 grid(pn2_ceil_div(mns, 1024), channel_groups(c, 8), b);
   if (mns % 4 == 0)
-    hipLaunchKernelGGL(group_points_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream_, c, n,
+    hipLaunchKernelGGL(group_points_kernel<true>, grid, dim3(256), 0, stream, c, n,
                        (int)mns, points, idx, out);
   else
-    hipLaunchKernelGGL(group_points_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream_, c,
+    hipLaunchKernelGGL(group_points_kernel<false>, grid, dim3(256), 0, stream, c,
                        n, (int)mns, points, idx, out);
   return pn2_launch_status();
 }

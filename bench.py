@@ -270,9 +270,9 @@ def main():
             table, pair_us = kernel_table(device)
             achieved = PAIR_BYTES / (pair_us * 1e-6) / 1e9
             # HBM bytes per pair from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-            # WRITE_SIZE in separate runs, gfx950 correction applied; profiles/r1_pair_pmc_v2.json)
+            # WRITE_SIZE in separate runs, gfx950 correction applied; profiles/r1_pair_pmc_v3.json)
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r1_pair_pmc_v2.json")
+            pmc = os.path.join(ROOT, "profiles", "r1_pair_pmc_v3.json")
             if os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get("traffic_bytes_per_pair")
             out["roofline"] = {

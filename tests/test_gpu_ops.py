@@ -119,7 +119,11 @@ def test_ballquery_vs_oracle(ext, oracle, synth, b, n, m, r, ns):
 
 
 @pytest.mark.parametrize("c,n,m,ns", [(1, 500, 33, 7), (3, 4096, 512, 32), (37, 700, 64, 16),
-                                      (128, 2048, 256, 32)])
+                                      (128, 2048, 256, 32),
+                                      # LDS-staged tier: 64 KB and 160 KB rows, ragged n / m*ns,
+                                      # the largest row that fits and the first that does not
+                                      (3, 40000, 128, 64), (2, 40960, 100, 41), (1, 30001, 99, 43),
+                                      (5, 16385, 64, 64), (2, 40961, 128, 32), (200, 1024, 128, 32)])
 def test_group_vs_oracle(ext, oracle, c, n, m, ns):
     g = np.random.default_rng(c + n)
     pts = g.standard_normal((2, c, n)).astype(np.float32)
