@@ -7,59 +7,11 @@ compute_objectness_loss :77-123, compute_box_and_sem_cls_loss :126-297, get_labe
 Device-agnostic.  The IoU labels come from the gfx950 kernel behind
 pcdet.ops.iou3d_nms.iou3d_nms_utils.boxes_iou3d_gpu.
 """
-import contextlib
-import os
-
 import numpy as np
 import torch
 import torch.nn.functional as F
 
 from pcdet.ops.iou3d_nms.iou3d_nms_utils import boxes_iou3d_gpu, boxes_iou3d_scene_max_gpu
-
-class _Branches(object):
-    """Independent loss terms on forked streams -- only while a HIP graph is being captured.
-
-    The loss is ~250 tiny kernels (plus as many in the backward) forming a wide DAG: vote loss,
-    objectness, centre, heading, size, class and the two IoU terms barely depend on each other.
-    Captured on one stream they replay strictly one after the other and each costs a dispatch
-    latency; forked over a few streams (fork = wait on the capturing stream, join = the capturing
-    stream waits back) the graph keeps several chains in flight.  autograd runs every backward
-    node on the stream of its forward op, so the backward is forked the same way.  Outside a
-    capture this is a no-op: eager execution keeps a single stream.
-
-    MEASURED (ROCm 7.2, MI355X): correct (graph replay == eager) but the step got SLOWER, 13.1 ->
-    17.9 ms -- every fork/join edge of a multi-stream HIP graph costs far more than the dispatch
-    latency it hides.  Hence off unless VOTENET_FORK_LOSS=1; kept as the record of the experiment
-    and because the branch structure is what a fused loss kernel would follow."""
-
-    _streams = {}
-
-    def __init__(self, like, count):
-        self.on = bool(like.is_cuda and os.environ.get("VOTENET_FORK_LOSS", "0") == "1"
-                       and torch.cuda.is_current_stream_capturing())
-        self.used = []
-        if self.on:
-            self.main = torch.cuda.current_stream(like.device)
-            pool = self._streams.setdefault(like.device, [])
-            while len(pool) < count:
-                pool.append(torch.cuda.Stream(device=like.device))
-            self.pool = pool
-
-    @contextlib.contextmanager
-    def branch(self, i):
-        if not self.on:
-            yield
-            return
-        stream = self.pool[i]
-        stream.wait_stream(self.main)
-        self.used.append(stream)
-        with torch.cuda.stream(stream):
-            yield
-
-    def join(self):
-        for stream in self.used:
-            self.main.wait_stream(stream)
-        self.used = []
 
 
 FAR_THRESHOLD = 0.6
@@ -249,80 +201,77 @@ def compute_box_and_sem_cls_loss(end_points, supervised_inds, dataset_config, co
     assign = end_points['object_assignment']
     obj = end_points['objectness_label'].float()
     sup = supervised_inds
-    fork = _Branches(assign, 6)
     terms = {}  # per-proposal (B,K) quantities averaged over the positive proposals
 
     def pick(key):
         return torch.gather(_sel(end_points[key], sup), 1, assign)
 
-    with fork.branch(0):  # centre: chamfer between predicted centres and GT centres
-        terms['center1'], _, dist2, _ = nn_distance(
-            _sel(end_points['center'], sup), _sel(end_points['center_label'], sup)[:, :, 0:3])
-        center_back = _masked_mean(dist2, _sel(end_points['box_label_mask'], sup))
+    # centre: chamfer between predicted centres and GT centres
+    terms['center1'], _, dist2, _ = nn_distance(
+        _sel(end_points['center'], sup), _sel(end_points['center_label'], sup)[:, :, 0:3])
+    center_back = _masked_mean(dist2, _sel(end_points['box_label_mask'], sup))
 
-    with fork.branch(1):  # heading: class + residual of the assigned GT
-        h_cls_label = pick('heading_class_label')
-        terms['heading_cls'] = F.cross_entropy(
-            _sel(end_points['heading_scores'], sup).transpose(2, 1), h_cls_label, reduction='none')
-        h_res_label = pick('heading_residual_label') / (np.pi / nh)
-        h_res_pred = _select(_sel(end_points['heading_residuals_normalized'], sup), h_cls_label)
-        terms['heading_reg'] = huber_loss(h_res_pred, delta=1.0, target=h_res_label)
+    # heading: class + residual of the assigned GT
+    h_cls_label = pick('heading_class_label')
+    terms['heading_cls'] = F.cross_entropy(
+        _sel(end_points['heading_scores'], sup).transpose(2, 1), h_cls_label, reduction='none')
+    h_res_label = pick('heading_residual_label') / (np.pi / nh)
+    h_res_pred = _select(_sel(end_points['heading_residuals_normalized'], sup), h_cls_label)
+    terms['heading_reg'] = huber_loss(h_res_pred, delta=1.0, target=h_res_label)
 
-    with fork.branch(2):  # size: class + normalised residual
-        s_cls_label = pick('size_class_label')
-        terms['size_cls'] = F.cross_entropy(
-            _sel(end_points['size_scores'], sup).transpose(2, 1), s_cls_label, reduction='none')
-        s_res_label = torch.gather(_sel(end_points['size_residual_label'], sup), 1,
-                                   assign.unsqueeze(-1).expand(-1, -1, 3))
-        s_res_pred = _select(_sel(end_points['size_residuals_normalized'], sup), s_cls_label)
-        mean_size_label = dataset_config.mean_size(s_res_pred.device)[s_cls_label]
-        terms['size_reg'] = torch.mean(
-            huber_loss(s_res_pred, delta=1.0, target=s_res_label / mean_size_label), -1)
+    # size: class + normalised residual
+    s_cls_label = pick('size_class_label')
+    terms['size_cls'] = F.cross_entropy(
+        _sel(end_points['size_scores'], sup).transpose(2, 1), s_cls_label, reduction='none')
+    s_res_label = torch.gather(_sel(end_points['size_residual_label'], sup), 1,
+                               assign.unsqueeze(-1).expand(-1, -1, 3))
+    s_res_pred = _select(_sel(end_points['size_residuals_normalized'], sup), s_cls_label)
+    mean_size_label = dataset_config.mean_size(s_res_pred.device)[s_cls_label]
+    terms['size_reg'] = torch.mean(
+        huber_loss(s_res_pred, delta=1.0, target=s_res_label / mean_size_label), -1)
 
-    with fork.branch(3):  # semantic class
-        sem_label = pick('sem_cls_label')
-        sem_scores = _sel(end_points['sem_cls_scores'], sup)
-        terms['sem_cls'] = F.cross_entropy(sem_scores.transpose(2, 1), sem_label, reduction='none')
-        terms['cls_acc'] = (sem_label == sem_scores.argmax(dim=-1)).float()
+    # semantic class
+    sem_label = pick('sem_cls_label')
+    sem_scores = _sel(end_points['sem_cls_scores'], sup)
+    terms['sem_cls'] = F.cross_entropy(sem_scores.transpose(2, 1), sem_label, reduction='none')
+    terms['cls_acc'] = (sem_label == sem_scores.argmax(dim=-1)).float()
 
     gt_bbox = _gt_boxes(end_points, sup, dataset_config)  # shared by the two IoU terms
-    with fork.branch(4):  # IoU labels of the decoded predictions, IoU-estimation loss
-        iou_labels, _, iou_assignment = compute_iou_labels(
-            end_points, sup, _sel(end_points['aggregated_vote_xyz'], sup),
-            _sel(end_points['center'], sup), None, None, _sel(end_points['heading_scores'], sup),
-            _sel(end_points['heading_residuals'], sup), _sel(end_points['size_scores'], sup),
-            _sel(end_points['size_residuals'], sup), config_dict={'dataset_config': dataset_config},
-            with_objectness=False, gt_bbox=gt_bbox)
-        end_points['pred_iou_value'] = iou_labels.mean()
-        terms['pred_iou_obj'] = iou_labels
-        if 'iou_scores' in end_points:
-            iou_pred = torch.sigmoid(_sel(end_points['iou_scores'], sup))
-            if iou_pred.shape[2] > 1:
-                iou_sem = torch.gather(_sel(end_points['sem_cls_label'], sup), 1, iou_assignment)
-                iou_pred = torch.gather(iou_pred, 2, iou_sem.unsqueeze(-1)).squeeze(-1)
-            else:
-                iou_pred = iou_pred.squeeze(-1)
-            iou_acc = torch.abs(iou_pred - iou_labels)
-            end_points['iou_acc'] = iou_acc.mean()
-            terms['iou_acc_obj'] = iou_acc
-            end_points['iou_loss'] = huber_loss(iou_pred, delta=1.0, target=iou_labels).mean()
+    # IoU labels of the decoded predictions, IoU-estimation loss
+    iou_labels, _, iou_assignment = compute_iou_labels(
+        end_points, sup, _sel(end_points['aggregated_vote_xyz'], sup),
+        _sel(end_points['center'], sup), None, None, _sel(end_points['heading_scores'], sup),
+        _sel(end_points['heading_residuals'], sup), _sel(end_points['size_scores'], sup),
+        _sel(end_points['size_residuals'], sup), config_dict={'dataset_config': dataset_config},
+        with_objectness=False, gt_bbox=gt_bbox)
+    end_points['pred_iou_value'] = iou_labels.mean()
+    terms['pred_iou_obj'] = iou_labels
+    if 'iou_scores' in end_points:
+        iou_pred = torch.sigmoid(_sel(end_points['iou_scores'], sup))
+        if iou_pred.shape[2] > 1:
+            iou_sem = torch.gather(_sel(end_points['sem_cls_label'], sup), 1, iou_assignment)
+            iou_pred = torch.gather(iou_pred, 2, iou_sem.unsqueeze(-1)).squeeze(-1)
+        else:
+            iou_pred = iou_pred.squeeze(-1)
+        iou_acc = torch.abs(iou_pred - iou_labels)
+        end_points['iou_acc'] = iou_acc.mean()
+        terms['iou_acc_obj'] = iou_acc
+        end_points['iou_loss'] = huber_loss(iou_pred, delta=1.0, target=iou_labels).mean()
 
-    with fork.branch(5):
-        if 'jitter_center' in end_points:
-            pred_bbox = torch.cat([_sel(end_points['jitter_center'], sup),
-                                   _sel(end_points['jitter_size'], sup),
-                                   -_sel(end_points['jitter_heading'], sup)[:, :, None]], dim=2)
-            jitter_iou_labels, jitter_assign = _scene_best_iou(pred_bbox, gt_bbox)
-            jitter_sem = torch.gather(_sel(end_points['sem_cls_label'], sup), 1, jitter_assign)
-            jitter_pred = torch.sigmoid(_sel(end_points['iou_scores_jitter'], sup))
-            jitter_pred = torch.gather(jitter_pred, 2, jitter_sem.unsqueeze(-1)).squeeze(-1) \
-                if jitter_pred.shape[2] > 1 else jitter_pred.squeeze(-1)
-            jitter_acc = torch.abs(jitter_pred - jitter_iou_labels)
-            end_points['jitter_iou_acc'] = jitter_acc.mean()
-            end_points['jitter_iou_acc_obj'] = jitter_acc.sum() / (jitter_acc.numel() + 1e-6)
-            end_points['jitter_iou_loss'] = huber_loss(
-                jitter_pred, delta=1.0, target=jitter_iou_labels).sum() / (jitter_acc.numel() + 1e-6)
-    fork.join()
+    if 'jitter_center' in end_points:
+        pred_bbox = torch.cat([_sel(end_points['jitter_center'], sup),
+                               _sel(end_points['jitter_size'], sup),
+                               -_sel(end_points['jitter_heading'], sup)[:, :, None]], dim=2)
+        jitter_iou_labels, jitter_assign = _scene_best_iou(pred_bbox, gt_bbox)
+        jitter_sem = torch.gather(_sel(end_points['sem_cls_label'], sup), 1, jitter_assign)
+        jitter_pred = torch.sigmoid(_sel(end_points['iou_scores_jitter'], sup))
+        jitter_pred = torch.gather(jitter_pred, 2, jitter_sem.unsqueeze(-1)).squeeze(-1) \
+            if jitter_pred.shape[2] > 1 else jitter_pred.squeeze(-1)
+        jitter_acc = torch.abs(jitter_pred - jitter_iou_labels)
+        end_points['jitter_iou_acc'] = jitter_acc.mean()
+        end_points['jitter_iou_acc_obj'] = jitter_acc.sum() / (jitter_acc.numel() + 1e-6)
+        end_points['jitter_iou_loss'] = huber_loss(
+            jitter_pred, delta=1.0, target=jitter_iou_labels).sum() / (jitter_acc.numel() + 1e-6)
 
     # sum(term * obj) / (sum(obj) + 1e-6) for every term, in one reduction
     names = list(terms)
@@ -350,13 +299,9 @@ def get_labeled_loss(end_points, dataset_config, config_dict=None):
         if supervised_inds is None:
             supervised_inds = torch.nonzero(end_points['supervised_mask']).squeeze(1).long()
 
-    fork = _Branches(end_points['objectness_scores'], 2)
-    with fork.branch(0):
-        end_points['vote_loss'] = compute_vote_loss(end_points, supervised_inds)
-    with fork.branch(1):
-        objectness_loss, objectness_label, objectness_mask, object_assignment = \
-            compute_objectness_loss(end_points, supervised_inds)
-    fork.join()
+    end_points['vote_loss'] = compute_vote_loss(end_points, supervised_inds)
+    objectness_loss, objectness_label, objectness_mask, object_assignment = \
+        compute_objectness_loss(end_points, supervised_inds)
     end_points['objectness_loss'] = objectness_loss
     end_points['objectness_label'] = objectness_label
     end_points['objectness_mask'] = objectness_mask
