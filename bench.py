@@ -286,6 +286,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(V, cfg)
         print(json.dumps(out), flush=True)
     if world > 1:
+        torch.distributed.barrier()  # rank 0 is still timing the per-operator table
         torch.distributed.destroy_process_group()
 
 
