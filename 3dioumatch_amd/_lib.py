@@ -1,5 +1,4 @@
-"""ctypes binding of lib3dioumatch_hip.so (the C ABI declared in include/pn2_hip.h and
-include/iou3d_hip.h).  PyTorch is used by the callers for device memory and streams only.
+"""ctypes binding of lib3dioumatch_hip.so (the C ABI declared in include/*.h).  PyTorch is used by the callers for device memory and streams only.
 
 There is NO CPU fallback: if the shared library is missing this module raises ImportError,
 and every device entry point raises RuntimeError for non-GPU tensors.
@@ -64,6 +63,9 @@ _SIGNATURES = {
     "iou3d_boxes_iou_bev": [_c_int, _vp, _c_int, _vp, _vp, _vp],
     "iou3d_boxes_iou3d": [_c_int, _vp, _c_int, _vp, _vp, _vp],
     "iou3d_scene_best_iou3d": [_c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp],
+    "votenet_loss_decode": [_vp, _vp],
+    "votenet_loss_forward_backward": [_vp, _vp],
+    "votenet_loss_scratch_floats": [_vp],
     "iou3d_corners_iou3d": [_c_int, _vp, _c_int, _vp, _vp, _vp],
     "iou3d_corners_best_match": [_c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "iou3d_nms_mask": [_vp, _vp, _c_int, _c_float, _vp],

@@ -1,0 +1,422 @@
+// 3dioumatch_amd/csrc/loss_core.h -- the supervised VoteNet-IoU loss and its gradient, per work
+// item (proposal / ground-truth slot / seed), as plain functions.
+//
+// What it replaces: models/loss_helper_labeled.py (compute_vote_loss :28-74,
+// compute_objectness_loss :77-123, compute_box_and_sem_cls_loss :126-297, get_labeled_loss
+// :300-370) with utils/nn_distance.py (huber_loss :16-33, nn_distance :35-62) and the box decoding
+// of models/loss_helper_iou.py:compute_iou_labels :52-112 -- about 150 small tensor kernels in the
+// forward and as many in the backward of every train step.  Here the whole loss is two launches
+// (csrc/votenet_loss.hip) around the per-scene IoU kernel, and the gradient with respect to every
+// head output is produced in the same pass (every term is a closed-form function of one proposal
+// and its assigned ground-truth box; only the normalisers are global sums).
+//
+// The functions are LOSS_HD (__host__ __device__ under hipcc, plain inline under a host
+// compiler): the kernel calls them from strided loops with block reductions in between, and
+// tests/loss_host.cpp calls the very same functions from plain loops so that the arithmetic and
+// the indexing are checked against autograd on a machine without a GPU.
+#pragma once
+#include <math.h>
+
+#ifndef LOSS_HD
+#define LOSS_HD inline
+#endif
+
+#include "../../include/loss_hip.h"
+
+typedef VnLossTensor LossTensor;
+typedef VnLossArgs LossArgs;
+
+LOSS_HD float lt_at(const LossTensor &t, int b, int k, int c, int d = 0) {
+  return t.p[b * t.sb + k * t.sk + c * t.sc + d * t.sd];
+}
+
+enum {  // partial sums of one pass over the proposals / GT slots / seeds
+  ACC_MASK, ACC_CE_MASK, ACC_POS, ACC_OBJACC, ACC_CENTER1, ACC_HCLS, ACC_HREG, ACC_SCLS, ACC_SREG,
+  ACC_SEM, ACC_CLSACC, ACC_IOULAB, ACC_IOULAB_OBJ, ACC_IOUACC, ACC_IOUACC_OBJ, ACC_IOUHUB,
+  ACC_JITACC, ACC_JITHUB, ACC_BLM, ACC_DIST2, ACC_VMASK, ACC_VDIST, ACC_COUNT
+};
+
+enum {
+  ST_LOSS = VN_ST_LOSS, ST_VOTE = VN_ST_VOTE, ST_OBJ = VN_ST_OBJ, ST_CENTER = VN_ST_CENTER,
+  ST_HCLS = VN_ST_HCLS, ST_HREG = VN_ST_HREG, ST_SCLS = VN_ST_SCLS, ST_SREG = VN_ST_SREG,
+  ST_SEM = VN_ST_SEM, ST_BOX = VN_ST_BOX, ST_IOU = VN_ST_IOU, ST_JIT = VN_ST_JIT,
+  ST_POS_RATIO = VN_ST_POS_RATIO, ST_NEG_RATIO = VN_ST_NEG_RATIO, ST_OBJ_ACC = VN_ST_OBJ_ACC,
+  ST_OBJ_COUNT = VN_ST_OBJ_COUNT, ST_CLS_ACC = VN_ST_CLS_ACC, ST_PRED_IOU = VN_ST_PRED_IOU,
+  ST_PRED_IOU_OBJ = VN_ST_PRED_IOU_OBJ, ST_IOU_ACC = VN_ST_IOU_ACC,
+  ST_IOU_ACC_OBJ = VN_ST_IOU_ACC_OBJ, ST_JIT_ACC = VN_ST_JIT_ACC,
+  ST_JIT_ACC_OBJ = VN_ST_JIT_ACC_OBJ, ST_COUNT = VN_ST_COUNT
+};
+
+// launch geometry shared by the kernels, the binding and the host harness: per scene
+// ceil(K/256) proposal workgroups, one GT workgroup, ceil(S/256) seed workgroups, each leaving one
+// row of ACC_COUNT partial sums in LossArgs.partials
+constexpr int kLossBlock = 256;
+LOSS_HD int loss_blocks_per_scene(int k, int s) {
+  return (k + kLossBlock - 1) / kLossBlock + 1 + (s + kLossBlock - 1) / kLossBlock;
+}
+
+constexpr float kLossWeight = 10.0f;   // get_labeled_loss: loss *= 10
+constexpr float kNear = 0.3f, kFar = 0.6f;
+
+LOSS_HD float huber1(float x) {  // delta = 1 (utils/nn_distance.py:16-33)
+  const float a = fabsf(x);
+  return a <= 1.0f ? 0.5f * x * x : a - 0.5f;
+}
+LOSS_HD float huber1_grad(float x) { return x > 1.0f ? 1.0f : (x < -1.0f ? -1.0f : x); }
+
+// One row of class scores.  Up to kRowMax classes are fetched with a fully unrolled, predicated
+// loop -- all loads in flight at once, the row then lives in registers for the max / sum / gradient
+// passes (a runtime-bound loop would pay one load latency per class and per pass).
+constexpr int kRowMax = 32;
+
+struct ScoreRow {
+  float v[kRowMax];
+};
+
+LOSS_HD void load_row(const LossTensor &t, int b, int k, int n, ScoreRow &r) {
+#pragma unroll
+  for (int j = 0; j < kRowMax; ++j) r.v[j] = j < n ? lt_at(t, b, k, j) : -INFINITY;
+}
+
+LOSS_HD float row_log_sum_exp(const ScoreRow &r) {
+  float m = r.v[0];
+#pragma unroll
+  for (int j = 1; j < kRowMax; ++j) m = r.v[j] > m ? r.v[j] : m;
+  float s = 0.0f;
+#pragma unroll
+  for (int j = 0; j < kRowMax; ++j) s += expf(r.v[j] - m);  // exp(-inf) = 0 for the padding
+  return m + logf(s);
+}
+
+LOSS_HD float log_sum_exp(const LossTensor &t, int b, int k, int n) {
+  float m = lt_at(t, b, k, 0);
+  for (int j = 1; j < n; ++j) { const float v = lt_at(t, b, k, j); m = v > m ? v : m; }
+  float s = 0.0f;
+  for (int j = 0; j < n; ++j) s += expf(lt_at(t, b, k, j) - m);
+  return m + logf(s);
+}
+
+LOSS_HD int arg_max(const LossTensor &t, int b, int k, int n) {
+  int best = 0;
+  float m = lt_at(t, b, k, 0);
+  for (int j = 1; j < n; ++j) { const float v = lt_at(t, b, k, j); if (v > m) { m = v; best = j; } }
+  return best;
+}
+
+LOSS_HD int row_arg_max(const LossTensor &t, int b, int k, int n) {  // first maximum
+  if (n > kRowMax) return arg_max(t, b, k, n);
+  ScoreRow r;
+  load_row(t, b, k, n, r);
+  int best = 0;
+  float m = r.v[0];
+#pragma unroll
+  for (int j = 1; j < kRowMax; ++j)
+    if (r.v[j] > m) { m = r.v[j]; best = j; }
+  return best;
+}
+
+// cross entropy of row (b,k) against `label` (returned), scale * (softmax - onehot) -> g, and the
+// arg-max class through *top
+LOSS_HD float ce_and_grad(const LossTensor &t, int b, int k, int n, int label, float scale, float *g,
+                          int *top) {
+  if (n <= kRowMax) {
+    ScoreRow r;
+    load_row(t, b, k, n, r);
+    const float lse = row_log_sum_exp(r);
+    float at_label = 0.0f, m = r.v[0];
+    int best = 0;
+#pragma unroll
+    for (int j = 0; j < kRowMax; ++j) {
+      if (j < n) {
+        g[j] = scale * (expf(r.v[j] - lse) - (j == label ? 1.0f : 0.0f));
+        if (j == label) at_label = r.v[j];
+        if (r.v[j] > m) { m = r.v[j]; best = j; }
+      }
+    }
+    *top = best;
+    return lse - at_label;
+  }
+  const float lse = log_sum_exp(t, b, k, n);
+  for (int j = 0; j < n; ++j)
+    g[j] = scale * (expf(lt_at(t, b, k, j) - lse) - (j == label ? 1.0f : 0.0f));
+  *top = arg_max(t, b, k, n);
+  return lse - lt_at(t, b, k, label);
+}
+
+LOSS_HD float class2angle(int cls, float residual, int nh) {  // config.class2angle_gpu
+  if (nh == 1) return 0.0f;
+  const float per = (float)(2.0 * M_PI / (double)nh);
+  float angle = (float)cls * per + residual;
+  if (angle > (float)M_PI) angle = angle - (float)(2.0 * M_PI);
+  return angle;
+}
+
+// ---- launch 1: boxes for the IoU kernel ----------------------------------------------------------
+// decoded prediction k of scene b (loss_helper_iou.py:60-96): arg-max heading / size class, their
+// residuals, size clamped to > 0, heading sign flipped
+LOSS_HD void decode_prediction(const LossArgs &a, int b, int k) {
+  const int rows = a.has_jitter ? 2 * a.K : a.K;
+  float *o = a.boxes + ((long long)b * rows + k) * 7;
+  const int hc = row_arg_max(a.h_scores, b, k, a.NH);
+  const int sc = row_arg_max(a.s_scores, b, k, a.NS);
+  const float h_res = lt_at(a.h_resn, b, k, hc) * (float)(M_PI / (double)a.NH);
+  for (int d = 0; d < 3; ++d) {
+    o[d] = lt_at(a.center, b, k, d);
+    const float mean = a.mean_size[sc * 3 + d];
+    float s = mean + lt_at(a.s_resn, b, k, sc, d) * mean;
+    if (s <= 0.0f) s = 1e-6f;
+    o[3 + d] = s;
+  }
+  o[6] = -class2angle(hc, h_res, a.NH);
+  if (a.has_jitter) {
+    float *j = a.boxes + ((long long)b * rows + a.K + k) * 7;
+    for (int d = 0; d < 3; ++d) {
+      j[d] = lt_at(a.jit_center, b, k, d);
+      j[3 + d] = lt_at(a.jit_size, b, k, d);
+    }
+    j[6] = -lt_at(a.jit_heading, b, k, 0);
+  }
+}
+
+// ground-truth box g of scene b (losses._gt_boxes): empty slots are moved to -1000
+LOSS_HD void decode_ground_truth(const LossArgs &a, int b, int g) {
+  const long long i = (long long)b * a.G + g;
+  float *o = a.gt_boxes + i * 7;
+  const bool empty = a.box_label_mask[i] != 1.0f;
+  const int sc = (int)a.size_class_label[i];
+  for (int d = 0; d < 3; ++d) {
+    o[d] = empty ? -1000.0f : a.center_label[i * 3 + d];
+    o[3 + d] = a.mean_size[sc * 3 + d] + a.size_residual_label[i * 3 + d];
+  }
+  o[6] = -class2angle((int)a.heading_class_label[i], a.heading_residual_label[i], a.NH);
+}
+
+// ---- launch 2: the terms ---------------------------------------------------------------------------
+// What the inner loops of one scene read (LDS copies in the kernel, the tensors themselves on the
+// host): GT centres / mask, the predicted centres, and -- second launch -- the proposal nearest to
+// each GT centre.
+struct SceneView {
+  const float *gt_center;   // (G,3) raw centre labels of the scene
+  const float *gt_mask;     // (G)   box_label_mask
+  const float *center;      // (K,3) predicted centres of the scene, contiguous
+  const int *nearest;       // (G)   gt_nearest of the scene
+};
+
+// proposal k of scene b: labels, every per-proposal term (into acc) and its UNNORMALISED gradient:
+// the objectness gradient still lacks 1/(sum(mask)+eps), the positive-proposal terms 1/(count+eps)
+LOSS_HD void loss_proposal(const LossArgs &a, const SceneView &sv, int b, int k, float *acc) {
+  const long long bk = (long long)b * a.K + k;
+  // objectness labels from the distance of the aggregated vote to the nearest (non-empty) GT centre
+  const float vx = lt_at(a.agg_xyz, b, k, 0), vy = lt_at(a.agg_xyz, b, k, 1), vz = lt_at(a.agg_xyz, b, k, 2);
+  const float cx = lt_at(a.center, b, k, 0), cy = lt_at(a.center, b, k, 1), cz = lt_at(a.center, b, k, 2);
+  float best = 0.0f, best_c = 0.0f;
+  int assign = 0, near_c = 0;
+  for (int g = 0; g < a.G; ++g) {
+    const float gx = sv.gt_center[g * 3], gy = sv.gt_center[g * 3 + 1], gz = sv.gt_center[g * 3 + 2];
+    const bool empty = sv.gt_mask[g] != 1.0f;
+    const float mx = empty ? -1000.0f : gx, my = empty ? -1000.0f : gy, mz = empty ? -1000.0f : gz;
+    const float d = ((vx - mx) * (vx - mx) + (vy - my) * (vy - my)) + (vz - mz) * (vz - mz);
+    if (g == 0 || d < best) { best = d; assign = g; }
+    const float dc = ((cx - gx) * (cx - gx) + (cy - gy) * (cy - gy)) + (cz - gz) * (cz - gz);
+    if (g == 0 || dc < best_c) { best_c = dc; near_c = g; }
+  }
+  const float dist = sqrtf(best + 1e-6f);
+  const int label = dist < kNear ? 1 : 0;
+  const float mask = (dist < kNear || dist > kFar) ? 1.0f : 0.0f;
+  const float obj = (float)label;
+  a.objectness_label[bk] = label;
+  a.objectness_mask[bk] = mask;
+  a.object_assignment[bk] = assign;
+  acc[ACC_MASK] += mask;
+  acc[ACC_POS] += obj;
+
+  // objectness: weighted cross entropy (weights 0.2 / 0.8)
+  {
+    const float w = label ? 0.8f : 0.2f;
+    const float s0 = lt_at(a.obj, b, k, 0), s1 = lt_at(a.obj, b, k, 1);
+    const float m = s0 > s1 ? s0 : s1;
+    const float lse = m + logf(expf(s0 - m) + expf(s1 - m));
+    const float scale = 0.5f * kLossWeight * mask * w;
+    a.g_obj[bk * 2] = scale * (expf(s0 - lse) - (label == 0 ? 1.0f : 0.0f));
+    a.g_obj[bk * 2 + 1] = scale * (expf(s1 - lse) - (label == 1 ? 1.0f : 0.0f));
+    acc[ACC_CE_MASK] += w * (lse - (label ? s1 : s0)) * mask;
+    acc[ACC_OBJACC] += ((s1 > s0 ? 1 : 0) == label ? 1.0f : 0.0f) * mask;
+  }
+  // centre: squared distance to the nearest GT centre (raw labels, padded slots included)
+  {
+    acc[ACC_CENTER1] += best_c * obj;
+    const float s = kLossWeight * obj * 2.0f;
+    a.g_center[bk * 3 + 0] = s * (cx - sv.gt_center[near_c * 3 + 0]);
+    a.g_center[bk * 3 + 1] = s * (cy - sv.gt_center[near_c * 3 + 1]);
+    a.g_center[bk * 3 + 2] = s * (cz - sv.gt_center[near_c * 3 + 2]);
+  }
+  const long long gi = (long long)b * a.G + assign;  // the assigned ground-truth box
+  // heading: class + normalised residual
+  {
+    const int hl = (int)a.heading_class_label[gi];
+    float *gs = a.g_h_scores + bk * a.NH, *gr = a.g_h_resn + bk * a.NH;
+    int top;
+    acc[ACC_HCLS] += obj * ce_and_grad(a.h_scores, b, k, a.NH, hl, 0.1f * kLossWeight * obj, gs, &top);
+    const float target = a.heading_residual_label[gi] / (float)(M_PI / (double)a.NH);
+    const float x = lt_at(a.h_resn, b, k, hl) - target;
+    acc[ACC_HREG] += obj * huber1(x);
+    for (int j = 0; j < a.NH; ++j) gr[j] = j == hl ? kLossWeight * obj * huber1_grad(x) : 0.0f;
+  }
+  // size: class + residual normalised by the class' mean size
+  {
+    const int sl = (int)a.size_class_label[gi];
+    float *gs = a.g_s_scores + bk * a.NS, *gr = a.g_s_resn + bk * a.NS * 3;
+    int top;
+    acc[ACC_SCLS] += obj * ce_and_grad(a.s_scores, b, k, a.NS, sl, 0.1f * kLossWeight * obj, gs, &top);
+    for (int j = 0; j < a.NS * 3; ++j) gr[j] = 0.0f;
+    float reg = 0.0f;
+    for (int d = 0; d < 3; ++d) {
+      const float x = lt_at(a.s_resn, b, k, sl, d) - a.size_residual_label[gi * 3 + d] / a.mean_size[sl * 3 + d];
+      reg += huber1(x);
+      gr[sl * 3 + d] = kLossWeight * obj * huber1_grad(x) / 3.0f;
+    }
+    acc[ACC_SREG] += obj * (reg / 3.0f);
+  }
+  // semantic class
+  {
+    const int cl = (int)a.sem_cls_label[gi];
+    int top;
+    acc[ACC_SEM] += obj * ce_and_grad(a.sem, b, k, a.NC, cl, 0.1f * kLossWeight * obj,
+                                      a.g_sem + bk * a.NC, &top);
+    acc[ACC_CLSACC] += obj * (top == cl ? 1.0f : 0.0f);
+  }
+  // IoU estimation: sigmoid(score of the class of the best-overlapping GT box) vs that IoU
+  const int rows = a.has_jitter ? 2 * a.K : a.K;
+  {
+    const long long r = (long long)b * rows + k;
+    const float lab = a.iou_lab[r];
+    const int sel = a.NI > 1 ? (int)a.sem_cls_label[(long long)b * a.G + a.iou_assign[r]] : 0;
+    const float p = 1.0f / (1.0f + expf(-lt_at(a.iou, b, k, sel)));
+    const float x = p - lab;
+    acc[ACC_IOULAB] += lab;
+    acc[ACC_IOULAB_OBJ] += lab * obj;
+    acc[ACC_IOUACC] += fabsf(x);
+    acc[ACC_IOUACC_OBJ] += fabsf(x) * obj;
+    acc[ACC_IOUHUB] += huber1(x);
+    const float s = kLossWeight / (float)(a.B * a.K) * huber1_grad(x) * p * (1.0f - p);
+    for (int j = 0; j < a.NI; ++j) a.g_iou[bk * a.NI + j] = j == sel ? s : 0.0f;
+  }
+  if (a.has_jitter) {
+    const long long r = (long long)b * rows + a.K + k;
+    const float lab = a.iou_lab[r];
+    const int sel = a.NI > 1 ? (int)a.sem_cls_label[(long long)b * a.G + a.iou_assign[r]] : 0;
+    const float p = 1.0f / (1.0f + expf(-lt_at(a.iou_jit, b, k, sel)));
+    const float x = p - lab;
+    acc[ACC_JITACC] += fabsf(x);
+    acc[ACC_JITHUB] += huber1(x);
+    const float s = kLossWeight / ((float)(a.B * a.K) + 1e-6f) * huber1_grad(x) * p * (1.0f - p);
+    for (int j = 0; j < a.NI; ++j) a.g_iou_jit[bk * a.NI + j] = j == sel ? s : 0.0f;
+  }
+}
+
+// GT slot g of scene b: the other direction of the centre chamfer -- nearest predicted centre
+LOSS_HD void loss_ground_truth(const LossArgs &a, const SceneView &sv, int b, int g, float *acc) {
+  const long long i = (long long)b * a.G + g;
+  const float gx = sv.gt_center[g * 3], gy = sv.gt_center[g * 3 + 1], gz = sv.gt_center[g * 3 + 2];
+  float best = 0.0f;
+  int arg = 0;
+  for (int k = 0; k < a.K; ++k) {
+    const float cx = sv.center[k * 3], cy = sv.center[k * 3 + 1], cz = sv.center[k * 3 + 2];
+    const float d = ((cx - gx) * (cx - gx) + (cy - gy) * (cy - gy)) + (cz - gz) * (cz - gz);
+    if (k == 0 || d < best) { best = d; arg = k; }
+  }
+  a.gt_nearest[i] = arg;
+  acc[ACC_BLM] += sv.gt_mask[g];
+  acc[ACC_DIST2] += best * sv.gt_mask[g];
+}
+
+// seed s of scene b: L1 distance of its closest (vote, GT vote) pair; returns the arg-min pair as
+// vote * 3 + gt and the mask through *m
+LOSS_HD int loss_seed(const LossArgs &a, int b, int s, float *acc, float *m) {
+  const int p = a.seed_inds[b * a.seed_inds_stride + s];
+  const long long row = (long long)b * a.N + p;
+  const float mask = (float)a.vote_label_mask[row];
+  float best = 0.0f;
+  int arg = 0;
+  for (int j = 0; j < a.VF; ++j)
+    for (int g = 0; g < 3; ++g) {
+      float d = 0.0f;
+      for (int c = 0; c < 3; ++c)
+        d += fabsf(lt_at(a.vote_xyz, b, s * a.VF + j, c) -
+                   (a.vote_label[row * 9 + g * 3 + c] + lt_at(a.seed_xyz, b, s, c)));
+      if ((j == 0 && g == 0) || d < best) { best = d; arg = j * 3 + g; }
+    }
+  acc[ACC_VMASK] += mask;
+  acc[ACC_VDIST] += best * mask;
+  *m = mask;
+  return arg;
+}
+
+LOSS_HD void loss_stats(const LossArgs &a, const float *acc) {
+  float *st = a.stats;
+  const float total = (float)(a.B * a.K);
+  const float cnt = acc[ACC_POS];
+  const float inv = 1.0f / (cnt + 1e-6f);
+  st[ST_VOTE] = acc[ACC_VDIST] / (acc[ACC_VMASK] + 1e-6f);
+  st[ST_OBJ] = acc[ACC_CE_MASK] / (acc[ACC_MASK] + 1e-6f);
+  st[ST_CENTER] = acc[ACC_CENTER1] * inv + acc[ACC_DIST2] / (acc[ACC_BLM] + 1e-6f);
+  st[ST_HCLS] = acc[ACC_HCLS] * inv;
+  st[ST_HREG] = acc[ACC_HREG] * inv;
+  st[ST_SCLS] = acc[ACC_SCLS] * inv;
+  st[ST_SREG] = acc[ACC_SREG] * inv;
+  st[ST_SEM] = acc[ACC_SEM] * inv;
+  st[ST_BOX] = 0.1f * st[ST_HCLS] + st[ST_HREG] + 0.1f * st[ST_SCLS] + st[ST_SREG] + st[ST_CENTER];
+  st[ST_IOU] = acc[ACC_IOUHUB] / total;
+  st[ST_JIT] = a.has_jitter ? acc[ACC_JITHUB] / (total + 1e-6f) : 0.0f;
+  st[ST_LOSS] = kLossWeight * (st[ST_VOTE] + 0.5f * st[ST_OBJ] + st[ST_BOX] + 0.1f * st[ST_SEM] +
+                               st[ST_IOU] + st[ST_JIT]);
+  st[ST_POS_RATIO] = cnt / total;
+  st[ST_NEG_RATIO] = acc[ACC_MASK] / total - st[ST_POS_RATIO];
+  st[ST_OBJ_ACC] = acc[ACC_OBJACC] / (acc[ACC_MASK] + 1e-6f);
+  st[ST_OBJ_COUNT] = cnt;
+  st[ST_CLS_ACC] = acc[ACC_CLSACC] * inv;
+  st[ST_PRED_IOU] = acc[ACC_IOULAB] / total;
+  st[ST_PRED_IOU_OBJ] = acc[ACC_IOULAB_OBJ] * inv;
+  st[ST_IOU_ACC] = acc[ACC_IOUACC] / total;
+  st[ST_IOU_ACC_OBJ] = acc[ACC_IOUACC_OBJ] * inv;
+  st[ST_JIT_ACC] = a.has_jitter ? acc[ACC_JITACC] / total : 0.0f;
+  st[ST_JIT_ACC_OBJ] = a.has_jitter ? acc[ACC_JITACC] / (total + 1e-6f) : 0.0f;
+}
+
+// ---- launch 3: once the sums are known -------------------------------------------------------------
+// normalise the gradient rows of proposal (b,k) and add the GT -> nearest-centre term of every GT
+// slot whose nearest prediction is this proposal
+LOSS_HD void finalize_proposal(const LossArgs &a, const SceneView &sv, int b, int k, const float *acc) {
+  const long long bk = (long long)b * a.K + k;
+  const float so = 1.0f / (acc[ACC_MASK] + 1e-6f), sp = 1.0f / (acc[ACC_POS] + 1e-6f);
+  a.g_obj[bk * 2] *= so;
+  a.g_obj[bk * 2 + 1] *= so;
+  float back[3] = {0.0f, 0.0f, 0.0f};
+  const float sb = kLossWeight / (acc[ACC_BLM] + 1e-6f) * 2.0f;
+  for (int g = 0; g < a.G; ++g)
+    if (sv.nearest[g] == k)
+      for (int d = 0; d < 3; ++d)
+        back[d] += sb * sv.gt_mask[g] * (lt_at(a.center, b, k, d) - sv.gt_center[g * 3 + d]);
+  for (int d = 0; d < 3; ++d) a.g_center[bk * 3 + d] = a.g_center[bk * 3 + d] * sp + back[d];
+  for (int j = 0; j < a.NH; ++j) { a.g_h_scores[bk * a.NH + j] *= sp; a.g_h_resn[bk * a.NH + j] *= sp; }
+  for (int j = 0; j < a.NS; ++j) a.g_s_scores[bk * a.NS + j] *= sp;
+  for (int j = 0; j < a.NS * 3; ++j) a.g_s_resn[bk * a.NS * 3 + j] *= sp;
+  for (int j = 0; j < a.NC; ++j) a.g_sem[bk * a.NC + j] *= sp;
+}
+
+// gradient rows of the VF votes of seed s
+LOSS_HD void vote_grad(const LossArgs &a, int b, int s, int arg, float mask, const float *acc) {
+  const int p = a.seed_inds[b * a.seed_inds_stride + s];
+  const long long row = (long long)b * a.N + p;
+  const float scale = kLossWeight * mask / (acc[ACC_VMASK] + 1e-6f);
+  for (int j = 0; j < a.VF; ++j)
+    for (int c = 0; c < 3; ++c) {
+      float v = 0.0f;
+      if (j == arg / 3) {
+        const float x = lt_at(a.vote_xyz, b, s * a.VF + j, c) -
+                        (a.vote_label[row * 9 + (arg % 3) * 3 + c] + lt_at(a.seed_xyz, b, s, c));
+        v = scale * (x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f));
+      }
+      a.g_vote[((long long)b * a.S * a.VF + s * a.VF + j) * 3 + c] = v;
+    }
+}

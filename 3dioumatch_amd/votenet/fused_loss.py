@@ -1,0 +1,240 @@
+"""The supervised loss as two kernel launches around the per-scene IoU kernel (binding of
+include/loss_hip.h; csrc/votenet_loss.hip, csrc/loss_core.h).
+
+`get_labeled_loss_fused` fills the same end_points keys as votenet/losses.py:get_labeled_loss
+(the mirror of models/loss_helper_labeled.py:300-370) from one statistics vector, and the gradient
+of the loss with respect to every head output comes out of the same launch: the autograd node
+below just hands those buffers over, scaled by the incoming gradient of `loss`.  Only
+`end_points['loss']` (= 'detection_loss') is differentiable; the other entries are logging values.
+"""
+import ctypes
+import importlib
+import os
+
+import torch
+
+_c_int, _ll, _vp = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p
+
+
+class VnLossTensor(ctypes.Structure):
+    _fields_ = [("p", _vp), ("sb", _ll), ("sk", _ll), ("sc", _ll), ("sd", _ll)]
+
+
+_PRED = ("agg_xyz", "obj", "center", "h_scores", "h_resn", "s_scores", "s_resn", "sem", "iou",
+         "iou_jit", "seed_xyz", "vote_xyz", "jit_center", "jit_size", "jit_heading")
+_GRADS = ("g_obj", "g_center", "g_h_scores", "g_h_resn", "g_s_scores", "g_s_resn", "g_sem", "g_iou",
+          "g_iou_jit", "g_vote")
+
+
+class VnLossArgs(ctypes.Structure):  # field order == include/loss_hip.h
+    _fields_ = ([(n, _c_int) for n in ("B", "K", "G", "S", "VF", "N", "NH", "NS", "NC", "NI",
+                                       "has_jitter")] +
+                [(n, _vp) for n in ("center_label", "box_label_mask", "heading_class_label",
+                                    "heading_residual_label", "size_class_label",
+                                    "size_residual_label", "sem_cls_label", "vote_label",
+                                    "vote_label_mask", "seed_inds")] +
+                [("seed_inds_stride", _ll), ("mean_size", _vp)] +
+                [(n, VnLossTensor) for n in _PRED] +
+                [(n, _vp) for n in ("boxes", "gt_boxes", "iou_lab", "iou_assign", "stats",
+                                    "objectness_label", "objectness_mask", "object_assignment")] +
+                [(n, _vp) for n in _GRADS] + [("gt_nearest", _vp), ("partials", _vp)])
+
+
+(ST_LOSS, ST_VOTE, ST_OBJ, ST_CENTER, ST_HCLS, ST_HREG, ST_SCLS, ST_SREG, ST_SEM, ST_BOX, ST_IOU,
+ ST_JIT, ST_POS_RATIO, ST_NEG_RATIO, ST_OBJ_ACC, ST_OBJ_COUNT, ST_CLS_ACC, ST_PRED_IOU,
+ ST_PRED_IOU_OBJ, ST_IOU_ACC, ST_IOU_ACC_OBJ, ST_JIT_ACC, ST_JIT_ACC_OBJ, ST_COUNT) = range(24)
+
+_STAT_KEYS = {
+    'vote_loss': ST_VOTE, 'objectness_loss': ST_OBJ, 'center_loss': ST_CENTER,
+    'heading_cls_loss': ST_HCLS, 'heading_reg_loss': ST_HREG, 'size_cls_loss': ST_SCLS,
+    'size_reg_loss': ST_SREG, 'sem_cls_loss': ST_SEM, 'box_loss': ST_BOX, 'iou_loss': ST_IOU,
+    'pos_ratio': ST_POS_RATIO, 'neg_ratio': ST_NEG_RATIO, 'obj_acc': ST_OBJ_ACC,
+    'obj_count': ST_OBJ_COUNT, 'cls_acc': ST_CLS_ACC, 'pred_iou_value': ST_PRED_IOU,
+    'pred_iou_obj_value': ST_PRED_IOU_OBJ, 'iou_acc': ST_IOU_ACC, 'iou_acc_obj': ST_IOU_ACC_OBJ,
+}
+_JITTER_KEYS = {'jitter_iou_loss': ST_JIT, 'jitter_iou_acc': ST_JIT_ACC,
+                'jitter_iou_acc_obj': ST_JIT_ACC_OBJ}
+
+
+def enabled():
+    return os.environ.get("VOTENET_FUSED_LOSS", "1") != "0"
+
+
+_HOST_BUILD = None  # tests: ctypes handle of tests/loss_host.cpp (same arithmetic, host pointers)
+
+
+def available(device):
+    return device.type == "cuda" or _HOST_BUILD is not None
+
+
+def _launch(name, args, device):
+    if device.type != "cuda":
+        if _HOST_BUILD is None:
+            raise RuntimeError("the fused loss runs on the GPU only (no CPU path)")
+        rc = getattr(_HOST_BUILD, name.replace("votenet_loss", "host_loss"))(ctypes.byref(args))
+        assert rc == 0
+        return
+    _L = importlib.import_module("3dioumatch_amd._lib")
+    with torch.cuda.device(device):
+        _L.check(getattr(_L.lib, name)(ctypes.byref(args), _L.current_stream_ptr(device)), name)
+
+
+def _scratch_floats(args, device):
+    if device.type != "cuda":
+        if _HOST_BUILD is None:
+            raise RuntimeError("the fused loss runs on the GPU only (no CPU path)")
+        return int(_HOST_BUILD.host_loss_scratch_floats(ctypes.byref(args)))
+    _L = importlib.import_module("3dioumatch_amd._lib")
+    return int(_L.lib.votenet_loss_scratch_floats(ctypes.byref(args)))
+
+
+def _scene_iou(boxes, gt_boxes):
+    """(best IoU (B,P) f32, first best same-scene GT index (B,P) i32)."""
+    if boxes.is_cuda:
+        cuda = importlib.import_module("pcdet.ops.iou3d_nms.iou3d_nms_cuda")
+        best = torch.empty(boxes.shape[:2], dtype=torch.float32, device=boxes.device)
+        idx = torch.empty(boxes.shape[:2], dtype=torch.int32, device=boxes.device)
+        cuda.scene_best_iou3d_gpu(boxes, gt_boxes, best, idx)
+        return best, idx
+    from .losses import _scene_best_iou
+    best, idx = _scene_best_iou(boxes, gt_boxes)
+    return best.float().contiguous(), idx.int().contiguous()
+
+
+def _view(t):
+    s = list(t.stride()) + [0] * (4 - t.dim())
+    return VnLossTensor(t.data_ptr(), s[0], s[1], s[2] if t.dim() > 2 else 0, s[3] if t.dim() > 3 else 0)
+
+
+def _label(end_points, key, dtype):
+    t = end_points[key]
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s" % (key, dtype))
+    return t.contiguous()
+
+
+class _FusedLabeledLoss(torch.autograd.Function):
+    """stats, labels <- launches; backward: the stored gradients times d(loss)."""
+
+    @staticmethod
+    def forward(ctx, end_points, config, nb, obj, center, h_scores, h_resn, s_scores, s_resn, sem,
+                iou, iou_jit, vote_xyz):
+        dev = center.device
+        k, g = center.shape[1], end_points['center_label'].shape[1]
+        s, vf = end_points['seed_xyz'].shape[1], vote_xyz.shape[1] // end_points['seed_xyz'].shape[1]
+        has_jitter = iou_jit is not None
+        rows = 2 * k if has_jitter else k
+        a = VnLossArgs()
+        a.B, a.K, a.G, a.S, a.VF, a.N = nb, k, g, s, vf, end_points['vote_label'].shape[1]
+        a.NH, a.NS, a.NC, a.NI = h_scores.shape[2], s_scores.shape[2], sem.shape[2], iou.shape[2]
+        a.has_jitter = 1 if has_jitter else 0
+        keep = []  # tensors whose storage the struct points into
+
+        def ptr(t):
+            keep.append(t)
+            return t.data_ptr()
+        for key, dt in (('center_label', torch.float32), ('box_label_mask', torch.float32),
+                        ('heading_class_label', torch.int64), ('heading_residual_label', torch.float32),
+                        ('size_class_label', torch.int64), ('size_residual_label', torch.float32),
+                        ('sem_cls_label', torch.int64), ('vote_label', torch.float32),
+                        ('vote_label_mask', torch.int64)):
+            setattr(a, key, ptr(_label(end_points, key, dt)))
+        seed_inds = end_points['seed_inds']
+        if seed_inds.dtype != torch.int32 or seed_inds.stride(1) != 1:
+            seed_inds = seed_inds.int().contiguous()
+        a.seed_inds, a.seed_inds_stride = ptr(seed_inds), seed_inds.stride(0)
+        a.mean_size = ptr(config.mean_size(dev).contiguous())
+        preds = {"agg_xyz": end_points['aggregated_vote_xyz'], "obj": obj, "center": center,
+                 "h_scores": h_scores, "h_resn": h_resn, "s_scores": s_scores, "s_resn": s_resn,
+                 "sem": sem, "iou": iou, "iou_jit": iou_jit if has_jitter else iou,
+                 "seed_xyz": end_points['seed_xyz'], "vote_xyz": vote_xyz}
+        if has_jitter:
+            preds.update(jit_center=end_points['jitter_center'], jit_size=end_points['jitter_size'],
+                         jit_heading=end_points['jitter_heading'])
+        else:
+            preds.update(jit_center=center, jit_size=center, jit_heading=center)
+        for name, t in preds.items():
+            if t.dtype != torch.float32 or t.device != dev:
+                raise RuntimeError("%s must be a float32 tensor on %s" % (name, dev))
+            keep.append(t)
+            setattr(a, name, _view(t))
+
+        f32 = dict(dtype=torch.float32, device=dev)
+        boxes = torch.empty((nb, rows, 7), **f32)
+        gt_boxes = torch.empty((nb, g, 7), **f32)
+        a.boxes, a.gt_boxes = ptr(boxes), ptr(gt_boxes)
+        _launch("votenet_loss_decode", a, dev)
+        iou_lab, iou_assign = _scene_iou(boxes, gt_boxes)
+        a.iou_lab, a.iou_assign = ptr(iou_lab), ptr(iou_assign)
+
+        stats = torch.empty(ST_COUNT, **f32)
+        objectness_label = torch.empty((nb, k), dtype=torch.int64, device=dev)
+        objectness_mask = torch.empty((nb, k), **f32)
+        object_assignment = torch.empty((nb, k), dtype=torch.int64, device=dev)
+        gt_nearest = torch.empty((nb, g), dtype=torch.int32, device=dev)
+        a.stats, a.objectness_label = ptr(stats), ptr(objectness_label)
+        a.objectness_mask, a.object_assignment = ptr(objectness_mask), ptr(object_assignment)
+        a.gt_nearest = ptr(gt_nearest)
+        a.partials = ptr(torch.empty(max(1, _scratch_floats(a, dev)), **f32))
+        shapes = [(nb, k, 2), (nb, k, 3), (nb, k, a.NH), (nb, k, a.NH), (nb, k, a.NS),
+                  (nb, k, a.NS, 3), (nb, k, a.NC), (nb, k, a.NI),
+                  (nb, k, a.NI) if has_jitter else (0,), (nb, s * vf, 3)]
+        sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+        flat = torch.empty(sum(sizes), **f32)  # every element is written by the kernel
+        grads, off = [], 0
+        for name, sh, n in zip(_GRADS, shapes, sizes):
+            grads.append(flat[off:off + n].view(sh))
+            setattr(a, name, flat.data_ptr() + 4 * off)
+            off += n
+        keep.append(flat)
+        _launch("votenet_loss_forward_backward", a, dev)
+        ctx.flat, ctx.shapes, ctx.sizes, ctx.has_jitter = flat, shapes, sizes, has_jitter
+        pred_bbox = boxes[:, :k]
+        ctx.mark_non_differentiable(objectness_label, objectness_mask, object_assignment, pred_bbox)
+        return stats, objectness_label, objectness_mask, object_assignment, pred_bbox
+
+    @staticmethod
+    def backward(ctx, g_stats, *unused):
+        scaled = ctx.flat * g_stats[ST_LOSS]
+        out, off = [], 0
+        for sh, n in zip(ctx.shapes, ctx.sizes):
+            out.append(scaled[off:off + n].view(sh) if n else None)
+            off += n
+        g_obj, g_center, g_hs, g_hr, g_ss, g_sr, g_sem, g_iou, g_jit, g_vote = out
+        return (None, None, None, g_obj, g_center, g_hs, g_hr, g_ss, g_sr, g_sem, g_iou,
+                g_jit if ctx.has_jitter else None, g_vote)
+
+
+def supported(end_points, supervised_inds):
+    return (supervised_inds is None or isinstance(supervised_inds, slice)) and \
+        'iou_scores' in end_points and end_points['center'].dim() == 3
+
+
+def get_labeled_loss_fused(end_points, dataset_config, supervised_inds=None):
+    """Same contract as losses.get_labeled_loss for `supervised_inds` None (every scene) or
+    slice(0, n) (labeled scenes first)."""
+    nb = end_points['center'].shape[0] if supervised_inds is None else int(supervised_inds.stop)
+
+    def sel(key):
+        t = end_points[key]
+        return t if t.shape[0] == nb else t[:nb]
+    has_jitter = 'jitter_center' in end_points
+    stats, objectness_label, objectness_mask, object_assignment, pred_bbox = _FusedLabeledLoss.apply(
+        end_points, dataset_config, nb, sel('objectness_scores'), sel('center'), sel('heading_scores'),
+        sel('heading_residuals_normalized'), sel('size_scores'), sel('size_residuals_normalized'),
+        sel('sem_cls_scores'), sel('iou_scores'), sel('iou_scores_jitter') if has_jitter else None,
+        sel('vote_xyz'))
+    log = stats.detach()
+    for key, i in _STAT_KEYS.items():
+        end_points[key] = log[i]
+    if has_jitter:
+        for key, i in _JITTER_KEYS.items():
+            end_points[key] = log[i]
+    end_points['objectness_label'] = objectness_label
+    end_points['objectness_mask'] = objectness_mask
+    end_points['object_assignment'] = object_assignment
+    end_points['pred_bbox'] = pred_bbox
+    loss = stats[ST_LOSS]
+    end_points['detection_loss'] = loss
+    end_points['loss'] = loss
+    return loss, end_points

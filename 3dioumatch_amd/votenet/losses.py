@@ -299,6 +299,11 @@ def get_labeled_loss(end_points, dataset_config, config_dict=None):
         if supervised_inds is None:
             supervised_inds = torch.nonzero(end_points['supervised_mask']).squeeze(1).long()
 
+    from . import fused_loss
+    if fused_loss.enabled() and fused_loss.supported(end_points, supervised_inds) and \
+            fused_loss.available(end_points['center'].device):
+        return fused_loss.get_labeled_loss_fused(end_points, dataset_config, supervised_inds)
+
     end_points['vote_loss'] = compute_vote_loss(end_points, supervised_inds)
     objectness_loss, objectness_label, objectness_mask, object_assignment = \
         compute_objectness_loss(end_points, supervised_inds)

@@ -1,0 +1,84 @@
+/* include/loss_hip.h -- C ABI of the fused supervised VoteNet-IoU loss (forward value, statistics
+ * and the gradient with respect to every head output), gfx950.  Plain pointers to DEVICE memory,
+ * explicit stream, returns hipError_t.  Not in the reference: its loss is ~300 small tensor kernels
+ * per step launched from Python (models/loss_helper_labeled.py:28-370, models/loss_helper_iou.py:
+ * 52-112, utils/nn_distance.py:16-62). */
+#ifndef LOSS_HIP_H
+#define LOSS_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* a (B, K, C[, 3]) float tensor with element strides (head outputs are transposed slices of the
+ * heads' (B, C, K) outputs; nothing is copied for the kernel) */
+typedef struct VnLossTensor {
+  const float *p;
+  long long sb, sk, sc, sd;
+} VnLossTensor;
+
+/* indices into VnLossArgs.stats */
+enum {
+  VN_ST_LOSS, VN_ST_VOTE, VN_ST_OBJ, VN_ST_CENTER, VN_ST_HCLS, VN_ST_HREG, VN_ST_SCLS, VN_ST_SREG,
+  VN_ST_SEM, VN_ST_BOX, VN_ST_IOU, VN_ST_JIT, VN_ST_POS_RATIO, VN_ST_NEG_RATIO, VN_ST_OBJ_ACC,
+  VN_ST_OBJ_COUNT, VN_ST_CLS_ACC, VN_ST_PRED_IOU, VN_ST_PRED_IOU_OBJ, VN_ST_IOU_ACC,
+  VN_ST_IOU_ACC_OBJ, VN_ST_JIT_ACC, VN_ST_JIT_ACC_OBJ, VN_ST_COUNT
+};
+
+typedef struct VnLossArgs {
+  int B, K, G, S, VF, N;   /* supervised scenes (the first B of the batch), proposals, GT slots,
+                              seeds, votes per seed, points per scene */
+  int NH, NS, NC, NI;      /* heading bins, size clusters, classes, IoU channels (1 or NC) */
+  int has_jitter;
+  /* labels (loss_helper_labeled.py end_points keys): contiguous, first B scenes are read */
+  const float *center_label;             /* (.,G,3) */
+  const float *box_label_mask;           /* (.,G)   */
+  const long long *heading_class_label;  /* (.,G)   */
+  const float *heading_residual_label;   /* (.,G)   */
+  const long long *size_class_label;     /* (.,G)   */
+  const float *size_residual_label;      /* (.,G,3) */
+  const long long *sem_cls_label;        /* (.,G)   */
+  const float *vote_label;               /* (.,N,9) */
+  const long long *vote_label_mask;      /* (.,N)   */
+  const int *seed_inds;                  /* (.,S), row stride seed_inds_stride */
+  long long seed_inds_stride;
+  const float *mean_size;                /* (NS,3)  */
+  /* predictions */
+  VnLossTensor agg_xyz, obj, center, h_scores, h_resn, s_scores, s_resn, sem, iou, iou_jit;
+  VnLossTensor seed_xyz, vote_xyz;               /* (B,S,3), (B,S*VF,3) */
+  VnLossTensor jit_center, jit_size, jit_heading; /* read by votenet_loss_decode only */
+  /* boxes: written by votenet_loss_decode, read by iou3d_scene_best_iou3d; its outputs */
+  float *boxes;            /* (B, K or 2K, 7): decoded predictions, then the jittered boxes */
+  float *gt_boxes;         /* (B, G, 7) */
+  const float *iou_lab;    /* (B, K or 2K) */
+  const int *iou_assign;   /* (B, K or 2K) */
+  /* outputs of votenet_loss_forward_backward */
+  float *stats;                  /* VN_ST_COUNT */
+  long long *objectness_label;   /* (B,K) */
+  float *objectness_mask;        /* (B,K) */
+  long long *object_assignment;  /* (B,K) */
+  float *g_obj, *g_center, *g_h_scores, *g_h_resn, *g_s_scores, *g_s_resn, *g_sem, *g_iou,
+      *g_iou_jit, *g_vote;       /* d(loss)/d(prediction), contiguous (B,K,C[,3]) / (B,S*VF,3) */
+  int *gt_nearest;               /* scratch (B,G) */
+  float *partials;               /* scratch: votenet_loss_scratch_floats(args) floats */
+} VnLossArgs;
+
+/* replaces the box decoding of compute_iou_labels (models/loss_helper_iou.py:60-96) and of the
+ * ground truth (:79-88): boxes / gt_boxes <- [centre, size, -heading]; `args` is a HOST struct of
+ * DEVICE pointers. */
+int votenet_loss_decode(const VnLossArgs *args, void *stream);
+
+/* replaces get_labeled_loss (models/loss_helper_labeled.py:300-370) after the IoU labels are
+ * known: every loss term, every statistic the training loop logs, the objectness labels / mask /
+ * assignment, and the gradient of `stats[VN_ST_LOSS]` with respect to each prediction.  Two
+ * launches (terms + partial sums; normalisation once the sums are known).  Limits: G <= 256,
+ * K <= 2048. */
+int votenet_loss_forward_backward(const VnLossArgs *args, void *stream);
+
+/* size of VnLossArgs.partials in floats: one row of partial sums per workgroup for the masked
+ * means of models/loss_helper_labeled.py:70-74, :118-123 and :283-297 */
+int votenet_loss_scratch_floats(const VnLossArgs *args);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOSS_HIP_H */

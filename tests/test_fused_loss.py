@@ -1,0 +1,197 @@
+"""The fused supervised loss (votenet/fused_loss.py, csrc/votenet_loss.hip, csrc/loss_core.h)
+against the tensor-op formulation (votenet/losses.py, itself pinned to the reference's
+get_labeled_loss by tests/golden/train_step_ref.npz).
+
+CPU: csrc/loss_core.h -- the functions the kernels call -- is compiled with g++
+(tests/loss_host.cpp) and driven through the same Python binding with host pointers, so every
+loss term, statistic, label and gradient is checked against autograd without a GPU.
+GPU: the kernels themselves against the tensor-op path on the device.
+"""
+import ctypes
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, load_pkg
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from make_layer_golden import seeded_state  # noqa: E402
+from make_step_golden import B, K, N, STAT_KEYS  # noqa: E402
+from test_train_step import _setup, _restore  # noqa: E402,F401  (autouse fixture restores the ops)
+
+LABELS = ("objectness_label", "objectness_mask", "object_assignment")
+LOGGED = STAT_KEYS + ["pos_ratio", "neg_ratio", "obj_acc", "cls_acc", "obj_count", "pred_iou_value",
+                      "pred_iou_obj_value", "iou_acc", "iou_acc_obj", "jitter_iou_acc",
+                      "jitter_iou_acc_obj", "box_loss", "detection_loss"]
+
+
+@pytest.fixture(scope="module")
+def host_build():
+    so = os.path.join(HERE, "_loss_host.so")
+    src = os.path.join(HERE, "loss_host.cpp")
+    core = os.path.join(os.path.dirname(HERE), "3dioumatch_amd", "csrc", "loss_core.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(core)):
+        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-ffp-contract=off", "-o", so, src])
+    return ctypes.CDLL(so)
+
+
+def _forward(V, cfg, dev, seed_net=21, seed_batch=33, scenes=B):
+    data = importlib.import_module("3dioumatch_amd.votenet.data")
+    net = V.VoteNet(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster, cfg.mean_size_arr,
+                    cfg, input_feature_dim=1, num_proposal=K, sampling="seed_fps")
+    seeded_state(net, seed=seed_net)
+    net = net.to(dev).train()
+    batch = {k: v.to(dev) for k, v in data.make_batch(scenes, N, cfg, seed=seed_batch, num_objects=6).items()}
+
+    def run():
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(5)
+        noise = [torch.randn(scenes, K, 3), torch.randn(scenes, K, 3)]
+        real = torch.randn
+        torch.randn = lambda *a, **k: noise.pop(0).to(dev)
+        try:
+            ep = net(batch, mode="jitter")
+        finally:
+            torch.randn = real
+        ep.update(batch)
+        return ep
+    return net, run
+
+
+def _both_paths(V, cfg, dev, monkeypatch, extra=None, **kw):
+    fused = importlib.import_module("3dioumatch_amd.votenet.fused_loss")
+    net, run = _forward(V, cfg, dev, **kw)
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("VOTENET_FUSED_LOSS", flag)
+        ep = run()
+        ep["all_supervised"] = True  # what SupervisedStep passes for a fully labeled batch
+        if extra:
+            ep.update(extra)
+            if "labeled_num" in extra:
+                del ep["all_supervised"]
+        loss, ep = V.get_labeled_loss(ep, cfg, {"dataset_config": cfg})
+        loss.backward()
+        grads = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+        out.append((ep, grads))
+    assert fused.enabled()
+    return out
+
+
+def _compare(ref, got, tol):
+    (ep0, g0), (ep1, g1) = ref, got
+    for key in LABELS + ("pred_bbox",):
+        a, b = ep0[key].detach().cpu().numpy(), ep1[key].detach().cpu().numpy()
+        if key == "pred_bbox":
+            np.testing.assert_allclose(b, a, rtol=0, atol=1e-6)
+        else:
+            assert np.array_equal(a.astype(np.float64), b.astype(np.float64)), key
+    for key in LOGGED + ["loss"]:
+        if key in ep0:
+            a, b = float(ep0[key].detach()), float(ep1[key].detach())
+            assert abs(a - b) <= tol * max(1.0, abs(a)), (key, a, b)
+    assert set(g0) == set(g1)
+    # (biases in front of a BatchNorm have a mathematically zero gradient: rounding noise in both
+    # formulations, hence the floor relative to the whole gradient)
+    whole = float(torch.sqrt(sum((v.double() ** 2).sum() for v in g0.values())))
+    for name in g0:
+        err = float((g0[name] - g1[name]).norm()) / max(0.01 * whole, float(g0[name].norm()))
+        assert err <= 20 * tol, (name, err)
+
+
+@pytest.mark.parametrize("tag", ["scannet", "sunrgbd"])
+def test_host_build_matches_tensor_ops(tag, oracle_omp, host_build, monkeypatch):
+    V, dev = _setup(False, oracle_omp)
+    fused = importlib.import_module("3dioumatch_amd.votenet.fused_loss")
+    monkeypatch.setattr(fused, "_HOST_BUILD", host_build)
+    cfg = V.scannet_config() if tag == "scannet" else V.sunrgbd_config()
+    calls = []
+    real_launch = fused._launch
+    monkeypatch.setattr(fused, "_launch", lambda name, a, d: (calls.append(name), real_launch(name, a, d)))
+    ref, got = _both_paths(V, cfg, dev, monkeypatch)
+    assert calls == ["votenet_loss_decode", "votenet_loss_forward_backward"]  # the fused path ran
+    _compare(ref, got, 2e-5)
+    # and against the reference's own numbers
+    g = golden("train_step_ref.npz")
+    for key in STAT_KEYS:
+        want = float(g["%s_%s" % (tag, key)])
+        assert abs(float(got[0][key]) - want) <= 1e-3 * max(1.0, abs(want)), (key, float(got[0][key]), want)
+
+
+def test_host_build_labeled_scenes_first(oracle_omp, host_build, monkeypatch):
+    """Stage-2 layout: only the first `labeled_num` scenes are supervised; the others get no
+    gradient from this loss."""
+    V, dev = _setup(False, oracle_omp)
+    fused = importlib.import_module("3dioumatch_amd.votenet.fused_loss")
+    monkeypatch.setattr(fused, "_HOST_BUILD", host_build)
+    cfg = V.scannet_config()
+    ref, got = _both_paths(V, cfg, dev, monkeypatch, extra={"labeled_num": B - 1})
+    assert got[0]["objectness_label"].shape[0] == B - 1
+    _compare(ref, got, 2e-5)
+
+
+def test_host_build_no_positive_proposals_and_empty_scene(oracle_omp, host_build, monkeypatch):
+    """All GT slots empty in one scene, and no proposal within 0.3 m anywhere: the positive-count
+    normaliser is 1e-6 and every positive-only term is exactly zero."""
+    V, dev = _setup(False, oracle_omp)
+    fused = importlib.import_module("3dioumatch_amd.votenet.fused_loss")
+    monkeypatch.setattr(fused, "_HOST_BUILD", host_build)
+    cfg = V.scannet_config()
+    data = importlib.import_module("3dioumatch_amd.votenet.data")
+    batch = data.make_batch(B, N, cfg, seed=33, num_objects=6)
+    far = batch["center_label"] + 50.0
+    mask = batch["box_label_mask"].clone()
+    mask[0] = 0
+    ref, got = _both_paths(V, cfg, dev, monkeypatch, extra={"center_label": far, "box_label_mask": mask})
+    assert float(got[0]["obj_count"]) == 0.0
+    _compare(ref, got, 2e-5)
+
+
+def test_fused_loss_has_no_cpu_path(oracle_omp, monkeypatch):
+    V, dev = _setup(False, oracle_omp)
+    fused = importlib.import_module("3dioumatch_amd.votenet.fused_loss")
+    assert not fused.available(torch.device("cpu"))
+    with pytest.raises(RuntimeError):
+        fused._launch("votenet_loss_decode", fused.VnLossArgs(), torch.device("cpu"))
+
+
+def test_args_struct_matches_header():
+    """ctypes mirror of VnLossArgs: same field names, in the header's order."""
+    import re
+    load_pkg()
+    fused = importlib.import_module("3dioumatch_amd.votenet.fused_loss")
+    text = open(os.path.join(os.path.dirname(HERE), "include", "loss_hip.h")).read()
+    body = text[text.index("typedef struct VnLossArgs {"):text.index("} VnLossArgs;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            names.append(re.findall(r"[A-Za-z_][A-Za-z_0-9]*", part)[-1])
+    assert names == [n for n, _ in fused.VnLossArgs._fields_]
+    assert ctypes.sizeof(fused.VnLossTensor) == 40
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["scannet", "sunrgbd"])
+def test_gpu_kernels_match_tensor_ops(tag, oracle_omp, monkeypatch):
+    V, dev = _setup(True, oracle_omp)
+    cfg = V.scannet_config() if tag == "scannet" else V.sunrgbd_config()
+    ref, got = _both_paths(V, cfg, dev, monkeypatch)
+    _compare(ref, got, 5e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_kernels_labeled_scenes_first(oracle_omp, monkeypatch):
+    V, dev = _setup(True, oracle_omp)
+    cfg = V.scannet_config()
+    ref, got = _both_paths(V, cfg, dev, monkeypatch, extra={"labeled_num": B - 1})
+    _compare(ref, got, 5e-5)
