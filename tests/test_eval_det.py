@@ -199,3 +199,77 @@ def test_gpu_best_match_matches_oracle(oracle):
     np.testing.assert_allclose(ov.cpu().numpy(), wov, rtol=0, atol=1e-13)
     assert np.isneginf(wov[::17]).all() and (wjm[::17] == -1).all()
     assert (wov > 0.25).sum() > 1000
+
+
+def _perfect_end_points(V, cfg, rng, scenes=3, k=48):
+    """Head outputs that decode to the ground-truth boxes of a synthetic batch (plus far-away
+    low-objectness clutter), so that the whole evaluation chain must report AP = 1."""
+    data = importlib.import_module("3dioumatch_amd.votenet.data")
+    batch = data.make_batch(scenes, 256, cfg, seed=int(rng.integers(1 << 30)), num_objects=6)
+    nh, ns, nc = cfg.num_heading_bin, cfg.num_size_cluster, cfg.num_class
+    mean = torch.from_numpy(cfg.mean_size_arr.astype(np.float32))
+    center = torch.full((scenes, k, 3), 40.0) + torch.arange(k).view(1, k, 1) * 3.0  # clutter, spread out
+    obj = torch.tensor([4.0, -4.0]).repeat(scenes, k, 1)                             # "no object"
+    h_scores = torch.zeros(scenes, k, nh)
+    h_res = torch.zeros(scenes, k, nh)
+    s_scores = torch.zeros(scenes, k, ns)
+    s_res = torch.zeros(scenes, k, ns, 3)
+    sem = torch.zeros(scenes, k, nc)
+    for b in range(scenes):
+        n = int(batch["box_label_mask"][b].sum())
+        for j in range(n):
+            # 2 mm off: an EXACT copy of a rotated box makes polygon_clip divide by zero (parallel
+            # coincident edges; the reference raises there, see the NaN case above)
+            center[b, j] = batch["center_label"][b, j] + 0.002
+            obj[b, j] = torch.tensor([-6.0, 6.0])
+            h_scores[b, j, batch["heading_class_label"][b, j]] = 8.0
+            h_res[b, j, batch["heading_class_label"][b, j]] = batch["heading_residual_label"][b, j]
+            s_scores[b, j, batch["size_class_label"][b, j]] = 8.0
+            s_res[b, j, batch["size_class_label"][b, j]] = batch["size_residual_label"][b, j]
+            sem[b, j, batch["sem_cls_label"][b, j]] = 12.0
+    ep = {"center": center, "objectness_scores": obj, "heading_scores": h_scores,
+          "heading_residuals": h_res, "size_scores": s_scores, "size_residuals": s_res,
+          "sem_cls_scores": sem, "iou_scores": torch.zeros(scenes, k, nc)}
+    ep.update(batch)
+    return ep
+
+
+@pytest.mark.parametrize("tag", ["scannet", "sunrgbd"])
+def test_evaluation_chain_perfect_predictions_cpu_hostlogic(tag, oracle, monkeypatch):
+    """parse_predictions -> parse_groundtruths -> APCalculator on predictions equal to the ground
+    truth: every class with a ground-truth box has AP = 1 and recall = 1 at IoU 0.25 and 0.5
+    (the device kernels are replaced by the oracle here; the GPU variant is below)."""
+    V, D, E = _mods()
+    from test_eval_helper import _oracle_nms
+    monkeypatch.setattr(E, "_nms3d", _oracle_nms(oracle))
+    monkeypatch.setattr(D, "_best_match", _oracle_best_match(oracle))
+    _run_perfect(V, E, tag, torch.device("cpu"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["scannet", "sunrgbd"])
+def test_evaluation_chain_perfect_predictions_gpu(tag):
+    V, D, E = _mods()
+    _run_perfect(V, E, tag, torch.device("cuda:0"))
+
+
+def _run_perfect(V, E, tag, dev):
+    cfg = V.sunrgbd_config() if tag == "sunrgbd" else V.scannet_config()
+    ep = {k: (v.to(dev) if torch.is_tensor(v) else v)
+          for k, v in _perfect_end_points(V, cfg, np.random.default_rng(3)).items()}
+    # (NMS threshold close to 1: synthetic ground-truth boxes of one class may overlap, and a
+    # suppressed true positive is not what this test is about)
+    config_dict = {"dataset_config": cfg, "remove_empty_box": False, "use_3d_nms": True,
+                   "nms_iou": 0.999, "use_old_type_nms": False, "cls_nms": True,
+                   "use_iou_for_nms": False, "per_class_proposal": True, "conf_thresh": 0.05}
+    preds = E.parse_predictions(ep, config_dict)
+    gts = E.parse_groundtruths(ep, config_dict)
+    assert sum(len(g) for g in gts) == int(ep["box_label_mask"].sum())
+    for thr in (0.25, 0.5):
+        calc = E.APCalculator(thr, None, device=str(dev) if dev.type == "cuda" else None)
+        calc.step(preds, gts)
+        metrics = calc.compute_metrics()
+        classes = sorted({c for g in gts for c, _ in g})
+        for c in classes:
+            assert metrics["%d Average Precision" % c] == pytest.approx(1.0, abs=1e-9), (thr, c)
+            assert metrics["%d Recall" % c] == pytest.approx(1.0, abs=1e-9), (thr, c)
