@@ -42,3 +42,15 @@ def test_bench_other_workloads(workload, scenes):
     d = _run("--workload", workload, "--no-kernels", "--no-cpu-baseline")
     assert REQUIRED <= set(d) and d["config"]["per_gpu_batch"] == scenes
     assert d["config"]["hip_graphs"] is True and d["value"] > 0
+
+
+def test_bench_fails_loudly_without_a_gpu():
+    """No CPU fallback in the measured path: on a machine without a GPU bench.py stops with a
+    clear message instead of timing something else."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this check is for GPU-less machines")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0
+    assert "needs a GPU" in r.stderr and "{" not in r.stdout
