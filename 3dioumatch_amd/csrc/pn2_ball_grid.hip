@@ -1,381 +1,584 @@
-// 3dioumatch_amd/csrc/pn2_ball_grid.hip -- cell-list tier of ball_query for large clouds.
+// 3dioumatch_amd/csrc/pn2_ball_grid.hip -- cell-list tier of ball_query for large clouds, and
+// the fused query + neighbourhood gather of QueryAndGroup on top of it.
 //
 // Semantics: ball_query_gpu.cu:14-49 (first nsample indices in ascending order with
-// d2 < r^2, tail padded with the first hit, zero row without a hit); SURVEY App. A.3.
+// d2 < r^2, tail padded with the first hit, zero row without a hit); group_points_gpu.cu:13-33
+// and pointnet2_utils.py:348-358 for the fused gather; SURVEY App. A.3/A.4.
 //
 // The brute-force formulation needs B*m*N distance tests (6.6e8 at B=8, N=40000, m=2048:
 // VALU-bound, ~0.4 ms) for 8 MB of compulsory traffic.  This tier brings the work down to the
-// ~27 cells around each centroid:
+// ~27 cells around each centroid.
 //
-//   build  : every point goes into a cell of side 1.001*r of a 32^3 PERIODIC lattice
-//            (cell = floor(p / side) mod 32 per axis -- no bounding box pass, far-apart cells
-//            may alias, which only adds candidates that the exact distance test rejects).
-//            Cells are fixed-capacity slot arrays of (x, y, z, index); each workgroup owns one
-//            z-layer and ranks its points with LDS atomics (no global atomics, no counter
-//            memset); points beyond a cell's capacity go to a per-layer overflow list that the
-//            queries of the neighbouring layers also scan (dense clumps stay exact and fast).
-//   query  : one wavefront per centroid.  Lanes 0..26 fetch the 27 neighbour cell counts;
-//            the nine x-rows of three cells are streamed 64 candidates at a time (all loads
-//            issued before the first use), hits are compacted into an LDS list by ballot
-//            rank, then the <=64 smallest indices are selected and ordered IN REGISTERS with a
-//            64-lane bitonic network built from DPP row moves and permlane swaps (no LDS, no
-//            scratch): chunk 0 is sorted ascending, every further chunk descending and folded
-//            in with one min + a 6-stage bitonic merge.  Lane s then writes slot s of the row.
-//            For 64 < nsample <= 128 a second pass collects the next 64 the same way.  Flagged
-//            clouds, rows with more than kMaxHits hits and nsample > 128 fall back to
-//            the brute-force scan of ball_common.h inside the same launch.
+//   lattice : cells of side 1.001*r of a 32^3 PERIODIC lattice (cell = floor(p / side) mod 32
+//             per axis -- no bounding-box pass; far-apart cells may alias, which only adds
+//             candidates that the exact distance test rejects).  Cell id = (z*32 + y)*32 + x.
+//   build   : a two-pass radix sort by cell id, EVERY POINT READ ONCE PER PASS, no global
+//             atomics, no memset, no capacity limits:
+//             (1) grid_split_kernel -- workgroup (chunk, cloud) reads its 1/32 of the cloud
+//                 (coalesced), counting-sorts it by z-layer in LDS and writes the chunk's
+//                 records (x, y, z, index) layer by layer + the 33 layer offsets of the chunk;
+//             (2) grid_bin_kernel -- workgroup (z-layer, cloud) collects its layer's segment of
+//                 every chunk (~1/14 of the cloud instead of all of it), counting-sorts it by
+//                 (y, x) in LDS and writes the records in cell order into the cloud-wide CSR
+//                 array `rec` plus the CSR offsets `start[cell]` of its 1024 cells (the layer's
+//                 base offset is the sum of the smaller layers' segment lengths: 1024 ints).
+//             The round-1 build made each of its 32 slab workgroups scan the whole cloud
+//             (32x redundant L2 reads, 15 us); this one moves 4 x 16 bytes per point.
+//   query   : one wavefront per centroid.  The nine x-rows of three cells around the centroid
+//             are nine contiguous CSR ranges (18 scalar loads); their candidates are loaded
+//             64 at a time -- all nine first loads are issued before the first test -- hits are
+//             compacted into an LDS list of records by mask rank, then RANKED by index with a
+//             counting sort over 64 index buckets (LDS atomics + one wave scan + a count of
+//             smaller indices inside the bucket); the hit of rank s is slot s of the row.
+//             Balls with more hits than the list holds fall back to the brute-force scan of
+//             ball_common.h inside the same launch.
+//   group   : in the fused kernel the lane that owns slot s takes its point's coordinates from
+//             the LDS record, gathers its feature channels and writes the (b, 3+c, m, ns) tensor
+//             directly: 256-byte row segments per wave, the index array is never re-read and no
+//             second / third launch exists.
 //
-// The order in which atomics fill a cell is irrelevant: selection and ordering are by index.
+// The order in which LDS atomics fill a cell is irrelevant: selection and ordering are by index.
 #include "common.h"
+#include <stdlib.h>
 #include "ball_common.h"
 
 namespace {
 
 constexpr int kG = 32;                  // lattice cells per axis (periodic)
-constexpr int kCellsPerCloud = kG * kG * kG;
-constexpr int kCap = 64;                // slots per cell
-constexpr int kMaxHits = 384;           // LDS hit list per wave
-constexpr int kRowSlots = 3 * kCap;     // candidates in one x-row of cells (<= 192)
-constexpr int kRowPasses = kRowSlots / kWave;  // 3
+constexpr int kLayerCells = kG * kG;    // cells of one z-layer
+constexpr int kCells = kG * kG * kG;
+constexpr int kStartStride = kCells + 32;  // ints per cloud in `start` (start[kCells] = n)
+constexpr int kChunks = 32;             // chunks a cloud is split into by pass 1
+constexpr int kSegOff = kG + 1;         // layer offsets per chunk (+ total)
+constexpr int kBuildThreads = 1024;
+constexpr int kGridMaxPoints = kChunks * 4096;  // pass 1 keeps a chunk's points in registers
 
-constexpr int kOvfCap = 2048;           // overflow points kept per (cloud, z-layer)
+__host__ __device__ inline int grid_chunk_points(int n) {
+  return (((n + kChunks - 1) / kChunks) + 3) & ~3;
+}
 
-// ints: cell counters, then per (cloud, slab): overflow flag and overflow-list length
-__host__ __device__ inline size_t grid_cnt_bytes(int b) {
-  return sizeof(int) * ((size_t)b * kCellsPerCloud + (size_t)((b * 64 + 63) / 64) * 64);
+struct GridWs {
+  int *start;     // [b][kStartStride]
+  int *segoff;    // [b][kChunks][kSegOff]
+  float4 *rec;    // [b][n]  records in cell order
+  float4 *seg;    // [b][kChunks][chunk_pts]  records in (chunk, layer) order
+  size_t bytes;
+};
+
+inline GridWs grid_ws_layout(void *base, int b, int n) {
+  GridWs w;
+  char *p = reinterpret_cast<char *>(base);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char *q = p + off; off += (bytes + 255) & ~(size_t)255; return q; };
+  w.start = reinterpret_cast<int *>(take(sizeof(int) * (size_t)b * kStartStride));
+  w.segoff = reinterpret_cast<int *>(take(sizeof(int) * (size_t)b * kChunks * kSegOff));
+  w.rec = reinterpret_cast<float4 *>(take(sizeof(float4) * (size_t)b * n));
+  w.seg = reinterpret_cast<float4 *>(take(sizeof(float4) * (size_t)b * kChunks * grid_chunk_points(n)));
+  w.bytes = off;
+  return w;
 }
 
 __device__ __forceinline__ int cell_coord(float v, float inv_side) {
   return (int)floorf(v * inv_side);
 }
 
-__device__ __forceinline__ int cell_index(int cx, int cy, int cz) {
-  return ((cz & (kG - 1)) * kG + (cy & (kG - 1))) * kG + (cx & (kG - 1));
+// ---- pass 1: split each chunk of the cloud by z-layer ----------------------------------------
+// T lanes per workgroup, up to kSplitPoints / T points per lane kept in registers between the
+// ranking (LDS atomics on the 32 layer counters) and the scatter.
+constexpr int kSplitPoints = 4096;  // points per chunk at most -> n <= 32 * 4096
+
+template <int T>
+__global__ void __launch_bounds__(T)
+grid_split_kernel(int n, int chunk_pts, float inv_side, const float *__restrict__ xyz,
+                  int *__restrict__ segoff, float4 *__restrict__ seg) {
+  constexpr int PPL = kSplitPoints / T;
+  __shared__ int lcnt[kG];
+  const BlockId blk = xcd_block_id();  // all chunks of a cloud on one XCD (L2-local hand-over)
+  const int chunk = blk.x, b = blk.y;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  if (tid < kG) lcnt[tid] = 0;
+  __syncthreads();
+  const float *pts = xyz + (size_t)b * n * 3;
+  const int k0 = chunk * chunk_pts;
+  const int k1 = k0 + chunk_pts < n ? k0 + chunk_pts : n;
+  float px[PPL], py[PPL], pz[PPL];
+  int layer[PPL], rank[PPL];
+#pragma unroll
+  for (int u = 0; u < PPL; ++u) {
+    const int k = k0 + tid + u * T;
+    layer[u] = -1;
+    if (k < k1) {
+      px[u] = pts[k * 3 + 0]; py[u] = pts[k * 3 + 1]; pz[u] = pts[k * 3 + 2];
+      layer[u] = cell_coord(pz[u], inv_side) & (kG - 1);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < PPL; ++u)
+    if (layer[u] >= 0) rank[u] = atomicAdd(&lcnt[layer[u]], 1);
+  __syncthreads();
+  // every wave scans the 32 layer counts itself (no second barrier); lane l holds layer l's offset
+  const int v = lane < kG ? lcnt[lane] : 0;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < kG; o <<= 1) {
+    const int t = __shfl_up(incl, o, kWave);
+    if (lane >= o) incl += t;
+  }
+  const int excl = incl - v;
+  if (tid < kG) {
+    int *so = segoff + ((size_t)b * kChunks + chunk) * kSegOff;
+    so[tid] = excl;
+    if (tid == kG - 1) so[kG] = incl;
+  }
+  float4 *my = seg + ((size_t)b * kChunks + chunk) * chunk_pts;
+#pragma unroll
+  for (int u = 0; u < PPL; ++u) {
+    const int off = __shfl(excl, layer[u] >= 0 ? layer[u] : 0, kWave);
+    if (layer[u] >= 0)
+      my[off + rank[u]] = make_float4(px[u], py[u], pz[u], __builtin_bit_cast(float, k0 + tid + u * T));
+  }
 }
 
-// Build without global atomics and without a memset: the lattice is cut into kSlabs slabs of
-// kLayers z-layers; workgroup (slab, cloud) scans the WHOLE cloud (480 KB from L2, coalesced),
-// keeps the points whose z-layer falls in its slab, ranks them with LDS atomics (its
-// kLayers*1024 counters live in LDS) and writes their slots; finally it writes every counter of
-// its slab, so all 32768 counters of the cloud are (re)written on every call.
-// (Returning device-scope atomics execute at the memory side on this multi-XCD part:
-// one per point cost 20 us for 320 000 points; this formulation costs a few us.)
-constexpr int kSlabs = 32;                     // (grid_cnt_bytes reserves 32 flags per cloud)
-constexpr int kLayers = kG / kSlabs;           // 1 z-layer per slab
-constexpr int kSlabCells = kLayers * kG * kG;  // 1024 cells
-constexpr int kBuildThreads = 1024;
+// ---- pass 2: one z-layer of one cloud -> CSR rows of its 1024 cells --------------------------
+// Work item = (chunk segment, 64-record block), dealt round-robin to the 16 waves; the first
+// kBinCache items of a wave stay in registers between the ranking and the scatter (a layer of a
+// uniform cloud is ~45 items), later ones are re-read and ranked by a second cursor.
+constexpr int kBinCache = 4;
 
 __global__ void __launch_bounds__(kBuildThreads)
-grid_build_kernel(int n, float inv_side, const float *__restrict__ xyz, int *__restrict__ cnt,
-                  int *__restrict__ flags, float4 *__restrict__ slots,
-                  float4 *__restrict__ ovf) {
-  __shared__ int lcnt[kSlabCells];
-  __shared__ int l_ovf;
-  const BlockId blk = xcd_block_id();  // all 32 slabs of a cloud on one XCD: one HBM read
-  const int slab = blk.x, b = blk.y;
-  for (int t = threadIdx.x; t < kSlabCells; t += kBuildThreads) lcnt[t] = 0;
-  if (threadIdx.x == 0) l_ovf = 0;
+grid_bin_kernel(int n, int chunk_pts, float inv_side, const int *__restrict__ segoff,
+                const float4 *__restrict__ seg, int *__restrict__ start,
+                float4 *__restrict__ rec) {
+  constexpr int kWaves = kBuildThreads / kWave;
+  __shared__ int cnt_a[kLayerCells];    // cached records per cell, then the cell's start
+  __shared__ int cnt_b[kLayerCells];    // other records per cell, then their scatter cursor
+  __shared__ int seg_begin[kChunks];    // my layer's segment of chunk c: offset in the chunk ...
+  __shared__ int seg_len[kChunks];
+  __shared__ int blk_pref[kChunks + 1]; // ... and prefix sum of its 64-record blocks
+  __shared__ int wave_part[kWaves];
+  const BlockId blk = xcd_block_id();
+  const int layer = blk.x, b = blk.y;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
+  // lane (c, l): length of chunk c's segment of layer l; the layer's base offset in `rec` is the
+  // total length of the smaller layers' segments
+  const int c_of = tid >> 5, l_of = tid & (kG - 1);
+  const int *so = segoff + ((size_t)b * kChunks + c_of) * kSegOff;
+  const int o0 = so[l_of], o1 = so[l_of + 1];
+  int below = l_of < layer ? o1 - o0 : 0;
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) below += __shfl_xor(below, o, kWave);
+  if (lane == 0) wave_part[w] = below;
+  if (l_of == layer) { seg_begin[c_of] = o0; seg_len[c_of] = o1 - o0; }
+  cnt_a[tid] = 0;
+  cnt_b[tid] = 0;
   __syncthreads();
-  float4 *my_ovf = ovf + ((size_t)b * kSlabs + slab) * kOvfCap;
-  const float *pts = xyz + (size_t)b * n * 3;
-  const size_t cell0 = (size_t)b * kCellsPerCloud + (size_t)slab * kSlabCells;
-  bool overflow = false;
-  auto place = [&](float x, float y, float z, int k) {
-    const int cz = cell_coord(z, inv_side) & (kG - 1);
-    if (cz / kLayers != slab) return;
-    const int local = ((cz % kLayers) * kG + (cell_coord(y, inv_side) & (kG - 1))) * kG +
-                      (cell_coord(x, inv_side) & (kG - 1));
-    const int slot = atomicAdd(&lcnt[local], 1);
-    const float4 rec = make_float4(x, y, z, __builtin_bit_cast(float, k));
-    if (slot < kCap) {
-      slots[(cell0 + local) * kCap + slot] = rec;
-    } else {  // dense cell: the point goes to this z-layer's overflow list
-      const int o = atomicAdd(&l_ovf, 1);
-      if (o < kOvfCap) my_ovf[o] = rec; else overflow = true;
+  int base = 0;
+#pragma unroll
+  for (int q = 0; q < kWaves; ++q) base += wave_part[q];
+  {  // every wave computes the block prefix of the 32 segments itself (wave 0 publishes it)
+    const int nb = lane < kChunks ? (seg_len[lane] + kWave - 1) / kWave : 0;
+    int incl = nb;
+#pragma unroll
+    for (int o = 1; o < kChunks; o <<= 1) {
+      const int t = __shfl_up(incl, o, kWave);
+      if (lane >= o) incl += t;
     }
+    if (w == 0 && lane < kChunks) {
+      blk_pref[lane] = incl - nb;
+      if (lane == kChunks - 1) blk_pref[kChunks] = incl;
+    }
+  }
+  __syncthreads();
+  const int n_blocks = blk_pref[kChunks];
+  const float4 *cloud_seg = seg + (size_t)b * kChunks * chunk_pts;
+  auto locate = [&](int item, const float4 *&src) {  // -> is there a record for this lane
+    const unsigned long long le =
+        __ballot(lane < kChunks && blk_pref[lane < kChunks ? lane + 1 : 0] <= item);
+    const int c = __popcll(le);  // blk_pref[c] <= item < blk_pref[c + 1]
+    const int p = (item - blk_pref[c]) * kWave + lane;
+    src = cloud_seg + (size_t)c * chunk_pts + seg_begin[c] + p;
+    return p < seg_len[c];
   };
-  if ((n & 3) == 0) {
-    // 4 points = 48 contiguous bytes = three 16-byte loads per lane, fully coalesced and with
-    // no dependent second load; two groups in flight per lane
-    const float4 *v = reinterpret_cast<const float4 *>(pts);
-    const int groups = n / 4;
-    for (int g0 = threadIdx.x; g0 < groups; g0 += 2 * kBuildThreads) {
-      float4 a[2][3];
+  auto cell_of = [&](const float4 &q) {
+    return (cell_coord(q.y, inv_side) & (kG - 1)) * kG + (cell_coord(q.x, inv_side) & (kG - 1));
+  };
+  float4 cq[kBinCache];
+  int ccell[kBinCache], crank[kBinCache];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int g = g0 + u * kBuildThreads;
-        if (g < groups) { a[u][0] = v[g * 3]; a[u][1] = v[g * 3 + 1]; a[u][2] = v[g * 3 + 2]; }
-      }
+  for (int u = 0; u < kBinCache; ++u) {  // loads first, then the LDS atomics
+    ccell[u] = -1;
+    const int item = w + u * kWaves;
+    const float4 *src;
+    if (item < n_blocks && locate(item, src)) { cq[u] = *src; ccell[u] = 0; }
+  }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int g = g0 + u * kBuildThreads;
-        if (g < groups) {
-          place(a[u][0].x, a[u][0].y, a[u][0].z, g * 4 + 0);
-          place(a[u][0].w, a[u][1].x, a[u][1].y, g * 4 + 1);
-          place(a[u][1].z, a[u][1].w, a[u][2].x, g * 4 + 2);
-          place(a[u][2].y, a[u][2].z, a[u][2].w, g * 4 + 3);
-        }
-      }
+  for (int u = 0; u < kBinCache; ++u)
+    if (ccell[u] >= 0) {
+      ccell[u] = cell_of(cq[u]);
+      crank[u] = atomicAdd(&cnt_a[ccell[u]], 1);
     }
-  } else {
-    for (int k = threadIdx.x; k < n; k += kBuildThreads)
-      place(pts[k * 3 + 0], pts[k * 3 + 1], pts[k * 3 + 2], k);
+  for (int item = w + kBinCache * kWaves; item < n_blocks; item += kWaves) {
+    const float4 *src;
+    if (locate(item, src)) atomicAdd(&cnt_b[cell_of(*src)], 1);
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < kSlabCells; t += kBuildThreads) cnt[cell0 + t] = lcnt[t];
-  // flag + overflow length per (cloud, slab), always written: no clearing pass is needed
-  const int any = __syncthreads_or(overflow ? 1 : 0);
-  if (threadIdx.x == 0) {
-    flags[(b * kSlabs + slab) * 2] = any;
-    flags[(b * kSlabs + slab) * 2 + 1] = l_ovf < kOvfCap ? l_ovf : kOvfCap;
+  {  // exclusive scan of the 1024 cell counts (one per lane)
+    const int va = cnt_a[tid], v = va + cnt_b[tid];
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const int t = __shfl_up(incl, o, kWave);
+      if (lane >= o) incl += t;
+    }
+    __syncthreads();  // wave_part is reused
+    if (lane == kWave - 1) wave_part[w] = incl;
+    __syncthreads();
+    int before = base;
+    for (int q = 0; q < w; ++q) before += wave_part[q];
+    const int excl = before + incl - v;
+    cnt_a[tid] = excl;
+    cnt_b[tid] = excl + va;
+    int *st = start + (size_t)b * kStartStride;
+    st[layer * kLayerCells + tid] = excl;
+    if (layer == kG - 1 && tid == kBuildThreads - 1) st[kCells] = excl + v;  // == n
+  }
+  __syncthreads();
+  float4 *out = rec + (size_t)b * n;
+#pragma unroll
+  for (int u = 0; u < kBinCache; ++u)
+    if (ccell[u] >= 0) out[cnt_a[ccell[u]] + crank[u]] = cq[u];
+  for (int item = w + kBinCache * kWaves; item < n_blocks; item += kWaves) {
+    const float4 *src;
+    if (locate(item, src)) {
+      const float4 q = *src;
+      out[atomicAdd(&cnt_b[cell_of(q)], 1)] = q;
+    }
   }
 }
 
-// ---- 64-lane bitonic network on unsigned keys, entirely in registers ---------------------
-template <int CTRL>
-__device__ __forceinline__ unsigned dppu(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
-}
+struct GroupOut {      // fused gather (GROUP kernels only)
+  const float *features;  // (b, c, n) or nullptr
+  float *out;             // (b, ctot, m, ns)
+  int c;                  // feature channels gathered by this kernel (into channels 3 .. 3+c-1)
+  int ctot;               // channels of `out` (>= 3 + c; the caller fills the rest)
+  int normalize;
+  float inv_radius;
+};
 
-// value held by lane (lane ^ D)
-template <int D>
-__device__ __forceinline__ unsigned partner(unsigned v, int lane) {
-  if (D == 1) return dppu<0xB1>(v);                  // quad_perm [1,0,3,2]
-  if (D == 2) return dppu<0x4E>(v);                  // quad_perm [2,3,0,1]
-  if (D == 4) {                                      // row_shl:4 / row_shr:4
-    const unsigned up = dppu<0x104>(v), dn = dppu<0x114>(v);
-    return (lane & 4) ? dn : up;
-  }
-  if (D == 8) return dppu<0x128>(v);                 // row_ror:8
-  unsigned r0, r1;
-  if (D == 16) {
-    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-    r0 = r[0]; r1 = r[1];
-    return (lane & 16) ? r0 : r1;
-  }
-  auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-  r0 = r[0]; r1 = r[1];
-  return (lane & 32) ? r0 : r1;
-}
+// LDS of one wave (= one centroid at a time)
+template <int MAXH>
+struct alignas(16) WaveLds {
+  float4 list[MAXH];          // records (x, y, z, index) of the hits, in arrival order
+  unsigned tmp[MAXH];         // indices grouped by bucket (order inside a bucket: arrival)
+  unsigned char perm[MAXH];   // perm[rank] = list position of the hit with that rank
+  int cnt[kWave];             // hits per index bucket
+  int off[kWave];             // exclusive prefix of cnt
+};
 
-template <int D>
-__device__ __forceinline__ unsigned cmpx(unsigned v, int lane, bool ascending) {
-  const unsigned p = partner<D>(v, lane);
-  const bool lower = (lane & D) == 0;
-  const unsigned lo = v < p ? v : p, hi = v < p ? p : v;
-  return (lower == ascending) ? lo : hi;
+// inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS traffic)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add(int v) {
+  return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
 }
-
-// merge a bitonic sequence of 64 keys into ascending (or descending) order
-__device__ __forceinline__ unsigned bitonic_merge64(unsigned v, int lane, bool asc) {
-  v = cmpx<32>(v, lane, asc); v = cmpx<16>(v, lane, asc); v = cmpx<8>(v, lane, asc);
-  v = cmpx<4>(v, lane, asc);  v = cmpx<2>(v, lane, asc);  v = cmpx<1>(v, lane, asc);
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8   -> scan inside each row of 16
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
   return v;
 }
 
-__device__ __forceinline__ unsigned bitonic_sort64(unsigned v, int lane, bool asc) {
-#define DIR(K) (((lane & (K)) == 0) == asc)
-  v = cmpx<1>(v, lane, DIR(2));
-  v = cmpx<2>(v, lane, DIR(4)); v = cmpx<1>(v, lane, DIR(4));
-  v = cmpx<4>(v, lane, DIR(8)); v = cmpx<2>(v, lane, DIR(8)); v = cmpx<1>(v, lane, DIR(8));
-  v = cmpx<8>(v, lane, DIR(16)); v = cmpx<4>(v, lane, DIR(16)); v = cmpx<2>(v, lane, DIR(16));
-  v = cmpx<1>(v, lane, DIR(16));
-  v = cmpx<16>(v, lane, DIR(32)); v = cmpx<8>(v, lane, DIR(32)); v = cmpx<4>(v, lane, DIR(32));
-  v = cmpx<2>(v, lane, DIR(32)); v = cmpx<1>(v, lane, DIR(32));
-#undef DIR
-  return bitonic_merge64(v, lane, asc);
-}
-
-// WIDE: nsample in (64, 128] -- two result registers per lane (the 64 smallest and the next 64)
-template <bool WIDE>
+// MAXH : capacity of the hit list (<= 256; denser balls: in-launch brute force); nsample <= MAXH / 2
+// CPW  : centroids a wave handles one after the other (amortises the per-wave set-up)
+// GROUP: also write the grouped (b, ctot, m, ns) tensor
+// ABL  : 0 = the operator; 1 / 2 = timing ablations (no ranking / no candidate tests), used by
+//        tools/pair_bench.py --sweep only
+//
+// Instruction budget (the kernel is issue bound -- 16 384 centroids x ~430 vector and ~400
+// scalar instructions was the chip's whole issue capacity for the 18 us of the first version):
+// the distance tests of all nine rows are done first, branch-free, and leave nine 64-bit hit
+// masks; a hit's slot in the list is (scalar popcount prefix) + mbcnt(mask).  Ordering: instead
+// of a 64-lane bitonic network per 64 hits (~105 instructions, and a second network + merge for
+// every further 64), the hits are RANKED: bucket = index * 64 / n (monotone in the index), an
+// LDS atomic counts each bucket and hands out arrival slots, a DPP scan gives the bucket
+// offsets, and a hit's rank inside its bucket (1-2 elements for a ball of a shuffled cloud) is a
+// count of smaller indices among the bucket's elements.  rank -> output slot directly, for any
+// number of hits, so nsample in (64, 128] needs no second pass.
+template <int MAXH, int CPW, bool GROUP, int ABL>
 __global__ void __launch_bounds__(256)
-grid_query_kernel(int n, int m, float radius2, float inv_side, int nsample,
-                  const float *__restrict__ new_xyz, const float *__restrict__ xyz,
-                  const int *__restrict__ cnt, const int *__restrict__ flags,
-                  const float4 *__restrict__ slots, const float4 *__restrict__ ovf,
-                  int *__restrict__ idx) {
-  __shared__ unsigned hits[256 / kWave][kMaxHits];
-  const BlockId blk = xcd_block_id();
-  const int b = blk.y;
+grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side, int nsample,
+                  unsigned bucket_mul, const float *__restrict__ new_xyz,
+                  const float *__restrict__ xyz, const int *__restrict__ start,
+                  const float4 *__restrict__ rec, int *__restrict__ idx, GroupOut g) {
+  static_assert(MAXH <= 256, "perm holds list positions in a byte");
+  constexpr int TMAX = MAXH / kWave;
+  constexpr int NH = MAXH >= 4 * kWave ? 2 : 1;  // nsample <= 64 * NH
+  __shared__ WaveLds<MAXH> lds[256 / kWave];
+  // 1-D grid, XCD-contiguous: cloud = id / wg_per_cloud (one division per workgroup)
+  const int wg = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
+  const int b = wg / wg_per_cloud;
   const int lane = lane_id();
-  const int wave = threadIdx.x / kWave;
-  const int j = blk.x * (256 / kWave) + wave;
-  if (j >= m) return;  // whole wave
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));  // an SGPR
+  WaveLds<MAXH> &L = lds[wave];
   const float *pts = xyz + (size_t)b * n * 3;
-  const float *ctr = new_xyz + ((size_t)b * m + j) * 3;
-  int *row = idx + ((size_t)b * m + j) * nsample;
-  const bool flagged = __ballot(lane < kSlabs && flags[(b * kSlabs + lane) * 2] != 0) != 0ull;
-  if (flagged) {  // an overflow list of this cloud overflowed: exact brute-force scan instead
-    ball_query_wave_scan<1>(pts, n, ctr, 1, radius2, nsample, row);
-    return;
-  }
-  const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
-  const int gx = cell_coord(cx, inv_side), gy = cell_coord(cy, inv_side),
-            gz = cell_coord(cz, inv_side);
+  const int *st = start + (size_t)b * kStartStride;
+  const float4 *cloud = rec + (size_t)b * n;
+  const size_t plane = (size_t)m * nsample;
 
-  // counts of the 27 neighbour cells: lane l <-> (dz, dy, dx) = (l/9, (l/3)%3, l%3) - 1
-  int my_cell = 0, my_cnt = 0;
-  if (lane < 27) {
-    my_cell = cell_index(gx + lane % 3 - 1, gy + (lane / 3) % 3 - 1, gz + lane / 9 - 1);
-    my_cnt = cnt[(size_t)b * kCellsPerCloud + my_cell];
-    my_cnt = my_cnt < kCap ? my_cnt : kCap;
-  }
-  const float4 *cloud_slots = slots + (size_t)b * kCellsPerCloud * kCap;
+#pragma unroll 1
+  for (int cq = 0; cq < CPW; ++cq) {
+    const int j = ((wg - b * wg_per_cloud) * (256 / kWave) + wave) * CPW + cq;
+    if (j >= m) return;  // whole wave
+    const float *ctr = new_xyz + ((size_t)b * m + j) * 3;
+    int *row = idx + ((size_t)b * m + j) * nsample;
+    const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
+    const int gx = __builtin_amdgcn_readfirstlane(cell_coord(cx, inv_side)) & (kG - 1);
+    const int gy = __builtin_amdgcn_readfirstlane(cell_coord(cy, inv_side));
+    const int gz = __builtin_amdgcn_readfirstlane(cell_coord(cz, inv_side));
 
-  // ---- stream the nine x-rows; hits go to the LDS list in arrival order --------------------
-  // Software-pipelined: the loads of row r+1 are issued before row r is tested, so a query
-  // pays about five L2 round trips instead of nine.
-  int total = 0;
-  unsigned *list = hits[wave];
-  struct Row { float4 q[kRowPasses]; int rc; };
-  auto load_row = [&](int r, Row &o) {
-    const int c0 = __builtin_amdgcn_readlane(my_cnt, r * 3 + 0);
-    const int c1 = __builtin_amdgcn_readlane(my_cnt, r * 3 + 1);
-    const int c2 = __builtin_amdgcn_readlane(my_cnt, r * 3 + 2);
-    const int e0 = __builtin_amdgcn_readlane(my_cell, r * 3 + 0);
-    const int e1 = __builtin_amdgcn_readlane(my_cell, r * 3 + 1);
-    const int e2 = __builtin_amdgcn_readlane(my_cell, r * 3 + 2);
-    const int c01 = c0 + c1;
-    o.rc = c01 + c2;
+    // ---- the nine x-rows: CSR ranges [s0, s0 + len) -------------------------------------------
+    // (the row's cells gx-1 .. gx+1 are adjacent in memory; at the lattice seam the cell that
+    //  wraps around is handled as an extra range below)
+    const int xa = gx > 0 ? gx - 1 : 0, xb = gx < kG - 1 ? gx + 1 : kG - 1;
+    int s0[9], len[9];
+    bool fast = gx != 0 && gx != kG - 1;
 #pragma unroll
-    for (int p = 0; p < kRowPasses; ++p) {
-      if (p * kWave < o.rc) {  // wave-uniform: the second / third pass of a row is rare
-        // lanes past the end re-read the row's last candidate (a valid slot: no masked load, no
-        // zero fill); they are excluded by `live` when the row is tested
-        int t = p * kWave + lane;
-        t = t < o.rc ? t : o.rc - 1;
-        int cell = e0, s = t;
-        if (t >= c0) { cell = e1; s = t - c0; }
-        if (t >= c01) { cell = e2; s = t - c01; }
-        o.q[p] = cloud_slots[cell * kCap + s];
+    for (int r = 0; r < 9; ++r) {
+      const int rowbase = (((gz + r / 3 - 1) & (kG - 1)) * kG + ((gy + r % 3 - 1) & (kG - 1))) * kG;
+      s0[r] = st[rowbase + xa];
+      len[r] = st[rowbase + xb + 1] - s0[r];
+      fast = fast && len[r] <= kWave;
+    }
+    int total = 0;
+    if (ABL != 2) {
+      // all nine loads are in flight before the first test (one L2 round trip for ~400
+      // candidates); only the lanes that own a candidate load (a row holds ~44)
+      float4 q[9];
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        q[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < len[r]) q[r] = cloud[(unsigned)(s0[r] + lane)];
+      }
+      bool hit[9];
+      int at[9];
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {  // branch-free: dead lanes compute on zeros and are masked
+        const bool near = sqdist3(cx, cy, cz, q[r].x, q[r].y, q[r].z) < radius2;
+        hit[r] = near & (lane < len[r]);
+        const unsigned long long mask = __ballot(hit[r]);
+        at[r] = total + mask_rank(mask);
+        total += __popcll(mask);
+      }
+      if (total <= MAXH) {
+#pragma unroll
+        for (int r = 0; r < 9; ++r)
+          if (hit[r]) L.list[at[r]] = q[r];
       }
     }
-  };
-  Row rows[2];
-  load_row(0, rows[0]);
-#pragma unroll
-  for (int r = 0; r < 9; ++r) {
-    if (r + 1 < 9) load_row(r + 1, rows[(r + 1) & 1]);
-    const Row &cur = rows[r & 1];
-#pragma unroll
-    for (int p = 0; p < kRowPasses; ++p) {
-      if (p * kWave < cur.rc) {  // wave-uniform
-        const bool live = p * kWave + lane < cur.rc;
-        const float d2 = sqdist3(cx, cy, cz, cur.q[p].x, cur.q[p].y, cur.q[p].z);
-        const bool hit = live && d2 < radius2;
-        const unsigned long long mask = __ballot(hit);
-        if (mask) {
-          const int pos = total + mask_rank(mask);
-          if (hit && pos < kMaxHits) list[pos] = __builtin_bit_cast(unsigned, cur.q[p].w);
-          total += __popcll(mask);
+    if (!fast) {  // rows longer than a wave, and the wrapped cell at the lattice seam (both rare)
+      auto scan_range = [&](int from, int to) {
+        for (int p0 = from; p0 < to; p0 += kWave) {
+          const int p = p0 + lane;
+          float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p < to) q = cloud[p];
+          const bool h = p < to && sqdist3(cx, cy, cz, q.x, q.y, q.z) < radius2;
+          const unsigned long long hm = __ballot(h);
+          const int pos = total + mask_rank(hm);
+          if (h && pos < MAXH) L.list[pos] = q;
+          total += __popcll(hm);
+        }
+      };
+#pragma unroll 1
+      for (int r = 0; r < 9; ++r) {
+        if (len[r] > kWave) scan_range(s0[r] + kWave, s0[r] + len[r]);
+        if (gx == 0 || gx == kG - 1) {
+          const int cell = (((gz + r / 3 - 1) & (kG - 1)) * kG + ((gy + r % 3 - 1) & (kG - 1))) * kG +
+                           (gx == 0 ? kG - 1 : 0);
+          scan_range(st[cell], st[cell + 1]);
         }
       }
     }
-  }
-  // points that did not fit their cell sit in the overflow list of their z-layer: scan the
-  // lists of the three layers around the centroid (empty unless the cloud has dense clumps)
-#pragma unroll 1
-  for (int dz = -1; dz <= 1; ++dz) {
-    const int layer = (gz + dz) & (kG - 1);
-    const int no = flags[(b * kSlabs + layer) * 2 + 1];
-    const float4 *src = ovf + ((size_t)b * kSlabs + layer) * kOvfCap;
-    for (int base = 0; base < no && total <= kMaxHits; base += kWave) {
-      const bool live = base + lane < no;
-      const float4 q = live ? src[base + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-      const bool hit = live && sqdist3(cx, cy, cz, q.x, q.y, q.z) < radius2;
-      const unsigned long long mask = __ballot(hit);
-      if (mask) {
-        const int pos = total + mask_rank(mask);
-        if (hit && pos < kMaxHits) list[pos] = __builtin_bit_cast(unsigned, q.w);
-        total += __popcll(mask);
-      }
-    }
-  }
-  if (total > kMaxHits) {  // very dense ball: exact brute-force scan for this centroid
-    ball_query_wave_scan<1>(pts, n, ctr, 1, radius2, nsample, row);
-    return;
-  }
-  if (total == 0) {
-    for (int s = lane; s < nsample; s += kWave) row[s] = 0;
-    return;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
 
-  // ---- the 64 smallest indices, ascending, one per lane --------------------------------------
-  const unsigned kNone = 0xFFFFFFFFu;
-  unsigned a = lane < total ? list[lane] : kNone;
-  a = bitonic_sort64(a, lane, true);
-  for (int base = kWave; base < total; base += kWave) {
-    unsigned c = base + lane < total ? list[base + lane] : kNone;
-    c = bitonic_sort64(c, lane, false);   // descending: lane i holds the (63-i)-th smallest
-    a = a < c ? a : c;                    // the 64 smallest of the union (a bitonic sequence)
-    a = bitonic_merge64(a, lane, true);
-  }
-  const unsigned first = (unsigned)__builtin_amdgcn_readlane((int)a, 0);
-  if (!WIDE) {
-    const int have = total < kWave ? total : kWave;
-    if (lane < nsample) row[lane] = (int)(lane < have ? a : first);
-    return;
-  }
-  // WIDE: `a` holds the 64 smallest; a second pass over the list collects the next 64 -- the 64
-  // smallest among the hits LARGER than a's maximum (indices are distinct, so "larger than the
-  // 64th smallest" is exactly "not among the first 64")
-  const unsigned cut = (unsigned)__builtin_amdgcn_readlane((int)a, 63);
-  unsigned a1 = kNone;
-  if (total > kWave) {
-    bool started = false;
-    for (int base = 0; base < total; base += kWave) {
-      unsigned c = base + lane < total ? list[base + lane] : kNone;
-      if (c <= cut) c = kNone;
-      if (!started) {
-        a1 = bitonic_sort64(c, lane, true);
-        started = true;
-      } else {
-        c = bitonic_sort64(c, lane, false);
-        a1 = a1 < c ? a1 : c;
-        a1 = bitonic_merge64(a1, lane, true);
+    // rr[h]: the record (x, y, z, index) of slot h * 64 + lane of the row
+    float4 rr[NH];
+    bool have_rr = true;
+    if (total > MAXH) {  // very dense ball: exact brute-force scan for this centroid
+      ball_query_wave_scan<1>(pts, n, ctr, 1, radius2, nsample, row);
+      if (GROUP) {
+        // the gather below needs the row: make this wave's own stores visible to its loads
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          const int s = h * kWave + lane;
+          const int v = s < nsample ? row[s] : 0;
+          rr[h] = make_float4(pts[v * 3 + 0], pts[v * 3 + 1], pts[v * 3 + 2], __builtin_bit_cast(float, v));
+        }
+      }
+    } else if (total > 0) {
+      const int have = total < nsample ? total : nsample;
+      if (ABL != 1) {
+        // ---- rank the hits by index ----------------------------------------------------------
+        L.cnt[lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        unsigned key[TMAX];
+        int bk[TMAX], slot[TMAX];
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+          bk[t] = -1;
+          if (t * kWave < total) {  // wave-uniform: whole passes beyond the list are skipped
+            const int e = t * kWave + lane;
+            if (e < total) {
+              key[t] = __builtin_bit_cast(unsigned, L.list[e].w);
+              bk[t] = (int)__umulhi(key[t], bucket_mul);  // < 64 for every index < n
+              slot[t] = atomicAdd(&L.cnt[bk[t]], 1);
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {
+          const int c = L.cnt[lane];
+          L.off[lane] = wave_inclusive_scan(c) - c;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+          if (t * kWave < total && bk[t] >= 0) {
+            slot[t] += L.off[bk[t]];
+            L.tmp[slot[t]] = key[t];
+          }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+          if (t * kWave < total && bk[t] >= 0) {
+            const int o = L.off[bk[t]], sz = L.cnt[bk[t]];
+            int rank = o;
+#pragma clang loop vectorize(disable) unroll(disable)
+            for (int u = 0; u < sz; ++u) rank += L.tmp[o + u] < key[t] ? 1 : 0;
+            if (rank < have) L.perm[rank] = (unsigned char)(t * kWave + lane);
+          }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int s = h * kWave + lane;
+        const int e = ABL == 1 ? (s < have ? s : 0) : L.perm[s < have ? s : 0];  // tail: first hit
+        rr[h] = L.list[e];
+        if (s < nsample) row[s] = __builtin_bit_cast(int, rr[h].w);
+      }
+    } else {  // no hit: the reference's zero-initialised row -> point 0 everywhere
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        if (h * kWave + lane < nsample) row[h * kWave + lane] = 0;
+        if (GROUP) rr[h] = make_float4(pts[0], pts[1], pts[2], 0.f);
       }
     }
+    (void)have_rr;
+    if (GROUP) {
+      // ---- fused gather: slot s of centroid j in every channel --------------------------------
+      float *ob = g.out + (size_t)b * g.ctot * plane + (size_t)j * nsample;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int s = h * kWave + lane;
+        if (s < nsample) {
+          float rx = __fsub_rn(rr[h].x, cx), ry = __fsub_rn(rr[h].y, cy), rz = __fsub_rn(rr[h].z, cz);
+          if (g.normalize) {
+            rx = __fmul_rn(rx, g.inv_radius); ry = __fmul_rn(ry, g.inv_radius); rz = __fmul_rn(rz, g.inv_radius);
+          }
+          ob[s] = rx;
+          ob[plane + s] = ry;
+          ob[2 * plane + s] = rz;
+          const unsigned v = __builtin_bit_cast(unsigned, rr[h].w);
+          for (int l = 0; l < g.c; ++l)
+            ob[(size_t)(3 + l) * plane + s] = g.features[((size_t)b * g.c + l) * n + v];
+        }
+      }
+    }
+    if (CPW > 1) {  // the next centroid reuses this wave's LDS
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
   }
-  const int have = total < 2 * kWave ? total : 2 * kWave;
-  if (lane < nsample) row[lane] = (int)(lane < have ? a : first);
-  if (kWave + lane < nsample) row[kWave + lane] = (int)(kWave + lane < have ? a1 : first);
 }
 
 }  // namespace
 
 size_t pn2_ball_query_grid_workspace(int b, int n, int m, int nsample) {
   (void)m;
-  if (n < 4096 || nsample > 2 * kWave) return 0;
-  return grid_cnt_bytes(b) + sizeof(float4) * (size_t)b * kCellsPerCloud * kCap +
-         sizeof(float4) * (size_t)b * kSlabs * kOvfCap;
+  if (n < 4096 || n > kGridMaxPoints || nsample > 2 * kWave) return 0;
+  return grid_ws_layout(nullptr, b, n).bytes;
+}
+
+// Build the cell lists of `xyz` for `radius` in `workspace`, then answer the queries; with
+// group != nullptr the fused kernel also writes the grouped tensor.
+static int grid_run(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                    const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
+                    hipStream_t stream, const GroupOut *group, int *handled) {
+  *handled = 0;
+  const size_t need = pn2_ball_query_grid_workspace(b, n, m, nsample);
+  if (need == 0 || workspace == nullptr || workspace_bytes < need) return 0;
+  if (!(radius > 1e-6f) || !(radius < 1e6f)) return 0;  // also rejects NaN
+  const GridWs ws = grid_ws_layout(workspace, b, n);
+  const float inv_side = 1.0f / (radius * 1.001f);
+  const int chunk_pts = grid_chunk_points(n);
+  const int split_t = getenv("PN2_GRID_SPLIT_T") ? atoi(getenv("PN2_GRID_SPLIT_T")) : 1024;
+  if (split_t == 256)
+    hipLaunchKernelGGL(grid_split_kernel<256>, dim3(kChunks, b), dim3(256), 0, stream, n, chunk_pts,
+                       inv_side, xyz, ws.segoff, ws.seg);
+  else if (split_t == 512)
+    hipLaunchKernelGGL(grid_split_kernel<512>, dim3(kChunks, b), dim3(512), 0, stream, n, chunk_pts,
+                       inv_side, xyz, ws.segoff, ws.seg);
+  else
+    hipLaunchKernelGGL(grid_split_kernel<1024>, dim3(kChunks, b), dim3(1024), 0, stream, n,
+                       chunk_pts, inv_side, xyz, ws.segoff, ws.seg);
+  hipLaunchKernelGGL(grid_bin_kernel, dim3(kG, b), dim3(kBuildThreads), 0, stream, n, chunk_pts,
+                     inv_side, ws.segoff, ws.seg, ws.start, ws.rec);
+  const float radius2 = radius * radius;  // fp32 product, as ball_query_gpu.cu:27
+  GroupOut g = {nullptr, nullptr, 0, 3, 0, 1.f};
+  if (group) g = *group;
+  // bucket of an index = floor(index * 64 / n), as a multiply-high
+  const unsigned bucket_mul = (unsigned)(((unsigned long long)64 << 32) / (unsigned long long)n);
+  const char *abl_env = getenv("PN2_GRID_ABLATE");  // timing ablations (tools/pair_bench.py)
+  const int abl = abl_env ? atoi(abl_env) : 0;
+#define GRID_QUERY(MAXH, GROUP, ABL)                                                               \
+  do {                                                                                             \
+    const int wpc = pn2_ceil_div(m, 256 / kWave);                                                  \
+    hipLaunchKernelGGL((grid_query_kernel<MAXH, 1, GROUP, ABL>), dim3(wpc * b), dim3(256), 0,      \
+                       stream, n, m, wpc, radius2, inv_side, nsample, bucket_mul, new_xyz, xyz,    \
+                       ws.start, ws.rec, idx, g);                                                  \
+  } while (0)
+  if (nsample > kWave) { if (group) GRID_QUERY(256, true, 0); else GRID_QUERY(256, false, 0); }
+  else if (!group) GRID_QUERY(192, false, 0);
+  else if (abl == 1) GRID_QUERY(192, true, 1);
+  else if (abl == 2) GRID_QUERY(192, true, 2);
+  else GRID_QUERY(192, true, 0);
+#undef GRID_QUERY
+  *handled = 1;
+  return pn2_launch_status();
 }
 
 int pn2_ball_query_grid_try(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                             const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
                             hipStream_t stream, int *handled) {
-  *handled = 0;
-  const size_t need = pn2_ball_query_grid_workspace(b, n, m, nsample);
-  if (need == 0 || workspace == nullptr || workspace_bytes < need) return 0;
-  if (!(radius > 1e-6f) || !(radius < 1e6f)) return 0;  // also rejects NaN
-  char *ws = reinterpret_cast<char *>(workspace);
-  int *cnt = reinterpret_cast<int *>(ws);
-  int *flags = cnt + (size_t)b * kCellsPerCloud;
-  float4 *slots = reinterpret_cast<float4 *>(ws + grid_cnt_bytes(b));
-  float4 *ovf = slots + (size_t)b * kCellsPerCloud * kCap;
-  const float inv_side = 1.0f / (radius * 1.001f);
-  hipLaunchKernelGGL(grid_build_kernel, dim3(kSlabs, b), dim3(kBuildThreads), 0, stream, n,
-                     inv_side, xyz, cnt, flags, slots, ovf);
-  const float radius2 = radius * radius;  // fp32 product, as ball_query_gpu.cu:27
-  if (nsample > kWave)
-    hipLaunchKernelGGL(grid_query_kernel<true>, dim3(pn2_ceil_div(m, 256 / kWave), b), dim3(256),
-                       0, stream, n, m, radius2, inv_side, nsample, new_xyz, xyz, cnt, flags,
-                       slots, ovf, idx);
-  else
-    hipLaunchKernelGGL(grid_query_kernel<false>, dim3(pn2_ceil_div(m, 256 / kWave), b), dim3(256),
-                       0, stream, n, m, radius2, inv_side, nsample, new_xyz, xyz, cnt, flags,
-                       slots, ovf, idx);
-  *handled = 1;
-  return pn2_launch_status();
+  return grid_run(b, n, m, radius, nsample, new_xyz, xyz, idx, workspace, workspace_bytes, stream,
+                  nullptr, handled);
+}
+
+// fused ball query + gathers of QueryAndGroup (pointnet2_utils.py:335-358) on the cell lists
+// (c_gather of the ctot - 3 feature channels are gathered here, the caller fills the others)
+int pn2_query_group_grid_try(int b, int n, int m, int c_gather, int ctot, float radius,
+                             int nsample, int normalize_xyz, const float *new_xyz,
+                             const float *xyz, const float *features, int *idx, float *out,
+                             void *workspace, size_t workspace_bytes, hipStream_t stream,
+                             int *handled) {
+  // torch divides by a scalar as x * (1/r)
+  GroupOut g = {features, out, c_gather, ctot, normalize_xyz, 1.0f / radius};
+  return grid_run(b, n, m, radius, nsample, new_xyz, xyz, idx, workspace, workspace_bytes, stream,
+                  &g, handled);
 }

@@ -235,7 +235,7 @@ group_points_grad_lds_kernel(int c, int n, int mns, const float *__restrict__ gr
 // channels 3.. = features[idx].
 template <bool VEC>
 __global__ void __launch_bounds__(256)
-group_concat_kernel(int c, int n, int m, int ns, float inv_radius, int normalize,
+group_concat_kernel(int c, int n, int m, int ns, float inv_radius, int normalize, int skip_xyz,
                     const float *__restrict__ new_xyz, const float *__restrict__ xyz,
                     const float *__restrict__ features, const int *__restrict__ idx,
                     float *__restrict__ out) {
@@ -254,7 +254,7 @@ group_concat_kernel(int c, int n, int m, int ns, float inv_radius, int normalize
     for (int t = 0; t < live; ++t) ii[t] = ib[t];
   }
   const int ctot = 3 + c;
-  if (blk.y == 0) {
+  if (blk.y == 0 && !skip_xyz) {
     const float *pts = xyz + (size_t)b * n * 3;
     const float *ctr = new_xyz + (size_t)b * m * 3;
     float r[3][4];
@@ -304,6 +304,11 @@ int channel_groups(int c, int per_thread) {
 int pn2_ball_query_grid_try(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                             const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
                             hipStream_t stream, int *handled);
+int pn2_query_group_grid_try(int b, int n, int m, int c_gather, int ctot, float radius,
+                             int nsample, int normalize_xyz, const float *new_xyz,
+                             const float *xyz, const float *features, int *idx, float *out,
+                             void *workspace, size_t workspace_bytes, hipStream_t stream,
+                             int *handled);
 size_t pn2_ball_query_grid_workspace(int b, int n, int m, int nsample);
 
 PN2_API size_t pn2_ball_query_workspace_bytes(int b, int n, int m, int nsample) {
@@ -435,9 +440,25 @@ PN2_API int pn2_group_points_grad(int b, int c, int n, int npoints, int nsample,
   return pn2_launch_status();
 }
 
-PN2_API int pn2_group_concat(int b, int n, int m, int c, float radius, int nsample,
-                             int normalize_xyz, const float *new_xyz, const float *xyz,
-                             const float *features, const int *idx, float *out, void *stream_);
+static int group_concat_launch(int b, int n, int m, int c, float radius, int nsample,
+                               int normalize_xyz, int skip_xyz, const float *new_xyz,
+                               const float *xyz, const float *features, const int *idx, float *out,
+                               hipStream_t stream) {
+  const long long mns = (long long)m * nsample;
+  dim3 grid(pn2_ceil_div(mns, 1024), channel_groups(c, 8), b);
+  const float inv_radius = 1.0f / radius;  // torch divides by a scalar as x * (1/r)
+  if (mns % 4 == 0)
+    hipLaunchKernelGGL(group_concat_kernel<true>, grid, dim3(256), 0, stream, c, n, m, nsample,
+                       inv_radius, normalize_xyz, skip_xyz, new_xyz, xyz, features, idx, out);
+  else
+    hipLaunchKernelGGL(group_concat_kernel<false>, grid, dim3(256), 0, stream, c, n, m, nsample,
+                       inv_radius, normalize_xyz, skip_xyz, new_xyz, xyz, features, idx, out);
+  return pn2_launch_status();
+}
+
+// feature channels the fused cell-list kernel gathers itself (one scattered 4-byte load per
+// channel and lane); wider feature tensors go through the channel-parallel gather kernel
+constexpr int kFusedGatherChannels = 8;
 
 PN2_API int pn2_query_and_group(int b, int n, int m, int c, float radius, int nsample,
                                 int normalize_xyz, const float *new_xyz, const float *xyz,
@@ -445,11 +466,25 @@ PN2_API int pn2_query_and_group(int b, int n, int m, int c, float radius, int ns
                                 size_t workspace_bytes, void *stream_) {
   if (b <= 0 || m <= 0 || nsample <= 0) return 0;
   if (c > 0 && !features) return (int)hipErrorInvalidValue;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n > 0) {  // large clouds: ball query and gathers in one kernel on the cell lists
+    int handled = 0;
+    const int cg = c <= kFusedGatherChannels ? c : 0;
+    int rc = pn2_query_group_grid_try(b, n, m, cg, 3 + c, radius, nsample, normalize_xyz, new_xyz,
+                                      xyz, features, idx, out, workspace, workspace_bytes, stream,
+                                      &handled);
+    if (rc != 0) return rc;
+    if (handled) {
+      if (cg == c) return 0;
+      return group_concat_launch(b, n, m, c, radius, nsample, normalize_xyz, 1, new_xyz, xyz,
+                                 features, idx, out, stream);
+    }
+  }
   int rc = pn2_ball_query(b, n, m, radius, nsample, new_xyz, xyz, idx, workspace,
                           workspace_bytes, stream_);
   if (rc != 0) return rc;
-  return pn2_group_concat(b, n, m, c, radius, nsample, normalize_xyz, new_xyz, xyz, features, idx,
-                          out, stream_);
+  return group_concat_launch(b, n, m, c, radius, nsample, normalize_xyz, 0, new_xyz, xyz, features,
+                             idx, out, stream);
 }
 
 PN2_API int pn2_group_concat(int b, int n, int m, int c, float radius, int nsample,
@@ -457,14 +492,6 @@ PN2_API int pn2_group_concat(int b, int n, int m, int c, float radius, int nsamp
                              const float *features, const int *idx, float *out, void *stream_) {
   if (b <= 0 || m <= 0 || nsample <= 0) return 0;
   if (c > 0 && !features) return (int)hipErrorInvalidValue;
-  const long long mns = (long long)m * nsample;
-  dim3 grid(pn2_ceil_div(mns, 1024), channel_groups(c, 8), b);
-  const float inv_radius = 1.0f / radius;  // torch divides by a scalar as x * (1/r)
-  if (mns % 4 == 0)
-    hipLaunchKernelGGL(group_concat_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream_, c, n,
-                       m, nsample, inv_radius, normalize_xyz, new_xyz, xyz, features, idx, out);
-  else
-    hipLaunchKernelGGL(group_concat_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream_, c,
-                       n, m, nsample, inv_radius, normalize_xyz, new_xyz, xyz, features, idx, out);
-  return pn2_launch_status();
+  return group_concat_launch(b, n, m, c, radius, nsample, normalize_xyz, 0, new_xyz, xyz, features,
+                             idx, out, (hipStream_t)stream_);
 }

@@ -488,6 +488,61 @@ def test_ballquery_cell_list_tier_edge_cases(ext, oracle_omp, synth, case):
     assert np.all(got[:, -1] == 0)
 
 
+@pytest.mark.parametrize("case", ["plain", "c0", "c12", "ns_100", "dense_hits", "negative",
+                                  "aliasing", "clumps", "ragged"])
+def test_query_and_group_fused_cell_list(ext, oracle_omp, synth, case):
+    """The fused ball query + gather kernel of the cell-list tier (n >= 4096): idx, gathered
+    features (bit-exact) and relative xyz against the reference composition
+    (pointnet2_utils.py:335-358) done with the oracle -- with 0 / 1 / 12 feature channels (more
+    than 8 go through the channel-parallel gather), 64 < nsample <= 128, balls with > 384 hits
+    (in-launch brute force, then the gather), the lattice seam (negative coordinates put
+    centroids in cells 0 and 31), aliasing, clumps, and n / m that are not multiples of 4."""
+    g = np.random.default_rng(17)
+    b, n, m, c, r, ns = 2, 6000, 300, 1, 0.2, 64
+    xyz = synth.cloud_uniform(b, n, 2.0, seed=31)
+    if case == "c0":
+        c = 0
+    elif case == "c12":
+        c = 12
+    elif case == "ns_100":
+        ns, r = 100, 0.3
+    elif case == "dense_hits":
+        r = 0.6
+    elif case == "negative":
+        xyz = xyz - 1.0
+        xyz[1] *= -3.0
+    elif case == "aliasing":
+        xyz = synth.cloud_uniform(b, n, 30.0, seed=32)
+        xyz[:, ::2] *= 0.1
+    elif case == "clumps":
+        for q in range(6):
+            lo = 400 * q
+            xyz[:, lo:lo + 400] = g.random(3, dtype=np.float32) * 1.5 + \
+                g.random((b, 400, 3), dtype=np.float32) * 0.25
+    elif case == "ragged":
+        n, m, c, ns = 4099, 203, 3, 33
+        xyz = synth.cloud_uniform(b, n, 1.7, seed=33)
+    cen = xyz[:, g.permutation(n)[:m]].copy()
+    cen[:, -1] = 1000.0                                        # empty ball -> zero row
+    feats = g.standard_normal((b, c, n)).astype(np.float32) if c else None
+    want_idx = oracle_omp.ball_query(cen, xyz, r, ns)
+    gx = oracle_omp.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), want_idx)
+    gx = gx - cen.transpose(0, 2, 1)[..., None]
+    for normalize in (False, True):
+        idx, out = ext.query_and_group(dev(cen), dev(xyz), dev(feats) if c else None, r, ns,
+                                       normalize)
+        assert np.array_equal(idx.cpu().numpy(), want_idx), np.argwhere(idx.cpu().numpy() != want_idx)[:5]
+        out = out.cpu().numpy()
+        assert out.shape == (b, 3 + c, m, ns)
+        if c:
+            assert np.array_equal(bits(out[:, 3:]), bits(oracle_omp.group_points(feats, want_idx)))
+        ref_xyz = gx * (np.float32(1.0) / np.float32(r)) if normalize else gx
+        assert np.array_equal(bits(out[:, :3]), bits(ref_xyz.astype(np.float32)))
+    # and the fused result equals the unfused operators of the reference surface
+    idx2 = ext.ball_query(dev(cen), dev(xyz), r, ns)
+    assert torch.equal(idx2, idx)
+
+
 def test_lhs_nms_vs_reference_golden_and_oracle(oracle, synth):
     """Device pseudo-label NMS == the reference's numpy lhs_3d_faster_samecls (committed vectors)
     and == the oracle on a batch of crowded random scenes."""

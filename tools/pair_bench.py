@@ -1,10 +1,19 @@
-"""Run only the north-star kernel pair (ball_query + group_points xyz + group_points feat at
-B=8, N=40000, m=2048, nsample=64) a few times -- to be wrapped by rocprofv3 for PMC passes:
+"""The north-star kernel pair at B=8, N=40000, m=2048, nsample=64, r=0.2 -- alone.
 
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p1 -o pair -- python tools/pair_bench.py
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/p2 -o pair -- python tools/pair_bench.py
+Two forms of the same work (38 516 736 algorithmic bytes):
+  api   : ball_query + group_points(xyz, C=3) + group_points(feat, C=1), the three calls of the
+          reference's operator surface;
+  fused : query_and_group, the QueryAndGroup front end as the SA module runs it (cell-list build,
+          then ONE kernel that answers the queries and writes the (B, 4, m, ns) tensor).
+
+    python tools/pair_bench.py [iters] [--json out.json]        # events around HIP-graph replays
+    rocprofv3 --kernel-trace --stats ... -- python tools/pair_bench.py 20
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE ... -- python tools/pair_bench.py 5 --plain
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE ... -- python tools/pair_bench.py 5 --plain
+(--plain: eager launches only, no graph capture -- what the counter passes want.)
 """
 import importlib
+import json
 import os
 import sys
 
@@ -15,18 +24,64 @@ sys.path.insert(0, ROOT)
 importlib.import_module("3dioumatch_amd")
 ext = importlib.import_module("pointnet2._ext")
 synth = importlib.import_module("3dioumatch_amd.synth")
+import bench  # noqa: E402  (time_op: events around a HIP-graph replay)
 
-B, N = 8, 40000
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+iters = int(args[0]) if args else 20
+plain = "--plain" in sys.argv
+out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+
+B, N, M, NS, R = 8, 40000, 2048, 64, 0.2
 dev = torch.device("cuda:0")
-xyz = torch.from_numpy(synth.cloud_uniform(B, N, synth.cube_side(N, 0.2, 64), seed=1)).to(dev)
+xyz = torch.from_numpy(synth.cloud_uniform(B, N, synth.cube_side(N, R, NS), seed=1)).to(dev)
 flipped = xyz.transpose(1, 2).contiguous()
 feat = torch.rand(B, 1, N, device=dev)
-inds = ext.furthest_point_sampling(xyz, 2048)
+inds = ext.furthest_point_sampling(xyz, M)
 new_xyz = ext.gather_points(flipped, inds).transpose(1, 2).contiguous()
 torch.cuda.synchronize()
-for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
-    idx = ext.ball_query(new_xyz, xyz, 0.2, 64)
-    gx = ext.group_points(flipped, idx)
-    gf = ext.group_points(feat, idx)
-torch.cuda.synchronize()
-print("pair_bench done")
+
+
+def api():
+    idx = ext.ball_query(new_xyz, xyz, R, NS)
+    ext.group_points(flipped, idx)
+    ext.group_points(feat, idx)
+
+
+def fused():
+    ext.query_and_group(new_xyz, xyz, feat, R, NS, True)
+
+
+if plain:
+    for _ in range(iters):
+        api()
+        fused()
+    if "--ablate" in sys.argv:  # counter passes of the timing ablations (kernel names differ)
+        for a in ("1", "2"):
+            os.environ["PN2_GRID_ABLATE"] = a
+            for _ in range(iters):
+                fused()
+        os.environ.pop("PN2_GRID_ABLATE")
+    torch.cuda.synchronize()
+    print("pair_bench done (plain)")
+else:
+    res = {"shape": {"B": B, "N": N, "m": M, "nsample": NS, "radius": R},
+           "algorithmic_bytes": bench.PAIR_BYTES}
+    for name, fn in (("api", api), ("fused", fused)):
+        us = bench.time_op(fn, iters=iters, warm=3)
+        res[name + "_us"] = round(us, 2)
+        res[name + "_frac_of_8TBs"] = round(bench.PAIR_BYTES / (us * 1e-6) / 8e12, 4)
+    if "--sweep" in sys.argv:  # tuning switches / timing ablations of the cell-list kernels
+        sweep = {}
+        for a, what in (("1", "no_ordering_network"), ("2", "no_candidate_tests")):
+            os.environ["PN2_GRID_ABLATE"] = a
+            sweep["fused_%s_us" % what] = round(bench.time_op(fused, iters=iters, warm=2), 2)
+        os.environ.pop("PN2_GRID_ABLATE")
+        idx = ext.ball_query(new_xyz, xyz, R, NS)
+        sweep["ball_query_us"] = round(bench.time_op(lambda: ext.ball_query(new_xyz, xyz, R, NS), iters=iters), 2)
+        sweep["group_xyz_us"] = round(bench.time_op(lambda: ext.group_points(flipped, idx), iters=iters), 2)
+        sweep["group_feat_us"] = round(bench.time_op(lambda: ext.group_points(feat, idx), iters=iters), 2)
+        res["sweep"] = sweep
+    print(json.dumps(res))
+    if out_json:
+        with open(out_json, "w") as f:
+            json.dump(res, f, indent=1)
