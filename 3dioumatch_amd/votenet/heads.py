@@ -180,9 +180,27 @@ class GridConv(nn.Module):
         relative = whole - center.unsqueeze(2).expand(-1, -1, g3, -1).reshape(b, k * g3, 3)
 
         dist, idx = pointnet2_utils.three_nn(whole, origin_xyz)
-        weight = 1 / (dist + 1e-8)
-        weight = (weight / torch.sum(weight, dim=2, keepdim=True)).contiguous()
-        interp = pointnet2_utils.three_interpolate(origin_features, idx, weight)  # (B, C, K*64)
+        if torch.is_grad_enabled() and whole.requires_grad:
+            # Test-time IoU optimisation (train.py:431-492; VoteNet.forward(iou_opt=True) and
+            # forward_onlyiou_faster): d(iou_scores)/d(center, size, heading) also flows through
+            # the interpolation WEIGHTS.  three_nn's distances are non-differentiable and the
+            # fused interpolation has no weight gradient, so -- exactly like the reference
+            # (grid_conv_module.py:87-104) -- the distances are recomputed from the gathered
+            # seeds with tensor ops and the weighted sum is a tensor op too.
+            c = origin_features.shape[1]
+            flat = idx.view(b, -1, 1).long()
+            nbr = torch.gather(origin_xyz, 1, flat.expand(-1, -1, 3))          # (B, K*64*3, 3)
+            diff = nbr - whole.unsqueeze(2).expand(-1, -1, 3, -1).reshape(b, -1, 3)
+            dist = torch.sqrt(torch.sum(diff * diff, dim=2)).view(b, -1, 3)
+            weight = 1 / (dist + 1e-8)
+            weight = weight / torch.sum(weight, dim=2, keepdim=True)
+            picked = torch.gather(origin_features.transpose(1, 2), 1, flat.expand(-1, -1, c))
+            interp = torch.sum(picked.view(b, -1, 3, c) * weight.unsqueeze(-1), dim=2)
+            interp = interp.transpose(1, 2).contiguous()                       # (B, C, K*64)
+        else:
+            weight = 1 / (dist + 1e-8)
+            weight = (weight / torch.sum(weight, dim=2, keepdim=True)).contiguous()
+            interp = pointnet2_utils.three_interpolate(origin_features, idx, weight)  # (B, C, K*64)
         feats = torch.cat([relative.transpose(1, 2).reshape(b, 3, k, g3),
                            interp.view(b, -1, k, g3)], dim=1)
         iou_features = self.mlp_before_iou.forward_pooled(feats)

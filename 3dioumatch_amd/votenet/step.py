@@ -107,12 +107,17 @@ class SupervisedStep(object):
         G2  Adam on the flat parameter buffer
 
     Inputs are staged into static buffers (`next` while G0 runs, copied to `cur` for G1).  The
-    graphs bake in tensor shapes, the set of supervised samples and the BatchNorm momentum; a
-    change of any of them re-captures.  On the CPU (tests, gloo) the same functions run eagerly.
+    graphs bake in tensor shapes, the set of supervised samples (the contents of
+    `supervised_mask`, see _mask_facts) and the BatchNorm momentum; a change of any of them
+    re-captures.  On the CPU (tests, gloo) the same functions run eagerly.
     """
 
-    def __init__(self, cfg, device, world_size=1, num_proposal=256, lr=1e-3, seed=0, graphs=None):
+    def __init__(self, cfg, device, world_size=1, num_proposal=256, lr=1e-3, seed=0, graphs=None,
+                 graphs_fallback=False):
         self.cfg = cfg
+        # False: a failed HIP-graph capture raises.  True: it is reported on stderr and the
+        # runner continues with eager launches (`runner.graphs` tells which one is running).
+        self.graphs_fallback = bool(graphs_fallback)
         self.device = device
         self.world = world_size
         self.net = build_detector(cfg, num_proposal=num_proposal, seed=seed).to(device).train()
@@ -130,6 +135,7 @@ class SupervisedStep(object):
                                           capturable=on_gpu)
         self._side = None
         self._captured = None  # signature the graphs were captured for
+        self._mask_cache = (None, None)
         self._token = 0
         self.global_step = 0
 
@@ -248,8 +254,26 @@ class SupervisedStep(object):
         batch["_geometry_ready"] = done
 
     # ---------------------------------------------------------------- HIP graphs
+    def _mask_facts(self, batch):
+        """The CONTENTS of supervised_mask are host-side control flow baked into G1 (which samples
+        the labeled loss indexes, how many are labeled), so they are part of the capture
+        signature.  A loader should hand over a host copy (`supervised_mask_host`, any sequence of
+        0/1) next to the device tensor; otherwise the device tensor is read back -- once per
+        distinct (storage, version), so a resident mask costs one synchronisation in total."""
+        mask = batch.get("supervised_mask")
+        if mask is None:
+            return None
+        host = batch.get("supervised_mask_host")
+        if host is None:
+            key = (mask.data_ptr(), mask._version, tuple(mask.shape), str(mask.device))
+            if self._mask_cache[0] != key:
+                self._mask_cache = (key, tuple(int(v) for v in mask.detach().cpu().reshape(-1).tolist()))
+            host = self._mask_cache[1]
+        return tuple(int(v) != 0 for v in host)
+
     def _signature(self, batch):
-        return tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in _tensor_items(batch).items()))
+        shapes = tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in _tensor_items(batch).items()))
+        return shapes, self._mask_facts(batch)
 
     def _stage(self, slot, batch):
         src = _tensor_items(batch)
@@ -264,9 +288,11 @@ class SupervisedStep(object):
         try:
             self._capture(batch, sig)
             return True
-        except Exception as err:  # noqa: BLE001 -- keep training, but say so loudly
+        except Exception as err:  # noqa: BLE001
+            if not self.graphs_fallback:
+                raise  # a silent eager fallback would hide a broken capture (and a 1.6x slower step)
             sys.stderr.write("SupervisedStep: HIP graph capture failed (%s: %s); running the "
-                             "step eagerly\n" % (type(err).__name__, err))
+                             "step eagerly (graphs_fallback=True)\n" % (type(err).__name__, err))
             torch.cuda.synchronize(self.device)
             self.graphs = False
             self._captured = None
@@ -400,9 +426,10 @@ class SemiSupervisedStep(SupervisedStep):
     The teacher's parameters are a second flat buffer, so the EMA update is a single lerp."""
 
     def __init__(self, cfg, device, world_size=1, num_proposal=256, lr=2e-3, seed=0, graphs=None,
-                 unlabeled_loss_weight=2.0, ema_decay=0.999, dataset="scannet", config_dict=None):
+                 unlabeled_loss_weight=2.0, ema_decay=0.999, dataset="scannet", config_dict=None,
+                 graphs_fallback=False):
         super().__init__(cfg, device, world_size=world_size, num_proposal=num_proposal, lr=lr,
-                         seed=seed, graphs=graphs)
+                         seed=seed, graphs=graphs, graphs_fallback=graphs_fallback)
         from .losses_unlabeled import default_config_dict
         self.teacher = build_detector(cfg, num_proposal=num_proposal, seed=seed).to(device).train()
         for p in self.teacher.parameters():

@@ -10,8 +10,9 @@ pretrain.py:train_one_epoch body (pretrain.py:310-347) at BASELINE config 2:
     -> get_labeled_loss (incl. two (B*K)x(B*64) 3-D IoU matrices) -> backward -> Adam,
 B=8 scenes of 40 000 points (xyz + height), 256 proposals, fp32, random-init weights,
 synthetic scenes (no dataset, no checkpoint).  Inputs are resident in HBM before the timed
-region.  N > 1: one process per GPU, same per-GPU batch (weak scaling), DistributedDataParallel
-over RCCL with a single gradient bucket.
+region.  N > 1: one process per GPU, same per-GPU batch (weak scaling); the data-parallel
+exchange is ONE all_reduce of the flat 4.26 MB gradient buffer per step (RCCL by default,
+--backend gloo for a CPU-mediated run), between the backward graph and the Adam graph.
 
 The JSON line also carries
   roofline     -- the north-star kernel pair ball_query + group_points(xyz) + group_points(feat)
@@ -63,6 +64,8 @@ def parse():
                     help="pretrain = BASELINE configs[1] (the headline metric); semi = configs[3]: "
                          "stage-2 step, 4 labeled + 8 unlabeled scenes per GPU, EMA teacher; "
                          "sunrgbd = configs[2]: SUN RGB-D pretrain, 20000 pts, batch 16, oriented boxes")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="compute the FPS chain inline instead of one step ahead on a side stream")
     return ap.parse_args()
@@ -70,9 +73,11 @@ def parse():
 
 def build_step(V, cfg, device, world, local_rank, workload="pretrain"):
     if workload == "semi":
-        runner = V.SemiSupervisedStep(cfg, device, world_size=world, num_proposal=KPROP, lr=2e-3)
+        runner = V.SemiSupervisedStep(cfg, device, world_size=world, num_proposal=KPROP, lr=2e-3,
+                                      graphs_fallback=True)
     else:
-        runner = V.SupervisedStep(cfg, device, world_size=world, num_proposal=KPROP, lr=1e-3)
+        runner = V.SupervisedStep(cfg, device, world_size=world, num_proposal=KPROP, lr=1e-3,
+                                  graphs_fallback=True)  # reported as config.hip_graphs
 
     def step(batch):
         return runner(batch)[0]
@@ -198,7 +203,10 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device)
+        else:
+            torch.distributed.init_process_group("gloo")
     importlib.import_module("3dioumatch_amd")
     V = importlib.import_module("3dioumatch_amd.votenet")
     data = importlib.import_module("3dioumatch_amd.votenet.data")

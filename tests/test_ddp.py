@@ -159,3 +159,84 @@ def test_semi_supervised_ddp_two_ranks_gloo(tmp_path):
     assert np.array_equal(r0["teacher"], r1["teacher"])
     assert np.isfinite(r0["loss"]) and np.isfinite(r1["loss"]) and r0["loss"] != r1["loss"]
     assert r0["pseudo"] > 0 and r1["pseudo"] > 0
+
+
+# ------------------------------------------------------------ N > 1 WITH HIP graphs, on a GPU
+def _gpu_graph_worker(rank, world, port, out_dir, semi):
+    """Two processes share cuda:0 (backend gloo moves the flat gradient through the host): the
+    captured path of step.py -- G1 replay -> eager all-reduce -> G2 replay -- with world_size 2."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    load_pkg()
+    V = importlib.import_module("3dioumatch_amd.votenet")
+    step_mod = importlib.import_module("3dioumatch_amd.votenet.step")
+    cfg = V.scannet_config()
+
+    def batch(step):
+        if semi:
+            return V.make_semi_batch(1, 2, 4096, cfg, seed=300 + rank + 10 * step, num_objects=5,
+                                     device=dev)
+        data = importlib.import_module("3dioumatch_amd.votenet.data")
+        return data.make_batch(2, 4096, cfg, seed=200 + rank + 10 * step, num_objects=5, device=dev)
+
+    def make(graphs, w):
+        if semi:
+            unl = importlib.import_module("3dioumatch_amd.votenet.losses_unlabeled")
+            filt = unl.default_config_dict(cfg, unlabeled_batch_size=2)
+            filt.update(obj_threshold=0.3, cls_threshold=0.03, iou_threshold=0.2)
+            return V.SemiSupervisedStep(cfg, dev, world_size=w, num_proposal=K, graphs=graphs,
+                                        config_dict=filt)
+        return V.SupervisedStep(cfg, dev, world_size=w, num_proposal=K, graphs=graphs)
+
+    out = {}
+    for name, graphs in (("graph", True), ("eager", False)):
+        runner = make(graphs, world)
+        torch.manual_seed(100 + rank)
+        for s in range(3):
+            loss, _ = runner(batch(s))
+            if s == 0:
+                out[name + "_grad"] = runner.flat_grad.detach().cpu().numpy().copy()
+        assert bool(runner.graphs) == graphs, "graph capture fell back to eager"
+        out[name + "_params"] = runner.flat_params.detach().cpu().numpy().copy()
+        out[name + "_loss"] = float(loss)
+        if semi:
+            out[name + "_teacher"] = runner.flat_teacher.detach().cpu().numpy().copy()
+    # this rank's own gradient of step 0, computed without any exchange
+    single = make(False, 1)
+    torch.manual_seed(100 + rank)
+    single(batch(0))
+    out["single_grad"] = single.flat_grad.detach().cpu().numpy().copy()
+    np.savez(os.path.join(out_dir, "g%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("semi", [False, True], ids=["supervised", "semi"])
+def test_graph_step_two_ranks_share_one_gpu(tmp_path, semi):
+    """The HIP-graph N > 1 path: 3 steps, parameters bit-identical across
+    ranks, equal to the eager N > 1 path, and the exchanged gradient of step 0 equal to the mean
+    of the two single-process gradients."""
+    world = 2
+    port = 33500 + (os.getpid() % 2000) + (7 if semi else 0)
+    mp.spawn(_gpu_graph_worker, args=(world, port, str(tmp_path), semi), nprocs=world, join=True)
+    r = [np.load(tmp_path / ("g%d.npz" % i)) for i in range(world)]
+    for key in ("graph_params", "eager_params") + (("graph_teacher",) if semi else ()):
+        assert np.array_equal(r[0][key], r[1][key]), key
+    assert np.array_equal(r[0]["graph_grad"], r[1]["graph_grad"])
+    rel = lambda a, b: np.linalg.norm(a - b) / max(1e-12, np.linalg.norm(b))  # noqa: E731
+    # graph replay == eager launches: the exchanged gradient of step 0 (same weights) agrees to
+    # the reordering of atomic sums; after three Adam steps the weights agree to what Adam makes
+    # of that (the sign of a near-zero gradient is a full +-lr step: bounded, not tiny)
+    assert rel(r[0]["graph_grad"], r[0]["eager_grad"]) < 1e-4
+    lr = 2e-3 if semi else 1e-3
+    assert np.abs(r[0]["graph_params"] - r[0]["eager_params"]).max() <= 3 * 3 * lr
+    assert rel(r[0]["graph_params"], r[0]["eager_params"]) < 3e-3
+    want = (r[0]["single_grad"] + r[1]["single_grad"]) / 2
+    assert rel(r[0]["graph_grad"], want) < 1e-4, rel(r[0]["graph_grad"], want)
+    assert np.isfinite(r[0]["graph_loss"]) and r[0]["graph_loss"] != r[1]["graph_loss"]

@@ -111,4 +111,4 @@ def test_semi_graph_replay_matches_eager(oracle_omp, monkeypatch):
     # differ from run to run (scatter-add order); the bound is ~2x what those parameters can add
     assert float((eager[3] - graph[3]).norm() / eager[3].norm()) < 1.2e-2
     assert float((eager[4] - graph[4]).norm() / eager[4].norm()) < 1.2e-2
-    assert torch.allclose(eager[5], graph[5], rtol=1e-3, atol=1e-5)
+    assert torch.allclose(eager[5], graph[5], rtol=3e-3, atol=5e-5)  # teacher BN mean (second step sees EMA weights)

@@ -79,31 +79,53 @@ def test_supervised_step_matches_reference(use_gpu, tag, oracle_omp):
     for k in ("aggregated_vote_inds", "seed_inds"):
         assert np.array_equal(end_points[k].cpu().numpy(), g["%s_%s" % (tag, k)]), k
     rtol = 2e-3 if use_gpu else 2e-4
+    # Label flips.  The goldens were made on the CPU; on the GPU the fp32 contractions add in
+    # a different order (MFMA tiles), so a proposal whose vote sits on the 0.3 m / 0.6 m
+    # objectness thresholds, or whose two best GT boxes are equally far, can receive another
+    # label.  Those proposals are COUNTED and excluded; everything else is held tight.
+    flipped = np.zeros((B, K), dtype=bool)
     for k in ("objectness_label", "object_assignment"):
-        mismatch = (end_points[k].cpu().numpy() != g["%s_%s" % (tag, k)]).mean()
-        assert mismatch <= (0.02 if use_gpu else 0.0), (k, mismatch)
+        flipped |= end_points[k].cpu().numpy() != g["%s_%s" % (tag, k)]
+    n_flips = int(flipped.sum())
+    assert n_flips <= (0.03 * B * K if use_gpu else 0), ("label flips", n_flips)
     for k in ("center", "objectness_scores", "iou_scores"):
         want = g["%s_%s" % (tag, k)]
         got = end_points[k].detach().cpu().numpy()
         bad = np.abs(got - want) > rtol * max(1.0, np.abs(want).max())
-        # on the GPU the fp32 convolutions round differently from the CPU that made the goldens;
-        # a near-tied size/heading arg-max can flip for a few proposals and move their boxes
-        assert bad.mean() <= (0.03 if use_gpu else 0.0), (k, bad.mean())
+        bad = bad.reshape(B, K, -1).any(-1) & ~flipped
+        # (a near-tied size / heading arg-max can still move a box: at most 2 proposals)
+        assert bad.sum() <= (2 if use_gpu else 0), (k, int(bad.sum()), n_flips)
     for k in STAT_KEYS:
         want = float(g["%s_%s" % (tag, k)])
         got = float(end_points[k])
-        assert abs(got - want) <= (20 if use_gpu else 5) * rtol * max(1.0, abs(want)), (k, got, want)
+        # statistics are means over all proposals: each flip moves them by O(1 / (B K))
+        bound = (5 * rtol + (2.0 * n_flips) / (B * K)) * max(1.0, abs(want))
+        assert abs(got - want) <= bound, (k, got, want, n_flips)
     grads = dict(net.named_parameters())
+    # Gradients.  CPU leg: against the float32 golden, 2e-3.  GPU leg: against the FLOAT64
+    # evaluation of the same reference step (train_step_ref_f64.npz, same indices and labels).
+    # Several first-layer weight gradients are sums with heavy cancellation: the float32 CPU golden
+    # itself is 1.2e-2 (sa1 layer0) and 6.9e-2 (grid_conv layer0) away from the float64 value, so
+    # the bound on the GPU result is 2x the CPU golden's own float32 error + 5e-3 -- tight (a few
+    # 1e-3) where the sum is well conditioned, and never looser than what float32 can resolve.
+    # A flipped label re-routes a whole proposal's loss terms: 5e-2 more per flip.
+    g64 = golden("train_step_ref_f64.npz")
+    rel = lambda a, b: np.linalg.norm(a - b) / max(1e-12, np.linalg.norm(b))  # noqa: E731
     for key in g.files:
         if key.startswith(tag + "_grad::"):
             name = key.split("::", 1)[1]
             got = grads[name].grad.detach().cpu().numpy()
             got = got.reshape(got.shape[0], -1)[::4, ::4]
-            want = g[key]
-            err = np.linalg.norm(got - want) / max(1e-12, np.linalg.norm(want))
-            assert err <= (0.15 if use_gpu else 2e-3), (name, err)
+            if use_gpu:
+                truth = g64["%s_grad64::%s" % (tag, name)]
+                bound = 5e-3 + 2 * rel(g[key], truth) + 5e-2 * n_flips
+                assert rel(got, truth) <= bound, (name, rel(got, truth), bound, n_flips)
+            else:
+                assert rel(got, g[key]) <= 2e-3, (name, rel(got, g[key]))
     gn = float(torch.sqrt(sum((p.grad ** 2).sum() for p in net.parameters() if p.grad is not None)))
-    assert abs(gn - float(g[tag + "_gradnorm"])) <= (0.15 if use_gpu else 2e-3) * float(g[tag + "_gradnorm"])
+    want_gn = float(g64[tag + "_gradnorm64"]) if use_gpu else float(g[tag + "_gradnorm"])
+    assert abs(gn - want_gn) <= ((5e-3 + 5e-2 * n_flips) if use_gpu else 2e-3) * want_gn, (gn, want_gn)
+    print("train-step parity [%s, %s]: %d label flips of %d" % (tag, dev, n_flips, B * K))
 
 
 def test_state_dict_is_interchangeable_with_reference_layout():
@@ -276,3 +298,44 @@ def test_graph_recapture_on_shape_or_schedule_change(oracle_omp):
 
 def step_params(runner):
     return importlib.import_module("3dioumatch_amd.votenet.step").flat_params(runner.net).clone()
+
+
+# ------------------------------------------------------------------ IoU labels vs the reference
+@pytest.mark.parametrize("tag", ["scannet", "sunrgbd"])
+@pytest.mark.parametrize("use_gpu", [pytest.param(False, id="cpu-hostlogic"),
+                                     pytest.param(True, id="gpu-hip", marks=pytest.mark.gpu)])
+def test_iou_labels_match_reference(use_gpu, tag, oracle_omp):
+    """compute_iou_labels (votenet/losses.py) against the REFERENCE's function
+    (models/loss_helper_iou.py:52-112) run on the same seeded predictions / labels
+    (tests/golden/iou_labels_ref.npz, made by make_iou_labels_golden.py): the (B,K) IoU labels per
+    element, the objectness labels, the GT assignment, the decoded boxes, and the reverse
+    (GT x prediction) matrix.  CPU: the mirror's host logic with the oracle's IoU -> identical
+    numbers.  GPU: the per-scene IoU kernel -> 1e-4 per element (north_star tolerance), the
+    assignment identical wherever the best IoU is not (numerically) tied."""
+    V, dev = _setup(use_gpu, oracle_omp)
+    losses = importlib.import_module("3dioumatch_amd.votenet.losses")
+    g = golden("iou_labels_ref.npz")
+    cfg = V.scannet_config() if tag == "scannet" else V.sunrgbd_config()
+    get = lambda k: torch.from_numpy(g["%s_in::%s" % (tag, k)]).to(dev)  # noqa: E731
+    ep = {k: get(k) for k in ("center_label", "box_label_mask", "heading_class_label",
+                              "heading_residual_label", "size_class_label", "size_residual_label")}
+    args = [get(k) for k in ("pred_votes", "pred_center", "pred_sem_cls", "pred_objectness",
+                             "pred_heading_scores", "pred_heading_residuals", "pred_size_scores",
+                             "pred_size_residuals")]
+    inds = torch.arange(ep["center_label"].shape[0], device=dev)
+    iou, objl, assign = losses.compute_iou_labels(dict(ep), inds, *args, {"dataset_config": cfg})
+    ep2 = dict(ep)
+    losses.compute_iou_labels(ep2, inds, *args, {"dataset_config": cfg})
+    want_iou = g[tag + "_iou_labels"]
+    tol = 1e-4 if use_gpu else 1e-7
+    np.testing.assert_allclose(ep2["pred_bbox"].cpu().numpy(), g[tag + "_pred_bbox"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(iou.cpu().numpy(), want_iou, rtol=0, atol=tol)
+    assert np.array_equal(objl.cpu().numpy(), g[tag + "_objectness_label"])
+    got_assign, want_assign = assign.cpu().numpy(), g[tag + "_object_assignment"]
+    differs = got_assign != want_assign
+    if not use_gpu:
+        assert not differs.any()
+    else:  # a different winner is only acceptable between numerically tied candidates
+        assert np.all(want_iou[differs] <= 1e-4), (want_iou[differs], got_assign[differs])
+    rev = losses.compute_iou_labels(dict(ep), inds, *args, {"dataset_config": cfg}, reverse=True)
+    np.testing.assert_allclose(rev.cpu().numpy(), g[tag + "_reverse"], rtol=0, atol=tol)
