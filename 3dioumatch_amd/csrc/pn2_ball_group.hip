@@ -230,6 +230,40 @@ group_points_grad_lds_kernel(int c, int n, int mns, const float *__restrict__ gr
   for (int t = threadIdx.x; t < nc * n; t += 1024) dst[t] = acc[t];
 }
 
+// The same with ONE destination row in the CU's whole LDS (n <= 40960 floats = 160 KB): SA1-sized
+// clouds, where the global-atomic kernel ran at 135 GB/s (every add a memory-side atomic) and
+// needed a zero-fill pass.  A row's indices are re-read by each of its channels' workgroups
+// (an L2 hit on the cloud's XCD).
+template <bool VEC>
+__global__ void __launch_bounds__(1024)
+group_points_grad_lds_big_kernel(int c, int n, int mns, const float *__restrict__ grad_out,
+                                 const int *__restrict__ idx, float *__restrict__ grad_points) {
+  __shared__ float acc[40960];
+  const BlockId blk = xcd_block_id();
+  const int b = blk.y, l = blk.x;
+  for (int t = threadIdx.x; t < n; t += 1024) acc[t] = 0.f;
+  __syncthreads();
+  const int *ib = idx + (size_t)b * mns;
+  const float *g = grad_out + ((size_t)b * c + l) * mns;
+  if (VEC) {
+    for (int e = threadIdx.x * 4; e < mns; e += 1024 * 4) {
+      const int4 i = *reinterpret_cast<const int4 *>(ib + e);
+      const float4 v = *reinterpret_cast<const float4 *>(g + e);
+      // first-hit padding repeats one index many times in a row: merge equal neighbours
+      float a1 = v.y, a2 = v.z, a3 = v.w;
+      if (i.y == i.x) { a1 = __fadd_rn(v.x, a1); } else { atomicAdd(acc + i.x, v.x); }
+      if (i.z == i.y) { a2 = __fadd_rn(a1, a2); } else { atomicAdd(acc + i.y, a1); }
+      if (i.w == i.z) { a3 = __fadd_rn(a2, a3); } else { atomicAdd(acc + i.z, a2); }
+      atomicAdd(acc + i.w, a3);
+    }
+  } else {
+    for (int e = threadIdx.x; e < mns; e += 1024) atomicAdd(acc + ib[e], g[e]);
+  }
+  __syncthreads();
+  float *dst = grad_points + ((size_t)b * c + l) * n;
+  for (int t = threadIdx.x; t < n; t += 1024) dst[t] = acc[t];
+}
+
 // Fused tail of QueryAndGroup (pointnet2_utils.py:348-358): given idx, write the
 // (b, 3+c, m, ns) tensor: channels 0..2 = xyz[idx] - centroid (optionally * 1/radius),
 // channels 3.. = features[idx].
@@ -425,6 +459,16 @@ PN2_API int pn2_group_points_grad(int b, int c, int n, int npoints, int nsample,
       case 2: launch_grad_lds<2>(b, c, n, mns, grad_out, idx, grad_points, stream); break;
       default: launch_grad_lds<1>(b, c, n, mns, grad_out, idx, grad_points, stream);
     }
+    return pn2_launch_status();
+  }
+  if (mns > 0 && n <= kGroupLdsFloats && c <= 65535) {  // one row per workgroup, 160 KB of LDS
+    const dim3 grid(c, b);
+    if (mns % 4 == 0)
+      hipLaunchKernelGGL(group_points_grad_lds_big_kernel<true>, grid, dim3(1024), 0, stream, c, n,
+                         (int)mns, grad_out, idx, grad_points);
+    else
+      hipLaunchKernelGGL(group_points_grad_lds_big_kernel<false>, grid, dim3(1024), 0, stream, c, n,
+                         (int)mns, grad_out, idx, grad_points);
     return pn2_launch_status();
   }
   const int e = pn2_zero_async(grad_points, sizeof(float) * (size_t)b * c * n, stream);

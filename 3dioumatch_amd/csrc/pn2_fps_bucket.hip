@@ -180,13 +180,21 @@ fps_bucket_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
   }
 
   // ---- P4: per-bucket state ---------------------------------------------------------------
+  // bucket jj of the wave <-> metadata set jj / 64 of lane jj % 64 (one set up to 4096 points
+  // per wave, two sets beyond: 65 536 < N <= 81 920)
+  constexpr int META = (NBW + kWave - 1) / kWave;
   const float4 *wave_base = sp + w * kWave;          // bucket (w + 16 jj) starts 16 KiB * jj later
   const unsigned lane_off = (unsigned)lane * (unsigned)sizeof(float4);
   float td[NBW];                       // running distance of MY point of bucket jj
-  float blx = 0.f, bly = 0.f, blz = 0.f, bhx = 0.f, bhy = 0.f, bhz = 0.f;  // bucket `lane`
-  float bval = -2.0f, bx = 0.f, by = 0.f, bz = 0.f;
-  int bidx = 0;
+  float blx[META], bly[META], blz[META], bhx[META], bhy[META], bhz[META];  // bucket `lane` of set s
+  float bval[META], bx[META], by[META], bz[META];
+  int bidx[META];
 #pragma unroll
+  for (int s = 0; s < META; ++s) {
+    blx[s] = bly[s] = blz[s] = bhx[s] = bhy[s] = bhz[s] = 0.f;
+    bval[s] = -2.0f; bx[s] = by[s] = bz[s] = 0.f; bidx[s] = 0;
+  }
+#pragma clang loop unroll(full)
   for (int jj = 0; jj < NBW; ++jj) {
     const int bid = w + kWaves * jj;
     td[jj] = -1.0f;
@@ -197,9 +205,10 @@ fps_bucket_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
       const float lx = wave_min_f32(real ? q.x : 3.0e38f), hx = wave_max_f32(real ? q.x : -3.0e38f);
       const float ly = wave_min_f32(real ? q.y : 3.0e38f), hy = wave_max_f32(real ? q.y : -3.0e38f);
       const float lz = wave_min_f32(real ? q.z : 3.0e38f), hz = wave_max_f32(real ? q.z : -3.0e38f);
-      if (lane == jj) {
-        blx = lx; bly = ly; blz = lz; bhx = hx; bhy = hy; bhz = hz;
-        bval = 1e10f;  // forces the first round to visit the bucket
+      if (lane == jj % kWave) {
+        blx[jj / kWave] = lx; bly[jj / kWave] = ly; blz[jj / kWave] = lz;
+        bhx[jj / kWave] = hx; bhy[jj / kWave] = hy; bhz[jj / kWave] = hz;
+        bval[jj / kWave] = 1e10f;  // forces the first round to visit the bucket
       }
     }
   }
@@ -207,14 +216,17 @@ fps_bucket_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
   // ---- rounds -----------------------------------------------------------------------------
   float x1 = pts[0], y1 = pts[1], z1 = pts[2];
   for (int j = 1; j < m; ++j) {
-    // (1) which of my wave's buckets can change?  lane jj answers for bucket jj
-    const float lb = box_dist2(x1, y1, z1, blx, bly, blz, bhx, bhy, bhz);
-    const bool touch = bval > -2.0f && lb * 0.999999f < bval;
-    const unsigned long long visit = __ballot(touch);
-    // (2) update the selected buckets
+    // (1) which of my wave's buckets can change?  lane jj % 64 answers for bucket jj
+    unsigned long long visit[META];
 #pragma unroll
+    for (int s = 0; s < META; ++s) {
+      const float lb = box_dist2(x1, y1, z1, blx[s], bly[s], blz[s], bhx[s], bhy[s], bhz[s]);
+      visit[s] = __ballot(bval[s] > -2.0f && lb * 0.999999f < bval[s]);
+    }
+    // (2) update the selected buckets
+#pragma clang loop unroll(full)
     for (int jj = 0; jj < NBW; ++jj) {
-      if ((visit >> jj) & 1ull) {  // wave-uniform
+      if ((visit[jj / kWave] >> (jj % kWave)) & 1ull) {  // wave-uniform
         const float4 q = load_bucket(wave_base, jj, lane_off);
         const float d = sqdist3(q.x, q.y, q.z, x1, y1, z1);
         const float d2 = fminf(d, td[jj]);
@@ -226,11 +238,23 @@ fps_bucket_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
         const float vx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.x), win));
         const float vy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.y), win));
         const float vz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.z), win));
-        if (lane == jj) { bval = v; bidx = vi; bx = vx; by = vy; bz = vz; }
+        if (lane == jj % kWave) {
+          bval[jj / kWave] = v; bidx[jj / kWave] = vi;
+          bx[jj / kWave] = vx; by[jj / kWave] = vy; bz[jj / kWave] = vz;
+        }
       }
     }
-    // (3) best bucket of the wave, then of the workgroup
-    const FpsPick p = fps_block_pick<kWaves>(bval, bidx, bx, by, bz, slots[j & 1], log2bs);
+    // (3) best bucket of the lane's sets (value, then the reference's tie order), of the wave,
+    //     then of the workgroup
+    float cv = bval[0], cx = bx[0], cy = by[0], cz = bz[0];
+    int ci = bidx[0];
+#pragma unroll
+    for (int s = 1; s < META; ++s) {
+      const bool better = bval[s] > cv ||
+                          (bval[s] == cv && fps_key(bidx[s], log2bs) < fps_key(ci, log2bs));
+      if (better) { cv = bval[s]; ci = bidx[s]; cx = bx[s]; cy = by[s]; cz = bz[s]; }
+    }
+    const FpsPick p = fps_block_pick<kWaves>(cv, ci, cx, cy, cz, slots[j & 1], log2bs);
     if (p.idx == 0) { x1 = pts[0]; y1 = pts[1]; z1 = pts[2]; } else { x1 = p.x; y1 = p.y; z1 = p.z; }
     if (tid == 0) out[j] = p.idx;
   }
@@ -238,8 +262,9 @@ fps_bucket_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
 
 }  // namespace
 
-// largest cloud the bucketed tier accepts: 16 waves x 64 buckets x 64 points
-constexpr int kBucketMaxPoints = kThreads * 64;
+// largest cloud the bucketed tier accepts: 16 waves x 80 buckets x 64 points (the running
+// distances are one VGPR per owned point: 80 of the 128 a 1024-lane workgroup may use)
+constexpr int kBucketMaxPoints = kThreads * 80;
 
 size_t pn2_fps_bucket_scratch_bytes(int b, int n) {
   if (n > kBucketMaxPoints) return 0;
@@ -267,7 +292,9 @@ int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, vo
   else if (nbw <= 40) FPS_BUCKET(40);
   else if (nbw <= 48) FPS_BUCKET(48);
   else if (nbw <= 56) FPS_BUCKET(56);
-  else FPS_BUCKET(64);
+  else if (nbw <= 64) FPS_BUCKET(64);
+  else if (nbw <= 72) FPS_BUCKET(72);
+  else FPS_BUCKET(80);
 #undef FPS_BUCKET
   *handled = 1;
   return pn2_launch_status();

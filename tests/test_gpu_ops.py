@@ -187,6 +187,56 @@ def test_north_star_pair_config2_properties(ext, synth):
     assert torch.equal(grouped, want)
 
 
+def test_stress_config5_sa1_front_end(ext, oracle_omp, synth):
+    """BASELINE configs[4] (stress): B=32, N=80000, nsample=128, the SA1 front end end to end at
+    full size -- FPS on the bucketed tier (two metadata sets per lane beyond 65 536 points),
+    ball query + gathers on the cell-list tier with 64 < nsample <= 128.  FPS and the ball query
+    of two clouds against the oracle; sampled rows of all clouds against a direct numpy scan;
+    the fused grouped tensor against torch.gather of the same indices."""
+    b, n, m, r, ns = 32, 80000, 2048, 0.2, 128
+    xyz = synth.cloud_uniform(b, n, synth.cube_side(n, r, ns), seed=5)
+    d_xyz = dev(xyz)
+    fps = ext.furthest_point_sampling(d_xyz, m)
+    got_fps = fps.cpu().numpy()
+    assert np.array_equal(got_fps[:2], oracle_omp.furthest_point_sampling(xyz[:2], m))
+    assert np.all(got_fps[:, 0] == 0) and all(len(np.unique(row)) == m for row in got_fps)
+    flipped = d_xyz.transpose(1, 2).contiguous()
+    new_xyz = ext.gather_points(flipped, fps).transpose(1, 2).contiguous()
+    feat = torch.rand(b, 1, n, device=DEV)
+    idx, grouped = ext.query_and_group(new_xyz, d_xyz, feat, r, ns, True)
+    idx_np, cen = idx.cpu().numpy(), new_xyz.cpu().numpy()
+    assert np.array_equal(idx_np[:2], oracle_omp.ball_query(cen[:2], xyz[:2], r, ns))
+    r2 = np.float32(r) * np.float32(r)
+    rng = np.random.default_rng(1)
+    for bi, j in zip(rng.integers(0, b, 150), rng.integers(0, m, 150)):
+        d = cen[bi, j] - xyz[bi]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        hits = np.nonzero(d2 < r2)[0][:ns]
+        want = np.full(ns, hits[0])
+        want[:len(hits)] = hits
+        assert np.array_equal(idx_np[bi, j], want)
+    assert torch.equal(ext.ball_query(new_xyz, d_xyz, r, ns), idx)
+    both = torch.cat([flipped, feat], dim=1)
+    want = torch.gather(both.unsqueeze(2).expand(b, 4, m, n), 3,
+                        idx.long().unsqueeze(1).expand(b, 4, m, ns))
+    want[:, :3] = (want[:, :3] - new_xyz.transpose(1, 2).unsqueeze(-1)) * (np.float32(1.0) / np.float32(r))
+    assert torch.equal(grouped, want)
+    # the reference-surface operators on the same indices (group_points falls back from the
+    # LDS-staged tier: a channel row of 80 000 floats does not fit 160 KB)
+    assert torch.equal(ext.group_points(feat, idx), want[:, 3:])
+    g = ext.group_points_grad(torch.ones(b, 1, m, ns, device=DEV), idx, n)
+    assert abs(float(g.sum()) - b * m * ns) < 1e-3 * b * m * ns
+
+
+def test_stress_config5_iou_matrix_and_nms(oracle_omp, synth):
+    """BASELINE configs[4]: the 1024 x 1024 oriented 3-D IoU matrix against the oracle (1e-4)."""
+    load = __import__("importlib").import_module
+    ut = load("pcdet.ops.iou3d_nms.iou3d_nms_utils")
+    a, bb = synth.boxes_pair(1024, seed=11)
+    got = ut.boxes_iou3d_gpu(dev(a), dev(bb)).cpu().numpy()
+    np.testing.assert_allclose(got, oracle_omp.boxes_iou3d(a, bb), rtol=0, atol=1e-4)
+
+
 # ------------------------------------------------------------------------------ three_nn etc.
 def test_interp_golden(ext):
     g = golden("ops_interp.npz")

@@ -42,11 +42,15 @@ def main():
     t["group_xyz"] = bench.time_op(lambda: ext.group_points(xyz_t, idx), iters=10, warm=2)
     feat = torch.randn(B, 1, N, device=dev)
     t["group_feat_c1"] = bench.time_op(lambda: ext.group_points(feat, idx), iters=10, warm=2)
+    t["query_and_group_fused"] = bench.time_op(
+        lambda: ext.query_and_group(new_xyz, xyz, feat, 0.2, NS, True), iters=5, warm=1)
     pair_bytes = 12 * B * N + 12 * B * M + 4 * B * M * NS + 2 * 4 * B * M * NS \
         + 4 * B * 3 * N + 4 * B * 3 * M * NS + 4 * B * N + 4 * B * M * NS
     pair_us = t["ball_query_ns128"] + t["group_xyz"] + t["group_feat_c1"]
     out["pair"] = {"algorithmic_bytes": pair_bytes, "us": round(pair_us, 1),
-                   "GBps": round(pair_bytes / pair_us / 1e3, 1)}
+                   "GBps": round(pair_bytes / pair_us / 1e3, 1),
+                   "fused_us": round(t["query_and_group_fused"], 1),
+                   "fused_GBps": round(pair_bytes / t["query_and_group_fused"] / 1e3, 1)}
     a, b = synth.boxes_pair(K, seed=3)
     a_d, b_d = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
     t["iou3d_1024x1024"] = bench.time_op(lambda: ut.boxes_iou3d_gpu(a_d, b_d), iters=10, warm=2)
