@@ -29,6 +29,14 @@ _SIGNATURES = {
                             _vp, _vp, _vp, _vp, _sz, _vp],
     "pn2_group_concat": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _vp, _vp,
                          _vp, _vp, _vp, _vp],
+    "pn2_grid_bytes": [_c_int, _c_int],
+    "pn2_grid_build": [_c_int, _c_int, _c_float, _vp, _vp, _sz, _vp],
+    "pn2_ball_query_prebuilt": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp, _sz, _vp],
+    "pn2_query_and_group_prebuilt": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _vp,
+                                     _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "pn2_fps_grid_supported": [_c_int],
+    "pn2_furthest_point_sampling_grid": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _sz, _c_float, _vp,
+                                         _sz, _vp],
     "pn2_error_string": [_c_int],
     "mlp_bn_workspace_floats": [_c_int, _c_int, _c_int],
     "mlp_bn_train_stats": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _c_float, _c_float, _vp, _vp, _vp,
@@ -73,7 +81,7 @@ _SIGNATURES = {
     "iou3d_nms": [_vp, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp],
     "iou3d_boxes_iou_bev_cpu": [_c_int, _vp, _c_int, _vp, _vp],
 }
-_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_fps_workspace_bytes": _sz, "mlp_bn_workspace_floats": _sz, "mlp_gemm_wgrad_workspace_floats": _sz, "pn2_error_string": ctypes.c_char_p}
+_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_grid_bytes": _sz, "pn2_fps_workspace_bytes": _sz, "mlp_bn_workspace_floats": _sz, "mlp_gemm_wgrad_workspace_floats": _sz, "pn2_error_string": ctypes.c_char_p}
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -230,6 +230,170 @@ gemm_nn_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int
     }
 }
 
+// ---- pipelined variant -------------------------------------------------------------------------
+// Same tiles and operand transforms as gemm_nn_kernel, different inner machinery (the first
+// kernel kept its matrix pipes 50-63 % busy: two barriers per 16-deep K chunk with the LDS stores
+// between them, and an A tile fetched as eight bounds-checked single dwords per lane):
+//   * LDS is double buffered: chunk i+1 is stored while chunk i is being multiplied -- ONE
+//     barrier per chunk, and the stores sit in the middle of the MFMA stream;
+//   * the A tile (weights) is fetched as 16-byte pieces with one row predicate each (two per lane
+//     and chunk), or -- rows that are not 16-byte aligned, K = 131 / 259 -- as range-checked
+//     BUFFER dwords (hardware bounds check instead of per-element exec masks); only the last,
+//     partial K chunk takes the masked dword path;
+//   * the loads of chunk i+2 are issued right after chunk i+1 left the registers.
+// Requires r % TN == 0 and r % 4 == 0 (every shape of the network); other shapes use the kernel
+// above.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+// A_VEC: the rows of A are 16-byte aligned (lda % 4 == 0 and an aligned base)
+template <int TM, int TN, int WM, int WN, int MODE, bool A_TRANS, bool A_VEC>
+__global__ void __launch_bounds__(256, (MODE <= OP_BNRELU && TM <= 128) ? 4 : 2)
+gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int lda,
+                unsigned a_bytes, OperandB opb, float *__restrict__ c, size_t b_stride_in,
+                size_t b_stride_out) {
+  constexpr int MB = TM / WM / 32, NB = TN / WN / 32;
+  constexpr int LDA = TM + 4;       // [k][m] rows; 16-byte aligned rows, conflict-free fragments
+  constexpr int AV = TM * KC / 4 / 256;  // 16-byte A pieces per lane and chunk
+  constexpr int SEG = TN / 16;      // B elements per lane: 16 lanes share one row
+  static_assert(AV >= 1 && SEG % 4 == 0, "tile too small for the vector paths");
+  __shared__ __attribute__((aligned(16))) float As[2][KC * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][KC * TN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r0 = blockIdx.x * TN, m0 = blockIdx.y * TM, b = blockIdx.z;
+  OperandB op = opb;
+  const size_t in_off = (size_t)b * b_stride_in;
+  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(a, a_bytes);
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  // A piece e of a lane: !A_TRANS: row mm, four consecutive k;  A_TRANS: k row kk, four
+  // consecutive m (the weight as stored, coalesced either way)
+  float4 areg[AV];
+  const int bkk = tid >> 4, bnn = (tid & 15) * SEG;
+  float bx[SEG], bdz[SEG];
+  RowCoef rc;
+  auto fetch = [&](int k0) {
+    if (k0 + KC <= k_total) {  // full chunk: range-checked 16-byte loads, no exec masks
+#pragma unroll
+      for (int e = 0; e < AV; ++e) {
+        const int t = tid + e * 256;
+        unsigned off;
+        if (A_TRANS) off = (unsigned)((k0 + t / (TM / 4)) * lda + m0 + (t % (TM / 4)) * 4);
+        else off = (unsigned)((m0 + t / (KC / 4)) * lda + k0 + (t % (KC / 4)) * 4);
+        if (A_VEC) {  // 16-byte aligned rows: one load, one row predicate
+          const int gm = m0 + (A_TRANS ? (t % (TM / 4)) * 4 : t / (KC / 4));
+          areg[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (gm < m_total) areg[e] = *reinterpret_cast<const float4 *>(a + off);
+        } else {  // rows that are not 16-byte aligned (K = 131, 259): four range-checked dwords
+          const unsigned s = A_TRANS ? 4u : 4u;
+          const unsigned v0 = __builtin_amdgcn_raw_buffer_load_b32(rsrc_a, off * 4u, 0, 0);
+          const unsigned v1 = __builtin_amdgcn_raw_buffer_load_b32(rsrc_a, off * 4u + s, 0, 0);
+          const unsigned v2 = __builtin_amdgcn_raw_buffer_load_b32(rsrc_a, off * 4u + 2 * s, 0, 0);
+          const unsigned v3 = __builtin_amdgcn_raw_buffer_load_b32(rsrc_a, off * 4u + 3 * s, 0, 0);
+          areg[e] = make_float4(__builtin_bit_cast(float, v0), __builtin_bit_cast(float, v1),
+                                __builtin_bit_cast(float, v2), __builtin_bit_cast(float, v3));
+        }
+      }
+    } else {  // K tail: per-element masks
+#pragma unroll
+      for (int e = 0; e < AV; ++e) {
+        const int t = tid + e * 256;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int gk = k0 + (A_TRANS ? t / (TM / 4) : (t % (KC / 4)) * 4 + q);
+          const int gm = m0 + (A_TRANS ? (t % (TM / 4)) * 4 + q : t / (KC / 4));
+          const size_t at = A_TRANS ? (size_t)gk * lda + gm : (size_t)gm * lda + gk;
+          v[q] = (gm < m_total && gk < k_total) ? a[at] : 0.f;
+        }
+        areg[e] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    const int gk = k0 + bkk;
+    const bool row_ok = gk < k_total;
+    // rows beyond K: zero coefficients AND zero data -> the staged operand is exactly zero
+    rc = load_row_coef<MODE>(op, gk, row_ok);
+    if (!row_ok) { rc.sc = 0.f; rc.sh = 0.f; rc.a = 0.f; }
+    load_raw_segment<MODE, SEG>(op, in_off + (size_t)gk * r + r0 + bnn, r0 + bnn, r, true, row_ok,
+                                bx, bdz, b * k_total + gk);
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < AV; ++e) {
+      const int t = tid + e * 256;
+      if (A_TRANS) {
+        *reinterpret_cast<float4 *>(&As[buf][(t / (TM / 4)) * LDA + (t % (TM / 4)) * 4]) = areg[e];
+      } else {
+        float *dst = &As[buf][((t % (KC / 4)) * 4) * LDA + t / (KC / 4)];
+        dst[0] = areg[e].x; dst[LDA] = areg[e].y; dst[2 * LDA] = areg[e].z; dst[3 * LDA] = areg[e].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < SEG; i += 4) {
+      float4 v;
+      v.x = transform<MODE>(bx[i + 0], bdz[i + 0], rc);
+      v.y = transform<MODE>(bx[i + 1], bdz[i + 1], rc);
+      v.z = transform<MODE>(bx[i + 2], bdz[i + 2], rc);
+      v.w = transform<MODE>(bx[i + 3], bdz[i + 3], rc);
+      *reinterpret_cast<float4 *>(&Bs[buf][bkk * TN + bnn + i]) = v;
+    }
+  };
+  auto multiply = [&](int buf, int kk_lo, int kk_hi) {
+#pragma unroll
+    for (int kk = kk_lo; kk < kk_hi; kk += 2) {
+      const int krow = kk + (lane >> 5);
+      float af[MB], bf[NB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) af[i] = As[buf][krow * LDA + (wm * MB + i) * 32 + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bf[j] = Bs[buf][krow * TN + (wn * NB + j) * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int chunks = (k_total + KC - 1) / KC;
+  fetch(0);
+  stash(0);
+  if (chunks > 1) fetch(KC);
+  __syncthreads();
+  for (int i = 0; i < chunks; ++i) {
+    const int cur = i & 1;
+    multiply(cur, 0, KC / 2);
+    if (i + 1 < chunks) stash(cur ^ 1);            // chunk i+1: registers -> the other buffer
+    if (i + 2 < chunks) fetch((i + 2) * KC);       // chunk i+2: in flight during the MFMAs
+    multiply(cur, KC / 2, KC);
+    __syncthreads();  // buffer cur is free again, buffer cur^1 is complete
+  }
+  // C/D layout of the 32x32 block: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
+  float *cb = c + (size_t)b * b_stride_out;
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int col = r0 + (wn * NB + j) * 32 + (lane & 31);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = m0 + (wm * MB + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (row < m_total) cb[(size_t)row * r + col] = acc[i][j][q];
+      }
+    }
+}
+
 // Small-problem variant of gemm_nn_kernel (R of a few hundred columns per cloud: the FP layers
 // and the vote / proposal / IoU heads).  There the K loop of the big kernel is a chain of
 // K/16 exposed load latencies with about one workgroup per CU.  Here a workgroup owns a 64 x 64
@@ -529,20 +693,41 @@ int launch_nn(int b, int m, int k, int r, const float *a, int lda, const Operand
     return pn2_launch_status();
   }
   // rows are covered by 256-row tiles, then one smaller tile for the remainder
+  const char *v2env = getenv("MLP_GEMM_PIPELINED");
+  const bool pipelined = !(v2env && atoi(v2env) == 0) && (r % 256 == 0);
+  const size_t a_total = A_TRANS ? (size_t)k * lda : (size_t)m * lda;  // floats from `a` on
   int done = 0;
   while (done < m) {
     const int left = m - done;
     const float *a_t = A_TRANS ? a + done : a + (size_t)done * lda;
+    const unsigned a_bytes = (unsigned)(4 * (A_TRANS ? a_total - done : a_total - (size_t)done * lda));
     float *c_t = c + (size_t)done * r;
+    const bool a_vec = (lda & 3) == 0 && (reinterpret_cast<size_t>(a_t) & 15) == 0;
 #define NN(TM, TN, WM, WN)                                                                      \
-  hipLaunchKernelGGL((gemm_nn_kernel<TM, TN, WM, WN, MODE, A_TRANS>),                                    \
-                     dim3(pn2_ceil_div(r, TN), 1, b), dim3(256), 0, stream, rows, k, r, a_t, lda, \
-                     op, c_t, in_stride, out_stride)
+  do {                                                                                          \
+    if (pipelined && a_vec)                                                                     \
+      hipLaunchKernelGGL((gemm_nn2_kernel<TM, TN, WM, WN, MODE, A_TRANS, true>),                \
+                         dim3(pn2_ceil_div(r, TN), 1, b), dim3(256), 0, stream, rows, k, r, a_t,  \
+                         lda, a_bytes, op, c_t, in_stride, out_stride);                         \
+    else if (pipelined)                                                                         \
+      hipLaunchKernelGGL((gemm_nn2_kernel<TM, TN, WM, WN, MODE, A_TRANS, false>),               \
+                         dim3(pn2_ceil_div(r, TN), 1, b), dim3(256), 0, stream, rows, k, r, a_t,  \
+                         lda, a_bytes, op, c_t, in_stride, out_stride);                         \
+    else                                                                                        \
+      hipLaunchKernelGGL((gemm_nn_kernel<TM, TN, WM, WN, MODE, A_TRANS>),                       \
+                         dim3(pn2_ceil_div(r, TN), 1, b), dim3(256), 0, stream, rows, k, r, a_t,  \
+                         lda, op, c_t, in_stride, out_stride);                                  \
+  } while (0)
     int rows;
     if (left >= 256) { rows = 256; NN(256, 64, 4, 1); }
     else if (left > 64) { rows = left < 128 ? left : 128; NN(128, 128, 2, 2); }
     else if (left > 32) { rows = left; NN(64, 128, 2, 2); }
-    else { rows = left; NN(32, 256, 1, 4); }
+    else {  // (a 32-row tile is narrower than the 16-byte A pieces of the pipelined kernel)
+      rows = left;
+      hipLaunchKernelGGL((gemm_nn_kernel<32, 256, 1, 4, MODE, A_TRANS>),
+                         dim3(pn2_ceil_div(r, 256), 1, b), dim3(256), 0, stream, rows, k, r, a_t,
+                         lda, op, c_t, in_stride, out_stride);
+    }
 #undef NN
     done += rows;
   }

@@ -41,46 +41,13 @@
 #include "common.h"
 #include <stdlib.h>
 #include "ball_common.h"
+#include "grid_common.h"
 
 namespace {
 
-constexpr int kG = 32;                  // lattice cells per axis (periodic)
-constexpr int kLayerCells = kG * kG;    // cells of one z-layer
-constexpr int kCells = kG * kG * kG;
-constexpr int kStartStride = kCells + 32;  // ints per cloud in `start` (start[kCells] = n)
-constexpr int kChunks = 32;             // chunks a cloud is split into by pass 1
-constexpr int kSegOff = kG + 1;         // layer offsets per chunk (+ total)
+using namespace grid;
+
 constexpr int kBuildThreads = 1024;
-constexpr int kGridMaxPoints = kChunks * 4096;  // pass 1 keeps a chunk's points in registers
-
-__host__ __device__ inline int grid_chunk_points(int n) {
-  return (((n + kChunks - 1) / kChunks) + 3) & ~3;
-}
-
-struct GridWs {
-  int *start;     // [b][kStartStride]
-  int *segoff;    // [b][kChunks][kSegOff]
-  float4 *rec;    // [b][n]  records in cell order
-  float4 *seg;    // [b][kChunks][chunk_pts]  records in (chunk, layer) order
-  size_t bytes;
-};
-
-inline GridWs grid_ws_layout(void *base, int b, int n) {
-  GridWs w;
-  char *p = reinterpret_cast<char *>(base);
-  size_t off = 0;
-  auto take = [&](size_t bytes) { char *q = p + off; off += (bytes + 255) & ~(size_t)255; return q; };
-  w.start = reinterpret_cast<int *>(take(sizeof(int) * (size_t)b * kStartStride));
-  w.segoff = reinterpret_cast<int *>(take(sizeof(int) * (size_t)b * kChunks * kSegOff));
-  w.rec = reinterpret_cast<float4 *>(take(sizeof(float4) * (size_t)b * n));
-  w.seg = reinterpret_cast<float4 *>(take(sizeof(float4) * (size_t)b * kChunks * grid_chunk_points(n)));
-  w.bytes = off;
-  return w;
-}
-
-__device__ __forceinline__ int cell_coord(float v, float inv_side) {
-  return (int)floorf(v * inv_side);
-}
 
 // ---- pass 1: split each chunk of the cloud by z-layer ----------------------------------------
 // T lanes per workgroup, up to kSplitPoints / T points per lane kept in registers between the
@@ -308,7 +275,8 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
 // number of hits, so nsample in (64, 128] needs no second pass.
 template <int MAXH, int CPW, bool GROUP, int ABL>
 __global__ void __launch_bounds__(256)
-grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side, int nsample,
+grid_query_kernel(int n, int m, int wg_per_cloud, unsigned wpc_recip, float radius2, float inv_side,
+                  int nsample,
                   unsigned bucket_mul, const float *__restrict__ new_xyz,
                   const float *__restrict__ xyz, const int *__restrict__ start,
                   const float4 *__restrict__ rec, int *__restrict__ idx, GroupOut g) {
@@ -318,7 +286,7 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
   __shared__ WaveLds<MAXH> lds[256 / kWave];
   // 1-D grid, XCD-contiguous: cloud = id / wg_per_cloud (one division per workgroup)
   const int wg = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
-  const int b = wg / wg_per_cloud;
+  const int b = (int)__umulhi((unsigned)wg, wpc_recip);  // wg / wg_per_cloud (exact: wg < 2^16)
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));  // an SGPR
   WaveLds<MAXH> &L = lds[wave];
@@ -344,30 +312,44 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
     const int xa = gx > 0 ? gx - 1 : 0, xb = gx < kG - 1 ? gx + 1 : kG - 1;
     int s0[9], len[9];
     bool fast = gx != 0 && gx != kG - 1;
+    {
+      // lanes 0..8 fetch the row starts, lanes 16..24 the row ends: ONE vector load and 18 lane
+      // reads instead of 18 scalar loads with their scalar address arithmetic (the scalar unit
+      // is shared by the CU's four SIMDs and was this kernel's busiest resource)
+      const int rr9 = lane & 15;
+      const int r = rr9 < 9 ? rr9 : 0;
+      const int rz = (r * 11) >> 5;              // r / 3 for r < 9
+      const int rowbase = (((gz + rz - 1) & (kG - 1)) * kG + ((gy + (r - 3 * rz) - 1) & (kG - 1))) * kG;
+      const int v = st[rowbase + ((lane & 16) ? xb + 1 : xa)];
+      // lane q < 9: row q's length (its end sits 16 lanes up: row_shl needs same-row lanes, so
+      // the end is fetched with one LDS-free permute through the upper half of the row pair)
+      const int vend = __shfl_down(v, 16, kWave);
+      const int lenv = vend - v;
+      fast = fast && __builtin_amdgcn_ballot_w64(rr9 < 9 && (lane & 48) == 0 && lenv > kWave) == 0ull;
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      const int rowbase = (((gz + r / 3 - 1) & (kG - 1)) * kG + ((gy + r % 3 - 1) & (kG - 1))) * kG;
-      s0[r] = st[rowbase + xa];
-      len[r] = st[rowbase + xb + 1] - s0[r];
-      fast = fast && len[r] <= kWave;
+      for (int q = 0; q < 9; ++q) {
+        s0[q] = __builtin_amdgcn_readlane(v, q);
+        len[q] = __builtin_amdgcn_readlane(lenv, q);
+      }
     }
     int total = 0;
     if (ABL != 2) {
       // all nine loads are in flight before the first test (one L2 round trip for ~400
-      // candidates); only the lanes that own a candidate load (a row holds ~44)
+      // candidates); lanes past the end of a row read the cloud's last record (always valid)
+      // and are masked out of the hit test
       float4 q[9];
 #pragma unroll
       for (int r = 0; r < 9; ++r) {
-        q[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane < len[r]) q[r] = cloud[(unsigned)(s0[r] + lane)];
+        const int p = s0[r] + lane;
+        q[r] = cloud[(unsigned)(p < n ? p : n - 1)];
       }
       bool hit[9];
       int at[9];
 #pragma unroll
-      for (int r = 0; r < 9; ++r) {  // branch-free: dead lanes compute on zeros and are masked
+      for (int r = 0; r < 9; ++r) {  // branch-free
         const bool near = sqdist3(cx, cy, cz, q[r].x, q[r].y, q[r].z) < radius2;
         hit[r] = near & (lane < len[r]);
-        const unsigned long long mask = __ballot(hit[r]);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit[r]);
         at[r] = total + mask_rank(mask);
         total += __popcll(mask);
       }
@@ -515,30 +497,39 @@ size_t pn2_ball_query_grid_workspace(int b, int n, int m, int nsample) {
   return grid_ws_layout(nullptr, b, n).bytes;
 }
 
-// Build the cell lists of `xyz` for `radius` in `workspace`, then answer the queries; with
+size_t pn2_grid_layout_bytes(int b, int n) {
+  if (n < 4096 || n > kGridMaxPoints) return 0;
+  return grid_ws_layout(nullptr, b, n).bytes;
+}
+
+// the two-pass build of the cell lists of `xyz` for `radius`
+int pn2_grid_build_launch(int b, int n, float radius, const float *xyz, void *workspace,
+                          hipStream_t stream) {
+  const GridWs ws = grid_ws_layout(workspace, b, n);
+  const float inv_side = grid_inv_side(radius);
+  const int chunk_pts = grid_chunk_points(n);
+  hipLaunchKernelGGL(grid_split_kernel<1024>, dim3(kChunks, b), dim3(1024), 0, stream, n, chunk_pts,
+                     inv_side, xyz, ws.segoff, ws.seg);
+  hipLaunchKernelGGL(grid_bin_kernel, dim3(kG, b), dim3(kBuildThreads), 0, stream, n, chunk_pts,
+                     inv_side, ws.segoff, ws.seg, ws.start, ws.rec);
+  return pn2_launch_status();
+}
+
+// Answer the queries on the cell lists in `workspace` (built here unless `prebuilt`); with
 // group != nullptr the fused kernel also writes the grouped tensor.
 static int grid_run(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                     const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
-                    hipStream_t stream, const GroupOut *group, int *handled) {
+                    hipStream_t stream, const GroupOut *group, bool prebuilt, int *handled) {
   *handled = 0;
   const size_t need = pn2_ball_query_grid_workspace(b, n, m, nsample);
   if (need == 0 || workspace == nullptr || workspace_bytes < need) return 0;
   if (!(radius > 1e-6f) || !(radius < 1e6f)) return 0;  // also rejects NaN
   const GridWs ws = grid_ws_layout(workspace, b, n);
-  const float inv_side = 1.0f / (radius * 1.001f);
-  const int chunk_pts = grid_chunk_points(n);
-  const int split_t = getenv("PN2_GRID_SPLIT_T") ? atoi(getenv("PN2_GRID_SPLIT_T")) : 1024;
-  if (split_t == 256)
-    hipLaunchKernelGGL(grid_split_kernel<256>, dim3(kChunks, b), dim3(256), 0, stream, n, chunk_pts,
-                       inv_side, xyz, ws.segoff, ws.seg);
-  else if (split_t == 512)
-    hipLaunchKernelGGL(grid_split_kernel<512>, dim3(kChunks, b), dim3(512), 0, stream, n, chunk_pts,
-                       inv_side, xyz, ws.segoff, ws.seg);
-  else
-    hipLaunchKernelGGL(grid_split_kernel<1024>, dim3(kChunks, b), dim3(1024), 0, stream, n,
-                       chunk_pts, inv_side, xyz, ws.segoff, ws.seg);
-  hipLaunchKernelGGL(grid_bin_kernel, dim3(kG, b), dim3(kBuildThreads), 0, stream, n, chunk_pts,
-                     inv_side, ws.segoff, ws.seg, ws.start, ws.rec);
+  const float inv_side = grid_inv_side(radius);
+  if (!prebuilt) {
+    const int rc = pn2_grid_build_launch(b, n, radius, xyz, workspace, stream);
+    if (rc != 0) return rc;
+  }
   const float radius2 = radius * radius;  // fp32 product, as ball_query_gpu.cu:27
   GroupOut g = {nullptr, nullptr, 0, 3, 0, 1.f};
   if (group) g = *group;
@@ -549,9 +540,10 @@ static int grid_run(int b, int n, int m, float radius, int nsample, const float 
 #define GRID_QUERY(MAXH, GROUP, ABL)                                                               \
   do {                                                                                             \
     const int wpc = pn2_ceil_div(m, 256 / kWave);                                                  \
+    const unsigned recip = (unsigned)(((1ull << 32) + wpc - 1) / wpc);                            \
     hipLaunchKernelGGL((grid_query_kernel<MAXH, 1, GROUP, ABL>), dim3(wpc * b), dim3(256), 0,      \
-                       stream, n, m, wpc, radius2, inv_side, nsample, bucket_mul, new_xyz, xyz,    \
-                       ws.start, ws.rec, idx, g);                                                  \
+                       stream, n, m, wpc, recip, radius2, inv_side, nsample, bucket_mul, new_xyz,  \
+                       xyz, ws.start, ws.rec, idx, g);                                             \
   } while (0)
   if (nsample > kWave) { if (group) GRID_QUERY(256, true, 0); else GRID_QUERY(256, false, 0); }
   else if (!group) GRID_QUERY(192, false, 0);
@@ -565,9 +557,9 @@ static int grid_run(int b, int n, int m, float radius, int nsample, const float 
 
 int pn2_ball_query_grid_try(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                             const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
-                            hipStream_t stream, int *handled) {
+                            hipStream_t stream, int prebuilt, int *handled) {
   return grid_run(b, n, m, radius, nsample, new_xyz, xyz, idx, workspace, workspace_bytes, stream,
-                  nullptr, handled);
+                  nullptr, prebuilt != 0, handled);
 }
 
 // fused ball query + gathers of QueryAndGroup (pointnet2_utils.py:335-358) on the cell lists
@@ -576,9 +568,9 @@ int pn2_query_group_grid_try(int b, int n, int m, int c_gather, int ctot, float 
                              int nsample, int normalize_xyz, const float *new_xyz,
                              const float *xyz, const float *features, int *idx, float *out,
                              void *workspace, size_t workspace_bytes, hipStream_t stream,
-                             int *handled) {
+                             int prebuilt, int *handled) {
   // torch divides by a scalar as x * (1/r)
   GroupOut g = {features, out, c_gather, ctot, normalize_xyz, 1.0f / radius};
   return grid_run(b, n, m, radius, nsample, new_xyz, xyz, idx, workspace, workspace_bytes, stream,
-                  &g, handled);
+                  &g, prebuilt != 0, handled);
 }

@@ -337,13 +337,16 @@ int channel_groups(int c, int per_thread) {
 
 int pn2_ball_query_grid_try(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                             const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
-                            hipStream_t stream, int *handled);
+                            hipStream_t stream, int prebuilt, int *handled);
 int pn2_query_group_grid_try(int b, int n, int m, int c_gather, int ctot, float radius,
                              int nsample, int normalize_xyz, const float *new_xyz,
                              const float *xyz, const float *features, int *idx, float *out,
                              void *workspace, size_t workspace_bytes, hipStream_t stream,
-                             int *handled);
+                             int prebuilt, int *handled);
 size_t pn2_ball_query_grid_workspace(int b, int n, int m, int nsample);
+size_t pn2_grid_layout_bytes(int b, int n);
+int pn2_grid_build_launch(int b, int n, float radius, const float *xyz, void *workspace,
+                          hipStream_t stream);
 
 PN2_API size_t pn2_ball_query_workspace_bytes(int b, int n, int m, int nsample) {
   return pn2_ball_query_grid_workspace(b, n, m, nsample);
@@ -359,7 +362,7 @@ PN2_API int pn2_ball_query(int b, int n, int m, float radius, int nsample, const
   }
   int handled = 0;
   const int rc = pn2_ball_query_grid_try(b, n, m, radius, nsample, new_xyz, xyz, idx, workspace,
-                                         workspace_bytes, stream, &handled);
+                                         workspace_bytes, stream, 0, &handled);
   if (rc != 0 || handled) return rc;
 
   const float radius2 = radius * radius;  // fp32 product, as ball_query_gpu.cu:27
@@ -504,10 +507,10 @@ static int group_concat_launch(int b, int n, int m, int c, float radius, int nsa
 // channel and lane); wider feature tensors go through the channel-parallel gather kernel
 constexpr int kFusedGatherChannels = 8;
 
-PN2_API int pn2_query_and_group(int b, int n, int m, int c, float radius, int nsample,
+static int query_and_group_impl(int b, int n, int m, int c, float radius, int nsample,
                                 int normalize_xyz, const float *new_xyz, const float *xyz,
                                 const float *features, int *idx, float *out, void *workspace,
-                                size_t workspace_bytes, void *stream_) {
+                                size_t workspace_bytes, int prebuilt, void *stream_) {
   if (b <= 0 || m <= 0 || nsample <= 0) return 0;
   if (c > 0 && !features) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
@@ -516,7 +519,7 @@ PN2_API int pn2_query_and_group(int b, int n, int m, int c, float radius, int ns
     const int cg = c <= kFusedGatherChannels ? c : 0;
     int rc = pn2_query_group_grid_try(b, n, m, cg, 3 + c, radius, nsample, normalize_xyz, new_xyz,
                                       xyz, features, idx, out, workspace, workspace_bytes, stream,
-                                      &handled);
+                                      prebuilt, &handled);
     if (rc != 0) return rc;
     if (handled) {
       if (cg == c) return 0;
@@ -524,11 +527,54 @@ PN2_API int pn2_query_and_group(int b, int n, int m, int c, float radius, int ns
                                  features, idx, out, stream);
     }
   }
+  if (prebuilt) return (int)hipErrorInvalidValue;  // the cell lists do not cover this shape
   int rc = pn2_ball_query(b, n, m, radius, nsample, new_xyz, xyz, idx, workspace,
                           workspace_bytes, stream_);
   if (rc != 0) return rc;
   return group_concat_launch(b, n, m, c, radius, nsample, normalize_xyz, 0, new_xyz, xyz, features,
                              idx, out, stream);
+}
+
+PN2_API int pn2_query_and_group(int b, int n, int m, int c, float radius, int nsample,
+                                int normalize_xyz, const float *new_xyz, const float *xyz,
+                                const float *features, int *idx, float *out, void *workspace,
+                                size_t workspace_bytes, void *stream_) {
+  return query_and_group_impl(b, n, m, c, radius, nsample, normalize_xyz, new_xyz, xyz, features,
+                              idx, out, workspace, workspace_bytes, 0, stream_);
+}
+
+// ---- cell lists as an object: built once (by pn2_grid_build or as a by-product of
+// pn2_furthest_point_sampling_grid), queried by any number of ball queries of the same radius
+PN2_API size_t pn2_grid_bytes(int b, int n) { return pn2_grid_layout_bytes(b, n); }
+
+PN2_API int pn2_grid_build(int b, int n, float radius, const float *xyz, void *grid,
+                           size_t grid_bytes, void *stream_) {
+  const size_t need = pn2_grid_layout_bytes(b, n);
+  if (b <= 0) return 0;
+  if (need == 0 || !grid || grid_bytes < need || !(radius > 1e-6f) || !(radius < 1e6f))
+    return (int)hipErrorInvalidValue;
+  return pn2_grid_build_launch(b, n, radius, xyz, grid, (hipStream_t)stream_);
+}
+
+PN2_API int pn2_ball_query_prebuilt(int b, int n, int m, float radius, int nsample,
+                                    const float *new_xyz, const float *xyz, int *idx,
+                                    const void *grid, size_t grid_bytes, void *stream_) {
+  if (b <= 0 || m <= 0 || nsample <= 0) return 0;
+  int handled = 0;
+  const int rc = pn2_ball_query_grid_try(b, n, m, radius, nsample, new_xyz, xyz, idx,
+                                         const_cast<void *>(grid), grid_bytes,
+                                         (hipStream_t)stream_, 1, &handled);
+  if (rc != 0) return rc;
+  return handled ? 0 : (int)hipErrorInvalidValue;
+}
+
+PN2_API int pn2_query_and_group_prebuilt(int b, int n, int m, int c, float radius, int nsample,
+                                         int normalize_xyz, const float *new_xyz,
+                                         const float *xyz, const float *features, int *idx,
+                                         float *out, const void *grid, size_t grid_bytes,
+                                         void *stream_) {
+  return query_and_group_impl(b, n, m, c, radius, nsample, normalize_xyz, new_xyz, xyz, features,
+                              idx, out, const_cast<void *>(grid), grid_bytes, 1, stream_);
 }
 
 PN2_API int pn2_group_concat(int b, int n, int m, int c, float radius, int nsample,

@@ -29,6 +29,7 @@
 // depends on atomic ordering) cannot influence the result.
 #include "common.h"
 #include "fps_common.h"
+#include "grid_common.h"
 
 namespace {
 
@@ -39,7 +40,22 @@ constexpr int kWaves = kThreads / kWave;  // 16
 constexpr int kGrid = 16;                 // cells per axis
 constexpr int kCells = kGrid * kGrid * kGrid;
 
-__device__ __forceinline__ float wave_min_f32(float v) { return -wave_max_f32(-v); }
+// (NOT -wave_max_f32(-v): clang 22 / ROCm 7.2 folds the negations into source modifiers of the
+//  v_cndmask_b32 selects of the DPP steps and the result came out wrong for negative inputs --
+//  bounding boxes of clouds with negative coordinates were too tight, buckets were pruned that
+//  still held the farthest point: regression test test_fps_negative_coordinates)
+__device__ __forceinline__ float wave_min_f32(float v) {
+#define FPS_MIN_STEP(CTRL) { const float o = __builtin_bit_cast(float, dpp_mov<CTRL>(__builtin_bit_cast(unsigned, v))); v = o < v ? o : v; }
+  FPS_MIN_STEP(kQuadXor1) FPS_MIN_STEP(kQuadXor2) FPS_MIN_STEP(kRowHalfMirror) FPS_MIN_STEP(kRowMirror)
+#undef FPS_MIN_STEP
+  unsigned r0, r1;
+  swap_rows<false>(__builtin_bit_cast(unsigned, v), r0, r1);
+  float f0 = __builtin_bit_cast(float, r0), f1 = __builtin_bit_cast(float, r1);
+  v = f0 < f1 ? f0 : f1;
+  swap_rows<true>(__builtin_bit_cast(unsigned, v), r0, r1);
+  f0 = __builtin_bit_cast(float, r0); f1 = __builtin_bit_cast(float, r1);
+  return f0 < f1 ? f0 : f1;
+}
 
 __device__ __forceinline__ unsigned spread4(unsigned v) {  // abcd -> 00a00b00c00d
   v &= 0xF;
@@ -83,7 +99,8 @@ __device__ __forceinline__ float4 load_bucket(const float4 *wave_base, int jj, u
 template <int NBW>
 __global__ void __launch_bounds__(kThreads)
 fps_bucket_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
-                  float4 *__restrict__ scratch, int *__restrict__ idxs) {
+                  float4 *__restrict__ scratch, int *__restrict__ idxs, float grid_inv_side,
+                  int *__restrict__ grid_start, float4 *__restrict__ grid_rec) {
   __shared__ int cell_cnt[kCells];                 // histogram, then scatter cursors
   __shared__ float red[kWaves * 8];
   __shared__ __attribute__((aligned(16))) float slots[2][kWaves * 8];
@@ -96,6 +113,63 @@ fps_bucket_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
   const float *pts = dataset + (size_t)blockIdx.x * n * 3;
   float4 *sp = scratch + (size_t)blockIdx.x * (kThreads * NBW);
   int *out = idxs + (size_t)blockIdx.x * m;
+
+  // ---- G: by-product -- the ball-query cell lists of this cloud (grid_common.h) -------------
+  // The set-abstraction layer that samples this cloud queries balls in it right afterwards.
+  // This workgroup streams the cloud anyway (and has ~6 ms of serial rounds ahead of it), so it
+  // also counting-sorts the points by lattice cell: 32768 16-bit counters packed in 64 KB of LDS
+  // (n < 65536 on this path), scan, scatter.  The separate two-kernel build of the ball query
+  // (15 us on all CUs) disappears from the layer.
+  if (grid_start != nullptr) {
+    __shared__ unsigned gcnt[grid::kCells / 2];
+    __shared__ int g_wave_tot[kWaves];
+    for (int t = tid; t < grid::kCells / 2; t += kThreads) gcnt[t] = 0u;
+    __syncthreads();
+    for (int k = tid; k < n; k += kThreads) {
+      const int cell = grid::cell_id(pts[k * 3 + 0], pts[k * 3 + 1], pts[k * 3 + 2], grid_inv_side);
+      atomicAdd(&gcnt[cell >> 1], 1u << ((cell & 1) * 16));
+    }
+    __syncthreads();
+    {  // exclusive scan over the 32768 cells: 32 consecutive cells (16 words) per lane
+      unsigned wds[16];
+      int sum = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        wds[q] = gcnt[tid * 16 + q];
+        sum += (int)(wds[q] & 0xFFFFu) + (int)(wds[q] >> 16);
+      }
+      int incl = sum;
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const int o = __shfl_up(incl, off, kWave);
+        if (lane >= off) incl += o;
+      }
+      if (lane == kWave - 1) g_wave_tot[w] = incl;
+      __syncthreads();
+      int run = incl - sum;
+      for (int q = 0; q < w; ++q) run += g_wave_tot[q];
+      int *st = grid_start + (size_t)blockIdx.x * grid::kStartStride + tid * 32;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int lo = run, hi = run + (int)(wds[q] & 0xFFFFu);
+        st[2 * q] = lo;
+        st[2 * q + 1] = hi;
+        gcnt[tid * 16 + q] = (unsigned)lo | ((unsigned)hi << 16);  // scatter cursors (n < 65536)
+        run = hi + (int)(wds[q] >> 16);
+      }
+      if (tid == kThreads - 1) grid_start[(size_t)blockIdx.x * grid::kStartStride + grid::kCells] = run;
+    }
+    __syncthreads();
+    float4 *rec = grid_rec + (size_t)blockIdx.x * n;
+    for (int k = tid; k < n; k += kThreads) {
+      const float x = pts[k * 3 + 0], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
+      const int cell = grid::cell_id(x, y, z, grid_inv_side);
+      const int sh = (cell & 1) * 16;
+      const unsigned old = atomicAdd(&gcnt[cell >> 1], 1u << sh);
+      rec[(old >> sh) & 0xFFFFu] = make_float4(x, y, z, __builtin_bit_cast(float, k));
+    }
+    __syncthreads();
+  }
 
   // ---- P0: bounding box of the participating points --------------------------------------
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
@@ -275,16 +349,30 @@ size_t pn2_fps_bucket_scratch_bytes(int b, int n) {
 }
 
 // returns 0 and sets *handled when the bucketed kernel was launched
+// largest cloud whose cell lists the kernel can emit (16-bit scatter cursors)
+int pn2_fps_bucket_grid_max_points() { return 65535; }
+
 int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, void *scratch,
-                       size_t scratch_bytes, int *idxs, hipStream_t stream, int *handled) {
+                       size_t scratch_bytes, int *idxs, hipStream_t stream, int *handled,
+                       float grid_radius, void *grid) {
   *handled = 0;
   if (n > kBucketMaxPoints || scratch == nullptr) return 0;
   if (scratch_bytes < pn2_fps_bucket_scratch_bytes(b, n)) return 0;
   const int nbw = (n + kThreads - 1) / kThreads;
   float4 *sc = reinterpret_cast<float4 *>(scratch);
+  int *g_start = nullptr;
+  float4 *g_rec = nullptr;
+  float g_inv = 0.f;
+  if (grid != nullptr) {  // also leave the cell lists for ball queries of grid_radius behind
+    if (n > pn2_fps_bucket_grid_max_points() || n < 4096) return (int)hipErrorInvalidValue;
+    const grid::GridWs ws = grid::grid_ws_layout(grid, b, n);
+    g_start = ws.start;
+    g_rec = ws.rec;
+    g_inv = grid::grid_inv_side(grid_radius);
+  }
 #define FPS_BUCKET(T)                                                                         \
   hipLaunchKernelGGL((fps_bucket_kernel<T>), dim3(b), dim3(kThreads), 0, stream, n, m, log2bs, \
-                     dataset, sc, idxs)
+                     dataset, sc, idxs, g_inv, g_start, g_rec)
   if (nbw <= 8) FPS_BUCKET(8);
   else if (nbw <= 16) FPS_BUCKET(16);
   else if (nbw <= 24) FPS_BUCKET(24);

@@ -141,8 +141,11 @@ int ref_log2_block(int n) {
 }  // namespace
 
 size_t pn2_fps_bucket_scratch_bytes(int b, int n);
+int pn2_fps_bucket_grid_max_points();
+size_t pn2_grid_layout_bytes(int b, int n);
 int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, void *scratch,
-                       size_t scratch_bytes, int *idxs, hipStream_t stream, int *handled);
+                       size_t scratch_bytes, int *idxs, hipStream_t stream, int *handled,
+                       float grid_radius, void *grid);
 
 // clouds with at least this many points use the bucketed (spatially pruned) tier when a
 // workspace is supplied; overridable for experiments with PN2_FPS_BUCKET_MIN_N
@@ -175,7 +178,7 @@ PN2_API int pn2_furthest_point_sampling_ws(int b, int n, int m, const float *dat
   if (n >= fps_bucket_min_n()) {
     int handled = 0;
     const int rc = pn2_fps_bucket_try(b, n, m, log2bs, dataset, workspace, workspace_bytes, idxs,
-                                      stream, &handled);
+                                      stream, &handled, 0.f, nullptr);
     if (rc != 0 || handled) return rc;
   }
 #define FPS_REG(T, P)                                                                     \
@@ -203,6 +206,28 @@ PN2_API int pn2_furthest_point_sampling_ws(int b, int n, int m, const float *dat
   }
 #undef FPS_REG
   return pn2_launch_status();
+}
+
+// Can pn2_furthest_point_sampling_grid leave cell lists behind for a cloud of n points?
+PN2_API int pn2_fps_grid_supported(int n) {
+  return n >= fps_bucket_min_n() && n >= 4096 && n <= pn2_fps_bucket_grid_max_points() &&
+         pn2_grid_layout_bytes(1, n) != 0;
+}
+
+PN2_API int pn2_furthest_point_sampling_grid(int b, int n, int m, const float *dataset, int *idxs,
+                                             void *workspace, size_t workspace_bytes,
+                                             float grid_radius, void *grid, size_t grid_bytes,
+                                             void *stream_) {
+  if (b <= 0 || m <= 0) return 0;
+  if (!pn2_fps_grid_supported(n) || !grid || grid_bytes < pn2_grid_layout_bytes(b, n) ||
+      !(grid_radius > 1e-6f) || !(grid_radius < 1e6f))
+    return (int)hipErrorInvalidValue;
+  int handled = 0;
+  const int rc = pn2_fps_bucket_try(b, n, m, ref_log2_block(n), dataset, workspace,
+                                    workspace_bytes, idxs, (hipStream_t)stream_, &handled,
+                                    grid_radius, grid);
+  if (rc != 0) return rc;
+  return handled ? 0 : (int)hipErrorInvalidValue;  // (workspace too small for the bucketed tier)
 }
 
 // Reference-shaped entry point: `temp` is the (b,n) float scratch of the reference ABI, which

@@ -203,12 +203,87 @@ def group_points_grad(grad_out, idx, n):
     return out
 
 
-# ---- addition (not in the reference's pybind surface) ------------------------------------
-def query_and_group(new_xyz, xyz, features, radius, nsample, normalize_xyz, idx=None):
+# ---- additions (not in the reference's pybind surface) -----------------------------------
+class CellLists(object):
+    """Cell lists of one (B,N,3) cloud for ball queries of one radius (include/pn2_hip.h
+    pn2_grid_*): built once, queried by ball_query / query_and_group via `grid=`."""
+
+    def __init__(self, buf, b, n, radius):
+        self.buf, self.b, self.n, self.radius = buf, b, n, float(radius)
+
+    def check(self, xyz, radius):
+        if tuple(xyz.shape[:2]) != (self.b, self.n) or float(radius) != self.radius:
+            raise RuntimeError("cell lists were built for another cloud shape / radius")
+        if xyz.device != self.buf.device:
+            raise RuntimeError("cell lists live on %s" % self.buf.device)
+
+
+def grid_supported(b, n):
+    return int(_lib.pn2_grid_bytes(int(b), int(n))) > 0
+
+
+def build_grid(xyz, radius):
+    """CellLists of xyz (B,N,3) for `radius` (the stand-alone two-kernel build)."""
+    _chk_f32(xyz, "xyz")
+    if not xyz.is_cuda:
+        raise RuntimeError("CPU not supported")
+    b, n, _ = xyz.shape
+    need = int(_lib.pn2_grid_bytes(b, n))
+    if need <= 0:
+        raise RuntimeError("no cell lists for clouds of %d points" % n)
+    buf = torch.empty(need, dtype=torch.uint8, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _L.check(_lib.pn2_grid_build(b, n, float(radius), xyz.data_ptr(), buf.data_ptr(), need,
+                                     _stream(xyz)), "grid_build")
+    return CellLists(buf, b, n, radius)
+
+
+def furthest_point_sampling_with_grid(points, nsamples, radius):
+    """furthest_point_sampling that also leaves the CellLists of `points` for `radius` behind
+    (one kernel; indices identical).  Returns (inds (B,nsamples) i32, CellLists or None when the
+    cloud size is outside the by-product's range)."""
+    _chk_f32(points, "points")
+    if not points.is_cuda:
+        raise RuntimeError("CPU not supported")
+    b, n, _ = points.shape
+    nsamples = int(nsamples)
+    if not _lib.pn2_fps_grid_supported(n):
+        return furthest_point_sampling(points, nsamples), None
+    out = torch.zeros((b, nsamples), dtype=torch.int32, device=points.device)
+    with torch.cuda.device(points.device):
+        need = int(_lib.pn2_fps_workspace_bytes(b, n, nsamples))
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=points.device)
+        gbytes = int(_lib.pn2_grid_bytes(b, n))
+        gbuf = torch.empty(gbytes, dtype=torch.uint8, device=points.device)
+        _L.check(_lib.pn2_furthest_point_sampling_grid(b, n, nsamples, points.data_ptr(),
+                                                       out.data_ptr(), ws.data_ptr(), need,
+                                                       float(radius), gbuf.data_ptr(), gbytes,
+                                                       _stream(points)),
+                 "furthest_point_sampling_grid")
+    return out, CellLists(gbuf, b, n, radius)
+
+
+def ball_query_prebuilt(new_xyz, xyz, radius, nsample, grid):
+    """ball_query on CellLists built earlier for (xyz, radius)."""
+    _chk_f32(new_xyz, "new_xyz"); _chk_f32(xyz, "xyz"); _chk_dev(new_xyz, (xyz, "xyz"))
+    grid.check(xyz, radius)
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = torch.empty((b, m, int(nsample)), dtype=torch.int32, device=new_xyz.device)
+    with torch.cuda.device(new_xyz.device):
+        _L.check(_lib.pn2_ball_query_prebuilt(b, n, m, float(radius), int(nsample),
+                                              new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr(),
+                                              grid.buf.data_ptr(), grid.buf.numel(),
+                                              _stream(new_xyz)), "ball_query_prebuilt")
+    return idx
+
+
+def query_and_group(new_xyz, xyz, features, radius, nsample, normalize_xyz, idx=None, grid=None):
     """Fused QueryAndGroup front end (pointnet2_utils.py:335-358): returns
     (idx (B,m,ns) i32, grouped (B,3+C,m,ns) f32) with channels 0..2 = relative xyz
     (optionally / radius) and 3.. = gathered features (features may be None).
-    A ball-query result computed earlier may be passed as `idx` (then only the gathers run)."""
+    A ball-query result computed earlier may be passed as `idx` (then only the gathers run);
+    CellLists built earlier for (xyz, radius) as `grid` (then one kernel does everything)."""
     _chk_f32(new_xyz, "new_xyz"); _chk_f32(xyz, "xyz"); _chk_dev(new_xyz, (xyz, "xyz"))
     b, n, _ = xyz.shape
     m = new_xyz.shape[1]
@@ -231,6 +306,17 @@ def query_and_group(new_xyz, xyz, features, radius, nsample, normalize_xyz, idx=
                                            _stream(new_xyz)), "group_concat")
         return idx, out
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
+    if grid is not None and nsample <= 128:
+        grid.check(xyz, radius)
+        with torch.cuda.device(new_xyz.device):
+            _L.check(_lib.pn2_query_and_group_prebuilt(b, n, m, c, float(radius), nsample,
+                                                       1 if normalize_xyz else 0,
+                                                       new_xyz.data_ptr(), xyz.data_ptr(), fptr,
+                                                       idx.data_ptr(), out.data_ptr(),
+                                                       grid.buf.data_ptr(), grid.buf.numel(),
+                                                       _stream(new_xyz)),
+                     "query_and_group_prebuilt")
+        return idx, out
     with torch.cuda.device(new_xyz.device):
         ws_buf, ws, ws_size = _ball_ws(new_xyz, b, n, m, nsample)
         _L.check(_lib.pn2_query_and_group(b, n, m, c, float(radius), nsample,

@@ -27,13 +27,19 @@ except ImportError:  # imported flat, as the reference models do after sys.path.
     import pytorch_utils as pt_utils
 
 
-def _sample_centroids(xyz, npoint, inds=None):
-    """FPS (unless `inds` is given) and the centroid coordinates (B, npoint, 3)."""
+def _sample_centroids(xyz, npoint, inds=None, radius=None):
+    """FPS (unless `inds` is given) and the centroid coordinates (B, npoint, 3).  With `radius`
+    the sampling may also leave the cloud's cell lists for ball queries of that radius behind
+    (third return value, None otherwise)."""
+    lists = None
     if inds is None:
-        inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
+        if radius is not None:
+            inds, lists = pointnet2_utils.sample_with_cell_lists(xyz, npoint, radius)
+        else:
+            inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
     flipped = xyz.transpose(1, 2).contiguous()
     new_xyz = pointnet2_utils.gather_operation(flipped, inds).transpose(1, 2).contiguous()
-    return new_xyz, inds
+    return (new_xyz, inds, lists) if radius is not None else (new_xyz, inds)
 
 
 def _pool_max(x):
@@ -142,14 +148,22 @@ class PointnetSAModuleVotes(nn.Module):
         coordinates only; see votenet/step.py)."""
         if inds is not None:
             assert inds.shape[1] == self.npoint
+        lists = None
         if new_xyz is not None and inds is not None:
             pass  # the index chain was computed ahead of time
         elif self.npoint is not None:
-            new_xyz, inds = _sample_centroids(xyz, self.npoint, inds)
+            fused = isinstance(self.grouper, pointnet2_utils.QueryAndGroup) and \
+                not self.grouper.sample_uniformly and ball_idx is None
+            if fused:  # the sampling kernel may leave the cell lists of this layer's balls behind
+                new_xyz, inds, lists = _sample_centroids(xyz, self.npoint, inds, self.radius)
+            else:
+                new_xyz, inds = _sample_centroids(xyz, self.npoint, inds)
         else:
             new_xyz = None
         if ball_idx is not None and isinstance(self.grouper, pointnet2_utils.QueryAndGroup):
             grouped = self.grouper(xyz, new_xyz, features, ball_idx)
+        elif lists is not None:
+            grouped = self.grouper(xyz, new_xyz, features, None, lists)
         else:
             grouped = self.grouper(xyz, new_xyz, features)
         unique_cnt = grouped[2] if self.ret_unique_cnt else None

@@ -103,6 +103,18 @@ class GroupingOperation(Function):
 grouping_operation = GroupingOperation.apply
 
 
+def sample_with_cell_lists(xyz, npoint, radius):
+    """furthest_point_sample(xyz, npoint) that also returns the cell lists of `xyz` for ball
+    queries of `radius` when the sampling kernel can leave them behind (large clouds on the GPU:
+    SA1), else None.  A set-abstraction layer samples a cloud and then queries balls in the same
+    cloud (pointnet2_modules.py:236-250): with the lists the query + gathers are one kernel."""
+    make = getattr(_ext, "furthest_point_sampling_with_grid", None)
+    if make is None or not xyz.is_cuda or radius is None:
+        return furthest_point_sample(xyz, npoint), None
+    inds, lists = make(xyz.detach(), npoint, radius)
+    return inds, lists
+
+
 class BallQuery(Function):
     @staticmethod
     def forward(ctx, radius, nsample, xyz, new_xyz):
@@ -128,9 +140,13 @@ class _FusedQueryAndGroup(Function):
     """
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, features, radius, nsample, normalize_xyz, idx=None):
-        idx, grouped = _ext.query_and_group(new_xyz, xyz, features, radius, nsample,
-                                            normalize_xyz, idx)
+    def forward(ctx, xyz, new_xyz, features, radius, nsample, normalize_xyz, idx=None, lists=None):
+        if lists is not None and idx is None:
+            idx, grouped = _ext.query_and_group(new_xyz, xyz, features, radius, nsample,
+                                                normalize_xyz, None, lists)
+        else:
+            idx, grouped = _ext.query_and_group(new_xyz, xyz, features, radius, nsample,
+                                                normalize_xyz, idx)
         ctx.save_for_backward(idx)
         ctx.n_points = xyz.size(1)
         ctx.scale = (1.0 / radius) if normalize_xyz else 1.0
@@ -153,7 +169,7 @@ class _FusedQueryAndGroup(Function):
                 g_xyz = _ext.group_points_grad(gx.contiguous(), idx, ctx.n_points).transpose(1, 2)
             if need_new_xyz:
                 g_new = -gx.sum(dim=3).transpose(1, 2)
-        return g_xyz, g_new, g_feat, None, None, None, None
+        return g_xyz, g_new, g_feat, None, None, None, None, None
 
 
 class QueryAndGroup(nn.Module):
@@ -187,14 +203,15 @@ class QueryAndGroup(nn.Module):
                 idx[b, j, :] = torch.cat((members, members[draw]))
         return unique_cnt
 
-    def forward(self, xyz, new_xyz, features=None, idx=None):
-        """idx: optional ball-query result for (xyz, new_xyz) computed earlier."""
+    def forward(self, xyz, new_xyz, features=None, idx=None, lists=None):
+        """idx: optional ball-query result for (xyz, new_xyz) computed earlier; lists: optional
+        cell lists of xyz for this radius (sample_with_cell_lists)."""
         if features is None:
             assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
         unique_cnt = None
         if not self.sample_uniformly:
             grouped, _idx = _FusedQueryAndGroup.apply(xyz, new_xyz, features, self.radius,
-                                                      self.nsample, self.normalize_xyz, idx)
+                                                      self.nsample, self.normalize_xyz, idx, lists)
             grouped_xyz = grouped[:, :3]
             new_features = grouped if self.use_xyz else grouped[:, 3:]
         else:

@@ -52,13 +52,19 @@ class Pointnet2Backbone(nn.Module):
         geometry = {}
         for i in range(1, 5):
             sa = getattr(self, "sa%d" % i)
-            inds = pointnet2_utils.furthest_point_sample(xyz, sa.npoint)
+            # (large clouds: the sampling kernel leaves the cloud's cell lists behind and the
+            #  ball query runs on them -- no separate cell-list build in the chain)
+            inds, lists = pointnet2_utils.sample_with_cell_lists(xyz, sa.npoint, sa.radius)
             new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(),
                                                        inds).transpose(1, 2).contiguous()
             geometry["sa%d_inds" % i] = inds
             geometry["sa%d_new_xyz" % i] = new_xyz
-            geometry["sa%d_ball_idx" % i] = pointnet2_utils.ball_query(sa.radius, sa.nsample, xyz,
-                                                                       new_xyz)
+            if lists is not None and sa.nsample <= 128:
+                geometry["sa%d_ball_idx" % i] = pointnet2_utils._ext.ball_query_prebuilt(
+                    new_xyz, xyz, sa.radius, sa.nsample, lists)
+            else:
+                geometry["sa%d_ball_idx" % i] = pointnet2_utils.ball_query(sa.radius, sa.nsample,
+                                                                           xyz, new_xyz)
             xyz = new_xyz
         # the two feature-propagation layers interpolate sa4 -> sa3 and sa3 -> sa2
         for name, unknown, known in (("fp1", "sa3", "sa4"), ("fp2", "sa2", "sa3")):

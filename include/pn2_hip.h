@@ -114,6 +114,49 @@ int pn2_group_concat(int b, int n, int m, int c, float radius, int nsample, int 
                      const float *new_xyz, const float *xyz, const float *features,
                      const int *idx, float *out, void *stream);
 
+/* ---- cell lists as an object (no reference counterpart: the reference's ball query scans the
+ * whole cloud per centroid, ball_query_gpu.cu:24-47) ------------------------------------------
+ * pn2_ball_query / pn2_query_and_group above build the cell lists of `xyz` inside the call (two
+ * kernels) and throw them away.  A set-abstraction layer samples the cloud (FPS) and then queries
+ * balls in the SAME cloud (pointnet2_modules.py:236-250), so the lists can be left behind by the
+ * sampling kernel, which streams the cloud anyway, and be queried any number of times. */
+
+/* bytes of a cell-list object for b clouds of n points; 0 = shape not covered (n < 4096 or
+ * n > 131072): use pn2_ball_query (the reference allocates nothing, ball_query.cpp:24-33) */
+size_t pn2_grid_bytes(int b, int n);
+
+/* build the cell lists of xyz (b,n,3) for balls of `radius` into grid (pn2_grid_bytes bytes);
+ * the stand-alone form of what query_ball_point_kernel_wrapper's replacement does internally
+ * (ball_query.cpp:9-11) */
+int pn2_grid_build(int b, int n, float radius, const float *xyz, void *grid, size_t grid_bytes,
+                   void *stream);
+
+/* pn2_ball_query on prebuilt cell lists (same radius as at build time): replaces
+ * query_ball_point_kernel_wrapper (ball_query.cpp:9-11, ball_query_gpu.cu:14-59), same result;
+ * nsample <= 128 */
+int pn2_ball_query_prebuilt(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                            const float *xyz, int *idx, const void *grid, size_t grid_bytes,
+                            void *stream);
+
+/* pn2_query_and_group on prebuilt cell lists: ONE kernel for the ball query and the gathers of
+ * QueryAndGroup.forward (pointnet2_utils.py:335-358) */
+int pn2_query_and_group_prebuilt(int b, int n, int m, int c, float radius, int nsample,
+                                 int normalize_xyz, const float *new_xyz, const float *xyz,
+                                 const float *features, int *idx, float *out, const void *grid,
+                                 size_t grid_bytes, void *stream);
+
+/* 1 if pn2_furthest_point_sampling_grid can leave cell lists behind for clouds of n points
+ * (bucketed tier, 8192 <= n <= 65535); the reference's kernel has no such by-product
+ * (sampling_gpu.cu:75-178) */
+int pn2_fps_grid_supported(int n);
+
+/* pn2_furthest_point_sampling_ws (furthest_point_sampling_kernel_wrapper, sampling.cpp:16-18)
+ * that ALSO fills `grid` with the cell lists of `dataset` for balls of grid_radius -- the indices
+ * are exactly those of pn2_furthest_point_sampling_ws. */
+int pn2_furthest_point_sampling_grid(int b, int n, int m, const float *dataset, int *idxs,
+                                     void *workspace, size_t workspace_bytes, float grid_radius,
+                                     void *grid, size_t grid_bytes, void *stream);
+
 /* Human-readable text for a non-zero return value (hipGetErrorString); stands in for the
  * message the reference prints before exit(-1) in CUDA_CHECK_ERRORS (cuda_utils.h:35-44). */
 const char *pn2_error_string(int code);

@@ -94,7 +94,11 @@ def test_shared_mlp_fused_matches_sequential():
 @pytest.mark.parametrize("b,m,k,r", [(2, 64, 4, 640), (1, 128, 64, 1000), (2, 256, 131, 512),
                                      (3, 259, 128, 96), (1, 3, 7, 33), (2, 131, 259, 1024),
                                      (1, 512, 256, 64), (2, 32, 512, 200), (2, 64, 64, 3001),
-                                     (1, 100, 100, 2050), (2, 70, 160, 1537), (1, 65, 300, 777)])
+                                     (1, 100, 100, 2050), (2, 70, 160, 1537), (1, 65, 300, 777),
+                                     # column counts the pipelined kernels take (r % 256 == 0),
+                                     # every tile shape, K below / at / across the 16-deep chunk
+                                     (1, 64, 4, 1024), (2, 64, 64, 512), (1, 128, 64, 256),
+                                     (2, 40, 16, 768), (1, 96, 17, 512), (2, 300, 128, 256)])
 @pytest.mark.parametrize("small", [True, False], ids=["small-tile", "big-tile"])
 def test_mfma_gemm_primitives_vs_torch(b, m, k, r, small, monkeypatch):
     """forward / dgrad / wgrad of the 1x1 convolution on the matrix cores, every operand mode,

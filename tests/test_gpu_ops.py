@@ -48,6 +48,19 @@ def test_fps_sizes_vs_oracle(ext, oracle, synth, n, m):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("shift", [0.3, 1.1, 5.0])
+def test_fps_negative_coordinates(ext, oracle_omp, synth, shift):
+    """Clouds that straddle / lie below the origin (real scans are centred arbitrarily) on the
+    bucketed tier: the per-bucket bounding boxes prune correctly for negative coordinates
+    (round-1 regression: a mis-compiled wave minimum made them too tight there)."""
+    xyz = synth.cloud_uniform(2, 12000, 2.2, seed=41) - np.float32(shift)
+    want = oracle_omp.furthest_point_sampling(xyz, 600)
+    assert np.array_equal(ext.furthest_point_sampling(dev(xyz), 600).cpu().numpy(), want)
+    room = synth.cloud_room(2, 40000, seed=3) - np.array([3.0, 2.5, 1.0], np.float32)
+    want = oracle_omp.furthest_point_sampling(room, 1024)
+    assert np.array_equal(ext.furthest_point_sampling(dev(room), 1024).cpu().numpy(), want)
+
+
 def test_fps_all_ties(ext, oracle):
     # every point identical: the winner is decided purely by the reduction-tree order
     xyz = np.ones((1, 1024, 3), np.float32)
@@ -591,6 +604,63 @@ def test_query_and_group_fused_cell_list(ext, oracle_omp, synth, case):
     # and the fused result equals the unfused operators of the reference surface
     idx2 = ext.ball_query(dev(cen), dev(xyz), r, ns)
     assert torch.equal(idx2, idx)
+
+
+@pytest.mark.parametrize("case", ["uniform", "skipped_points", "negative", "ns_100", "small_m"])
+def test_cell_lists_from_fps_and_standalone(ext, oracle_omp, synth, case):
+    """Cell lists as an object (include/pn2_hip.h pn2_grid_*): built by the two-kernel build or
+    left behind by the furthest-point-sampling kernel, then queried -- same indices as the oracle
+    (and as the self-contained operators), same FPS indices as the plain sampling.  Includes
+    points the sampling skips (|p|^2 <= 1e-3: never sampled, but inside balls) and the lattice
+    seam."""
+    g = np.random.default_rng(23)
+    b, n, m, r, ns = 2, 12000, 600, 0.2, 64
+    xyz = synth.cloud_uniform(b, n, 2.2, seed=41)
+    if case == "skipped_points":
+        xyz[:, 100:400] = (g.random((b, 300, 3), dtype=np.float32) - 0.5) * 0.05  # |p|^2 <= 1e-3
+    elif case == "negative":
+        xyz = xyz - 1.1
+    elif case == "ns_100":
+        ns, r = 100, 0.3
+    elif case == "small_m":
+        m = 37
+    d_xyz = dev(xyz)
+    assert ext.grid_supported(b, n)
+    inds, lists = ext.furthest_point_sampling_with_grid(d_xyz, m, r)
+    assert lists is not None
+    assert torch.equal(inds, ext.furthest_point_sampling(d_xyz, m))
+    assert np.array_equal(inds.cpu().numpy(), oracle_omp.furthest_point_sampling(xyz, m))
+    new_xyz = ext.gather_points(d_xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+    want = oracle_omp.ball_query(new_xyz.cpu().numpy(), xyz, r, ns)
+    standalone = ext.build_grid(d_xyz, r)
+    for which in (lists, standalone):
+        assert np.array_equal(ext.ball_query_prebuilt(new_xyz, d_xyz, r, ns, which).cpu().numpy(), want)
+    feats = torch.randn(b, 3, n, device=DEV)
+    idx_a, out_a = ext.query_and_group(new_xyz, d_xyz, feats, r, ns, True)
+    idx_b, out_b = ext.query_and_group(new_xyz, d_xyz, feats, r, ns, True, None, lists)
+    assert torch.equal(idx_a, idx_b) and torch.equal(out_a, out_b)
+    assert np.array_equal(idx_b.cpu().numpy(), want)
+    with pytest.raises(RuntimeError):
+        ext.ball_query_prebuilt(new_xyz, d_xyz, r * 2, ns, lists)  # lists are per radius
+
+
+def test_sa_module_uses_cell_lists_of_the_sampling_kernel(ext, oracle_omp, synth):
+    """PointnetSAModuleVotes on a large cloud: the layer samples and groups through the cell
+    lists left behind by the sampling kernel (one fused query + gather kernel) and returns exactly
+    what the precomputed-index path returns."""
+    mods = __import__("importlib").import_module("pointnet2.pointnet2_modules")
+    torch.manual_seed(0)
+    sa = mods.PointnetSAModuleVotes(npoint=512, radius=0.2, nsample=32, mlp=[1, 16, 16, 32],
+                                    use_xyz=True, normalize_xyz=True).to(DEV).eval()
+    xyz = dev(synth.cloud_uniform(2, 9000, 2.0, seed=8))
+    feats = torch.randn(2, 1, 9000, device=DEV)
+    with torch.no_grad():
+        new_xyz, out, inds = sa(xyz, feats)
+        want_inds = ext.furthest_point_sampling(xyz, 512)
+        assert torch.equal(inds, want_inds)
+        ball = ext.ball_query(new_xyz, xyz, 0.2, 32)
+        new_xyz2, out2, _ = sa(xyz, feats, want_inds, ball, new_xyz)
+    assert torch.equal(new_xyz, new_xyz2) and torch.equal(out, out2)
 
 
 def test_lhs_nms_vs_reference_golden_and_oracle(oracle, synth):

@@ -80,6 +80,12 @@ def main():
                 continue
             dem = subprocess.run(["c++filt", k], stdout=subprocess.PIPE, text=True).stdout.strip()
             dem = re.sub(r"\(anonymous namespace\)::", "", dem)
+            if os.environ.get("ISA_SHORT"):
+                print("%-60s V %3s A %3s S %3s LDS %6s occ %s scr %s" % (
+                    dem.split("(")[0][-60:], u.get("VGPRs", "?"), u.get("AGPRs", "?"),
+                    u.get("TotalSGPRs", u.get("SGPRs", "?")), u.get("LDS Size [bytes/block]", "?"),
+                    u.get("Occupancy [waves/SIMD]", "?"), u.get("ScratchSize [bytes/lane]", "?")))
+                continue
             print(dem[:150])
             print("   VGPR %s AGPR %s SGPR %s  LDS %s  occupancy %s  scratch %s" % (
                 u.get("VGPRs", "?"), u.get("AGPRs", "?"), u.get("TotalSGPRs", u.get("SGPRs", "?")),

@@ -3,8 +3,10 @@
 Two forms of the same work (38 516 736 algorithmic bytes):
   api   : ball_query + group_points(xyz, C=3) + group_points(feat, C=1), the three calls of the
           reference's operator surface;
-  fused : query_and_group, the QueryAndGroup front end as the SA module runs it (cell-list build,
-          then ONE kernel that answers the queries and writes the (B, 4, m, ns) tensor).
+  fused : query_and_group, self-contained: cell-list build (two kernels), then ONE kernel that
+          answers the queries and writes the (B, 4, m, ns) tensor;
+  layer : the same ONE kernel on the cell lists the layer's furthest-point-sampling kernel left
+          behind (how PointnetSAModuleVotes runs SA1: no build between sampling and grouping).
 
     python tools/pair_bench.py [iters] [--json out.json]        # events around HIP-graph replays
     rocprofv3 --kernel-trace --stats ... -- python tools/pair_bench.py 20
@@ -51,10 +53,23 @@ def fused():
     ext.query_and_group(new_xyz, xyz, feat, R, NS, True)
 
 
+_, LISTS = ext.furthest_point_sampling_with_grid(xyz, M, R)  # the SA layer's own sampling call
+
+
+def layer():
+    """as the set-abstraction layer runs it: cell lists left behind by the sampling kernel"""
+    ext.query_and_group(new_xyz, xyz, feat, R, NS, True, None, LISTS)
+
+
+def build_only():
+    ext.build_grid(xyz, R)
+
+
 if plain:
     for _ in range(iters):
         api()
         fused()
+        layer()
     if "--ablate" in sys.argv:  # counter passes of the timing ablations (kernel names differ)
         for a in ("1", "2"):
             os.environ["PN2_GRID_ABLATE"] = a
@@ -66,7 +81,7 @@ if plain:
 else:
     res = {"shape": {"B": B, "N": N, "m": M, "nsample": NS, "radius": R},
            "algorithmic_bytes": bench.PAIR_BYTES}
-    for name, fn in (("api", api), ("fused", fused)):
+    for name, fn in (("api", api), ("fused", fused), ("layer", layer), ("build_only", build_only)):
         us = bench.time_op(fn, iters=iters, warm=3)
         res[name + "_us"] = round(us, 2)
         res[name + "_frac_of_8TBs"] = round(bench.PAIR_BYTES / (us * 1e-6) / 8e12, 4)
