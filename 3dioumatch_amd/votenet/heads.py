@@ -174,8 +174,11 @@ class GridConv(nn.Module):
         # unit grid, x slowest / z fastest: (g3, 3)
         unit = torch.stack(torch.meshgrid(step, step, step, indexing='ij'), dim=-1).view(g3, 3)
         local = unit.view(1, 1, g3, 3) * size.unsqueeze(2)  # (B, K, 64, 3): half-sizes scale it
-        rot = rot_z(heading).view(-1, 3, 3)
-        whole = torch.bmm(local.view(b * k, g3, 3), rot.transpose(1, 2)).view(b, k, g3, 3)
+        # local @ rot_z(heading)^T, written out (a 3x3 rotation about z is two multiply-adds per
+        # coordinate; the reference's torch.bmm, grid_conv_module.py:78-79, launches a BLAS kernel)
+        cos, sin = torch.cos(heading).view(b, k, 1), torch.sin(heading).view(b, k, 1)
+        lx, ly = local[..., 0], local[..., 1]
+        whole = torch.stack([lx * cos + ly * sin, ly * cos - lx * sin, local[..., 2]], dim=-1)
         whole = (whole + center.unsqueeze(2)).view(b, k * g3, 3).contiguous()
         relative = whole - center.unsqueeze(2).expand(-1, -1, g3, -1).reshape(b, k * g3, 3)
 

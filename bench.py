@@ -15,12 +15,18 @@ exchange is ONE all_reduce of the flat 4.26 MB gradient buffer per step (RCCL by
 --backend gloo for a CPU-mediated run), between the backward graph and the Adam graph.
 
 The JSON line also carries
-  roofline     -- the north-star kernel pair ball_query + group_points(xyz) + group_points(feat)
-                  at B=8, N=40000, m=2048, nsample=64: algorithmic bytes (38 516 736 B, SURVEY
-                  section 8d) / measured duration (events on the launch stream), vs 8 TB/s HBM;
+  roofline     -- the north-star pair ball_query + group_points(xyz) + group_points(feat) at B=8,
+                  N=40000, m=2048, nsample=64: algorithmic bytes (38 516 736 B)
+                  / measured duration (events on the launch stream around HIP-graph replays) vs
+                  8 TB/s HBM.  `frac` is the DOMINANT KERNEL: the fused query + gather kernel on
+                  the cell lists the layer's sampling kernel leaves behind (how SA1 runs); the
+                  self-contained operator (cell-list build included) and the three calls of the
+                  reference's operator surface are reported next to it (`forms`);
+  kernels      -- every hot-path kernel at the config-2 shapes: us, algorithmic bytes or flops,
+                  the bound, the fraction of that roofline;
+  ms_per_step_no_prefetch -- the same step with the coordinate-only index chain run inline;
   cpu_baseline -- the same train step on the host cores with the oracle (OpenMP build) behind
-                  the same Python modules, on a bounded sample (B=1), rank 0 / N=1 only;
-  kernels      -- per-op device times (us) at the config-2 shapes, for the record.
+                  the same Python modules, on a bounded sample (B=1), rank 0 / N=1 only.
 """
 import argparse
 import importlib
@@ -37,6 +43,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (~6.3 TB/s achievable)
+F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 B, NPTS, KPROP = 8, 40000, 256
 PAIR_BYTES = 38516736  # ball_query 8 230 912 + group(xyz) 20 617 216 + group(feat) 9 668 608
 
@@ -117,50 +124,105 @@ def time_op(fn, iters=20, warm=3):
 
 
 def kernel_table(device):
-    """Device time of each hot-path operator at the config-2 shapes (us per call)."""
+    """Every hot-path operator at the config-2 shapes: device time (us per call, events around
+    HIP-graph replays), algorithmic bytes / flops / tests per SURVEY section 8(d), the bound and the
+    achieved fraction of that roofline.  Returns (table, forms of the north-star pair)."""
     ext = importlib.import_module("pointnet2._ext")
     ut = importlib.import_module("pcdet.ops.iou3d_nms.iou3d_nms_utils")
     synth = importlib.import_module("3dioumatch_amd.synth")
     t = {}
+
+    def hbm(name, us, nbytes):
+        t[name] = {"us": round(us, 2), "bytes": int(nbytes), "bound": "hbm",
+                   "GBps": round(nbytes / us / 1e3, 1),
+                   "frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    def valu(name, us, work, unit, note):
+        t[name] = {"us": round(us, 2), "bound": note, unit: int(work),
+                   "G%s_per_s" % unit: round(work / us / 1e3, 2)}
+
+    m1, ns1, m2, ns2 = 2048, 64, 1024, 32
     xyz = torch.from_numpy(synth.cloud_uniform(B, NPTS, synth.cube_side(NPTS, 0.2, 64), seed=1)).to(device)
     flipped = xyz.transpose(1, 2).contiguous()
     feat = torch.rand(B, 1, NPTS, device=device)
-    t["fps_40000_2048"] = time_op(lambda: ext.furthest_point_sampling(xyz, 2048), iters=3, warm=1)
-    inds = ext.furthest_point_sampling(xyz, 2048)
+    us = time_op(lambda: ext.furthest_point_sampling(xyz, m1), iters=3, warm=1)
+    valu("fps_40000_2048", us, B * (m1 - 1) * NPTS, "dist_updates",
+         "latency of 2047 dependent rounds (8 workgroups); brute-force-equivalent updates")
+    inds, lists = ext.furthest_point_sampling_with_grid(xyz, m1, 0.2)
+    us = time_op(lambda: ext.furthest_point_sampling_with_grid(xyz, m1, 0.2), iters=3, warm=1)
+    valu("fps_40000_2048_with_cell_lists", us, B * (m1 - 1) * NPTS, "dist_updates",
+         "the same kernel also leaving SA1's cell lists behind")
     new_xyz = ext.gather_points(flipped, inds).transpose(1, 2).contiguous()
-    t["gather_3x2048"] = time_op(lambda: ext.gather_points(flipped, inds))
-    t["ball_query_sa1"] = time_op(lambda: ext.ball_query(new_xyz, xyz, 0.2, 64))
-    idx = ext.ball_query(new_xyz, xyz, 0.2, 64)
-    t["group_xyz_sa1"] = time_op(lambda: ext.group_points(flipped, idx))
-    t["group_feat_sa1"] = time_op(lambda: ext.group_points(feat, idx))
-    t["query_and_group_sa1_fused"] = time_op(
-        lambda: ext.query_and_group(new_xyz, xyz, feat, 0.2, 64, True))
-    g4 = torch.rand(B, 4, 2048, 64, device=device)
-    t["group_grad_sa1_c4"] = time_op(lambda: ext.group_points_grad(g4, idx, NPTS))
-    # SA2-scale gather / scatter (the large-C case)
+    hbm("gather_3x2048", time_op(lambda: ext.gather_points(flipped, inds)), 4 * B * m1 + 8 * B * 3 * m1)
+    bq_bytes = 12 * B * NPTS + 12 * B * m1 + 4 * B * m1 * ns1
+    gx_bytes = 4 * B * 3 * NPTS + 4 * B * m1 * ns1 + 4 * B * 3 * m1 * ns1
+    gf_bytes = 4 * B * 1 * NPTS + 4 * B * m1 * ns1 + 4 * B * 1 * m1 * ns1
+    assert bq_bytes + gx_bytes + gf_bytes == PAIR_BYTES
+    idx = ext.ball_query(new_xyz, xyz, 0.2, ns1)
+    hbm("ball_query_sa1", time_op(lambda: ext.ball_query(new_xyz, xyz, 0.2, ns1)), bq_bytes)
+    hbm("ball_query_sa1_prebuilt_lists", time_op(
+        lambda: ext.ball_query_prebuilt(new_xyz, xyz, 0.2, ns1, lists)), bq_bytes)
+    hbm("group_xyz_sa1", time_op(lambda: ext.group_points(flipped, idx)), gx_bytes)
+    hbm("group_feat_sa1", time_op(lambda: ext.group_points(feat, idx)), gf_bytes)
+    hbm("cell_list_build_sa1", time_op(lambda: ext.build_grid(xyz, 0.2)), 12 * B * NPTS + 16 * B * NPTS)
+
+    def api():
+        i = ext.ball_query(new_xyz, xyz, 0.2, ns1)
+        ext.group_points(flipped, i)
+        ext.group_points(feat, i)
+
+    forms = {
+        "layer": time_op(lambda: ext.query_and_group(new_xyz, xyz, feat, 0.2, ns1, True, None, lists)),
+        "self_contained": time_op(lambda: ext.query_and_group(new_xyz, xyz, feat, 0.2, ns1, True)),
+        "reference_api_3_calls": time_op(api),
+    }
+    hbm("query_and_group_sa1_fused_kernel", forms["layer"], PAIR_BYTES)
+    g4 = torch.rand(B, 4, m1, ns1, device=device)
+    hbm("group_grad_sa1_c4", time_op(lambda: ext.group_points_grad(g4, idx, NPTS)),
+        4 * B * 4 * m1 * ns1 + 4 * B * m1 * ns1 + 4 * B * 4 * NPTS)
+    # SA2-scale (the large-C case)
     xyz2 = new_xyz
-    inds2 = ext.furthest_point_sampling(xyz2, 1024)
-    t["fps_2048_1024"] = time_op(lambda: ext.furthest_point_sampling(xyz2, 1024), iters=5)
+    us = time_op(lambda: ext.furthest_point_sampling(xyz2, m2), iters=5)
+    valu("fps_2048_1024", us, B * (m2 - 1) * m1, "dist_updates", "latency of 1023 dependent rounds")
+    inds2 = ext.furthest_point_sampling(xyz2, m2)
     new2 = ext.gather_points(xyz2.transpose(1, 2).contiguous(), inds2).transpose(1, 2).contiguous()
-    idx2 = ext.ball_query(new2, xyz2, 0.4, 32)
-    t["ball_query_sa2"] = time_op(lambda: ext.ball_query(new2, xyz2, 0.4, 32))
-    f128 = torch.rand(B, 128, 2048, device=device)
-    t["group_feat_sa2_c128"] = time_op(lambda: ext.group_points(f128, idx2))
-    g128 = torch.rand(B, 128, 1024, 32, device=device)
-    t["group_grad_sa2_c128"] = time_op(lambda: ext.group_points_grad(g128, idx2, 2048))
-    grid = torch.rand(B, 32768, 3, device=device) * 3
-    seeds = torch.rand(B, 1024, 3, device=device) * 3
-    t["three_nn_gridconv"] = time_op(lambda: ext.three_nn(grid, seeds))
+    idx2 = ext.ball_query(new2, xyz2, 0.4, ns2)
+    us = time_op(lambda: ext.ball_query(new2, xyz2, 0.4, ns2))
+    valu("ball_query_sa2", us, B * m2 * m1, "tests", "VALU (brute-force tier: B*m*N distance tests)")
+    f128 = torch.rand(B, 128, m1, device=device)
+    c128 = 4 * B * 128 * m1 + 4 * B * m2 * ns2 + 4 * B * 128 * m2 * ns2
+    hbm("group_feat_sa2_c128", time_op(lambda: ext.group_points(f128, idx2)), c128)
+    g128 = torch.rand(B, 128, m2, ns2, device=device)
+    hbm("group_grad_sa2_c128", time_op(lambda: ext.group_points_grad(g128, idx2, m1)), c128)
+    ng, ms = 32768, 1024
+    grid = torch.rand(B, ng, 3, device=device) * 3
+    seeds = torch.rand(B, ms, 3, device=device) * 3
+    us = time_op(lambda: ext.three_nn(grid, seeds))
+    valu("three_nn_gridconv", us, B * ng * ms, "tests", "VALU (n*m distance tests, 3-slot insertion)")
     d2, nidx = ext.three_nn(grid, seeds)
-    w = torch.rand(B, 32768, 3, device=device)
-    f256 = torch.rand(B, 256, 1024, device=device)
-    t["three_interpolate_gridconv"] = time_op(lambda: ext.three_interpolate(f256, nidx, w))
+    w = torch.rand(B, ng, 3, device=device)
+    f256 = torch.rand(B, 256, ms, device=device)
+    hbm("three_interpolate_gridconv", time_op(lambda: ext.three_interpolate(f256, nidx, w)),
+        4 * B * 256 * ms + 24 * B * ng + 4 * B * 256 * ng)
     a, b = synth.boxes_pair(2048, seed=3)
     a_d, b_d = torch.from_numpy(a).to(device), torch.from_numpy(b[:512]).to(device)
-    t["iou3d_2048x512"] = time_op(lambda: ut.boxes_iou3d_gpu(a_d, b_d))
-    t["iou3d_256x256"] = time_op(lambda: ut.boxes_iou3d_gpu(a_d[:256], b_d[:256]))
-    pair_us = t["ball_query_sa1"] + t["group_xyz_sa1"] + t["group_feat_sa1"]
-    return {k: round(v, 2) for k, v in t.items()}, pair_us
+    us = time_op(lambda: ut.boxes_iou3d_gpu(a_d, b_d))
+    valu("iou3d_2048x512", us, 2048 * 512, "pairs", "VALU + transcendentals (~1 kFLOP per pair)")
+    us = time_op(lambda: ut.boxes_iou3d_gpu(a_d[:256], b_d[:256]))
+    valu("iou3d_256x256", us, 256 * 256, "pairs", "VALU + transcendentals; launch latency at this size")
+    # shared-MLP GEMMs (forward, BN+ReLU folded into the operand load) at two network shapes
+    K = importlib.import_module("pointnet2._mlp_ext")
+    for name, r, mm, kk in (("mlp_fwd_sa2_128x128", 32768, 128, 128), ("mlp_fwd_sa1_128x64", 131072, 128, 64)):
+        wgt = torch.randn(mm, kk, device=device) / kk ** 0.5
+        x = torch.randn(B, kk, r, device=device)
+        coeff = (torch.rand(kk, device=device) + 0.5, torch.rand(kk, device=device))
+        us = time_op(lambda: K.gemm_forward(wgt, x, coeff), iters=5, warm=2)
+        flops = 2.0 * B * mm * kk * r
+        t[name] = {"us": round(us, 2), "flops": int(flops), "bound": "mfma (fp32)",
+                   "TFLOPs": round(flops / us * 1e-6, 1),
+                   "frac": round(flops / (us * 1e-6) / 1e12 / F32_PEAK_TFLOPS, 4),
+                   "hbm_GBps": round(4.0 * B * r * (mm + kk) / us / 1e3, 1)}
+    return t, forms
 
 
 def cpu_baseline(V, cfg, steps=5):
@@ -258,6 +320,18 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(history).all().item(), "loss diverged: %s" % history.tolist()
+    # the same step with the index chain inline (not part of `value`): what the one-step-ahead
+    # prefetch of the coordinate-only chain hides
+    ms_inline = None
+    if pipelined and world == 1:
+        extra = max(2, args.steps // 2)
+        step(views[(args.warmup + args.steps) % 2])  # consumes the last prefetched slot
+        fence()
+        t1 = time.perf_counter()
+        for i in range(extra):
+            step(views[i % 2])
+        fence()
+        ms_inline = (time.perf_counter() - t1) * 1e3 / extra
 
     if rank == 0:
         ms = elapsed * 1e3 / args.steps
@@ -266,7 +340,9 @@ def main():
             else "scenes/sec train-step (SUN RGB-D 20k pts, 256 proposals)",
             "value": round(scenes * world * args.steps / elapsed, 3), "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms, 3),
+            "ms_per_step_no_prefetch": None if ms_inline is None else round(ms_inline, 3),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload],
                        "per_gpu_batch": scenes, "global_batch": scenes * world, "num_points": npts,
@@ -275,21 +351,32 @@ def main():
                        "hip_graphs": bool(step.runner.graphs)},
         }
         if not args.no_kernels:
-            table, pair_us = kernel_table(device)
-            achieved = PAIR_BYTES / (pair_us * 1e-6) / 1e9
-            # HBM bytes per pair from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-            # WRITE_SIZE in separate runs, gfx950 correction applied; profiles/r1_pair_pmc_v3.json)
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r1_pair_pmc_v3.json")
+            table, forms = kernel_table(device)
+            layer_us = forms["layer"]
+            achieved = PAIR_BYTES / (layer_us * 1e-6) / 1e9
+            # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+            # WRITE_SIZE in separate runs, gfx950 correction of the guide applied): measured by
+            # tools/pair_bench.py --plain under the profiler, NOT by this run
+            traffic, source = None, None
+            pmc = os.path.join(ROOT, "profiles", "r2_pair_pmc.json")
             if os.path.exists(pmc):
-                traffic = json.load(open(pmc)).get("traffic_bytes_per_pair")
+                traffic = json.load(open(pmc)).get("traffic_bytes_fused_kernel")
+                source = "profiles/r2_pair_pmc.json (separate rocprofv3 --pmc passes)"
             out["roofline"] = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "ball_query + group_points(xyz,C=3) + group_points(feat,C=1) @ B=8 "
-                          "N=40000 m=2048 ns=64", "algorithmic_bytes": PAIR_BYTES,
-                "duration_us": round(pair_us, 2)}
-            out["kernels_us"] = table
+                "traffic_source": source,
+                "kernel": "grid_query_kernel<192,1,true,0>: ball_query + group_points(xyz,C=3) + "
+                          "group_points(feat,C=1) in ONE launch @ B=8 N=40000 m=2048 ns=64, on the "
+                          "cell lists the layer's furthest-point-sampling kernel leaves behind",
+                "algorithmic_bytes": PAIR_BYTES, "duration_us": round(layer_us, 2),
+                "forms": {k: {"us": round(v, 2),
+                              "frac": round(PAIR_BYTES / (v * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                          for k, v in forms.items()},
+                "forms_note": "layer = the kernel above; self_contained = pn2_query_and_group "
+                              "(two-kernel cell-list build + the kernel above); "
+                              "reference_api_3_calls = ball_query, group_points, group_points"}
+            out["kernels"] = table
         if world == 1 and not args.no_cpu_baseline and args.workload == "pretrain":
             out["cpu_baseline"] = cpu_baseline(V, cfg)
         print(json.dumps(out), flush=True)
