@@ -51,6 +51,11 @@ _SIGNATURES = {
     "mlp_bn_relu_backward_stats": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_gemm_forward": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp, _vp, _vp],
+    "mlp_gemm_forward_stats_parts": [_c_int, _c_int, _c_int, _c_int, _vp],
+    "mlp_gemm_forward_stats": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "mlp_bn_finalize_pairs": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _c_float, _c_float, _vp, _vp,
+                              _vp, _vp, _vp, _vp, _vp, _vp],
+    "mlp_bn_finalize_pairs_scratch_bytes": [_c_int],
     "mlp_gemm_dgrad": [_c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                        _vp, _vp, _vp, _vp],
     "mlp_gemm_wgrad": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -81,7 +86,7 @@ _SIGNATURES = {
     "iou3d_nms": [_vp, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp],
     "iou3d_boxes_iou_bev_cpu": [_c_int, _vp, _c_int, _vp, _vp],
 }
-_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_grid_bytes": _sz, "pn2_fps_workspace_bytes": _sz, "mlp_bn_workspace_floats": _sz, "mlp_gemm_wgrad_workspace_floats": _sz, "pn2_error_string": ctypes.c_char_p}
+_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_grid_bytes": _sz, "pn2_fps_workspace_bytes": _sz, "mlp_bn_workspace_floats": _sz, "mlp_gemm_wgrad_workspace_floats": _sz, "mlp_bn_finalize_pairs_scratch_bytes": _sz, "pn2_error_string": ctypes.c_char_p}
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -156,6 +156,86 @@ bn_finalize_kernel(int c, int parts, const float *__restrict__ partial,
   }
 }
 
+// The same from equal-count (mean, M2) pairs laid out [part][channel][2] (the epilogue of the
+// forward GEMM, mlp_gemm.hip): mean = average of the part means, M2 = sum of the part M2 plus
+// n_part * sum (mean_i - mean)^2, accumulated in double.  Stage 1: workgroup (channel block of
+// 64, slice of the parts) -- lane = channel (512-byte contiguous reads per part), 16 waves split
+// the slice, eight loads in flight per lane -- writes three double sums per channel and slice;
+// stage 2 combines the slices.  (A single workgroup per channel block walked thousands of parts
+// with one dependent load per step: 0.3 ms for SA1.)
+constexpr int kPairSlices = 32;
+
+__global__ void __launch_bounds__(1024)
+bn_pairs_stage1_kernel(int c, int parts, const float *__restrict__ pairs,
+                       double *__restrict__ sums) {
+  __shared__ double red[16][3][kWave];
+  const int lane = lane_id(), w = threadIdx.x / kWave;
+  const int ch = blockIdx.x * kWave + lane;
+  const int per = (parts + kPairSlices - 1) / kPairSlices;
+  const int p0 = blockIdx.y * per, p1 = p0 + per < parts ? p0 + per : parts;
+  double s1 = 0.0, s2 = 0.0, sm2 = 0.0;
+  if (ch < c) {
+    const double ref = (double)pairs[(size_t)ch * 2];  // part 0's mean: no cancellation in s2
+    int p = p0 + w;
+    for (; p + 7 * 16 < p1; p += 8 * 16) {
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = *reinterpret_cast<const float2 *>(pairs + ((size_t)(p + u * 16) * c + ch) * 2);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const double d = (double)v[u].x - ref;
+        s1 += d; s2 += d * d; sm2 += (double)v[u].y;
+      }
+    }
+    for (; p < p1; p += 16) {
+      const float2 v = *reinterpret_cast<const float2 *>(pairs + ((size_t)p * c + ch) * 2);
+      const double d = (double)v.x - ref;
+      s1 += d; s2 += d * d; sm2 += (double)v.y;
+    }
+  }
+  red[w][0][lane] = s1; red[w][1][lane] = s2; red[w][2][lane] = sm2;
+  __syncthreads();
+  if (w != 0 || ch >= c) return;
+  for (int q = 1; q < 16; ++q) { s1 += red[q][0][lane]; s2 += red[q][1][lane]; sm2 += red[q][2][lane]; }
+  double *o = sums + ((size_t)blockIdx.y * c + ch) * 3;
+  o[0] = s1; o[1] = s2; o[2] = sm2;
+}
+
+__global__ void __launch_bounds__(256)
+bn_pairs_stage2_kernel(int c, int parts, int n_part, const float *__restrict__ pairs,
+                       const double *__restrict__ sums, const float *__restrict__ gamma,
+                       const float *__restrict__ beta, float eps, float momentum,
+                       float *__restrict__ running_mean, float *__restrict__ running_var,
+                       float *__restrict__ mean_out, float *__restrict__ invstd_out,
+                       float *__restrict__ scale_out, float *__restrict__ shift_out) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  double s1 = 0.0, s2 = 0.0, sm2 = 0.0;
+  for (int q = 0; q < kPairSlices; ++q) {
+    const double *o = sums + ((size_t)q * c + ch) * 3;
+    s1 += o[0]; s2 += o[1]; sm2 += o[2];
+  }
+  const double ref = (double)pairs[(size_t)ch * 2];
+  const double P = (double)parts, n = P * (double)n_part;
+  const double mean = ref + s1 / P;
+  double m2 = sm2 + (double)n_part * (s2 - s1 * s1 / P);
+  if (m2 < 0.0) m2 = 0.0;
+  const double var = m2 / n;  // biased, used for normalisation
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float fmean = (float)mean;
+  mean_out[ch] = fmean;
+  invstd_out[ch] = invstd;
+  const float sc = gamma[ch] * invstd;
+  scale_out[ch] = sc;
+  shift_out[ch] = beta[ch] - fmean * sc;
+  if (running_mean != nullptr) {  // nn.BatchNorm: unbiased variance in the running estimate
+    const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
+    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * fmean;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+  }
+}
+
 // eval mode: coefficients from the running statistics
 __global__ void __launch_bounds__(256)
 bn_eval_coeff_kernel(int c, const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -435,6 +515,30 @@ MLP_API int mlp_bn_train_stats(int b, int c, int r, const float *y, const float 
                      r, slices, y, workspace);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(pn2_ceil_div(c, 256 / kWave)), dim3(256), 0, stream, c,
                      b * slices, workspace, gamma, beta, eps, momentum, running_mean,
+                     running_var, mean, invstd, scale, shift);
+  return pn2_launch_status();
+}
+
+// Training-mode coefficients from the (mean, M2) pairs the forward GEMM left behind
+// (mlp_gemm_forward_stats): the statistics pass over y is gone.  scratch: device memory of
+// mlp_bn_finalize_pairs_scratch_bytes(c) bytes.
+MLP_API size_t mlp_bn_finalize_pairs_scratch_bytes(int c) {
+  return sizeof(double) * 3 * (size_t)kPairSlices * (size_t)(c > 0 ? c : 0);
+}
+
+MLP_API int mlp_bn_finalize_pairs(int c, int parts, int n_part, const float *pairs,
+                                  const float *gamma, const float *beta, float eps, float momentum,
+                                  float *running_mean, float *running_var, float *mean,
+                                  float *invstd, float *scale, float *shift, void *scratch,
+                                  void *stream_) {
+  if (c <= 0 || parts <= 0 || n_part <= 0) return 0;
+  if (!scratch) return (int)hipErrorInvalidValue;
+  hipStream_t stream = (hipStream_t)stream_;
+  double *sums = reinterpret_cast<double *>(scratch);
+  hipLaunchKernelGGL(bn_pairs_stage1_kernel, dim3(pn2_ceil_div(c, kWave), kPairSlices), dim3(1024),
+                     0, stream, c, parts, pairs, sums);
+  hipLaunchKernelGGL(bn_pairs_stage2_kernel, dim3(pn2_ceil_div(c, 256)), dim3(256), 0, stream, c,
+                     parts, n_part, pairs, sums, gamma, beta, eps, momentum, running_mean,
                      running_var, mean, invstd, scale, shift);
   return pn2_launch_status();
 }

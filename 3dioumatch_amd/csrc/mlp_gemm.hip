@@ -49,17 +49,25 @@ struct OperandB {
 
 constexpr bool is_dy(int mode) { return mode == OP_DY || mode == OP_POOLDY; }
 
-// Per-row constants of an operand (loaded once per row, kept in registers)
-struct RowCoef { float sc, sh, mu, is, a, c1, c2; };
+// Per-row constants of an operand (loaded once per row, kept in registers).  The BatchNorm+ReLU
+// backward  a*(g - c1 - ((x - mu)*is)*c2),  g = [x*sc + sh > 0] ? dz : 0,  is affine in x next
+// to the gated term:  a*g + (q*x + p)  with  q = -a*is*c2,  p = a*(is*c2*mu - c1)  -- folded per
+// row here, so that an element costs four fused multiply-adds / selects instead of ten
+// operations (these kernels spend a large share of their issue slots on operand transforms).
+struct RowCoef { float sc, sh, a, q, p; };
 
 template <int MODE>
 __device__ __forceinline__ RowCoef load_row_coef(const OperandB &op, int k, bool valid) {
-  RowCoef c = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  RowCoef c = {1.f, 0.f, 0.f, 0.f, 0.f};
   if (MODE == OP_DIRECT || !valid) return c;
   c.sc = op.scale[k]; c.sh = op.shift[k];
   if (is_dy(MODE)) {
-    c.mu = op.mean[k]; c.is = op.invstd[k];
-    c.a = op.coef[k * 3]; c.c1 = op.coef[k * 3 + 1]; c.c2 = op.coef[k * 3 + 2];
+    const float mu = op.mean[k], is = op.invstd[k];
+    const float a = op.coef[k * 3], c1 = op.coef[k * 3 + 1], c2 = op.coef[k * 3 + 2];
+    const float t = is * c2;
+    c.a = a;
+    c.q = -(a * t);
+    c.p = a * (t * mu - c1);
   }
   return c;
 }
@@ -67,9 +75,10 @@ __device__ __forceinline__ RowCoef load_row_coef(const OperandB &op, int k, bool
 template <int MODE>
 __device__ __forceinline__ float transform(float x, float dz, const RowCoef &c) {
   if (MODE == OP_DIRECT) return x;
-  if (MODE == OP_BNRELU) return fmaxf(x * c.sc + c.sh, 0.f);
-  const float g = (x * c.sc + c.sh > 0.f) ? dz : 0.f;
-  return c.a * (g - c.c1 - ((x - c.mu) * c.is) * c.c2);
+  const float z = __fmaf_rn(x, c.sc, c.sh);
+  if (MODE == OP_BNRELU) return fmaxf(z, 0.f);
+  const float lin = __fmaf_rn(c.q, x, c.p);
+  return z > 0.f ? __fmaf_rn(c.a, dz, lin) : lin;
 }
 
 // raw loads of N consecutive elements (x, and dz for OP_DY); zero outside the row / limit
@@ -249,12 +258,27 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsig
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
 }
 
+// sum over the 32 lanes of each half-wave; the total lands in lanes 16..31 / 48..63
+__device__ __forceinline__ float half_wave_sum(float v) {
+#define HW_STEP(CTRL, RM) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RM, 0xf, false))
+  HW_STEP(0xB1, 0xf);   // quad_perm [1,0,3,2]
+  HW_STEP(0x4E, 0xf);   // quad_perm [2,3,0,1]
+  HW_STEP(0x141, 0xf);  // row_half_mirror
+  HW_STEP(0x140, 0xf);  // row_mirror        -> every lane: the total of its row of 16
+  HW_STEP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3 -> the total of the half-wave
+#undef HW_STEP
+  return v;
+}
+
 // A_VEC: the rows of A are 16-byte aligned (lda % 4 == 0 and an aligned base)
-template <int TM, int TN, int WM, int WN, int MODE, bool A_TRANS, bool A_VEC>
+// STATS: the epilogue also reduces every output row over the tile's columns to a
+//        (mean, M2) pair for the BatchNorm that follows (one per row, cloud and column tile, all
+//        tiles hold TN columns): the statistics pass no longer re-reads y from HBM
+template <int TM, int TN, int WM, int WN, int MODE, bool A_TRANS, bool A_VEC, bool STATS = false>
 __global__ void __launch_bounds__(256, (MODE <= OP_BNRELU && TM <= 128) ? 4 : 2)
 gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int lda,
                 unsigned a_bytes, OperandB opb, float *__restrict__ c, size_t b_stride_in,
-                size_t b_stride_out) {
+                size_t b_stride_out, float *__restrict__ stats = nullptr, int stat_channels = 0) {
   constexpr int MB = TM / WM / 32, NB = TN / WN / 32;
   constexpr int LDA = TM + 4;       // [k][m] rows; 16-byte aligned rows, conflict-free fragments
   constexpr int AV = TM * KC / 4 / 256;  // 16-byte A pieces per lane and chunk
@@ -324,7 +348,7 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
     const bool row_ok = gk < k_total;
     // rows beyond K: zero coefficients AND zero data -> the staged operand is exactly zero
     rc = load_row_coef<MODE>(op, gk, row_ok);
-    if (!row_ok) { rc.sc = 0.f; rc.sh = 0.f; rc.a = 0.f; }
+    if (!row_ok) { rc.sc = 0.f; rc.sh = 0.f; rc.a = 0.f; rc.q = 0.f; rc.p = 0.f; }
     load_raw_segment<MODE, SEG>(op, in_off + (size_t)gk * r + r0 + bnn, r0 + bnn, r, true, row_ok,
                                 bx, bdz, b * k_total + gk);
   };
@@ -392,6 +416,51 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
         if (row < m_total) cb[(size_t)row * r + col] = acc[i][j][q];
       }
     }
+  if (STATS) {
+    // per output row: shifted sums over this wave's NB*32 columns (shift = the row's first
+    // column in the wave: no cancellation) -> (mean, M2); the WN wave columns of a row are merged
+    // by one lane per row (equal counts), and the workgroup writes TM contiguous pairs
+    __shared__ float2 wave_stat[WN][TM];
+    const int half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float v0 = acc[i][0][q];
+        const float s_lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v0), 0));
+        const float s_hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v0), 32));
+        const float shf = half ? s_hi : s_lo;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const float d = acc[i][j][q] - shf;
+          s1 += d;
+          s2 = __fmaf_rn(d, d, s2);
+        }
+        s1 = half_wave_sum(s1);
+        s2 = half_wave_sum(s2);
+        constexpr float kInvN = 1.0f / (float)(NB * 32);
+        if ((lane & 31) == 16) {
+          const int lrow = (wm * MB + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+          wave_stat[wn][lrow] = make_float2(shf + s1 * kInvN, fmaxf(s2 - s1 * s1 * kInvN, 0.f));
+        }
+      }
+    __syncthreads();
+    if (tid < TM && m0 + tid < m_total) {
+      float mean = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < WN; ++w2) { mean += wave_stat[w2][tid].x; m2 += wave_stat[w2][tid].y; }
+      mean *= 1.0f / (float)WN;
+#pragma unroll
+      for (int w2 = 0; w2 < WN; ++w2) {
+        const float d = wave_stat[w2][tid].x - mean;
+        m2 = __fmaf_rn((float)(NB * 32) * d, d, m2);
+      }
+      float *dst = stats + (((size_t)b * gridDim.x + blockIdx.x) * stat_channels + m0 + tid) * 2;
+      dst[0] = mean;
+      dst[1] = m2;
+    }
+  }
 }
 
 // Small-problem variant of gemm_nn_kernel (R of a few hundred columns per cloud: the FP layers
@@ -680,9 +749,29 @@ reduce_partials_kernel(int count, int parts, const float *__restrict__ part,
   }
 }
 
+// forward GEMM whose epilogue also leaves BatchNorm partials (see gemm_nn2_kernel STATS); only
+// instantiated for the operand modes of the forward pass
+template <int TM, int TN, int WM, int WN, int MODE, bool A_TRANS>
+void launch_stats(bool a_vec, int r, int b, hipStream_t stream, int rows, int k, const float *a_t,
+                  int lda, unsigned a_bytes, const OperandB &op, float *c_t, size_t in_stride,
+                  size_t out_stride, float *stats, int channels, int done) {
+  if constexpr (!A_TRANS && MODE <= OP_BNRELU) {
+    // partial (part, channel) pairs: part = cloud * tiles + tile, channel = done + row
+    float *st = stats + (size_t)done * 2;
+    if (a_vec)
+      hipLaunchKernelGGL((gemm_nn2_kernel<TM, TN, WM, WN, MODE, false, true, true>),
+                         dim3(pn2_ceil_div(r, TN), 1, b), dim3(256), 0, stream, rows, k, r, a_t, lda,
+                         a_bytes, op, c_t, in_stride, out_stride, st, channels);
+    else
+      hipLaunchKernelGGL((gemm_nn2_kernel<TM, TN, WM, WN, MODE, false, false, true>),
+                         dim3(pn2_ceil_div(r, TN), 1, b), dim3(256), 0, stream, rows, k, r, a_t, lda,
+                         a_bytes, op, c_t, in_stride, out_stride, st, channels);
+  }
+}
+
 template <int MODE, bool A_TRANS = false>
 int launch_nn(int b, int m, int k, int r, const float *a, int lda, const OperandB &op, float *c,
-              size_t in_stride, size_t out_stride, hipStream_t stream) {
+              size_t in_stride, size_t out_stride, hipStream_t stream, float *stats = nullptr) {
   // (read per call so that the tests can steer both kernels; a getenv costs nothing next to a launch)
   const char *env = getenv("MLP_SMALL_GEMM_COLS");
   const long long small_cols = env ? atoll(env) : 16384;
@@ -705,7 +794,10 @@ int launch_nn(int b, int m, int k, int r, const float *a, int lda, const Operand
     const bool a_vec = (lda & 3) == 0 && (reinterpret_cast<size_t>(a_t) & 15) == 0;
 #define NN(TM, TN, WM, WN)                                                                      \
   do {                                                                                          \
-    if (pipelined && a_vec)                                                                     \
+    if (stats)                                                                                  \
+      launch_stats<TM, TN, WM, WN, MODE, A_TRANS>(a_vec, r, b, stream, rows, k, a_t, lda, a_bytes, \
+                                                  op, c_t, in_stride, out_stride, stats, m, done); \
+    else if (pipelined && a_vec)                                                                \
       hipLaunchKernelGGL((gemm_nn2_kernel<TM, TN, WM, WN, MODE, A_TRANS, true>),                \
                          dim3(pn2_ceil_div(r, TN), 1, b), dim3(256), 0, stream, rows, k, r, a_t,  \
                          lda, a_bytes, op, c_t, in_stride, out_stride);                         \
@@ -747,6 +839,40 @@ MLP_API int mlp_gemm_forward(int b, int m, int k, int r, const float *w, const f
   if (mode == OP_DIRECT)
     return launch_nn<OP_DIRECT>(b, m, k, r, w, k, op, y, in_stride, out_stride, (hipStream_t)stream_);
   return launch_nn<OP_BNRELU>(b, m, k, r, w, k, op, y, in_stride, out_stride, (hipStream_t)stream_);
+}
+
+// Can the forward GEMM of this shape leave BatchNorm partials behind?  Returns the number of
+// (mean, M2) pairs per channel (0: no -- use mlp_bn_train_stats on y) and the columns each covers.
+MLP_API int mlp_gemm_forward_stats_parts(int b, int m, int k, int r, int *cols_per_part) {
+  (void)k;
+  const char *v2env = getenv("MLP_GEMM_PIPELINED");
+  const char *stenv = getenv("MLP_GEMM_EPILOGUE_STATS");
+  if ((v2env && atoi(v2env) == 0) || (stenv && atoi(stenv) == 0)) return 0;
+  const char *env = getenv("MLP_SMALL_GEMM_COLS");
+  const long long small_cols = env ? atoll(env) : 16384;
+  if (b <= 0 || r % 256 != 0 || (long long)b * r <= small_cols) return 0;
+  int tn;
+  if (m == 256) tn = 64;                 // one 256 x 64 tile per column block
+  else if (m > 32 && m <= 128) tn = 128; // one 128 x 128 / 64 x 128 tile
+  else return 0;                         // several row tiles of different widths: not covered
+  if (cols_per_part) *cols_per_part = tn;
+  return b * (r / tn);
+}
+
+// mlp_gemm_forward that also writes the (mean, M2) pairs of every output channel per part into
+// `pairs` (parts x m x 2 floats, parts from mlp_gemm_forward_stats_parts)
+MLP_API int mlp_gemm_forward_stats(int b, int m, int k, int r, const float *w, const float *x,
+                                   int mode, const float *scale, const float *shift, float *y,
+                                   float *pairs, void *stream_) {
+  if (b <= 0 || m <= 0 || k <= 0 || r <= 0) return 0;
+  if (!pairs || mlp_gemm_forward_stats_parts(b, m, k, r, nullptr) == 0) return (int)hipErrorInvalidValue;
+  OperandB op = {x, nullptr, scale, shift, nullptr, nullptr, nullptr};
+  const size_t in_stride = (size_t)k * r, out_stride = (size_t)m * r;
+  if (mode == OP_DIRECT)
+    return launch_nn<OP_DIRECT>(b, m, k, r, w, k, op, y, in_stride, out_stride,
+                                (hipStream_t)stream_, pairs);
+  return launch_nn<OP_BNRELU>(b, m, k, r, w, k, op, y, in_stride, out_stride, (hipStream_t)stream_,
+                              pairs);
 }
 
 // dX (b,k,r) = W^T (k x m, given as wt row-major) * dY, with dY either given (mode 0: dy) or

@@ -144,6 +144,43 @@ def gemm_forward(w, x, coeff=None):
     return y
 
 
+def gemm_forward_bn(w, x, coeff, gamma, beta, running_mean, running_var, momentum, eps):
+    """Training-mode layer: y = gemm_forward(w, x, coeff) and the BatchNorm coefficients of y
+    (mean, invstd, scale, shift), with the batch statistics reduced in the GEMM epilogue when the
+    shape allows (no second pass over y), else by bn_coefficients."""
+    import ctypes
+    _f32c(x, "x"); _f32c(w, "w")
+    b, k = x.shape[0], x.shape[1]
+    r = x.numel() // (b * k)
+    m = w.shape[0]
+    cols = ctypes.c_int(0)
+    parts = int(_lib.mlp_gemm_forward_stats_parts(b, m, k, r, ctypes.byref(cols)))
+    if parts <= 0:
+        y = gemm_forward(w, x, coeff)
+        return (y,) + tuple(bn_coefficients(y, gamma, beta, running_mean, running_var, momentum,
+                                            eps, True))
+    y = torch.empty((b, m) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    pairs = torch.empty((parts, m, 2), dtype=torch.float32, device=x.device)
+    out = torch.empty((4, m), dtype=torch.float32, device=x.device)
+    scratch = torch.empty(int(_lib.mlp_bn_finalize_pairs_scratch_bytes(m)), dtype=torch.uint8,
+                          device=x.device)
+    scale, shift = coeff if coeff is not None else (None, None)
+    with torch.cuda.device(x.device):
+        _L.check(_lib.mlp_gemm_forward_stats(b, m, k, r, w.data_ptr(), x.data_ptr(),
+                                             0 if coeff is None else 1, _ptr(scale), _ptr(shift),
+                                             y.data_ptr(), pairs.data_ptr(), _stream(x)),
+                 "mlp_gemm_forward_stats")
+        rm = running_mean.data_ptr() if running_mean is not None else None
+        rv = running_var.data_ptr() if running_var is not None else None
+        _L.check(_lib.mlp_bn_finalize_pairs(m, parts, cols.value, pairs.data_ptr(),
+                                            gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                            float(momentum), rm, rv, out[0].data_ptr(),
+                                            out[1].data_ptr(), out[2].data_ptr(),
+                                            out[3].data_ptr(), scratch.data_ptr(), _stream(x)),
+                 "mlp_bn_finalize_pairs")
+    return y, out[0], out[1], out[2], out[3]
+
+
 def bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, training):
     """-> dgamma, dbeta, coef (C,3): everything the on-the-fly dy needs."""
     _f32c(dz, "dz")

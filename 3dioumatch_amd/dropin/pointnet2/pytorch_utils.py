@@ -154,9 +154,13 @@ class _FusedMLPChain(Function):
         for i in range(n_layers):
             w, gamma, beta, rm, rv = params[5 * i:5 * i + 5]
             w2 = w.reshape(w.shape[0], -1)
-            y = K.gemm_forward(w2, cur, cur_coeff)
-            mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, momenta[i],
-                                                           epss[i], training)
+            if training:  # batch statistics come out of the GEMM epilogue where the shape allows
+                y, mean, invstd, scale, shift = K.gemm_forward_bn(w2, cur, cur_coeff, gamma, beta,
+                                                                  rm, rv, momenta[i], epss[i])
+            else:
+                y = K.gemm_forward(w2, cur, cur_coeff)
+                mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, momenta[i],
+                                                               epss[i], training)
             ys.append(y)
             coefs.append((mean, invstd, scale, shift))
             cur, cur_coeff = y, (scale, shift)

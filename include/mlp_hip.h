@@ -86,6 +86,25 @@ int mlp_bn_relu_backward_stats(int b, int c, int r, int training, const float *y
 int mlp_gemm_forward(int b, int m, int k, int r, const float *w, const float *x, int mode,
                      const float *scale, const float *shift, float *y, void *stream);
 
+/* BatchNorm statistics as a by-product of the convolution (nn.Conv2d + nn.BatchNorm2d of a
+ * shared-MLP layer, pytorch_utils.py:70-124, in training mode): the GEMM epilogue reduces every
+ * output channel over the tile's columns to a (mean, M2) pair, so the statistics pass does not
+ * re-read y.  mlp_gemm_forward_stats_parts: pairs per channel for this shape (0 = not covered:
+ * use mlp_bn_train_stats) and the columns each pair covers. */
+int mlp_gemm_forward_stats_parts(int b, int m, int k, int r, int *cols_per_part);
+/* mlp_gemm_forward (pytorch_utils.py:70-124) + pairs (parts x m x 2 floats) */
+int mlp_gemm_forward_stats(int b, int m, int k, int r, const float *w, const float *x, int mode,
+                           const float *scale, const float *shift, float *y, float *pairs,
+                           void *stream);
+/* mlp_bn_train_stats (nn.BatchNorm2d training statistics, pytorch_utils.py:14-39) from the pairs;
+ * scratch: mlp_bn_finalize_pairs_scratch_bytes(c) bytes of device memory */
+int mlp_bn_finalize_pairs(int c, int parts, int n_part, const float *pairs, const float *gamma,
+                          const float *beta, float eps, float momentum, float *running_mean,
+                          float *running_var, float *mean, float *invstd, float *scale,
+                          float *shift, void *scratch, void *stream);
+/* scratch size of mlp_bn_finalize_pairs (nn.BatchNorm2d keeps no scratch, pytorch_utils.py:14-39) */
+size_t mlp_bn_finalize_pairs_scratch_bytes(int c);
+
 /* input gradient: dx (b,k,r) = W^T * dy; wt is W^T (k,m) row-major.  mode 0: dy is given;
  * mode 2: dy is formed on the fly from (y, dz) and the vectors of mlp_bn_relu_backward_stats
  * (replaces conv2d backward-data + the BatchNorm/ReLU backward, pytorch_utils.py:70-124) */

@@ -141,6 +141,40 @@ def test_mfma_gemm_primitives_vs_torch(b, m, k, r, small, monkeypatch):
     close(K.gemm_wgrad(m, k, x, (scale_k, shift_k), fly=fly), want_dw_bn, tol)
 
 
+@pytest.mark.parametrize("b,m,k,r", [(2, 64, 4, 1024), (3, 128, 64, 512), (2, 256, 128, 768),
+                                     (1, 96, 131, 16640), (8, 128, 128, 4096)])
+@pytest.mark.parametrize("offset", [0.0, 40.0])
+def test_forward_gemm_leaves_batchnorm_statistics(b, m, k, r, offset):
+    """Training-mode layer with the batch statistics reduced in the GEMM epilogue
+    (mlp_gemm_forward_stats + mlp_bn_finalize_pairs) == the GEMM followed by the statistics pass
+    over y (and == torch): same y, same mean / invstd / scale / shift, same running statistics --
+    also when the channel means are 40 standard deviations away from zero (shifted sums)."""
+    load_pkg()
+    K = importlib.import_module("pointnet2._mlp_ext")
+    g = torch.Generator().manual_seed(b + m + k + r)
+    w = (torch.randn(m, k, generator=g) / k ** 0.5).to(DEV)
+    x = (torch.randn(b, k, r, generator=g) + offset).to(DEV)
+    gamma = (torch.rand(m, generator=g) + 0.5).to(DEV)
+    beta = torch.randn(m, generator=g).to(DEV)
+    coeff = None
+    if k > 4:
+        coeff = ((torch.rand(k, generator=g) + 0.5).to(DEV), (torch.randn(k, generator=g) * 0.3).to(DEV))
+    rm1, rv1 = torch.zeros(m, device=DEV), torch.ones(m, device=DEV)
+    rm2, rv2 = torch.zeros(m, device=DEV), torch.ones(m, device=DEV)
+    y1, mean1, inv1, sc1, sh1 = K.gemm_forward_bn(w, x, coeff, gamma, beta, rm1, rv1, 0.1, 1e-5)
+    y2 = K.gemm_forward(w, x, coeff)
+    mean2, inv2, sc2, sh2 = K.bn_coefficients(y2, gamma, beta, rm2, rv2, 0.1, 1e-5, True)
+    assert torch.equal(y1, y2)
+    ref = y2.double()
+    want_mean = ref.mean(dim=(0, 2))
+    want_var = ref.var(dim=(0, 2), unbiased=False)
+    scale = float(want_var.sqrt().max())
+    assert float((mean1.double() - want_mean).abs().max()) <= 2e-6 * max(1.0, float(want_mean.abs().max()), scale)
+    assert float((inv1.double() * torch.sqrt(want_var + 1e-5) - 1).abs().max()) <= 2e-5
+    close(mean1, mean2, 1e-6); close(inv1, inv2, 2e-5); close(sc1, sc2, 2e-5); close(sh1, sh2, 2e-5)
+    close(rm1, rm2, 1e-6); close(rv1, rv2, 2e-5)
+
+
 @pytest.mark.parametrize("b,m,k,groups,ns", [(2, 128, 64, 50, 64), (1, 256, 131, 33, 32),
                                              (2, 70, 259, 17, 16), (1, 64, 20, 40, 6),
                                              (2, 33, 7, 9, 3)])

@@ -33,6 +33,10 @@ for name, r, mk in LAYERS:
         t_f = bench.time_op(lambda: K.gemm_forward(w, x, None if li == 0 else coeff_k), iters=5, warm=2)
         t_d = bench.time_op(lambda: K.gemm_dgrad(w, fly=fly), iters=5, warm=2)
         t_w = bench.time_op(lambda: K.gemm_wgrad(m, k, x, None if li == 0 else coeff_k, fly=fly), iters=5, warm=2)
+        if "--direct" in sys.argv:  # the same GEMMs on a materialised dy / plain x (no transforms)
+            t_dd = bench.time_op(lambda: K.gemm_dgrad(w, dy=dz), iters=5, warm=2)
+            t_wd = bench.time_op(lambda: K.gemm_wgrad(m, k, x, None, dy=dz), iters=5, warm=2)
+            print("      direct operands: dgrad %7.1f us (fly %7.1f)   wgrad %7.1f us (fly %7.1f)" % (t_dd, t_d, t_wd, t_w))
         tot["fwd"] += t_f; tot["dgrad"] += t_d; tot["wgrad"] += t_w
         print("%-5s L%d M=%3d K=%3d R=%6d | fwd %7.1f us %5.1f TF | dgrad %7.1f us %5.1f TF | wgrad %7.1f us %5.1f TF"
               % (name, li, m, k, r, t_f, flops / t_f * 1e-6, t_d, flops / t_d * 1e-6, t_w, flops / t_w * 1e-6))
