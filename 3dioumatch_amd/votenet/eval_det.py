@@ -28,8 +28,9 @@ def corners_iou3d_gpu(a, b):
             raise RuntimeError("%s must be a (n,8,3) float32 GPU tensor" % name)
     n, m = a.shape[0], b.shape[0]
     out = torch.empty((n, m), dtype=torch.float64, device=a.device)
+    a, b = a.contiguous(), b.contiguous()  # (bound to locals: they must outlive the launch)
     with torch.cuda.device(a.device):
-        _L.check(_L.lib.iou3d_corners_iou3d(n, a.contiguous().data_ptr(), m, b.contiguous().data_ptr(),
+        _L.check(_L.lib.iou3d_corners_iou3d(n, a.data_ptr(), m, b.data_ptr(),
                                             out.data_ptr(), _L.current_stream_ptr(a.device)),
                  "iou3d_corners_iou3d")
     return out
@@ -46,10 +47,10 @@ def corners_best_match_gpu(det, gt_begin, gt_count, gt):
     nd = det.shape[0]
     ovmax = torch.empty(nd, dtype=torch.float64, device=det.device)
     jmax = torch.empty(nd, dtype=torch.int32, device=det.device)
+    det, gt_begin, gt_count, gt = (t.contiguous() for t in (det, gt_begin, gt_count, gt))
     with torch.cuda.device(det.device):
         _L.check(_L.lib.iou3d_corners_best_match(
-            nd, det.contiguous().data_ptr(), gt_begin.contiguous().data_ptr(),
-            gt_count.contiguous().data_ptr(), gt.contiguous().data_ptr(), ovmax.data_ptr(),
+            nd, det.data_ptr(), gt_begin.data_ptr(), gt_count.data_ptr(), gt.data_ptr(), ovmax.data_ptr(),
             jmax.data_ptr(), _L.current_stream_ptr(det.device)), "iou3d_corners_best_match")
     return ovmax, jmax
 

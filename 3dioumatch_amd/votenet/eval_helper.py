@@ -84,10 +84,11 @@ def parse_predictions(end_points, config_dict):
         scores = scores * iou.squeeze(-1)
     pred_mask = _nms3d(center.contiguous(), size64, heading64, scores.contiguous(), pred_sem_cls,
                        config_dict['nms_iou'], config_dict['use_old_type_nms'], same_class)
-    end_points['pred_mask'] = pred_mask
-
     # one device->host copy of the small results, then the reference's list layout
     keep = (pred_mask & (obj_prob > config_dict['conf_thresh'])).cpu().numpy()
+    # (B,K) float64 numpy array of 0/1 like the reference's (ap_helper.py:141-155), so that
+    # consumers such as dump_helper index / multiply it the same way
+    end_points['pred_mask'] = pred_mask.cpu().numpy().astype(np.float64)
     corners_h = corners.cpu().numpy()
     obj_h = obj_prob.cpu().numpy()
     sem_h = sem_probs.cpu().numpy()

@@ -25,11 +25,12 @@ def lhs_nms_samecls_gpu(center, size, heading, score, cls, thresh, old_type=Fals
     if n > 64:
         raise RuntimeError("lhs_nms_samecls: at most 64 boxes per scene (MAX_NUM_OBJ)")
     picked = torch.zeros((s, n), dtype=torch.int32, device=score.device)
+    # contiguous copies (if any) stay bound to locals until after the launch: a temporary's block
+    # could be handed to the next allocation on this stream before the kernel has read it
+    center, size, heading, score, cls = (t.contiguous() for t in (center, size, heading, score, cls))
     with torch.cuda.device(score.device):
-        _L.check(_lib.lhs_nms_samecls(s, n, center.contiguous().data_ptr(),
-                                      size.contiguous().data_ptr(),
-                                      heading.contiguous().data_ptr(),
-                                      score.contiguous().data_ptr(), cls.contiguous().data_ptr(),
+        _L.check(_lib.lhs_nms_samecls(s, n, center.data_ptr(), size.data_ptr(), heading.data_ptr(),
+                                      score.data_ptr(), cls.data_ptr(),
                                       float(thresh), 1 if old_type else 0, picked.data_ptr(),
                                       _L.current_stream_ptr(score.device)), "lhs_nms_samecls")
     return picked.bool()
@@ -47,10 +48,10 @@ def nms3d_aabb_gpu(center, size, heading, score, cls, thresh, old_type=False, sa
     if n > 256:
         raise RuntimeError("nms3d_aabb: at most 256 boxes per scene")
     picked = torch.zeros((s, n), dtype=torch.int32, device=score.device)
+    center, size, heading, score, cls = (t.contiguous() for t in (center, size, heading, score, cls))
     with torch.cuda.device(score.device):
-        _L.check(_lib.lhs_nms3d_aabb(s, n, center.contiguous().data_ptr(),
-                                     size.contiguous().data_ptr(), heading.contiguous().data_ptr(),
-                                     score.contiguous().data_ptr(), cls.contiguous().data_ptr(),
+        _L.check(_lib.lhs_nms3d_aabb(s, n, center.data_ptr(), size.data_ptr(), heading.data_ptr(),
+                                     score.data_ptr(), cls.data_ptr(),
                                      float(thresh), 1 if old_type else 0, 1 if same_class else 0,
                                      picked.data_ptr(), _L.current_stream_ptr(score.device)),
                  "lhs_nms3d_aabb")

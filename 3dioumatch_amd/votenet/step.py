@@ -106,6 +106,8 @@ class SupervisedStep(object):
         --  world_size > 1: ONE all-reduce of the flat gradient (RCCL / gloo), between graphs
         G2  Adam on the flat parameter buffer
 
+    In graph mode the returned loss / end_points are the graphs' STATIC output buffers: the next
+    replay overwrites them, so callers that accumulate statistics across steps must clone().
     Inputs are staged into static buffers (`next` while G0 runs, copied to `cur` for G1).  The
     graphs bake in tensor shapes, the set of supervised samples (the contents of
     `supervised_mask`, see _mask_facts) and the BatchNorm momentum; a change of any of them
@@ -152,6 +154,61 @@ class SupervisedStep(object):
                 if m.momentum != momentum:
                     self._captured = None  # the momentum is a kernel argument baked into G1
                 m.momentum = momentum
+
+    # ---------------------------------------------------------------- checkpoint interchange
+    def optimizer_state_dict(self):
+        """The Adam state in the REFERENCE's layout -- torch.optim.Adam over net.parameters(), one
+        entry per parameter tensor (pretrain.py:196,374 save / load `optimizer_state_dict`) --
+        split out of the flat buffers, so checkpoints move both ways."""
+        st = self.optimizer.state.get(self.flat_params, {})
+        group = {k: (float(v) if torch.is_tensor(v) else v)
+                 for k, v in self.optimizer.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(self._params)))
+        state, off = {}, 0
+        for i, p in enumerate(self._params):
+            n = p.numel()
+            if st:
+                step = st["step"]
+                state[i] = {"step": step.detach().clone().float().cpu() if torch.is_tensor(step)
+                            else torch.tensor(float(step)),
+                            "exp_avg": st["exp_avg"][off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": st["exp_avg_sq"][off:off + n].view(p.shape).clone()}
+            off += n
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, state_dict):
+        """Inverse of optimizer_state_dict(): a per-parameter Adam state (e.g. from a reference
+        checkpoint) merged into the flat moment buffers."""
+        state = state_dict["state"]
+        if not state:
+            return
+        if len(state) != len(self._params):
+            raise ValueError("optimizer state holds %d tensors, the detector has %d parameters"
+                             % (len(state), len(self._params)))
+        flat = self.flat_params
+        st = self.optimizer.state[flat]
+        if "exp_avg" not in st:
+            st["exp_avg"] = torch.zeros_like(flat.data)
+            st["exp_avg_sq"] = torch.zeros_like(flat.data)
+            st["step"] = torch.zeros((), dtype=torch.float32,
+                                     device=flat.device if self.device.type == "cuda" else "cpu")
+        off, steps = 0, []
+        for i, p in enumerate(self._params):
+            n = p.numel()
+            entry = state[i] if i in state else state[str(i)]
+            st["exp_avg"][off:off + n].copy_(entry["exp_avg"].reshape(-1))
+            st["exp_avg_sq"][off:off + n].copy_(entry["exp_avg_sq"].reshape(-1))
+            steps.append(float(entry["step"]))
+            off += n
+        if len(set(steps)) != 1:
+            raise ValueError("per-parameter Adam steps differ: cannot merge into one flat state")
+        if torch.is_tensor(st["step"]):
+            st["step"].fill_(steps[0])
+        else:
+            st["step"] = steps[0]
+        for k in ("betas", "eps", "weight_decay", "amsgrad"):
+            if k in state_dict["param_groups"][0]:
+                self.optimizer.param_groups[0][k] = state_dict["param_groups"][0][k]
 
     # ---------------------------------------------------------------- the step, eagerly
     def _forward_backward(self, batch):

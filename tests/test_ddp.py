@@ -119,6 +119,46 @@ def test_ema_update_and_schedules():
     assert V.bn_momentum_at(10000) == 0.001
 
 
+def test_adam_state_round_trips_through_the_reference_layout():
+    """The flat Adam state <-> the reference's per-parameter `optimizer_state_dict`
+    (pretrain.py:196,374): exported state loads into a torch.optim.Adam over net.parameters(),
+    continues identically there, and loads back."""
+    _install_standins()
+    V = importlib.import_module("3dioumatch_amd.votenet")
+    cfg = V.scannet_config()
+    runner = V.SupervisedStep(cfg, torch.device("cpu"), num_proposal=K)
+    torch.manual_seed(1)
+    runner(_batch(V, cfg, seed=7))
+    sd = runner.optimizer_state_dict()
+    assert len(sd["state"]) == len(list(runner.net.parameters())) == 96
+    clone = V.SupervisedStep(cfg, torch.device("cpu"), num_proposal=K)
+    clone.net.load_state_dict(runner.net.state_dict())
+    ref_opt = torch.optim.Adam(clone.net.parameters(), lr=1e-3)
+    ref_opt.load_state_dict(sd)  # the reference's optimizer accepts it as is
+    # one more identical step on both: flat Adam vs per-parameter Adam
+    batch = _batch(V, cfg, seed=8)
+    torch.manual_seed(2)
+    runner(dict(batch))
+    torch.manual_seed(2)
+    for p in clone.net.parameters():
+        p.grad = None
+    ep = clone.net(dict(batch), mode="jitter")
+    ep.update(batch)
+    loss, _ = V.get_labeled_loss(ep, cfg, {"dataset_config": cfg})
+    loss.backward()
+    ref_opt.step()
+    a = torch.cat([p.detach().reshape(-1) for p in runner.net.parameters()])
+    b = torch.cat([p.detach().reshape(-1) for p in clone.net.parameters()])
+    assert float((a - b).abs().max()) <= 1e-6
+    fresh = V.SupervisedStep(cfg, torch.device("cpu"), num_proposal=K)
+    fresh.load_optimizer_state_dict(ref_opt.state_dict())
+    back = fresh.optimizer_state_dict()
+    want = ref_opt.state_dict()
+    for i in range(96):
+        assert torch.allclose(back["state"][i]["exp_avg"], want["state"][i]["exp_avg"])
+        assert float(back["state"][i]["step"]) == float(want["state"][i]["step"]) == 2.0
+
+
 def _semi_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

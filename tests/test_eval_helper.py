@@ -42,7 +42,8 @@ def test_parse_predictions_matches_reference(use_gpu, tag, oracle, monkeypatch):
                    "nms_iou": 0.25, "use_old_type_nms": False, "cls_nms": cls_nms,
                    "use_iou_for_nms": use_iou, "per_class_proposal": cls_nms, "conf_thresh": 0.05}
     batch = E.parse_predictions(ep, config_dict)
-    np.testing.assert_array_equal(ep["pred_mask"].cpu().numpy().astype(np.int32), g[tag + "_pred_mask"])
+    assert isinstance(ep["pred_mask"], np.ndarray)  # the reference's layout: (B,K) numpy 0/1
+    np.testing.assert_array_equal(ep["pred_mask"].astype(np.int32), g[tag + "_pred_mask"])
     size64, heading64 = E.decode_boxes(ep, cfg)
     corners = E.corners_upright_camera(ep["center"], size64, heading64).cpu().numpy()
     np.testing.assert_allclose(corners, g[tag + "_corners"], rtol=0, atol=2e-6)
