@@ -75,7 +75,7 @@ template <int JP>
 __global__ void __launch_bounds__(256)
 three_interpolate_kernel(int c, int m, int n, const float *__restrict__ points,
                          const int *__restrict__ idx, const float *__restrict__ weight,
-                         float *__restrict__ out) {
+                         float *__restrict__ out, size_t out_bstride) {
   const BlockId blk = xcd_block_id();
   const int b = blk.z;
   const int j0 = (blk.x * 256 + threadIdx.x) * JP;
@@ -98,7 +98,7 @@ three_interpolate_kernel(int c, int m, int n, const float *__restrict__ points,
       r[t] = __fadd_rn(__fadd_rn(__fmul_rn(src[ii[t][0]], ww[t][0]),
                                  __fmul_rn(src[ii[t][1]], ww[t][1])),
                        __fmul_rn(src[ii[t][2]], ww[t][2]));
-    float *dst = out + ((size_t)b * c + l) * n + j0;
+    float *dst = out + (size_t)b * out_bstride + (size_t)l * n + j0;
     if (JP == 4) {
       *reinterpret_cast<float4 *>(dst) = make_float4(r[0], r[1], r[2], r[3]);
     } else {
@@ -115,7 +115,7 @@ template <int CPW>
 __global__ void __launch_bounds__(256)
 three_interpolate_lds_kernel(int c, int m, int n, const float *__restrict__ points,
                              const int *__restrict__ idx, const float *__restrict__ weight,
-                             float *__restrict__ out) {
+                             float *__restrict__ out, size_t out_bstride) {
   extern __shared__ __attribute__((aligned(16))) float rows[];
   const BlockId blk = xcd_block_id();
   const int b = blk.z, l0 = blk.y * CPW;
@@ -141,7 +141,7 @@ three_interpolate_lds_kernel(int c, int m, int n, const float *__restrict__ poin
         r[t] = __fadd_rn(__fadd_rn(__fmul_rn(row[ii[3 * t]], ww[3 * t]),
                                    __fmul_rn(row[ii[3 * t + 1]], ww[3 * t + 1])),
                          __fmul_rn(row[ii[3 * t + 2]], ww[3 * t + 2]));
-      *reinterpret_cast<float4 *>(out + ((size_t)b * c + l0 + cc) * n + j0) =
+      *reinterpret_cast<float4 *>(out + (size_t)b * out_bstride + (size_t)(l0 + cc) * n + j0) =
           make_float4(r[0], r[1], r[2], r[3]);
     }
   }
@@ -152,7 +152,8 @@ three_interpolate_lds_kernel(int c, int m, int n, const float *__restrict__ poin
 template <int CPW>
 __global__ void __launch_bounds__(256)
 three_interpolate_grad_lds_kernel(int c, int n, int m, const float *__restrict__ grad_out,
-                                  const int *__restrict__ idx, const float *__restrict__ weight,
+                                  size_t g_bstride, const int *__restrict__ idx,
+                                  const float *__restrict__ weight,
                                   float *__restrict__ grad_points) {
   extern __shared__ __attribute__((aligned(16))) float rows[];
   const BlockId blk = xcd_block_id();
@@ -168,7 +169,7 @@ three_interpolate_grad_lds_kernel(int c, int n, int m, const float *__restrict__
 #pragma unroll
     for (int cc = 0; cc < CPW; ++cc) {
       if (cc < nc) {
-        const float g = grad_out[((size_t)b * c + l0 + cc) * n + j];
+        const float g = grad_out[(size_t)b * g_bstride + (size_t)(l0 + cc) * n + j];
         float *row = rows + cc * m;
         atomicAdd(row + i1, __fmul_rn(g, w1));
         atomicAdd(row + i2, __fmul_rn(g, w2));
@@ -184,8 +185,8 @@ three_interpolate_grad_lds_kernel(int c, int n, int m, const float *__restrict__
 // grad_points[b,l,i_t] += grad_out[b,l,j] * w_t   (interpolate_gpu.cu:121-148)
 __global__ void __launch_bounds__(256)
 three_interpolate_grad_kernel(int c, int n, int m, const float *__restrict__ grad_out,
-                              const int *__restrict__ idx, const float *__restrict__ weight,
-                              float *__restrict__ grad_points) {
+                              size_t g_bstride, const int *__restrict__ idx,
+                              const float *__restrict__ weight, float *__restrict__ grad_points) {
   const BlockId blk = xcd_block_id();
   const int b = blk.z;
   const int j = blk.x * 256 + threadIdx.x;
@@ -195,7 +196,7 @@ three_interpolate_grad_kernel(int c, int n, int m, const float *__restrict__ gra
   const int i1 = ib[0], i2 = ib[1], i3 = ib[2];
   const float w1 = wb[0], w2 = wb[1], w3 = wb[2];
   for (int l = blk.y; l < c; l += gridDim.y) {
-    const float g = grad_out[((size_t)b * c + l) * n + j];
+    const float g = grad_out[(size_t)b * g_bstride + (size_t)l * n + j];
     float *dst = grad_points + ((size_t)b * c + l) * m;
     atomicAdd(dst + i1, __fmul_rn(g, w1));
     atomicAdd(dst + i2, __fmul_rn(g, w2));
@@ -221,47 +222,82 @@ PN2_API int pn2_three_nn(int b, int n, int m, const float *unknown, const float 
   return pn2_launch_status();
 }
 
-PN2_API int pn2_three_interpolate(int b, int c, int m, int n, const float *points,
-                                  const int *idx, const float *weight, float *out,
-                                  void *stream_) {
+// out may be a channel slice of a wider (b, C_total, n) tensor: out_bstride = C_total * n floats
+static int interpolate_run(int b, int c, int m, int n, const float *points, const int *idx,
+                           const float *weight, float *out, size_t out_bstride,
+                           hipStream_t stream) {
   if (b <= 0 || c <= 0 || n <= 0) return 0;
-  if (n % 4 == 0 && n >= 2048 && m > 0 && m <= 2048) {  // 8 source rows fit 64 KB of LDS
+  const bool vec = n % 4 == 0 && out_bstride % 4 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0;
+  if (vec && n >= 2048 && m > 0 && m <= 2048) {  // 8 source rows fit 64 KB of LDS
     constexpr int CPW = 8;
     dim3 grid(pn2_ceil_div(n, 1024), pn2_ceil_div(c, CPW), b);
     hipLaunchKernelGGL(three_interpolate_lds_kernel<CPW>, grid, dim3(256),
-                       sizeof(float) * (size_t)CPW * m, (hipStream_t)stream_, c, m, n, points, idx,
-                       weight, out);
+                       sizeof(float) * (size_t)CPW * m, stream, c, m, n, points, idx, weight, out,
+                       out_bstride);
     return pn2_launch_status();
   }
-  if (n % 4 == 0) {
+  if (vec) {
     dim3 grid(pn2_ceil_div(n, 1024), interp_channel_groups(c), b);
-    hipLaunchKernelGGL(three_interpolate_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream_, c,
-                       m, n, points, idx, weight, out);
+    hipLaunchKernelGGL(three_interpolate_kernel<4>, grid, dim3(256), 0, stream, c, m, n, points,
+                       idx, weight, out, out_bstride);
   } else {
     dim3 grid(pn2_ceil_div(n, 256), interp_channel_groups(c), b);
-    hipLaunchKernelGGL(three_interpolate_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream_, c,
-                       m, n, points, idx, weight, out);
+    hipLaunchKernelGGL(three_interpolate_kernel<1>, grid, dim3(256), 0, stream, c, m, n, points,
+                       idx, weight, out, out_bstride);
   }
   return pn2_launch_status();
 }
 
-PN2_API int pn2_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
-                                       const int *idx, const float *weight, float *grad_points,
-                                       void *stream_) {
+static int interpolate_grad_run(int b, int c, int n, int m, const float *grad_out, size_t g_bstride,
+                                const int *idx, const float *weight, float *grad_points,
+                                hipStream_t stream) {
   if (b <= 0 || c <= 0 || m <= 0) return 0;
-  hipStream_t stream = (hipStream_t)stream_;
   if (n > 0 && m <= 1024) {  // 16 destination rows fit 64 KB of LDS
     constexpr int CPW = 16;
     hipLaunchKernelGGL(three_interpolate_grad_lds_kernel<CPW>, dim3(pn2_ceil_div(c, CPW), b),
-                       dim3(256), sizeof(float) * (size_t)CPW * m, stream, c, n, m, grad_out, idx,
-                       weight, grad_points);
+                       dim3(256), sizeof(float) * (size_t)CPW * m, stream, c, n, m, grad_out,
+                       g_bstride, idx, weight, grad_points);
     return pn2_launch_status();
   }
   const int e = pn2_zero_async(grad_points, sizeof(float) * (size_t)b * c * m, stream);
   if (e != 0) return e;
   if (n <= 0) return 0;
   dim3 grid(pn2_ceil_div(n, 256), interp_channel_groups(c), b);
-  hipLaunchKernelGGL(three_interpolate_grad_kernel, grid, dim3(256), 0, stream, c, n, m,
-                     grad_out, idx, weight, grad_points);
+  hipLaunchKernelGGL(three_interpolate_grad_kernel, grid, dim3(256), 0, stream, c, n, m, grad_out,
+                     g_bstride, idx, weight, grad_points);
   return pn2_launch_status();
+}
+
+PN2_API int pn2_three_interpolate(int b, int c, int m, int n, const float *points,
+                                  const int *idx, const float *weight, float *out,
+                                  void *stream_) {
+  return interpolate_run(b, c, m, n, points, idx, weight, out, (size_t)c * n, (hipStream_t)stream_);
+}
+
+PN2_API int pn2_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                                       const int *idx, const float *weight, float *grad_points,
+                                       void *stream_) {
+  return interpolate_grad_run(b, c, n, m, grad_out, (size_t)c * n, idx, weight, grad_points,
+                              (hipStream_t)stream_);
+}
+
+// The same operators on channel SLICES of wider tensors: `out` / `grad_out` point at the first
+// channel of the slice inside a (b, c_total, n) tensor.  The feature-propagation layer
+// concatenates the interpolated features with the skip features (pointnet2_modules.py:404-410);
+// writing the interpolation straight into the concatenated buffer, and reading its gradient
+// straight out of the concatenated gradient, removes a full copy of both.
+PN2_API int pn2_three_interpolate_into(int b, int c, int m, int n, const float *points,
+                                       const int *idx, const float *weight, float *out,
+                                       int c_total, void *stream_) {
+  if (c_total < c) return (int)hipErrorInvalidValue;
+  return interpolate_run(b, c, m, n, points, idx, weight, out, (size_t)c_total * n,
+                         (hipStream_t)stream_);
+}
+
+PN2_API int pn2_three_interpolate_grad_from(int b, int c, int n, int m, const float *grad_out,
+                                            int c_total, const int *idx, const float *weight,
+                                            float *grad_points, void *stream_) {
+  if (c_total < c) return (int)hipErrorInvalidValue;
+  return interpolate_grad_run(b, c, n, m, grad_out, (size_t)c_total * n, idx, weight, grad_points,
+                              (hipStream_t)stream_);
 }

@@ -153,6 +153,40 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     return out
 
 
+def three_interpolate_into(points, idx, weight, out, channel0):
+    """three_interpolate written into channels [channel0, channel0 + C) of the preallocated
+    contiguous (B, C_total, n) tensor `out` (no intermediate, no concatenation copy)."""
+    _chk_f32(points, "points"); _chk_i32(idx, "idx"); _chk_f32(weight, "weight"); _chk_f32(out, "out")
+    _chk_dev(points, (idx, "idx"), (weight, "weight"), (out, "out"))
+    b, c, m = points.shape
+    n = idx.shape[1]
+    c_total = out.shape[1]
+    if out.shape[0] != b or out.shape[2] != n or channel0 < 0 or channel0 + c > c_total:
+        raise RuntimeError("out must be (B, C_total >= channel0 + C, n)")
+    with torch.cuda.device(points.device):
+        _L.check(_lib.pn2_three_interpolate_into(b, c, m, n, points.data_ptr(), idx.data_ptr(),
+                                                 weight.data_ptr(),
+                                                 out.data_ptr() + 4 * channel0 * n, c_total,
+                                                 _stream(points)), "three_interpolate_into")
+    return out
+
+
+def three_interpolate_grad_from(grad, channel0, c, idx, weight, m):
+    """three_interpolate_grad of channels [channel0, channel0 + c) of the contiguous
+    (B, C_total, n) gradient `grad` (read in place, no slice copy) -> (B, c, m)."""
+    _chk_f32(grad, "grad"); _chk_i32(idx, "idx"); _chk_f32(weight, "weight")
+    _chk_dev(grad, (idx, "idx"), (weight, "weight"))
+    b, c_total, n = grad.shape
+    out = torch.empty((b, int(c), int(m)), dtype=torch.float32, device=grad.device)
+    with torch.cuda.device(grad.device):
+        _L.check(_lib.pn2_three_interpolate_grad_from(b, int(c), n, int(m),
+                                                      grad.data_ptr() + 4 * channel0 * n, c_total,
+                                                      idx.data_ptr(), weight.data_ptr(),
+                                                      out.data_ptr(), _stream(grad)),
+                 "three_interpolate_grad_from")
+    return out
+
+
 def _ball_ws(t, b, n, m, nsample):
     """Private scratch per call, from torch's stream-aware caching allocator: ball queries run
     concurrently on the prefetch stream and on the main stream, so a shared buffer would race."""

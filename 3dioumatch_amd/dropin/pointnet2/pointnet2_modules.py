@@ -220,12 +220,15 @@ class PointnetFPModule(nn.Module):
     def forward(self, unknown, known, unknow_feats, known_feats, interpolation=None):
         if known is None:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
+            stacked = interpolated if unknow_feats is None else \
+                torch.cat([interpolated, unknow_feats], dim=1)
         else:
             idx, weight = interpolation if interpolation is not None else \
                 self.interpolation(unknown, known)
-            interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
-        stacked = interpolated if unknow_feats is None else \
-            torch.cat([interpolated, unknow_feats], dim=1)
+            if unknow_feats is None:
+                stacked = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+            else:  # interpolation written straight into the concatenated tensor
+                stacked = pointnet2_utils.interpolate_concat(known_feats, idx, weight, unknow_feats)
         return self.mlp(stacked.unsqueeze(-1)).squeeze(-1)
 
 

@@ -87,6 +87,42 @@ class ThreeInterpolate(Function):
 three_interpolate = ThreeInterpolate.apply
 
 
+class InterpolateConcat(Function):
+    """cat([three_interpolate(known_feats, idx, weight), skip_feats], dim=1) without the
+    intermediate: the interpolation is written straight into the first channels of the output,
+    and its gradient is read straight out of the incoming gradient (pointnet2_modules.py:404-410:
+    the feature-propagation layer's interpolate + torch.cat)."""
+
+    @staticmethod
+    def forward(ctx, known_feats, idx, weight, skip_feats):
+        b, c2, m = known_feats.shape
+        n = idx.shape[1]
+        c1 = skip_feats.shape[1]
+        out = torch.empty((b, c2 + c1, n), dtype=torch.float32, device=known_feats.device)
+        _ext.three_interpolate_into(known_feats.contiguous(), idx, weight, out, 0)
+        out[:, c2:].copy_(skip_feats)
+        ctx.save_for_backward(idx, weight)
+        ctx.dims = (c2, c1, m)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        idx, weight = ctx.saved_tensors
+        c2, c1, m = ctx.dims
+        grad = grad.contiguous()
+        g_known = _ext.three_interpolate_grad_from(grad, 0, c2, idx, weight, m) \
+            if ctx.needs_input_grad[0] else None
+        g_skip = grad[:, c2:] if ctx.needs_input_grad[3] else None
+        return g_known, None, None, g_skip
+
+
+def interpolate_concat(known_feats, idx, weight, skip_feats):
+    """The fused form on the GPU extension, the reference composition elsewhere."""
+    if hasattr(_ext, "three_interpolate_into") and known_feats.is_cuda:
+        return InterpolateConcat.apply(known_feats, idx, weight, skip_feats)
+    return torch.cat([three_interpolate(known_feats, idx, weight), skip_feats], dim=1)
+
+
 class GroupingOperation(Function):
     @staticmethod
     def forward(ctx, features, idx):

@@ -203,9 +203,22 @@ class GridConv(nn.Module):
         else:
             weight = 1 / (dist + 1e-8)
             weight = (weight / torch.sum(weight, dim=2, keepdim=True)).contiguous()
-            interp = pointnet2_utils.three_interpolate(origin_features, idx, weight)  # (B, C, K*64)
-        feats = torch.cat([relative.transpose(1, 2).reshape(b, 3, k, g3),
-                           interp.view(b, -1, k, g3)], dim=1)
+            into = getattr(pointnet2_utils._ext, "three_interpolate_into", None)
+            if into is not None and origin_features.is_cuda:
+                # (B, 3 + C, K*64) written once: the interpolation goes straight into channels
+                # 3.., no 136 MB intermediate and no concatenation copy (features are detached
+                # here, grid_conv_module.py:60-61, so nothing flows back through this)
+                feats = torch.empty((b, 3 + origin_features.shape[1], k * g3),
+                                    dtype=torch.float32, device=whole.device)
+                into(origin_features, idx, weight, feats, 3)
+                feats[:, :3].copy_(relative.transpose(1, 2))
+                interp = None
+                feats = feats.view(b, -1, k, g3)
+            else:
+                interp = pointnet2_utils.three_interpolate(origin_features, idx, weight)  # (B, C, K*64)
+        if interp is not None:
+            feats = torch.cat([relative.transpose(1, 2).reshape(b, 3, k, g3),
+                               interp.view(b, -1, k, g3)], dim=1)
         iou_features = self.mlp_before_iou.forward_pooled(feats)
         net = head_chain(iou_features, self.conv1_iou, self.bn1_iou, self.conv2_iou, self.bn2_iou,
                          self.conv3_iou)

@@ -96,6 +96,18 @@ int pn2_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out
                                const int *idx, const float *weight, float *grad_points,
                                void *stream);
 
+/* pn2_three_interpolate / pn2_three_interpolate_grad (interpolate.cpp:47-104) on channel SLICES
+ * of wider tensors: out / grad_out point at the first channel of a c-channel slice inside a
+ * (b, c_total, n) tensor.  PointnetFPModule concatenates the interpolated features with the skip
+ * features (pointnet2_modules.py:404-410): writing straight into the concatenated buffer and
+ * reading the gradient straight out of the concatenated gradient saves a copy of both. */
+int pn2_three_interpolate_into(int b, int c, int m, int n, const float *points, const int *idx,
+                               const float *weight, float *out, int c_total, void *stream);
+/* (interpolate.cpp:77-104, the intended scatter-add, on a slice of the gradient) */
+int pn2_three_interpolate_grad_from(int b, int c, int n, int m, const float *grad_out, int c_total,
+                                    const int *idx, const float *weight, float *grad_points,
+                                    void *stream);
+
 /* ---- additions (no reference counterpart; the reference composes these in Python) ---- */
 
 /* Fused QueryAndGroup front end (pointnet2_utils.py:335-358): ball query, gather of xyz and

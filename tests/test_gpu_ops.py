@@ -287,6 +287,28 @@ def test_three_interpolate_every_kernel_vs_oracle(ext, oracle, b, c, m, n):
     np.testing.assert_allclose(grad, want, rtol=0, atol=1e-4 * max(1.0, np.abs(want).max()))
 
 
+@pytest.mark.parametrize("b,c,m,n,ctot,c0", [(2, 20, 700, 4096, 31, 3), (1, 9, 2048, 2048, 9, 0),
+                                             (2, 33, 50, 2052, 40, 7), (1, 5, 3000, 37, 6, 1),
+                                             (8, 256, 1024, 16384, 259, 3)])
+def test_interpolate_on_channel_slices(ext, b, c, m, n, ctot, c0):
+    """three_interpolate written into / its gradient read out of a channel slice of a wider
+    tensor (the feature-propagation concatenation without the copy) == the plain operators on
+    separate tensors, bit for bit (forward) / to the atomics' summation order (backward)."""
+    g = torch.Generator().manual_seed(b * 100 + c + m + n)
+    pts = torch.randn(b, c, m, generator=g).to(DEV)
+    idx = torch.randint(0, m, (b, n, 3), generator=g, dtype=torch.int32).to(DEV)
+    w = torch.rand(b, n, 3, generator=g).to(DEV)
+    want = ext.three_interpolate(pts, idx, w)
+    out = torch.full((b, ctot, n), -7.0, device=DEV)
+    ext.three_interpolate_into(pts, idx, w, out, c0)
+    assert torch.equal(out[:, c0:c0 + c], want)
+    assert bool((out[:, :c0] == -7.0).all()) and bool((out[:, c0 + c:] == -7.0).all())
+    grad = torch.randn(b, ctot, n, generator=g).to(DEV)
+    want_g = ext.three_interpolate_grad(grad[:, c0:c0 + c].contiguous(), idx, w, m)
+    got_g = ext.three_interpolate_grad_from(grad, c0, c, idx, w, m)
+    torch.testing.assert_close(got_g, want_g, rtol=0, atol=1e-4)
+
+
 @pytest.mark.parametrize("b,n,m", [(2, 4096, 1024), (1, 1000, 1500), (3, 37, 5), (1, 2500, 2049)])
 def test_three_nn_vs_oracle(ext, oracle, synth, b, n, m):
     unk = synth.cloud_uniform(b, n, 2.0, seed=n)

@@ -1,7 +1,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r2q; mkdir -p $O
-export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof -o step -- python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-kernels > $O/bench_prof.log 2>&1
-python tools/prof_summary.py $O/prof/step_kernel_trace.csv fps_bucket_kernel 5 $O/step_summary.csv > /dev/null 2>&1
-rm -rf $O/prof
+O=gpurun_out/r2r; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_all.log 2>&1; echo "rc=$?" >> $O/pytest_all.log
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernels > $O/bench.log 2>&1
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernels --workload semi > $O/bench_semi.log 2>&1
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernels --workload sunrgbd > $O/bench_sun.log 2>&1
