@@ -258,7 +258,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
 }
 
 // MAXH : capacity of the hit list (<= 256; denser balls: in-launch brute force); nsample <= MAXH / 2
-// CPW  : centroids a wave handles one after the other (amortises the per-wave set-up)
+// WPB  : waves (= centroids in flight) per workgroup
 // GROUP: also write the grouped (b, ctot, m, ns) tensor
 // ABL  : 0 = the operator; 1 / 2 = timing ablations (no ranking / no candidate tests), used by
 //        tools/pair_bench.py --sweep only
@@ -273,8 +273,8 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
 // offsets, and a hit's rank inside its bucket (1-2 elements for a ball of a shuffled cloud) is a
 // count of smaller indices among the bucket's elements.  rank -> output slot directly, for any
 // number of hits, so nsample in (64, 128] needs no second pass.
-template <int MAXH, int CPW, bool GROUP, int ABL>
-__global__ void __launch_bounds__(256)
+template <int MAXH, int WPB, bool GROUP, int ABL>
+__global__ void __launch_bounds__(WPB * kWave)
 grid_query_kernel(int n, int m, int wg_per_cloud, unsigned wpc_recip, float radius2, float inv_side,
                   int nsample,
                   unsigned bucket_mul, const float *__restrict__ new_xyz,
@@ -283,7 +283,8 @@ grid_query_kernel(int n, int m, int wg_per_cloud, unsigned wpc_recip, float radi
   static_assert(MAXH <= 256, "perm holds list positions in a byte");
   constexpr int TMAX = MAXH / kWave;
   constexpr int NH = MAXH >= 4 * kWave ? 2 : 1;  // nsample <= 64 * NH
-  __shared__ WaveLds<MAXH> lds[256 / kWave];
+  constexpr int CPW = 1;
+  __shared__ WaveLds<MAXH> lds[WPB];
   // 1-D grid, XCD-contiguous: cloud = id / wg_per_cloud (one division per workgroup)
   const int wg = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
   const int b = (int)__umulhi((unsigned)wg, wpc_recip);  // wg / wg_per_cloud (exact: wg < 2^16)
@@ -297,7 +298,7 @@ grid_query_kernel(int n, int m, int wg_per_cloud, unsigned wpc_recip, float radi
 
 #pragma unroll 1
   for (int cq = 0; cq < CPW; ++cq) {
-    const int j = ((wg - b * wg_per_cloud) * (256 / kWave) + wave) * CPW + cq;
+    const int j = ((wg - b * wg_per_cloud) * WPB + wave) * CPW + cq;
     if (j >= m) return;  // whole wave
     const float *ctr = new_xyz + ((size_t)b * m + j) * 3;
     int *row = idx + ((size_t)b * m + j) * nsample;
@@ -539,17 +540,27 @@ static int grid_run(int b, int n, int m, float radius, int nsample, const float 
   const int abl = abl_env ? atoi(abl_env) : 0;
 #define GRID_QUERY(MAXH, GROUP, ABL)                                                               \
   do {                                                                                             \
-    const int wpc = pn2_ceil_div(m, 256 / kWave);                                                  \
-    const unsigned recip = (unsigned)(((1ull << 32) + wpc - 1) / wpc);                            \
-    hipLaunchKernelGGL((grid_query_kernel<MAXH, 1, GROUP, ABL>), dim3(wpc * b), dim3(256), 0,      \
-                       stream, n, m, wpc, recip, radius2, inv_side, nsample, bucket_mul, new_xyz,  \
-                       xyz, ws.start, ws.rec, idx, g);                                             \
+    if (wpb == 4) GRID_QUERY_W(MAXH, 4, GROUP, ABL);                                               \
+    else GRID_QUERY_W(MAXH, 1, GROUP, ABL);                                                        \
   } while (0)
+#define GRID_QUERY_W(MAXH, WPB, GROUP, ABL)                                                        \
+  do {                                                                                             \
+    const int wpc = pn2_ceil_div(m, WPB);                                                          \
+    const unsigned recip = (unsigned)(((1ull << 32) + wpc - 1) / wpc);                            \
+    hipLaunchKernelGGL((grid_query_kernel<MAXH, WPB, GROUP, ABL>), dim3(wpc * b),                  \
+                       dim3(WPB * kWave), 0, stream, n, m, wpc, recip, radius2, inv_side, nsample, \
+                       bucket_mul, new_xyz, xyz, ws.start, ws.rec, idx, g);                        \
+  } while (0)
+  // one wave per workgroup: a finished centroid frees its slot at once (18.35 vs 18.63 us with
+  // four waves per workgroup, tools/pair_bench.py --sweep); PN2_GRID_WPB=4 selects the latter
+  const char *wpb_env = getenv("PN2_GRID_WPB");
+  const int wpb = wpb_env ? atoi(wpb_env) : 1;
   if (nsample > kWave) { if (group) GRID_QUERY(256, true, 0); else GRID_QUERY(256, false, 0); }
   else if (!group) GRID_QUERY(192, false, 0);
-  else if (abl == 1) GRID_QUERY(192, true, 1);
-  else if (abl == 2) GRID_QUERY(192, true, 2);
+  else if (abl == 1) GRID_QUERY_W(192, 4, true, 1);
+  else if (abl == 2) GRID_QUERY_W(192, 4, true, 2);
   else GRID_QUERY(192, true, 0);
+#undef GRID_QUERY_W
 #undef GRID_QUERY
   *handled = 1;
   return pn2_launch_status();

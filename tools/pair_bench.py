@@ -87,6 +87,10 @@ else:
         res[name + "_frac_of_8TBs"] = round(bench.PAIR_BYTES / (us * 1e-6) / 8e12, 4)
     if "--sweep" in sys.argv:  # tuning switches / timing ablations of the cell-list kernels
         sweep = {}
+        for t in ("1", "4"):
+            os.environ["PN2_GRID_WPB"] = t
+            sweep["layer_wpb%s_us" % t] = round(bench.time_op(layer, iters=iters, warm=2), 2)
+        os.environ.pop("PN2_GRID_WPB")
         for a, what in (("1", "no_ordering_network"), ("2", "no_candidate_tests")):
             os.environ["PN2_GRID_ABLATE"] = a
             sweep["fused_%s_us" % what] = round(bench.time_op(fused, iters=iters, warm=2), 2)
