@@ -264,6 +264,115 @@ group_points_grad_lds_big_kernel(int c, int n, int mns, const float *__restrict_
   for (int t = threadIdx.x; t < n; t += 1024) dst[t] = acc[t];
 }
 
+// ---- scatter-add through an inverse index (no float atomics per element) --------------------
+// The LDS-privatised scatter-add above spends its time in ds_add_f32 (about 0.4 lane-adds per
+// clock and CU: 128 us for SA2's 134 MB).  The index array is reused by every channel and every
+// step's backward, so it is inverted ONCE (in the prefetched index chain): the m*ns positions of
+// a cloud counting-sorted by the point they refer to, one packed entry (point << 16 | position)
+// each.  The backward of a channel stages its gradient row in LDS; every lane owns CHUNK
+// consecutive sorted entries, gathers their values from the row (plain LDS reads, 32 lanes per
+// clock) and adds them up in a register; a run that starts and ends inside a lane is stored
+// once, only the two runs a lane may share with its neighbours use an LDS atomic.
+//
+// Entry s of the sorted order lives at [(s % CHUNK) * 1024 + s / CHUNK] so that lane t's j-th
+// entry is at [j * 1024 + t]: coalesced.  CHUNK = 4/8/16/32 (the smallest that covers m*ns),
+// unused slots hold 0xFFFFFFFF.
+constexpr int kInvMaxEntries = 32768;  // gradient row staged in 128 KB of LDS
+constexpr int kInvMaxPoints = 4096;    // destination row / counters in 16 KB of LDS
+constexpr unsigned kInvPad = 0xFFFFFFFFu;
+
+int inverse_chunk(int mns) {
+  int chunk = 4;
+  while (chunk * 1024 < mns) chunk *= 2;
+  return chunk;
+}
+
+__global__ void __launch_bounds__(1024)
+group_inverse_kernel(int n, int mns, int chunk_log2, const int *__restrict__ idx,
+                     unsigned *__restrict__ inv) {
+  __shared__ int cnt[kInvMaxPoints];
+  __shared__ int wave_tot[16];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int *ib = idx + (size_t)b * mns;
+  unsigned *out = inv + ((size_t)b << (chunk_log2 + 10));
+  const int chunk_mask = (1 << chunk_log2) - 1;
+  for (int t = tid; t < kInvMaxPoints; t += 1024) cnt[t] = 0;
+  __syncthreads();
+  for (int e = tid; e < mns; e += 1024) atomicAdd(&cnt[ib[e]], 1);
+  __syncthreads();
+  {  // exclusive scan of the counters, four per lane
+    int c4[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { c4[q] = cnt[tid * 4 + q]; sum += c4[q]; }
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int o = __shfl_up(incl, off, kWave);
+      if (lane >= off) incl += o;
+    }
+    if (lane == kWave - 1) wave_tot[w] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int q = 0; q < w; ++q) run += wave_tot[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { cnt[tid * 4 + q] = run; run += c4[q]; }
+  }
+  __syncthreads();
+  for (int e = tid; e < mns; e += 1024) {
+    const int k = ib[e];
+    const int s = atomicAdd(&cnt[k], 1);
+    out[((s & chunk_mask) << 10) + (s >> chunk_log2)] = ((unsigned)k << 16) | (unsigned)e;
+  }
+  for (int s = mns + tid; s < (1024 << chunk_log2); s += 1024)
+    out[((s & chunk_mask) << 10) + (s >> chunk_log2)] = kInvPad;
+}
+
+template <int CHUNK>
+__global__ void __launch_bounds__(1024)
+group_points_grad_sorted_kernel(int c, int n, int mns, const float *__restrict__ grad_out,
+                                const unsigned *__restrict__ inv, float *__restrict__ grad_points) {
+  __shared__ __attribute__((aligned(16))) float row[CHUNK * 1024];
+  __shared__ float acc[kInvMaxPoints];
+  const BlockId blk = xcd_block_id();  // the channels of a cloud share its entries in one L2
+  const int l = blk.x, b = blk.y;
+  const int tid = threadIdx.x;
+  const unsigned *ent = inv + (size_t)b * CHUNK * 1024 + tid;
+  unsigned e[CHUNK];
+#pragma clang loop unroll(full)
+  for (int j = 0; j < CHUNK; ++j) e[j] = ent[j * 1024];
+  const float *g = grad_out + ((size_t)b * c + l) * mns;
+  if ((mns & 3) == 0) {
+    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    float4 *r4 = reinterpret_cast<float4 *>(row);
+    for (int t = tid; t < mns / 4; t += 1024) r4[t] = g4[t];
+  } else {
+    for (int t = tid; t < mns; t += 1024) row[t] = g[t];
+  }
+  for (int t = tid; t < n; t += 1024) acc[t] = 0.f;
+  __syncthreads();
+  float v[CHUNK];
+#pragma clang loop unroll(full)
+  for (int j = 0; j < CHUNK; ++j) v[j] = row[e[j] & (CHUNK * 1024 - 1)];
+  unsigned cur = e[0] >> 16;
+  float sum = v[0];
+  bool shared_run = true;  // the lane's first run may have begun in the lane before
+#pragma clang loop unroll(full)
+  for (int j = 1; j < CHUNK; ++j) {
+    const unsigned key = e[j] >> 16;
+    if (key != cur) {
+      if (shared_run) atomicAdd(&acc[cur], sum); else acc[cur] = sum;
+      shared_run = false;
+      sum = 0.f;
+      cur = key;
+    }
+    sum = __fadd_rn(sum, v[j]);
+  }
+  if (cur != (kInvPad >> 16)) atomicAdd(&acc[cur], sum);  // may continue in the next lane
+  __syncthreads();
+  float *dst = grad_points + ((size_t)b * c + l) * n;
+  for (int t = tid; t < n; t += 1024) dst[t] = acc[t];
+}
+
 // Fused tail of QueryAndGroup (pointnet2_utils.py:348-358): given idx, write the
 // (b, 3+c, m, ns) tensor: channels 0..2 = xyz[idx] - centroid (optionally * 1/radius),
 // channels 3.. = features[idx].
@@ -575,6 +684,59 @@ PN2_API int pn2_query_and_group_prebuilt(int b, int n, int m, int c, float radiu
                                          void *stream_) {
   return query_and_group_impl(b, n, m, c, radius, nsample, normalize_xyz, new_xyz, xyz, features,
                               idx, out, const_cast<void *>(grid), grid_bytes, 1, stream_);
+}
+
+// ---- inverse index of an index array (group_points_gpu.cu:48-69 does a same-address atomic per
+// element instead) ------------------------------------------------------------------------------
+PN2_API int pn2_group_inverse_supported(int n, int npoints, int nsample) {
+  const long long mns = (long long)npoints * nsample;
+  return n > 0 && n <= kInvMaxPoints && mns > 0 && mns <= kInvMaxEntries;
+}
+
+PN2_API int pn2_group_inverse_entries(int npoints, int nsample) {
+  const long long mns = (long long)npoints * nsample;
+  if (mns <= 0 || mns > kInvMaxEntries) return 0;
+  return inverse_chunk((int)mns) * 1024;
+}
+
+PN2_API int pn2_group_inverse_build(int b, int n, int npoints, int nsample, const int *idx,
+                                    unsigned *inv, void *stream_) {
+  if (b <= 0) return 0;
+  if (!pn2_group_inverse_supported(n, npoints, nsample)) return (int)hipErrorInvalidValue;
+  const int chunk = inverse_chunk(npoints * nsample);
+  const int chunk_log2 = chunk == 4 ? 2 : chunk == 8 ? 3 : chunk == 16 ? 4 : 5;
+  hipLaunchKernelGGL(group_inverse_kernel, dim3(b), dim3(1024), 0, (hipStream_t)stream_, n,
+                     npoints * nsample, chunk_log2, idx, inv);
+  return pn2_launch_status();
+}
+
+PN2_API int pn2_group_points_grad_sorted(int b, int c, int n, int npoints, int nsample,
+                                         const float *grad_out, const unsigned *inv,
+                                         float *grad_points, void *stream_) {
+  if (b <= 0 || c <= 0) return 0;
+  if (!pn2_group_inverse_supported(n, npoints, nsample) || c > 65535)
+    return (int)hipErrorInvalidValue;
+  const int mns = npoints * nsample;
+  const dim3 grid(c, b);
+  hipStream_t stream = (hipStream_t)stream_;
+  switch (inverse_chunk(mns)) {
+    case 4:
+      hipLaunchKernelGGL(group_points_grad_sorted_kernel<4>, grid, dim3(1024), 0, stream, c, n,
+                         mns, grad_out, inv, grad_points);
+      break;
+    case 8:
+      hipLaunchKernelGGL(group_points_grad_sorted_kernel<8>, grid, dim3(1024), 0, stream, c, n,
+                         mns, grad_out, inv, grad_points);
+      break;
+    case 16:
+      hipLaunchKernelGGL(group_points_grad_sorted_kernel<16>, grid, dim3(1024), 0, stream, c, n,
+                         mns, grad_out, inv, grad_points);
+      break;
+    default:
+      hipLaunchKernelGGL(group_points_grad_sorted_kernel<32>, grid, dim3(1024), 0, stream, c, n,
+                         mns, grad_out, inv, grad_points);
+  }
+  return pn2_launch_status();
 }
 
 PN2_API int pn2_group_concat(int b, int n, int m, int c, float radius, int nsample,

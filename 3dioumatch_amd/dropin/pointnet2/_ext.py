@@ -153,6 +153,38 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     return out
 
 
+def group_inverse(idx, n):
+    """Inverse of a grouping index array idx (B,m,ns) i32 with values < n: the positions of each
+    cloud sorted by the point they refer to, packed (point << 16 | position) -> (B, entries) int32
+    bits (entries = m*ns rounded up to 4096 << k, surplus slots -1, lane-interleaved storage), or None when the shape is outside the fast backward's range.  Built once per index
+    array (it depends on coordinates only), consumed by group_points_grad(..., inverse=)."""
+    _chk_i32(idx, "idx")
+    if not idx.is_cuda:
+        raise RuntimeError("CPU not supported")
+    b, m, ns = idx.shape
+    if not _lib.pn2_group_inverse_supported(int(n), m, ns):
+        return None
+    inv = torch.empty((b, _lib.pn2_group_inverse_entries(m, ns)), dtype=torch.int32, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _L.check(_lib.pn2_group_inverse_build(b, int(n), m, ns, idx.data_ptr(), inv.data_ptr(),
+                                              _stream(idx)), "group_inverse_build")
+    return inv
+
+
+def group_points_grad_sorted(grad_out, inverse, n):
+    """group_points_grad through the inverse index: no float atomics per element."""
+    _chk_f32(grad_out, "grad_out"); _chk_i32(inverse, "inverse"); _chk_dev(grad_out, (inverse, "inverse"))
+    b, c, m, ns = grad_out.shape
+    if tuple(inverse.shape) != (b, _lib.pn2_group_inverse_entries(m, ns)) or not inverse.is_contiguous():
+        raise RuntimeError("inverse is not the group_inverse() of a (B,%d,%d) index array" % (m, ns))
+    out = torch.empty((b, c, int(n)), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        _L.check(_lib.pn2_group_points_grad_sorted(b, c, int(n), m, ns, grad_out.data_ptr(),
+                                                   inverse.data_ptr(), out.data_ptr(),
+                                                   _stream(grad_out)), "group_points_grad_sorted")
+    return out
+
+
 def three_interpolate_into(points, idx, weight, out, channel0):
     """three_interpolate written into channels [channel0, channel0 + C) of the preallocated
     contiguous (B, C_total, n) tensor `out` (no intermediate, no concatenation copy)."""

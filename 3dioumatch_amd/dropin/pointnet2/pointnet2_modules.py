@@ -142,10 +142,11 @@ class PointnetSAModuleVotes(nn.Module):
             return torch.sum(feats * rbf.unsqueeze(1), -1) / float(self.nsample)
         raise ValueError("unknown pooling %r" % (self.pooling,))
 
-    def forward(self, xyz, features=None, inds=None, ball_idx=None, new_xyz=None):
-        """ball_idx / new_xyz: optional precomputed ball-query indices (B,npoint,nsample) int32 and
-        centroid coordinates (B,npoint,3) for the centroids `inds` (all three depend on
-        coordinates only; see votenet/step.py)."""
+    def forward(self, xyz, features=None, inds=None, ball_idx=None, new_xyz=None, ball_inv=None):
+        """ball_idx / new_xyz / ball_inv: optional precomputed ball-query indices
+        (B,npoint,nsample) int32, centroid coordinates (B,npoint,3) for the centroids `inds`, and
+        the inverse index of ball_idx (_ext.group_inverse) -- all depend on coordinates only; see
+        votenet/step.py."""
         if inds is not None:
             assert inds.shape[1] == self.npoint
         lists = None
@@ -161,7 +162,7 @@ class PointnetSAModuleVotes(nn.Module):
         else:
             new_xyz = None
         if ball_idx is not None and isinstance(self.grouper, pointnet2_utils.QueryAndGroup):
-            grouped = self.grouper(xyz, new_xyz, features, ball_idx)
+            grouped = self.grouper(xyz, new_xyz, features, ball_idx, None, ball_inv)
         elif lists is not None:
             grouped = self.grouper(xyz, new_xyz, features, None, lists)
         else:

@@ -176,7 +176,8 @@ class _FusedQueryAndGroup(Function):
     """
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, features, radius, nsample, normalize_xyz, idx=None, lists=None):
+    def forward(ctx, xyz, new_xyz, features, radius, nsample, normalize_xyz, idx=None, lists=None,
+                inverse=None):
         if lists is not None and idx is None:
             idx, grouped = _ext.query_and_group(new_xyz, xyz, features, radius, nsample,
                                                 normalize_xyz, None, lists)
@@ -184,6 +185,7 @@ class _FusedQueryAndGroup(Function):
             idx, grouped = _ext.query_and_group(new_xyz, xyz, features, radius, nsample,
                                                 normalize_xyz, idx)
         ctx.save_for_backward(idx)
+        ctx.inverse = inverse  # inverse index of idx (group_inverse), when the caller has one
         ctx.n_points = xyz.size(1)
         ctx.scale = (1.0 / radius) if normalize_xyz else 1.0
         ctx.has_features = features is not None
@@ -196,7 +198,11 @@ class _FusedQueryAndGroup(Function):
         need_xyz, need_new_xyz, need_feat = ctx.needs_input_grad[:3]
         g_xyz = g_new = g_feat = None
         if need_feat and ctx.has_features:
-            g_feat = _ext.group_points_grad(grad_grouped[:, 3:].contiguous(), idx, ctx.n_points)
+            gf = grad_grouped[:, 3:].contiguous()
+            if ctx.inverse is not None:  # every element of the gradient is added exactly once
+                g_feat = _ext.group_points_grad_sorted(gf, ctx.inverse, ctx.n_points)
+            else:
+                g_feat = _ext.group_points_grad(gf, idx, ctx.n_points)
         if need_xyz or need_new_xyz:
             gx = grad_grouped[:, :3]
             if ctx.scale != 1.0:
@@ -205,7 +211,7 @@ class _FusedQueryAndGroup(Function):
                 g_xyz = _ext.group_points_grad(gx.contiguous(), idx, ctx.n_points).transpose(1, 2)
             if need_new_xyz:
                 g_new = -gx.sum(dim=3).transpose(1, 2)
-        return g_xyz, g_new, g_feat, None, None, None, None, None
+        return g_xyz, g_new, g_feat, None, None, None, None, None, None
 
 
 class QueryAndGroup(nn.Module):
@@ -239,15 +245,17 @@ class QueryAndGroup(nn.Module):
                 idx[b, j, :] = torch.cat((members, members[draw]))
         return unique_cnt
 
-    def forward(self, xyz, new_xyz, features=None, idx=None, lists=None):
+    def forward(self, xyz, new_xyz, features=None, idx=None, lists=None, inverse=None):
         """idx: optional ball-query result for (xyz, new_xyz) computed earlier; lists: optional
-        cell lists of xyz for this radius (sample_with_cell_lists)."""
+        cell lists of xyz for this radius (sample_with_cell_lists); inverse: optional inverse
+        index of idx (_ext.group_inverse) for the backward scatter-add."""
         if features is None:
             assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
         unique_cnt = None
         if not self.sample_uniformly:
             grouped, _idx = _FusedQueryAndGroup.apply(xyz, new_xyz, features, self.radius,
-                                                      self.nsample, self.normalize_xyz, idx, lists)
+                                                      self.nsample, self.normalize_xyz, idx, lists,
+                                                      inverse)
             grouped_xyz = grouped[:, :3]
             new_features = grouped if self.use_xyz else grouped[:, 3:]
         else:

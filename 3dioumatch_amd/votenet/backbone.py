@@ -65,6 +65,13 @@ class Pointnet2Backbone(nn.Module):
             else:
                 geometry["sa%d_ball_idx" % i] = pointnet2_utils.ball_query(sa.radius, sa.nsample,
                                                                            xyz, new_xyz)
+            # inverse index for the backward scatter-add of the layer's feature gradient (the
+            # first layer's features are network inputs: no gradient, no inverse)
+            make_inv = getattr(pointnet2_utils._ext, "group_inverse", None)
+            if i > 1 and make_inv is not None and xyz.is_cuda:
+                inv = make_inv(geometry["sa%d_ball_idx" % i], xyz.shape[1])
+                if inv is not None:
+                    geometry["sa%d_ball_inv" % i] = inv
             xyz = new_xyz
         # the two feature-propagation layers interpolate sa4 -> sa3 and sa3 -> sa2
         for name, unknown, known in (("fp1", "sa3", "sa4"), ("fp2", "sa2", "sa3")):
@@ -80,7 +87,9 @@ class Pointnet2Backbone(nn.Module):
             given = geometry["sa%d_inds" % i] if geometry is not None else None
             ball = geometry.get("sa%d_ball_idx" % i) if geometry is not None else None
             centroids = geometry.get("sa%d_new_xyz" % i) if geometry is not None else None
-            xyz, features, inds = getattr(self, "sa%d" % i)(xyz, features, given, ball, centroids)
+            inverse = geometry.get("sa%d_ball_inv" % i) if geometry is not None else None
+            xyz, features, inds = getattr(self, "sa%d" % i)(xyz, features, given, ball, centroids,
+                                                            inverse)
             end_points["sa%d_xyz" % i] = xyz
             end_points["sa%d_features" % i] = features
             if i <= 2:

@@ -193,7 +193,10 @@ def kernel_table(device):
     c128 = 4 * B * 128 * m1 + 4 * B * m2 * ns2 + 4 * B * 128 * m2 * ns2
     hbm("group_feat_sa2_c128", time_op(lambda: ext.group_points(f128, idx2)), c128)
     g128 = torch.rand(B, 128, m2, ns2, device=device)
-    hbm("group_grad_sa2_c128", time_op(lambda: ext.group_points_grad(g128, idx2, m1)), c128)
+    hbm("group_grad_sa2_c128_atomic", time_op(lambda: ext.group_points_grad(g128, idx2, m1)), c128)
+    inv2 = ext.group_inverse(idx2, m1)  # built once per batch in the prefetched index chain
+    hbm("group_grad_sa2_c128", time_op(lambda: ext.group_points_grad_sorted(g128, inv2, m1)), c128)
+    hbm("group_inverse_sa2", time_op(lambda: ext.group_inverse(idx2, m1)), 8 * B * m2 * ns2)
     ng, ms = 32768, 1024
     grid = torch.rand(B, ng, 3, device=device) * 3
     seeds = torch.rand(B, ms, 3, device=device) * 3

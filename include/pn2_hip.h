@@ -169,6 +169,27 @@ int pn2_furthest_point_sampling_grid(int b, int n, int m, const float *dataset, 
                                      void *workspace, size_t workspace_bytes, float grid_radius,
                                      void *grid, size_t grid_bytes, void *stream);
 
+/* ---- scatter-add through an inverse index ---------------------------------------------------
+ * group_points_grad (group_points.cpp:42-65, K6 group_points_gpu.cu:48-69) adds every element of
+ * grad_out into grad_points[idx] with a same-address atomic.  idx is reused by every channel and
+ * every step, so it can be inverted once: inv (b, npoints*nsample) holds the positions of a cloud
+ * sorted by the point they refer to (point << 16 | position).  Covered: n <= 4096 and
+ * npoints*nsample <= 32768 (SA2 .. SA4 and the vote aggregation of the network). */
+int pn2_group_inverse_supported(int n, int npoints, int nsample);
+/* entries per cloud of the inverse (npoints*nsample rounded up to 4096/8192/16384/32768; the
+ * surplus slots hold 0xFFFFFFFF); 0 when out of range (sizing helper for group_points.cpp:42-65) */
+int pn2_group_inverse_entries(int npoints, int nsample);
+/* idx (b,npoints,nsample) with values < n -> inv (b, pn2_group_inverse_entries()) uint32, sorted
+ * entry s stored at [(s % chunk) * 1024 + s / chunk], chunk = entries / 1024
+ * (no reference counterpart; input of the gradient kernel below, group_points.cpp:42-65) */
+int pn2_group_inverse_build(int b, int n, int npoints, int nsample, const int *idx,
+                            unsigned *inv, void *stream);
+/* replaces group_points_grad_kernel_wrapper (group_points.cpp:13-15, group_points_gpu.cu:48-80)
+ * given inv: grad_out (b,c,npoints,nsample) -> grad_points (b,c,n), every element written once */
+int pn2_group_points_grad_sorted(int b, int c, int n, int npoints, int nsample,
+                                 const float *grad_out, const unsigned *inv, float *grad_points,
+                                 void *stream);
+
 /* Human-readable text for a non-zero return value (hipGetErrorString); stands in for the
  * message the reference prints before exit(-1) in CUDA_CHECK_ERRORS (cuda_utils.h:35-44). */
 const char *pn2_error_string(int code);

@@ -149,6 +149,52 @@ def test_group_vs_oracle(ext, oracle, c, n, m, ns):
     np.testing.assert_allclose(got, oracle.group_points_grad(gout, idx, n), rtol=0, atol=1e-4)
 
 
+@pytest.mark.parametrize("c,n,m,ns", [(128, 2048, 1024, 32), (256, 1024, 512, 16), (256, 512, 256, 16),
+                                      (7, 4096, 511, 64), (1, 1, 3, 5), (3, 100, 7, 128),
+                                      (130, 257, 256, 128)])
+def test_group_grad_through_inverse_index(ext, oracle, c, n, m, ns):
+    """group_points_grad with the inverse of idx built once: every gradient element added once,
+    same result as the oracle's scatter-add (group_points_gpu.cu:48-69).  Ball-query style idx
+    (padding repeats the first hit) plus points nobody refers to."""
+    g = np.random.default_rng(c * n + ns)
+    idx = g.integers(0, max(1, n - n // 4), (3, m, ns)).astype(np.int32)
+    idx[:, :, ns // 2:] = idx[:, :, :1]
+    idx[1] = 0 if n < 3 else n - 1  # one cloud: every position on one point
+    gout = g.standard_normal((3, c, m, ns)).astype(np.float32)
+    inv = ext.group_inverse(dev(idx), n)
+    entries = inv.shape[1]
+    chunk = entries // 1024
+    assert inv is not None and entries in (4096, 8192, 16384, 32768) and m * ns <= entries < max(2 * m * ns, 4097)
+    # stored lane-interleaved: sorted entry s sits at [(s % chunk) * 1024 + s // chunk]
+    packed = inv.cpu().numpy().view(np.uint32).reshape(3, chunk, 1024).transpose(0, 2, 1).reshape(3, entries)
+    assert np.all(packed[:, m * ns:] == 0xFFFFFFFF)
+    packed = packed[:, :m * ns]
+    assert np.array_equal(np.sort(packed & 0xFFFF, axis=1),
+                          np.broadcast_to(np.arange(m * ns, dtype=np.uint32), (3, m * ns)))
+    assert np.all(np.diff((packed >> 16).astype(np.int64), axis=1) >= 0)
+    assert np.array_equal(packed >> 16, np.take_along_axis(
+        idx.reshape(3, -1).astype(np.uint32), (packed & 0xFFFF).astype(np.int64), axis=1))
+    got = ext.group_points_grad_sorted(dev(gout), inv, n).cpu().numpy()
+    for bi in (0, 2):
+        np.testing.assert_allclose(got[bi:bi + 1], oracle.group_points_grad(gout[bi:bi + 1], idx[bi:bi + 1], n),
+                                   rtol=0, atol=1e-4)
+    # fp32 sums in another order than the oracle's: bound by the float64 sum and the mass added
+    # (cloud 1 puts up to 32768 terms on one point)
+    truth = np.zeros((3, c, n)); mass = np.zeros((3, c, n))
+    for bi in range(3):
+        np.add.at(truth[bi], (slice(None), idx[bi].reshape(-1)), gout[bi].reshape(c, -1).astype(np.float64))
+        np.add.at(mass[bi], (slice(None), idx[bi].reshape(-1)), np.abs(gout[bi].reshape(c, -1)).astype(np.float64))
+    assert np.all(np.abs(got - truth) <= 1e-5 + 2e-7 * mass)
+
+
+def test_group_inverse_range(ext):
+    """Outside n <= 4096 / m*ns <= 32768 there is no inverse: callers keep the atomic kernel."""
+    idx = torch.zeros(1, 2048, 64, dtype=torch.int32, device=DEV)
+    assert ext.group_inverse(idx, 40000) is None
+    assert ext.group_inverse(idx[:, :1024], 4097) is None
+    assert ext.group_inverse(idx[:, :512], 4096) is not None
+
+
 def test_query_and_group_fused(ext, oracle, synth):
     """Fused front end == reference composition (pointnet2_utils.py:335-358) done with the
     oracle: idx exact, gathered features exact, relative xyz within 1 ulp-level 1e-6."""

@@ -1,3 +1,6 @@
+set -x
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r2s; mkdir -p $O
-timeout 300 python tools/pair_bench.py 20 --sweep --json $O/pair.json > $O/pair.log 2>&1
+mkdir -p gpurun_out/r2g
+timeout 600 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "inverse or group_vs_oracle" > gpurun_out/r2g/t1.log 2>&1; echo rc=$? >> gpurun_out/r2g/t1.log
+timeout 900 python -m pytest tests/test_train_step.py tests/test_semi_step.py tests/test_layers.py -q -m gpu -x > gpurun_out/r2g/t2.log 2>&1; echo rc=$? >> gpurun_out/r2g/t2.log
+timeout 600 python bench.py > gpurun_out/r2g/bench.log 2>&1
