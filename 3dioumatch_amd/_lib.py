@@ -28,7 +28,8 @@ _SIGNATURES = {
     "pn2_group_inverse_supported": [_c_int, _c_int, _c_int],
     "pn2_group_inverse_entries": [_c_int, _c_int],
     "pn2_group_inverse_build": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp],
-    "pn2_group_points_grad_sorted": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
+    "pn2_group_points_grad_sorted": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp,
+                                     _vp, _vp],
     "pn2_three_interpolate_into": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp],
     "pn2_three_interpolate_grad_from": [_c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp],
     "pn2_query_and_group": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _vp, _vp,

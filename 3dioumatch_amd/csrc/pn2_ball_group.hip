@@ -329,7 +329,8 @@ group_inverse_kernel(int n, int mns, int chunk_log2, const int *__restrict__ idx
 
 template <int CHUNK>
 __global__ void __launch_bounds__(1024)
-group_points_grad_sorted_kernel(int c, int n, int mns, const float *__restrict__ grad_out,
+group_points_grad_sorted_kernel(int c, int n, int mns, int c_total, int channel0,
+                                const float *__restrict__ grad_out,
                                 const unsigned *__restrict__ inv, float *__restrict__ grad_points) {
   __shared__ __attribute__((aligned(16))) float row[CHUNK * 1024];
   __shared__ float acc[kInvMaxPoints];
@@ -340,7 +341,9 @@ group_points_grad_sorted_kernel(int c, int n, int mns, const float *__restrict__
   unsigned e[CHUNK];
 #pragma clang loop unroll(full)
   for (int j = 0; j < CHUNK; ++j) e[j] = ent[j * 1024];
-  const float *g = grad_out + ((size_t)b * c + l) * mns;
+  // channels channel0 .. channel0+c-1 of a (b, c_total, m, ns) tensor: the feature slice of a
+  // grouped tensor's gradient is read in place
+  const float *g = grad_out + ((size_t)b * c_total + channel0 + l) * mns;
   if ((mns & 3) == 0) {
     const float4 *g4 = reinterpret_cast<const float4 *>(g);
     float4 *r4 = reinterpret_cast<float4 *>(row);
@@ -711,10 +714,11 @@ PN2_API int pn2_group_inverse_build(int b, int n, int npoints, int nsample, cons
 }
 
 PN2_API int pn2_group_points_grad_sorted(int b, int c, int n, int npoints, int nsample,
-                                         const float *grad_out, const unsigned *inv,
-                                         float *grad_points, void *stream_) {
+                                         const float *grad_out, int c_total, int channel0,
+                                         const unsigned *inv, float *grad_points, void *stream_) {
   if (b <= 0 || c <= 0) return 0;
-  if (!pn2_group_inverse_supported(n, npoints, nsample) || c > 65535)
+  if (!pn2_group_inverse_supported(n, npoints, nsample) || c > 65535 || channel0 < 0 ||
+      channel0 + c > c_total)
     return (int)hipErrorInvalidValue;
   const int mns = npoints * nsample;
   const dim3 grid(c, b);
@@ -722,19 +726,19 @@ PN2_API int pn2_group_points_grad_sorted(int b, int c, int n, int npoints, int n
   switch (inverse_chunk(mns)) {
     case 4:
       hipLaunchKernelGGL(group_points_grad_sorted_kernel<4>, grid, dim3(1024), 0, stream, c, n,
-                         mns, grad_out, inv, grad_points);
+                         mns, c_total, channel0, grad_out, inv, grad_points);
       break;
     case 8:
       hipLaunchKernelGGL(group_points_grad_sorted_kernel<8>, grid, dim3(1024), 0, stream, c, n,
-                         mns, grad_out, inv, grad_points);
+                         mns, c_total, channel0, grad_out, inv, grad_points);
       break;
     case 16:
       hipLaunchKernelGGL(group_points_grad_sorted_kernel<16>, grid, dim3(1024), 0, stream, c, n,
-                         mns, grad_out, inv, grad_points);
+                         mns, c_total, channel0, grad_out, inv, grad_points);
       break;
     default:
       hipLaunchKernelGGL(group_points_grad_sorted_kernel<32>, grid, dim3(1024), 0, stream, c, n,
-                         mns, grad_out, inv, grad_points);
+                         mns, c_total, channel0, grad_out, inv, grad_points);
   }
   return pn2_launch_status();
 }

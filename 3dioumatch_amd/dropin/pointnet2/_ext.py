@@ -171,16 +171,21 @@ def group_inverse(idx, n):
     return inv
 
 
-def group_points_grad_sorted(grad_out, inverse, n):
-    """group_points_grad through the inverse index: no float atomics per element."""
+def group_points_grad_sorted(grad_out, inverse, n, channel0=0):
+    """group_points_grad through the inverse index: no float atomics per element.  channel0 > 0
+    takes channels channel0.. of grad_out (the feature part of a grouped tensor's gradient) in
+    place."""
     _chk_f32(grad_out, "grad_out"); _chk_i32(inverse, "inverse"); _chk_dev(grad_out, (inverse, "inverse"))
-    b, c, m, ns = grad_out.shape
+    b, c_total, m, ns = grad_out.shape
+    c = c_total - int(channel0)
+    if c <= 0 or channel0 < 0:
+        raise RuntimeError("channel0 outside grad_out")
     if tuple(inverse.shape) != (b, _lib.pn2_group_inverse_entries(m, ns)) or not inverse.is_contiguous():
         raise RuntimeError("inverse is not the group_inverse() of a (B,%d,%d) index array" % (m, ns))
     out = torch.empty((b, c, int(n)), dtype=torch.float32, device=grad_out.device)
     with torch.cuda.device(grad_out.device):
-        _L.check(_lib.pn2_group_points_grad_sorted(b, c, int(n), m, ns, grad_out.data_ptr(),
-                                                   inverse.data_ptr(), out.data_ptr(),
+        _L.check(_lib.pn2_group_points_grad_sorted(b, c, int(n), m, ns, grad_out.data_ptr(), c_total,
+                                                   int(channel0), inverse.data_ptr(), out.data_ptr(),
                                                    _stream(grad_out)), "group_points_grad_sorted")
     return out
 

@@ -198,11 +198,12 @@ class _FusedQueryAndGroup(Function):
         need_xyz, need_new_xyz, need_feat = ctx.needs_input_grad[:3]
         g_xyz = g_new = g_feat = None
         if need_feat and ctx.has_features:
-            gf = grad_grouped[:, 3:].contiguous()
-            if ctx.inverse is not None:  # every element of the gradient is added exactly once
-                g_feat = _ext.group_points_grad_sorted(gf, ctx.inverse, ctx.n_points)
+            if ctx.inverse is not None:  # every element of the gradient is added exactly once,
+                # and the feature channels are read where they lie
+                g_feat = _ext.group_points_grad_sorted(grad_grouped.contiguous(), ctx.inverse,
+                                                       ctx.n_points, 3)
             else:
-                g_feat = _ext.group_points_grad(gf, idx, ctx.n_points)
+                g_feat = _ext.group_points_grad(grad_grouped[:, 3:].contiguous(), idx, ctx.n_points)
         if need_xyz or need_new_xyz:
             gx = grad_grouped[:, :3]
             if ctx.scale != 1.0:

@@ -185,10 +185,12 @@ int pn2_group_inverse_entries(int npoints, int nsample);
 int pn2_group_inverse_build(int b, int n, int npoints, int nsample, const int *idx,
                             unsigned *inv, void *stream);
 /* replaces group_points_grad_kernel_wrapper (group_points.cpp:13-15, group_points_gpu.cu:48-80)
- * given inv: grad_out (b,c,npoints,nsample) -> grad_points (b,c,n), every element written once */
+ * given inv: channels channel0 .. channel0+c-1 of grad_out (b,c_total,npoints,nsample) ->
+ * grad_points (b,c,n), every element written once (c_total = c, channel0 = 0: the reference's
+ * argument; the slice form reads the feature part of a QueryAndGroup gradient in place) */
 int pn2_group_points_grad_sorted(int b, int c, int n, int npoints, int nsample,
-                                 const float *grad_out, const unsigned *inv, float *grad_points,
-                                 void *stream);
+                                 const float *grad_out, int c_total, int channel0,
+                                 const unsigned *inv, float *grad_points, void *stream);
 
 /* Human-readable text for a non-zero return value (hipGetErrorString); stands in for the
  * message the reference prints before exit(-1) in CUDA_CHECK_ERRORS (cuda_utils.h:35-44). */

@@ -111,4 +111,7 @@ def test_semi_graph_replay_matches_eager(oracle_omp, monkeypatch):
     # differ from run to run (scatter-add order); the bound is ~2x what those parameters can add
     assert float((eager[3] - graph[3]).norm() / eager[3].norm()) < 1.2e-2
     assert float((eager[4] - graph[4]).norm() / eager[4].norm()) < 1.2e-2
-    assert torch.allclose(eager[5], graph[5], rtol=3e-3, atol=5e-5)  # teacher BN mean (second step sees EMA weights)
+    # teacher BN running mean: after step 0 the teacher IS the student (EMA weight 0), whose
+    # pre-BatchNorm biases carry the +-lr sign noise above; a bias moves the batch mean one to
+    # one and the running mean by momentum (0.1) of that: 0.1 * 2 * lr = 4e-4
+    assert torch.allclose(eager[5], graph[5], rtol=3e-3, atol=5e-4)
