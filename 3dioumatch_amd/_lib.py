@@ -76,6 +76,10 @@ _SIGNATURES = {
     "mlp_gemm_wgrad_pooled": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_gemm_wgrad_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
+    "mlp_gemm_backward_fused_supported": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int],
+    "mlp_gemm_backward_fused_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
+    "mlp_gemm_backward_fused": [_c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _c_int, _vp,
+                                _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "lhs_nms3d_aabb": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _c_int, _c_int, _vp,
                        _vp],
     "lhs_nms_samecls": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _c_int, _vp, _vp],
@@ -93,7 +97,7 @@ _SIGNATURES = {
     "iou3d_nms": [_vp, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp],
     "iou3d_boxes_iou_bev_cpu": [_c_int, _vp, _c_int, _vp, _vp],
 }
-_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_grid_bytes": _sz, "pn2_fps_workspace_bytes": _sz, "mlp_bn_workspace_floats": _sz, "mlp_gemm_wgrad_workspace_floats": _sz, "mlp_bn_finalize_pairs_scratch_bytes": _sz, "pn2_error_string": ctypes.c_char_p}
+_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_grid_bytes": _sz, "pn2_fps_workspace_bytes": _sz, "mlp_bn_workspace_floats": _sz, "mlp_gemm_wgrad_workspace_floats": _sz, "mlp_gemm_backward_fused_workspace_floats": _sz, "mlp_bn_finalize_pairs_scratch_bytes": _sz, "pn2_error_string": ctypes.c_char_p}
 
 EXPORTS = tuple(_SIGNATURES)
 

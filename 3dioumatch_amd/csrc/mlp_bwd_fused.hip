@@ -1,0 +1,377 @@
+// 3dioumatch_amd/csrc/mlp_bwd_fused.hip -- the backward of one shared-MLP layer in ONE pass over
+// its activations (gfx950, v_mfma_f32_32x32x2_f32).
+//
+// What it replaces: the two autograd GEMMs of a conv(1x1) layer (pointnet2/pytorch_utils.py:70-124),
+//     dgrad : dQ[b] = W^T * P[b]            (K x R)     gradient w.r.t. the layer's input
+//     wgrad : dW    = sum_b P[b] * Q[b]^T   (M x K)     gradient w.r.t. the weight
+// where P = the BatchNorm+ReLU backward of the incoming gradient (formed on the fly from the
+// pair (y, dz), or from y and the pooled tensors of an SA module's last layer) and Q = the
+// layer's input relu(bn(y_prev)) (formed on the fly from y_prev).  As two kernels
+// (mlp_gemm.hip) both read the pair behind P -- 2M floats per column, the larger part of the
+// traffic of either.  Here a workgroup stages a TN-column chunk of P and of Q in LDS once and
+// runs BOTH contractions from it: per column 2M + K floats read and K written instead of
+// 4M + K*(M/64) read and K written.  Both GEMMs sit at the HBM ridge of the fp32 matrix
+// cores (~31 flop/byte), so the bytes are the time.
+//
+// Shape of the kernel: 256 lanes = 4 waves, persistent over a contiguous range of chunks.
+//   * P chunk [TN][M+1] and Q chunk [TN][KP+1] in LDS (odd leading dimension: the same tile
+//     serves as MFMA A operand, unit stride, and as B operand, strided, conflict-free).
+//   * dgrad: a wave owns 32-row blocks of dQ; its W^T fragments live in registers for the whole
+//     kernel (M/2 values per lane and block), the P fragments come from LDS; the finished
+//     32 x 32 blocks go straight from the accumulators to HBM (128-byte row segments).
+//   * wgrad: a wave owns (M/32)/4 row blocks x all K column blocks of dW, accumulated in
+//     registers across all chunks of the workgroup; one partial dW per workgroup at the end,
+//     reduced by mlp_reduce_partials (deterministic, no atomics).
+//   * the raw operands of chunk c+1 are loaded into registers before the MFMAs of chunk c.
+//   * grouped inputs carry three coordinate channels in front of the features (K = 3 + 32*j):
+//     the feature rows of dQ go through the matrix cores at row offset 3, the three coordinate
+//     rows are 3*TN dot products per chunk on the vector ALU.
+#include "common.h"
+#include "mlp_operand.h"
+#include <stdlib.h>
+
+namespace {
+
+template <int MB, int KB, int KBD, int NB, int PMODE, int QMODE, int OCC>
+__global__ void __launch_bounds__(256, OCC)
+gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, int xyz,
+                      OperandB opp, OperandB opq, const float *__restrict__ w,
+                      float *__restrict__ dq, float *__restrict__ part) {
+  constexpr int M = 32 * MB, KP = 32 * KB, TN = 32 * NB;
+  constexpr int LDP = M + 1, LDQ = KP + 1;
+  constexpr int TPR = TN / 16;   // lanes per row: a lane loads 16 consecutive columns
+  constexpr int RPP = 256 / TPR; // rows per pass of the 256 lanes
+  constexpr int PP = (M + RPP - 1) / RPP, QP = (KP + RPP - 1) / RPP;
+  // wgrad: blocks of dW per wave
+  constexpr int WMB = MB >= 4 ? MB / 4 : 1;
+  constexpr int WKB = MB >= 4 ? KB : KB * MB / 4;
+  static_assert(MB >= 4 ? MB % 4 == 0 : (MB == 2 && KB % 2 == 0), "dW blocks must split over 4 waves");
+  // dgrad: blocks of dQ per wave (DK row blocks x DN column blocks of the chunk)
+  constexpr int DK = KBD >= 4 ? KBD / 4 : 1;
+  constexpr int DN = KBD >= 4 ? NB : 1;
+  static_assert(KBD >= 4 ? KBD % 4 == 0 : (KBD == 2 && NB == 2), "dQ blocks must split over 4 waves");
+
+  __shared__ float Ps[TN * LDP];
+  __shared__ float Qs[TN * LDQ];
+  __shared__ float Wx[3 * M];        // the coordinate columns of W (xyz == 3)
+  __shared__ float red[8 * 3 * 32];  // partial dot products of the coordinate rows
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int seg_row = tid / TPR, seg_c = (tid % TPR) * 16;
+  OperandB P = opp, Q = opq;
+
+  // per-row constants of the rows this lane loads (fixed for the whole kernel)
+  RowCoef pc[PP], qc[QP];
+  bool p_ok[PP], q_ok[QP];
+#pragma unroll
+  for (int p = 0; p < PP; ++p) {
+    p_ok[p] = seg_row + p * RPP < M;
+    pc[p] = load_row_coef<PMODE>(P, seg_row + p * RPP, p_ok[p]);
+  }
+#pragma unroll
+  for (int q = 0; q < QP; ++q) {
+    q_ok[q] = seg_row + q * RPP < k_total;
+    qc[q] = load_row_coef<QMODE>(Q, seg_row + q * RPP, q_ok[q]);
+  }
+
+  // W^T fragments of this wave's dQ row blocks: A operand of step s = W[2s + lhi][k0 + l31]
+  float wreg[DK][M / 2];
+#pragma unroll
+  for (int e = 0; e < DK; ++e) {
+    const int kbd = KBD >= 4 ? wave * DK + e : (wave >> 1);
+    const float *wc = w + xyz + 32 * kbd + l31;
+#pragma unroll
+    for (int s = 0; s < M / 2; ++s) wreg[e][s] = wc[(size_t)(2 * s + lhi) * k_total];
+  }
+  for (int t = tid; t < 3 * M; t += 256) Wx[t] = xyz ? w[(size_t)(t % M) * k_total + t / M] : 0.f;
+
+  f32x16 accW[WMB][WKB];
+#pragma unroll
+  for (int i = 0; i < WMB; ++i)
+#pragma unroll
+    for (int j = 0; j < WKB; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) accW[i][j][q] = 0.f;
+
+  const int per = (total_chunks + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int c_lo = (int)blockIdx.x * per;
+  const int c_hi = c_lo + per < total_chunks ? c_lo + per : total_chunks;
+
+  // raw operands of one chunk, in registers
+  float4 px[PP][4], pd[PP][4], qx[QP][4];
+  int pwin[PP];
+  float pdp[PP];
+#pragma unroll
+  for (int p = 0; p < PP; ++p) {
+    pwin[p] = -1; pdp[p] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { px[p][i] = make_float4(0.f, 0.f, 0.f, 0.f); pd[p][i] = px[p][i]; }
+  }
+#pragma unroll
+  for (int q = 0; q < QP; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qx[q][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto fetch = [&](int c) {
+    const int b = c / chunks_per_cloud;
+    const int col = (c - b * chunks_per_cloud) * TN + seg_c;
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+      if (!p_ok[p]) continue;
+      const size_t rowi = (size_t)b * M + seg_row + p * RPP;
+      const float4 *src = reinterpret_cast<const float4 *>(P.x + rowi * r + col);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) px[p][i] = src[i];
+      if (PMODE == OP_DY) {
+        const float4 *dsrc = reinterpret_cast<const float4 *>(P.dz + rowi * r + col);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pd[p][i] = dsrc[i];
+      } else if (PMODE == OP_POOLDY) {  // the 16 columns lie in one group (ns % 16 == 0)
+        const int g = col / P.ns;
+        pwin[p] = P.argmax[rowi * P.groups + g] - (col - g * P.ns);
+        pdp[p] = P.dz[rowi * P.groups + g];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+      if (!q_ok[q]) continue;
+      const size_t rowi = (size_t)b * k_total + seg_row + q * RPP;
+      const float4 *src = reinterpret_cast<const float4 *>(Q.x + rowi * r + col);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) qx[q][i] = src[i];
+    }
+  };
+
+  if (c_lo < c_hi) fetch(c_lo);
+  for (int c = c_lo; c < c_hi; ++c) {
+    __syncthreads();  // the previous chunk's fragments have been read
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+      if (!p_ok[p]) continue;
+      const int row = seg_row + p * RPP;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float xv[4] = {px[p][i].x, px[p][i].y, px[p][i].z, px[p][i].w};
+        const float dv[4] = {pd[p][i].x, pd[p][i].y, pd[p][i].z, pd[p][i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dz = PMODE == OP_POOLDY ? (4 * i + e == pwin[p] ? pdp[p] : 0.f) : dv[e];
+          Ps[(seg_c + 4 * i + e) * LDP + row] = transform<PMODE>(xv[e], dz, pc[p]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+      const int row = seg_row + q * RPP;
+      if (row >= KP) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float xv[4] = {qx[q][i].x, qx[q][i].y, qx[q][i].z, qx[q][i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          Qs[(seg_c + 4 * i + e) * LDQ + row] = q_ok[q] ? transform<QMODE>(xv[e], 0.f, qc[q]) : 0.f;
+      }
+    }
+    __syncthreads();
+    if (c + 1 < c_hi) fetch(c + 1);  // in flight during the MFMAs below
+
+    const int b = c / chunks_per_cloud;
+    const int col0 = (c - b * chunks_per_cloud) * TN;
+
+    // ---- dgrad: dQ block = W^T (registers) * P chunk (LDS)
+    {
+      f32x16 accD[DK][DN];
+#pragma unroll
+      for (int e = 0; e < DK; ++e)
+#pragma unroll
+        for (int n = 0; n < DN; ++n)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) accD[e][n][q] = 0.f;
+#pragma unroll
+      for (int s = 0; s < M / 2; ++s) {
+        float bp[DN];
+#pragma unroll
+        for (int n = 0; n < DN; ++n) {
+          const int nb = KBD >= 4 ? n : (wave & 1);
+          bp[n] = Ps[(nb * 32 + l31) * LDP + 2 * s + lhi];
+        }
+#pragma unroll
+        for (int e = 0; e < DK; ++e)
+#pragma unroll
+          for (int n = 0; n < DN; ++n)
+            accD[e][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[e][s], bp[n], accD[e][n], 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < DK; ++e) {
+        const int kbd = KBD >= 4 ? wave * DK + e : (wave >> 1);
+#pragma unroll
+        for (int n = 0; n < DN; ++n) {
+          const int nb = KBD >= 4 ? n : (wave & 1);
+          float *dst = dq + ((size_t)b * k_total + xyz + 32 * kbd + 4 * lhi) * r + col0 + nb * 32 + l31;
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            dst[(size_t)((q & 3) + 8 * (q >> 2)) * r] = accD[e][n][q];
+        }
+      }
+    }
+
+    // ---- wgrad: dW blocks += P chunk * Q chunk^T (both LDS)
+#pragma unroll
+    for (int s = 0; s < TN / 2; ++s) {
+      const int n = 2 * s + lhi;
+      float ap[WMB], bq[WKB];
+#pragma unroll
+      for (int i = 0; i < WMB; ++i) {
+        const int mb = MB >= 4 ? wave + 4 * i : wave % MB;
+        ap[i] = Ps[n * LDP + mb * 32 + l31];
+      }
+#pragma unroll
+      for (int j = 0; j < WKB; ++j) {
+        const int kb = MB >= 4 ? j : (wave / MB) + (4 / MB) * j;
+        bq[j] = Qs[n * LDQ + kb * 32 + l31];
+      }
+#pragma unroll
+      for (int i = 0; i < WMB; ++i)
+#pragma unroll
+        for (int j = 0; j < WKB; ++j)
+          accW[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i], bq[j], accW[i][j], 0, 0, 0);
+    }
+
+    // ---- the three coordinate rows of dQ (TN == 32): dot products on the vector ALU
+    if (NB == 1 && xyz) {
+      const int n = tid & 31, g8 = tid >> 5;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+      for (int mm = g8 * (M / 8); mm < (g8 + 1) * (M / 8); ++mm) {
+        const float pv = Ps[n * LDP + mm];
+        s0 = __fmaf_rn(pv, Wx[mm], s0);
+        s1 = __fmaf_rn(pv, Wx[M + mm], s1);
+        s2 = __fmaf_rn(pv, Wx[2 * M + mm], s2);
+      }
+      red[(g8 * 3 + 0) * 32 + n] = s0;
+      red[(g8 * 3 + 1) * 32 + n] = s1;
+      red[(g8 * 3 + 2) * 32 + n] = s2;
+      __syncthreads();
+      if (tid < 96) {
+        const int kx = tid >> 5;
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[(g * 3 + kx) * 32 + n];
+        dq[((size_t)b * k_total + kx) * r + col0 + n] = t;
+      }
+    }
+  }
+
+  float *out = part + (size_t)blockIdx.x * M * k_total;
+#pragma unroll
+  for (int i = 0; i < WMB; ++i) {
+    const int mb = MB >= 4 ? wave + 4 * i : wave % MB;
+#pragma unroll
+    for (int j = 0; j < WKB; ++j) {
+      const int kb = MB >= 4 ? j : (wave / MB) + (4 / MB) * j;
+      const int colk = kb * 32 + l31;
+      if (colk >= k_total) continue;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * lhi;
+        out[(size_t)row * k_total + colk] = accW[i][j][q];
+      }
+    }
+  }
+}
+
+// one supported layer shape
+struct FusedShape { int m, k, xyz, tn, occ; };
+
+bool fused_shape(int m, int k, FusedShape *s) {
+  static const FusedShape table[] = {
+      {64, 64, 0, 64, 2}, {128, 64, 0, 64, 2}, {128, 128, 0, 32, 2},
+      {256, 128, 0, 32, 1}, {128, 131, 3, 32, 2}, {128, 259, 3, 32, 1},
+  };
+  for (const FusedShape &t : table)
+    if (t.m == m && t.k == k) { *s = t; return true; }
+  return false;
+}
+
+int fused_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  return cus;
+}
+
+// workgroups of the persistent launch: one resident round, at least 8 chunks each (the partial
+// dW every workgroup writes must stay small next to the activations it read)
+int fused_workgroups(const FusedShape &s, long long total_chunks) {
+  static const long long forced = getenv("MLP_FUSED_BWD_WGS") ? atoll(getenv("MLP_FUSED_BWD_WGS")) : 0;
+  long long g = forced > 0 ? forced : (long long)fused_cus() * s.occ;
+  if (g > total_chunks / 8) g = total_chunks / 8;
+  return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+#define MLP_API extern "C" __attribute__((visibility("default")))
+
+// 1 when mlp_gemm_backward_fused covers the layer: (m,k) one of the shared-MLP shapes of the
+// network, whole chunks per cloud, the pooled form with nsample a multiple of 16
+MLP_API int mlp_gemm_backward_fused_supported(int b, int m, int k, int r, int pmode, int qmode,
+                                              int ns) {
+  static const bool off = getenv("MLP_FUSED_BACKWARD") && atoi(getenv("MLP_FUSED_BACKWARD")) == 0;
+  FusedShape s;
+  if (off || b <= 0 || r <= 0 || !fused_shape(m, k, &s)) return 0;
+  if (r % s.tn != 0 || (long long)b * (r / s.tn) < 64) return 0;
+  if (pmode != OP_DY && pmode != OP_POOLDY) return 0;
+  if (pmode == OP_POOLDY && (ns <= 0 || ns % 16 != 0 || r % ns != 0)) return 0;
+  // instantiated operand combinations (the layers of the network)
+  const bool first = s.xyz != 0;  // grouped input: the layer reads the network input directly
+  if (first != (qmode == OP_DIRECT)) return 0;
+  if (qmode != OP_DIRECT && qmode != OP_BNRELU) return 0;
+  const bool pooled_shape = (m == 128 && k == 64) || (m == 256 && k == 128);
+  if (pooled_shape != (pmode == OP_POOLDY)) return 0;
+  return 1;
+}
+
+MLP_API size_t mlp_gemm_backward_fused_workspace_floats(int b, int m, int k, int r) {
+  FusedShape s;
+  if (!fused_shape(m, k, &s) || r % s.tn != 0) return 0;
+  return (size_t)fused_workgroups(s, (long long)b * (r / s.tn)) * m * k;
+}
+
+// dq (b,k,r) = W^T * P[b] and dw (m,k) = sum_b P[b] * Q[b]^T in one pass.
+// pmode 2: P from (y, dz) (b,m,r); pmode 3: from y, dz = dpooled (b,m,r/ns) and argmax.
+// qmode 1: Q = relu(x*xscale + xshift); qmode 0: Q = x.
+MLP_API int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, int pmode,
+                                    const float *y, const float *dz, const int *argmax, int ns,
+                                    const float *scale, const float *shift, const float *mean,
+                                    const float *invstd, const float *coef, int qmode,
+                                    const float *x, const float *xscale, const float *xshift,
+                                    float *dq, float *dw, float *workspace, void *stream_) {
+  if (!mlp_gemm_backward_fused_supported(b, m, k, r, pmode, qmode, ns)) return (int)hipErrorInvalidValue;
+  FusedShape s;
+  fused_shape(m, k, &s);
+  hipStream_t stream = (hipStream_t)stream_;
+  const int cpc = r / s.tn;
+  const int total = b * cpc;
+  const int g = fused_workgroups(s, total);
+  OperandB P = {y, dz, scale, shift, mean, invstd, coef, argmax, ns, ns > 0 ? r / ns : 0};
+  OperandB Q = {x, nullptr, xscale, xshift, nullptr, nullptr, nullptr};
+#define FUSED(MB, KB, KBD, NB, PM, QM, OCC)                                                     \
+  hipLaunchKernelGGL((gemm_bwd_fused_kernel<MB, KB, KBD, NB, PM, QM, OCC>), dim3(g), dim3(256), \
+                     0, stream, k, r, total, cpc, s.xyz, P, Q, w, dq, workspace)
+  if (m == 64 && k == 64) FUSED(2, 2, 2, 2, OP_DY, OP_BNRELU, 2);
+  else if (m == 128 && k == 64) FUSED(4, 2, 2, 2, OP_POOLDY, OP_BNRELU, 2);
+  else if (m == 128 && k == 128) FUSED(4, 4, 4, 1, OP_DY, OP_BNRELU, 2);
+  else if (m == 256 && k == 128) FUSED(8, 4, 4, 1, OP_POOLDY, OP_BNRELU, 1);
+  else if (m == 128 && k == 131) FUSED(4, 5, 4, 1, OP_DY, OP_DIRECT, 2);
+  else FUSED(4, 9, 8, 1, OP_DY, OP_DIRECT, 1);
+#undef FUSED
+  int rc = pn2_launch_status();
+  if (rc) return rc;
+  return mlp_reduce_partials(m * k, g, workspace, dw, stream);
+}

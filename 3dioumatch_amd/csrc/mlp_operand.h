@@ -1,0 +1,119 @@
+// 3dioumatch_amd/csrc/mlp_operand.h -- what the operands of the shared-MLP GEMM kernels ARE:
+// tensors transformed on their way from HBM into LDS (the BatchNorm / ReLU algebra of
+// pointnet2/pytorch_utils.py:70-124 and its backward), shared by mlp_gemm.hip and
+// mlp_bwd_fused.hip.
+#pragma once
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+
+enum OperandMode { OP_DIRECT = 0, OP_BNRELU = 1, OP_DY = 2, OP_POOLDY = 3 };
+
+struct OperandB {
+  const float *x;        // OP_DIRECT / OP_BNRELU: the tensor; OP_DY: y
+  const float *dz;       // OP_DY only
+  const float *scale;    // per row k
+  const float *shift;
+  const float *mean;     // OP_DY
+  const float *invstd;   // OP_DY
+  const float *coef;     // OP_DY: [k][3] = a, c1, c2
+  const int *argmax;     // OP_POOLDY: (rows, r/ns) winning sample per group; dz holds dpooled
+  int ns;                // OP_POOLDY: samples per group
+  int groups;            // OP_POOLDY: r / ns (groups per row)
+};
+
+constexpr bool is_dy(int mode) { return mode == OP_DY || mode == OP_POOLDY; }
+
+// Per-row constants of an operand (loaded once per row, kept in registers).  The BatchNorm+ReLU
+// backward  a*(g - c1 - ((x - mu)*is)*c2),  g = [x*sc + sh > 0] ? dz : 0,  is affine in x next
+// to the gated term:  a*g + (q*x + p)  with  q = -a*is*c2,  p = a*(is*c2*mu - c1)  -- folded per
+// row here, so that an element costs four fused multiply-adds / selects instead of ten
+// operations (these kernels spend a large share of their issue slots on operand transforms).
+struct RowCoef { float sc, sh, a, q, p; };
+
+template <int MODE>
+__device__ __forceinline__ RowCoef load_row_coef(const OperandB &op, int k, bool valid) {
+  RowCoef c = {1.f, 0.f, 0.f, 0.f, 0.f};
+  if (MODE == OP_DIRECT || !valid) return c;
+  c.sc = op.scale[k]; c.sh = op.shift[k];
+  if (is_dy(MODE)) {
+    const float mu = op.mean[k], is = op.invstd[k];
+    const float a = op.coef[k * 3], c1 = op.coef[k * 3 + 1], c2 = op.coef[k * 3 + 2];
+    const float t = is * c2;
+    c.a = a;
+    c.q = -(a * t);
+    c.p = a * (t * mu - c1);
+  }
+  return c;
+}
+
+template <int MODE>
+__device__ __forceinline__ float transform(float x, float dz, const RowCoef &c) {
+  if (MODE == OP_DIRECT) return x;
+  const float z = __fmaf_rn(x, c.sc, c.sh);
+  if (MODE == OP_BNRELU) return fmaxf(z, 0.f);
+  const float lin = __fmaf_rn(c.q, x, c.p);
+  return z > 0.f ? __fmaf_rn(c.a, dz, lin) : lin;
+}
+
+// raw loads of N consecutive elements (x, and dz for OP_DY); zero outside the row / limit
+// (`row` = index of the operand row over the whole batch, b * rows + row: OP_POOLDY only)
+template <int MODE, int N>
+__device__ __forceinline__ void load_raw_segment(const OperandB &op, size_t off, int gr, int limit,
+                                                 bool vec_ok, bool row_ok, float *x, float *dz,
+                                                 int row = 0) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) { x[i] = 0.f; dz[i] = 0.f; }
+  if (!row_ok) return;
+  if (MODE == OP_POOLDY) {
+    // dz of the segment from the pooled tensors (B, rows, groups): no 64-bit division here
+    const size_t gbase = (size_t)row * op.groups;
+    if (op.ns % N == 0 && gr % N == 0) {  // the whole segment lies in one group
+      if (gr < limit) {
+        const int g = gr / op.ns, s0 = gr - g * op.ns;
+        const int win = op.argmax[gbase + g] - s0;
+        const float dp = op.dz[gbase + g];
+#pragma unroll
+        for (int i = 0; i < N; ++i) dz[i] = (i == win) ? dp : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        if (gr + i < limit) {
+          const int g = (gr + i) / op.ns;
+          dz[i] = (op.argmax[gbase + g] == gr + i - g * op.ns) ? op.dz[gbase + g] : 0.f;
+        }
+      }
+    }
+  }
+  if (vec_ok) {
+#pragma unroll
+    for (int i = 0; i < N; i += 4) {
+      if (gr + i < limit) {
+        const float4 v = *reinterpret_cast<const float4 *>(op.x + off + i);
+        x[i] = v.x; x[i + 1] = v.y; x[i + 2] = v.z; x[i + 3] = v.w;
+        if (MODE == OP_DY) {
+          const float4 d = *reinterpret_cast<const float4 *>(op.dz + off + i);
+          dz[i] = d.x; dz[i + 1] = d.y; dz[i + 2] = d.z; dz[i + 3] = d.w;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (gr + i < limit) {
+        x[i] = op.x[off + i];
+        if (MODE == OP_DY) dz[i] = op.dz[off + i];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// dw[i] = sum_p part[p][i], i < count (mlp_gemm.hip): the deterministic reduction of the
+// per-workgroup partial weight gradients
+int mlp_reduce_partials(int count, int parts, const float *part, float *out, hipStream_t stream);

@@ -262,3 +262,36 @@ def gemm_wgrad(m, k, x, xcoeff=None, dy=None, fly=None, pooled=None):
                                      dw.data_ptr(), ws.data_ptr(), _stream(x))
         _L.check(rc, "mlp_gemm_wgrad")
     return dw
+
+
+def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None):
+    """dgrad and wgrad of one layer in one pass: -> (dx (B,K,...), dw (M,K)), or None when the
+    layer's shape is outside the fused kernel (callers then use gemm_dgrad + gemm_wgrad).
+    x (B,K,...) direct or relu(bn(.)) via xcoeff=(scale, shift); the gradient operand on the fly
+    from fly / pooled as in gemm_dgrad."""
+    m, k = w.shape
+    _f32c(w, "w"); _f32c(x, "x")
+    b = x.shape[0]
+    r = x.numel() // (b * k)
+    if pooled is not None:
+        y, dz, argmax, scale, shift, mean, invstd, coef = pooled
+        pmode, ns = 3, y.shape[3]
+    else:
+        y, dz, scale, shift, mean, invstd, coef = fly
+        argmax, pmode, ns = None, 2, 0
+    qmode = 0 if xcoeff is None else 1
+    if not _lib.mlp_gemm_backward_fused_supported(b, m, k, r, pmode, qmode, ns):
+        return None
+    xs, xh = xcoeff if xcoeff is not None else (None, None)
+    dx = torch.empty_like(x)
+    dw = torch.empty((m, k), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        ws = torch.empty(max(int(_lib.mlp_gemm_backward_fused_workspace_floats(b, m, k, r)), 1),
+                         dtype=torch.float32, device=x.device)
+        _L.check(_lib.mlp_gemm_backward_fused(b, m, k, r, w.data_ptr(), pmode, y.data_ptr(),
+                                              dz.data_ptr(), _ptr(argmax), ns, scale.data_ptr(),
+                                              shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                              coef.data_ptr(), qmode, x.data_ptr(), _ptr(xs),
+                                              _ptr(xh), dx.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+                                              _stream(x)), "mlp_gemm_backward_fused")
+    return dx, dw

@@ -209,13 +209,22 @@ class _FusedMLPChain(Function):
                 dy_tensor, fly = None, (ys[i], dz, scale, shift, mean, invstd, coef)
             grads[5 * i + 1], grads[5 * i + 2] = dgamma, dbeta
             m, k = w2.shape
-            if i == 0:
+            src = x if i == 0 else ys[i - 1]
+            src_coeff = None if i == 0 else (coefs[i - 1][2], coefs[i - 1][3])
+            both = None
+            if i > 0 or need_dx:  # both GEMMs from one pass over (y_i, dz) where the shape allows
+                both = K.gemm_backward_fused(w2, src, src_coeff, fly, pooled)
+            if both is not None:
+                grads[5 * i] = both[1].view_as(w)
+                if i == 0:
+                    dx = both[0].view_as(x)
+                else:
+                    dz = both[0]
+            elif i == 0:
                 grads[0 + 5 * i] = K.gemm_wgrad(m, k, x, None, dy_tensor, fly, pooled).view_as(w)
                 dx = K.gemm_dgrad(w2, dy_tensor, fly, pooled).view_as(x) if need_dx else None
             else:
-                pscale, pshift = coefs[i - 1][2], coefs[i - 1][3]
-                grads[5 * i] = K.gemm_wgrad(m, k, ys[i - 1], (pscale, pshift), dy_tensor,
-                                            fly, pooled).view_as(w)
+                grads[5 * i] = K.gemm_wgrad(m, k, src, src_coeff, dy_tensor, fly, pooled).view_as(w)
                 dz = K.gemm_dgrad(w2, dy_tensor, fly, pooled)  # gradient w.r.t. relu(bn(y_{i-1}))
         return (dx if need_dx else None, None, None, None, None, *grads)
 

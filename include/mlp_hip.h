@@ -156,6 +156,31 @@ int mlp_gemm_wgrad_pooled(int b, int m, int k, int groups, int ns, const float *
                           const float *coef, int qmode, const float *x, const float *xscale,
                           const float *xshift, float *dw, float *workspace, void *stream);
 
+/* ---- dgrad + wgrad of one layer in one pass over its activations -----------------------------
+ * The two backward GEMMs of a conv(1x1)+BN+ReLU layer (pytorch_utils.py:70-124: the autograd of
+ * nn.Conv2d inside SharedMLP, :14-39) both consume the BatchNorm/ReLU backward of the incoming
+ * gradient; run separately (mlp_gemm_dgrad_nt + mlp_gemm_wgrad above) both read the pair it is
+ * formed from.  Covered: (m,k) in {(64,64), (128,64), (128,128), (256,128), (128,131), (128,259)},
+ * r a multiple of 64 / 32, pmode 2 (from y, dz) or 3 (pooled last layer: (128,64) and (256,128)),
+ * qmode 1 (x = raw output of the previous layer) or 0 (grouped network input: the k = 3+32j
+ * shapes). */
+/* 1 when mlp_gemm_backward_fused covers the layer (replaces nothing by itself: dispatch helper
+ * for the conv backward of pytorch_utils.py:70-124); ns = nsample for pmode 3, else 0 */
+int mlp_gemm_backward_fused_supported(int b, int m, int k, int r, int pmode, int qmode, int ns);
+/* scratch (floats): one partial dW per persistent workgroup (replaces cuDNN's backward-weight
+ * workspace behind pytorch_utils.py:70-124) */
+size_t mlp_gemm_backward_fused_workspace_floats(int b, int m, int k, int r);
+/* dq (b,k,r) = w^T * P[b] and dw (m,k) = sum_b P[b] * Q[b]^T (replaces conv2d backward-input AND
+ * backward-weight, pytorch_utils.py:70-124).  P as in mlp_gemm_dgrad_nt (pmode 2: y, dz (b,m,r))
+ * or mlp_gemm_dgrad_pooled_nt (pmode 3: y, dz = dpooled (b,m,r/ns), argmax); Q as in
+ * mlp_gemm_wgrad (qmode 1: relu(x*xscale + xshift), qmode 0: x). */
+int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, int pmode, const float *y,
+                            const float *dz, const int *argmax, int ns, const float *scale,
+                            const float *shift, const float *mean, const float *invstd,
+                            const float *coef, int qmode, const float *x, const float *xscale,
+                            const float *xshift, float *dq, float *dw, float *workspace,
+                            void *stream);
+
 /* scratch (floats) for mlp_gemm_wgrad: per-slice partial dW tiles (replaces cuDNN's
  * workspace of conv2d backward-weight, pytorch_utils.py:70-124) */
 size_t mlp_gemm_wgrad_workspace_floats(int b, int m, int k, int r);

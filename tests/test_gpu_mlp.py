@@ -207,6 +207,57 @@ def test_pooled_operand_mode_vs_materialised(b, m, k, groups, ns):
           K.gemm_wgrad(m, k, x, (scale_k, shift_k), dy=dy), 1e-5)
 
 
+@pytest.mark.parametrize("b,m,k,groups,ns,pooled", [
+    (2, 64, 64, 40, 64, False), (2, 128, 64, 36, 64, True), (3, 128, 128, 25, 32, False),
+    (2, 256, 128, 33, 32, True), (2, 128, 131, 40, 32, False), (5, 128, 259, 26, 16, False),
+    (8, 128, 128, 512, 16, False), (1, 256, 128, 2048, 16, True)])
+def test_fused_backward_vs_two_gemms(b, m, k, groups, ns, pooled):
+    """dgrad + wgrad of a layer from ONE pass over its activations (mlp_gemm_backward_fused) ==
+    the two separate on-the-fly GEMMs, for every layer shape of the network: gradient operand from
+    (y, dz) or from the pooled tensors, input operand direct (grouped input, 3 coordinate rows in
+    front) or relu(bn(.)); several chunks per workgroup and ragged chunk counts."""
+    load_pkg()
+    K = importlib.import_module("pointnet2._mlp_ext")
+    g = torch.Generator().manual_seed(m * 7 + k + groups + ns)
+    w = (torch.randn(m, k, generator=g) / k ** 0.5).to(DEV)
+    x = torch.randn(b, k, groups, ns, generator=g).to(DEV)
+    y = torch.randn(b, m, groups, ns, generator=g).to(DEV)
+    gamma = (torch.rand(m, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(m, generator=g) * 0.3).to(DEV)
+    rm, rv = torch.zeros(m, device=DEV), torch.ones(m, device=DEV)
+    mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, 0.1, 1e-5, True)
+    if pooled:
+        _, argmax, ymax = K.bn_relu_pool(y, scale, shift)
+        dpooled = torch.randn(b, m, groups, generator=g).to(DEV)
+        _, _, coef = K.bn_relu_pool_backward_stats(y, dpooled, argmax, ymax, gamma, scale, shift,
+                                                   mean, invstd, True)
+        kw = dict(pooled=(y, dpooled, argmax, scale, shift, mean, invstd, coef))
+    else:
+        dz = torch.randn(b, m, groups, ns, generator=g).to(DEV)
+        _, _, coef = K.bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, True)
+        kw = dict(fly=(y, dz, scale, shift, mean, invstd, coef))
+    xcoeff = None
+    if k % 32 == 0:  # not a grouped network input: the previous layer's raw output
+        xcoeff = ((torch.rand(k, generator=g) + 0.5).to(DEV), (torch.randn(k, generator=g) * 0.3).to(DEV))
+    both = K.gemm_backward_fused(w, x, xcoeff, **kw)
+    assert both is not None, "shape not routed to the fused kernel"
+    dx, dw = both
+    want_dx = K.gemm_dgrad(w, **kw).view_as(x)
+    want_dw = K.gemm_wgrad(m, k, x, xcoeff, **kw)
+    close(dx, want_dx, 1e-5)
+    close(dw, want_dw, 2e-5)
+
+
+def test_fused_backward_declines_other_shapes():
+    load_pkg()
+    K = importlib.import_module("pointnet2._mlp_ext")
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    fly = lambda m, *s: (z(2, m, *s), z(2, m, *s), z(m), z(m), z(m), z(m), z(3, m))
+    assert K.gemm_backward_fused(z(96, 64), z(2, 64, 64, 64), (z(64), z(64)), fly=fly(96, 64, 64)) is None
+    assert K.gemm_backward_fused(z(128, 128), z(2, 128, 10, 31), (z(128), z(128)), fly=fly(128, 10, 31)) is None
+    assert K.gemm_backward_fused(z(128, 128), z(2, 128, 4, 32), (z(128), z(128)), fly=fly(128, 4, 32)) is None
+
+
 @pytest.mark.parametrize("widths,shape", [([4, 64, 64, 128], (2, 4, 64, 64)),
                                           ([131, 128, 128, 256], (2, 131, 50, 32)),
                                           ([259, 128, 128], (3, 259, 20, 16)),
