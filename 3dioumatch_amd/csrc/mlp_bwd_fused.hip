@@ -22,7 +22,10 @@
 //   * wgrad: a wave owns (M/32)/4 row blocks x all K column blocks of dW, accumulated in
 //     registers across all chunks of the workgroup; one partial dW per workgroup at the end,
 //     reduced by mlp_reduce_partials (deterministic, no atomics).
-//   * the raw operands of chunk c+1 are loaded into registers before the MFMAs of chunk c.
+//   * software pipeline inside the workgroup, two LDS buffers: between the MFMA groups of chunk
+//     c every lane transforms its share of chunk c+1 into the other buffer and reloads its
+//     registers with chunk c+2 -- staging and loading hide in the shadow of the matrix pipe,
+//     one barrier per chunk.
 //   * grouped inputs carry three coordinate channels in front of the features (K = 3 + 32*j):
 //     the feature rows of dQ go through the matrix cores at row offset 3, the three coordinate
 //     rows are 3*TN dot products per chunk on the vector ALU.
@@ -50,9 +53,14 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
   constexpr int DK = KBD >= 4 ? KBD / 4 : 1;
   constexpr int DN = KBD >= 4 ? NB : 1;
   static_assert(KBD >= 4 ? KBD % 4 == 0 : (KBD == 2 && NB == 2), "dQ blocks must split over 4 waves");
+  // MFMA groups of one chunk: DG of dgrad (DU reduction steps each), WG of wgrad (WU steps each)
+  constexpr int DU = 4, DG = (M / 2) / DU;
+  constexpr int WU = WMB * WKB >= 4 ? 1 : 2, WG = (TN / 2) / WU;
+  // staging slices of one chunk per lane: a float4 (pair) of a P row, then of a Q row
+  constexpr int NS = 4 * (PP + QP), NG = DG + WG;
 
-  __shared__ float Ps[TN * LDP];
-  __shared__ float Qs[TN * LDQ];
+  __shared__ float Ps[2][TN * LDP];
+  __shared__ float Qs[2][TN * LDQ];
   __shared__ float Wx[3 * M];        // the coordinate columns of W (xyz == 3)
   __shared__ float red[8 * 3 * 32];  // partial dot products of the coordinate rows
 
@@ -61,19 +69,30 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
   const int seg_row = tid / TPR, seg_c = (tid % TPR) * 16;
   OperandB P = opp, Q = opq;
 
-  // per-row constants of the rows this lane loads (fixed for the whole kernel)
+  // per-row constants of the rows this lane loads (fixed for the whole kernel).  Every P row of a
+  // pass exists (M is a multiple of the rows per pass); Q rows past k_total (the padding of the
+  // 3 + 32j shapes) are loaded from the last real row and staged as zeros, so that the loop
+  // below has no divergent branch around a load (the wait counters stay exact).
+  static_assert(M % RPP == 0, "whole passes over the P rows");
   RowCoef pc[PP], qc[QP];
-  bool p_ok[PP], q_ok[QP];
+  bool q_ok[QP];
+  size_t p_lane[PP], q_lane[QP];  // element offset of the lane's 16 columns within a cloud
 #pragma unroll
   for (int p = 0; p < PP; ++p) {
-    p_ok[p] = seg_row + p * RPP < M;
-    pc[p] = load_row_coef<PMODE>(P, seg_row + p * RPP, p_ok[p]);
+    pc[p] = load_row_coef<PMODE>(P, seg_row + p * RPP, true);
+    p_lane[p] = (size_t)(seg_row + p * RPP) * r + seg_c;
   }
 #pragma unroll
   for (int q = 0; q < QP; ++q) {
-    q_ok[q] = seg_row + q * RPP < k_total;
-    qc[q] = load_row_coef<QMODE>(Q, seg_row + q * RPP, q_ok[q]);
+    const int row = seg_row + q * RPP;
+    q_ok[q] = row < k_total;
+    qc[q] = load_row_coef<QMODE>(Q, q_ok[q] ? row : k_total - 1, true);
+    q_lane[q] = (size_t)(q_ok[q] ? row : k_total - 1) * r + seg_c;
   }
+  // pooled form: the lane's 16 columns lie in group (col0 / ns) + lane_g, from sample
+  // (col0 % ns) + lane_s on (ns and TN divide one another)
+  const int lane_g = PMODE == OP_POOLDY ? seg_c / P.ns : 0;
+  const int lane_s = PMODE == OP_POOLDY ? seg_c % P.ns : 0;
 
   // W^T fragments of this wave's dQ row blocks: A operand of step s = W[2s + lhi][k0 + l31]
   float wreg[DK][M / 2];
@@ -113,69 +132,92 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
 #pragma unroll
     for (int i = 0; i < 4; ++i) qx[q][i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  auto fetch = [&](int c) {
+  // where chunk c lives (uniform values)
+  struct ChunkAt { size_t p, q, grp; int s0; };
+  auto chunk_at = [&](int c) {
     const int b = c / chunks_per_cloud;
-    const int col = (c - b * chunks_per_cloud) * TN + seg_c;
-#pragma unroll
-    for (int p = 0; p < PP; ++p) {
-      if (!p_ok[p]) continue;
-      const size_t rowi = (size_t)b * M + seg_row + p * RPP;
-      const float4 *src = reinterpret_cast<const float4 *>(P.x + rowi * r + col);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) px[p][i] = src[i];
-      if (PMODE == OP_DY) {
-        const float4 *dsrc = reinterpret_cast<const float4 *>(P.dz + rowi * r + col);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pd[p][i] = dsrc[i];
-      } else if (PMODE == OP_POOLDY) {  // the 16 columns lie in one group (ns % 16 == 0)
-        const int g = col / P.ns;
-        pwin[p] = P.argmax[rowi * P.groups + g] - (col - g * P.ns);
-        pdp[p] = P.dz[rowi * P.groups + g];
-      }
+    const int col0 = (c - b * chunks_per_cloud) * TN;
+    ChunkAt at;
+    at.p = (size_t)b * M * r + col0;
+    at.q = (size_t)b * k_total * r + col0;
+    at.grp = 0; at.s0 = 0;
+    if (PMODE == OP_POOLDY) {
+      const int g0 = col0 / P.ns;
+      at.grp = (size_t)b * M * P.groups + g0;
+      at.s0 = col0 - g0 * P.ns;
     }
+    return at;
+  };
+  // slice `sl` of a chunk: global -> registers
+  auto fetch_slice = [&](int sl, const ChunkAt &at) {
+    if (sl < 4 * PP) {
+      const int p = sl >> 2, i = sl & 3;
+      px[p][i] = *reinterpret_cast<const float4 *>(P.x + at.p + p_lane[p] + 4 * i);
+      if (PMODE == OP_DY) {
+        pd[p][i] = *reinterpret_cast<const float4 *>(P.dz + at.p + p_lane[p] + 4 * i);
+      } else if (PMODE == OP_POOLDY && i == 3) {
+        const size_t gi = at.grp + (size_t)(seg_row + p * RPP) * P.groups + lane_g;
+        pwin[p] = P.argmax[gi] - (at.s0 + lane_s);
+        pdp[p] = P.dz[gi];
+      }
+    } else {
+      const int q = (sl - 4 * PP) >> 2, i = (sl - 4 * PP) & 3;
+      qx[q][i] = *reinterpret_cast<const float4 *>(Q.x + at.q + q_lane[q] + 4 * i);
+    }
+  };
+  // slice `sl` of the chunk held in the registers: transform -> LDS buffer `buf`
+  auto stage_slice = [&](int sl, int buf) {
+    if (sl < 4 * PP) {
+      const int p = sl >> 2, i = sl & 3;
+      const int row = seg_row + p * RPP;
+      const float xv[4] = {px[p][i].x, px[p][i].y, px[p][i].z, px[p][i].w};
+      const float dv[4] = {pd[p][i].x, pd[p][i].y, pd[p][i].z, pd[p][i].w};
 #pragma unroll
-    for (int q = 0; q < QP; ++q) {
-      if (!q_ok[q]) continue;
-      const size_t rowi = (size_t)b * k_total + seg_row + q * RPP;
-      const float4 *src = reinterpret_cast<const float4 *>(Q.x + rowi * r + col);
+      for (int e = 0; e < 4; ++e) {
+        const float dz = PMODE == OP_POOLDY ? (4 * i + e == pwin[p] ? pdp[p] : 0.f) : dv[e];
+        Ps[buf][(seg_c + 4 * i + e) * LDP + row] = transform<PMODE>(xv[e], dz, pc[p]);
+      }
+    } else {
+      const int q = (sl - 4 * PP) >> 2, i = (sl - 4 * PP) & 3;
+      const int row = seg_row + q * RPP;
+      if (q * RPP >= KP) return;                   // (static) pass beyond the padded tile
+      if (KP % RPP != 0 && row >= KP) return;      // last, partial pass
+      const float xv[4] = {qx[q][i].x, qx[q][i].y, qx[q][i].z, qx[q][i].w};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) qx[q][i] = src[i];
+      for (int e = 0; e < 4; ++e)
+        Qs[buf][(seg_c + 4 * i + e) * LDQ + row] = q_ok[q] ? transform<QMODE>(xv[e], 0.f, qc[q]) : 0.f;
     }
   };
 
-  if (c_lo < c_hi) fetch(c_lo);
-  for (int c = c_lo; c < c_hi; ++c) {
-    __syncthreads();  // the previous chunk's fragments have been read
+  // prologue: chunk c_lo staged in buffer 0, chunk c_lo+1 on its way into the registers
+  // (chunk indices past the end are clamped: the surplus loads / stagings are never consumed)
+  if (c_lo < c_hi) {
+    const ChunkAt first = chunk_at(c_lo), second = chunk_at(c_lo + 1 < c_hi ? c_lo + 1 : c_lo);
 #pragma unroll
-    for (int p = 0; p < PP; ++p) {
-      if (!p_ok[p]) continue;
-      const int row = seg_row + p * RPP;
+    for (int sl = 0; sl < NS; ++sl) fetch_slice(sl, first);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float xv[4] = {px[p][i].x, px[p][i].y, px[p][i].z, px[p][i].w};
-        const float dv[4] = {pd[p][i].x, pd[p][i].y, pd[p][i].z, pd[p][i].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float dz = PMODE == OP_POOLDY ? (4 * i + e == pwin[p] ? pdp[p] : 0.f) : dv[e];
-          Ps[(seg_c + 4 * i + e) * LDP + row] = transform<PMODE>(xv[e], dz, pc[p]);
-        }
-      }
+    for (int sl = 0; sl < NS; ++sl) {
+      stage_slice(sl, 0);
+      fetch_slice(sl, second);
     }
-#pragma unroll
-    for (int q = 0; q < QP; ++q) {
-      const int row = seg_row + q * RPP;
-      if (row >= KP) continue;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float xv[4] = {qx[q][i].x, qx[q][i].y, qx[q][i].z, qx[q][i].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          Qs[(seg_c + 4 * i + e) * LDQ + row] = q_ok[q] ? transform<QMODE>(xv[e], 0.f, qc[q]) : 0.f;
-      }
-    }
-    __syncthreads();
-    if (c + 1 < c_hi) fetch(c + 1);  // in flight during the MFMAs below
+  }
+  __syncthreads();
 
+  for (int c = c_lo; c < c_hi; ++c) {
+    const int cur = (c - c_lo) & 1;
+    const float *Pc = Ps[cur], *Qc = Qs[cur];
+    const ChunkAt ahead = chunk_at(c + 2 < c_hi ? c + 2 : c_hi - 1);
+    // The matrix pipe works for 64 cycles per MFMA while the wave goes on issuing: between the
+    // MFMA groups of chunk c the lane transforms its slices of chunk c+1 (registers -> the other
+    // LDS buffer) and reloads the registers with chunk c+2, so staging costs no time of its own
+    // (two co-resident workgroups run in lock-step and do not hide it for each other).
+    auto between = [&](int g) {
+#pragma unroll
+      for (int sl = g * NS / NG; sl < (g + 1) * NS / NG; ++sl) {
+        stage_slice(sl, cur ^ 1);
+        fetch_slice(sl, ahead);
+      }
+    };
     const int b = c / chunks_per_cloud;
     const int col0 = (c - b * chunks_per_cloud) * TN;
 
@@ -188,19 +230,32 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
         for (int n = 0; n < DN; ++n)
 #pragma unroll
           for (int q = 0; q < 16; ++q) accD[e][n][q] = 0.f;
+      // the P fragments of group g+1 are requested before the MFMAs of group g are issued
+      float bp[2][DU][DN];
+      auto frag = [&](int g, float (&dst)[DU][DN]) {
 #pragma unroll
-      for (int s = 0; s < M / 2; ++s) {
-        float bp[DN];
+        for (int u = 0; u < DU; ++u)
 #pragma unroll
-        for (int n = 0; n < DN; ++n) {
-          const int nb = KBD >= 4 ? n : (wave & 1);
-          bp[n] = Ps[(nb * 32 + l31) * LDP + 2 * s + lhi];
-        }
+          for (int n = 0; n < DN; ++n) {
+            const int nb = KBD >= 4 ? n : (wave & 1);
+            dst[u][n] = Pc[(nb * 32 + l31) * LDP + 2 * (g * DU + u) + lhi];
+          }
+      };
+      frag(0, bp[0]);
 #pragma unroll
-        for (int e = 0; e < DK; ++e)
+      for (int g = 0; g < DG; ++g) {
+        if (g + 1 < DG) frag(g + 1, bp[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int n = 0; n < DN; ++n)
-            accD[e][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[e][s], bp[n], accD[e][n], 0, 0, 0);
+        for (int u = 0; u < DU; ++u)
+#pragma unroll
+          for (int e = 0; e < DK; ++e)
+#pragma unroll
+            for (int n = 0; n < DN; ++n)
+              accD[e][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[e][g * DU + u], bp[g & 1][u][n],
+                                                                accD[e][n], 0, 0, 0);
+        between(g);
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int e = 0; e < DK; ++e) {
@@ -217,25 +272,40 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
     }
 
     // ---- wgrad: dW blocks += P chunk * Q chunk^T (both LDS)
+    {
+      float ap[2][WU][WMB], bq[2][WU][WKB];
+      auto frag = [&](int g, float (&a)[WU][WMB], float (&bb)[WU][WKB]) {
 #pragma unroll
-    for (int s = 0; s < TN / 2; ++s) {
-      const int n = 2 * s + lhi;
-      float ap[WMB], bq[WKB];
+        for (int u = 0; u < WU; ++u) {
+          const int n = 2 * (g * WU + u) + lhi;
 #pragma unroll
-      for (int i = 0; i < WMB; ++i) {
-        const int mb = MB >= 4 ? wave + 4 * i : wave % MB;
-        ap[i] = Ps[n * LDP + mb * 32 + l31];
+          for (int i = 0; i < WMB; ++i) {
+            const int mb = MB >= 4 ? wave + 4 * i : wave % MB;
+            a[u][i] = Pc[n * LDP + mb * 32 + l31];
+          }
+#pragma unroll
+          for (int j = 0; j < WKB; ++j) {
+            const int kb = MB >= 4 ? j : (wave / MB) + (4 / MB) * j;
+            bb[u][j] = Qc[n * LDQ + kb * 32 + l31];
+          }
+        }
+      };
+      frag(0, ap[0], bq[0]);
+#pragma unroll
+      for (int g = 0; g < WG; ++g) {
+        if (g + 1 < WG) frag(g + 1, ap[(g + 1) & 1], bq[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < WU; ++u)
+#pragma unroll
+          for (int i = 0; i < WMB; ++i)
+#pragma unroll
+            for (int j = 0; j < WKB; ++j)
+              accW[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[g & 1][u][i], bq[g & 1][u][j],
+                                                                accW[i][j], 0, 0, 0);
+        between(DG + g);
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int j = 0; j < WKB; ++j) {
-        const int kb = MB >= 4 ? j : (wave / MB) + (4 / MB) * j;
-        bq[j] = Qs[n * LDQ + kb * 32 + l31];
-      }
-#pragma unroll
-      for (int i = 0; i < WMB; ++i)
-#pragma unroll
-        for (int j = 0; j < WKB; ++j)
-          accW[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i], bq[j], accW[i][j], 0, 0, 0);
     }
 
     // ---- the three coordinate rows of dQ (TN == 32): dot products on the vector ALU
@@ -244,7 +314,7 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
       float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll 4
       for (int mm = g8 * (M / 8); mm < (g8 + 1) * (M / 8); ++mm) {
-        const float pv = Ps[n * LDP + mm];
+        const float pv = Pc[n * LDP + mm];
         s0 = __fmaf_rn(pv, Wx[mm], s0);
         s1 = __fmaf_rn(pv, Wx[M + mm], s1);
         s2 = __fmaf_rn(pv, Wx[2 * M + mm], s2);
@@ -261,6 +331,7 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
         dq[((size_t)b * k_total + kx) * r + col0 + n] = t;
       }
     }
+    __syncthreads();  // chunk c read by everyone, chunk c+1 staged by everyone
   }
 
   float *out = part + (size_t)blockIdx.x * M * k_total;
@@ -286,8 +357,8 @@ struct FusedShape { int m, k, xyz, tn, occ; };
 
 bool fused_shape(int m, int k, FusedShape *s) {
   static const FusedShape table[] = {
-      {64, 64, 0, 64, 2}, {128, 64, 0, 64, 2}, {128, 128, 0, 32, 2},
-      {256, 128, 0, 32, 1}, {128, 131, 3, 32, 2}, {128, 259, 3, 32, 1},
+      {64, 64, 0, 64, 2}, {128, 64, 0, 64, 1}, {128, 128, 0, 32, 2},
+      {256, 128, 0, 32, 1}, {128, 131, 3, 32, 1}, {128, 259, 3, 32, 1},
   };
   for (const FusedShape &t : table)
     if (t.m == m && t.k == k) { *s = t; return true; }
@@ -327,7 +398,8 @@ MLP_API int mlp_gemm_backward_fused_supported(int b, int m, int k, int r, int pm
   if (off || b <= 0 || r <= 0 || !fused_shape(m, k, &s)) return 0;
   if (r % s.tn != 0 || (long long)b * (r / s.tn) < 64) return 0;
   if (pmode != OP_DY && pmode != OP_POOLDY) return 0;
-  if (pmode == OP_POOLDY && (ns <= 0 || ns % 16 != 0 || r % ns != 0)) return 0;
+  if (pmode == OP_POOLDY && (ns <= 0 || ns % 16 != 0 || r % ns != 0 || (ns % s.tn != 0 && s.tn % ns != 0)))
+    return 0;
   // instantiated operand combinations (the layers of the network)
   const bool first = s.xyz != 0;  // grouped input: the layer reads the network input directly
   if (first != (qmode == OP_DIRECT)) return 0;
@@ -365,10 +437,10 @@ MLP_API int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, 
   hipLaunchKernelGGL((gemm_bwd_fused_kernel<MB, KB, KBD, NB, PM, QM, OCC>), dim3(g), dim3(256), \
                      0, stream, k, r, total, cpc, s.xyz, P, Q, w, dq, workspace)
   if (m == 64 && k == 64) FUSED(2, 2, 2, 2, OP_DY, OP_BNRELU, 2);
-  else if (m == 128 && k == 64) FUSED(4, 2, 2, 2, OP_POOLDY, OP_BNRELU, 2);
+  else if (m == 128 && k == 64) FUSED(4, 2, 2, 2, OP_POOLDY, OP_BNRELU, 1);
   else if (m == 128 && k == 128) FUSED(4, 4, 4, 1, OP_DY, OP_BNRELU, 2);
   else if (m == 256 && k == 128) FUSED(8, 4, 4, 1, OP_POOLDY, OP_BNRELU, 1);
-  else if (m == 128 && k == 131) FUSED(4, 5, 4, 1, OP_DY, OP_DIRECT, 2);
+  else if (m == 128 && k == 131) FUSED(4, 5, 4, 1, OP_DY, OP_DIRECT, 1);
   else FUSED(4, 9, 8, 1, OP_DY, OP_DIRECT, 1);
 #undef FUSED
   int rc = pn2_launch_status();

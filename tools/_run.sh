@@ -1,6 +1,4 @@
-set -x
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2g
-timeout 900 python -m pytest tests/test_train_step.py tests/test_semi_step.py tests/test_layers.py -q -m gpu -x > gpurun_out/r2g/t2.log 2>&1; echo rc=$? >> gpurun_out/r2g/t2.log
-timeout 600 python bench.py > gpurun_out/r2g/bench.log 2>&1
-MLP_FUSED_BACKWARD=0 timeout 600 python bench.py > gpurun_out/r2g/bench_nofuse.log 2>&1
+python tools/bwd_bench.py sa2_l1 sa1_l2 2>&1 | grep "^sa"
+MLP_FUSED_BWD_WGS=768 python tools/bwd_bench.py sa1_l2 2>&1 | grep "^sa"
+timeout 600 python bench.py 2>&1 | tail -n 1 | cut -c1-260
