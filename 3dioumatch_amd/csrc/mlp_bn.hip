@@ -628,6 +628,19 @@ MLP_API int mlp_bn_relu_backward_stats(int b, int c, int r, int training, const 
   return pn2_launch_status();
 }
 
+// the same coefficients from (s1, s2) partials that another kernel left behind (the fused
+// backward GEMM of the layer above: mlp_gemm_backward_fused): partial (c, parts, 2)
+MLP_API int mlp_bn_backward_finalize(int c, int parts, double count, int training,
+                                     const float *partial, const float *gamma,
+                                     const float *invstd, float *dgamma, float *dbeta, float *coef,
+                                     void *stream_) {
+  if (c <= 0 || parts <= 0) return 0;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn2_ceil_div(c, 256 / kWave)), dim3(256), 0,
+                     (hipStream_t)stream_, c, parts, count, training, partial, gamma, invstd, dgamma,
+                     dbeta, coef);
+  return pn2_launch_status();
+}
+
 // pooled layer backward: dpooled (b,c,m) -> dy (b,c,m,ns)
 MLP_API int mlp_bn_relu_pool_backward(int b, int c, int m, int ns, int training, const float *y,
                                       const float *dpooled, const int *argmax, const float *ymax,

@@ -35,11 +35,12 @@
 
 namespace {
 
-template <int MB, int KB, int KBD, int NB, int PMODE, int QMODE, int OCC>
+template <int MB, int KB, int KBD, int NB, int PMODE, int QMODE, int OCC, bool STATS>
 __global__ void __launch_bounds__(256, OCC)
 gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, int xyz,
                       OperandB opp, OperandB opq, const float *__restrict__ w,
-                      float *__restrict__ dq, float *__restrict__ part) {
+                      float *__restrict__ dq, float *__restrict__ part,
+                      float *__restrict__ stats_part) {
   constexpr int M = 32 * MB, KP = 32 * KB, TN = 32 * NB;
   constexpr int LDP = M + 1, LDQ = KP + 1;
   constexpr int TPR = TN / 16;   // lanes per row: a lane loads 16 consecutive columns
@@ -61,6 +62,12 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
 
   __shared__ float Ps[2][TN * LDP];
   __shared__ float Qs[2][TN * LDQ];
+  // BatchNorm-backward sums of the layer BELOW (the one that produced Q) from the dQ blocks:
+  // s1 = sum g, s2 = sum g * xhat, g = dQ * [y*sc + sh > 0], xhat = (y - mu) * is
+  static_assert(!STATS || QMODE == OP_BNRELU, "the sums are those of a BatchNorm+ReLU layer below");
+  constexpr bool RAWQ = STATS;  // the Q tile then holds raw rows, rectified as fragments are read
+  constexpr int SROWS = STATS ? 32 * KBD : 1;
+  __shared__ float4 Rc[SROWS];       // per Q row: sc, sh, mu, is
   __shared__ float Wx[3 * M];        // the coordinate columns of W (xyz == 3)
   __shared__ float red[8 * 3 * 32];  // partial dot products of the coordinate rows
 
@@ -88,6 +95,20 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
     q_ok[q] = row < k_total;
     qc[q] = load_row_coef<QMODE>(Q, q_ok[q] ? row : k_total - 1, true);
     q_lane[q] = (size_t)(q_ok[q] ? row : k_total - 1) * r + seg_c;
+  }
+  if (STATS) {
+    for (int t = tid; t < SROWS; t += 256)
+      Rc[t] = make_float4(Q.scale[t], Q.shift[t], Q.mean[t], Q.invstd[t]);
+  }
+  // with STATS the Q tile holds the RAW rows of the layer below (the sums need them) and the
+  // wgrad fragments are rectified as they are read: constants of the rows kb*32 + l31
+  float fsc[WKB], fsh[WKB];
+#pragma unroll
+  for (int j = 0; j < WKB; ++j) {
+    const int kb = MB >= 4 ? j : (wave / MB) + (4 / MB) * j;
+    const int row = kb * 32 + l31;
+    fsc[j] = RAWQ && row < k_total ? Q.scale[row] : 1.f;
+    fsh[j] = RAWQ && row < k_total ? Q.shift[row] : 0.f;
   }
   // pooled form: the lane's 16 columns lie in group (col0 / ns) + lane_g, from sample
   // (col0 % ns) + lane_s on (ns and TN divide one another)
@@ -185,9 +206,17 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
       const float xv[4] = {qx[q][i].x, qx[q][i].y, qx[q][i].z, qx[q][i].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        Qs[buf][(seg_c + 4 * i + e) * LDQ + row] = q_ok[q] ? transform<QMODE>(xv[e], 0.f, qc[q]) : 0.f;
+        Qs[buf][(seg_c + 4 * i + e) * LDQ + row] =
+            q_ok[q] ? (RAWQ ? xv[e] : transform<QMODE>(xv[e], 0.f, qc[q])) : 0.f;
     }
   };
+
+  constexpr int SQ = STATS ? 16 : 1;
+  float st1[DK][SQ], st2[DK][SQ];
+#pragma unroll
+  for (int e = 0; e < DK; ++e)
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) { st1[e][q] = 0.f; st2[e][q] = 0.f; }
 
   // prologue: chunk c_lo staged in buffer 0, chunk c_lo+1 on its way into the registers
   // (chunk indices past the end are clamped: the surplus loads / stagings are never consumed)
@@ -222,8 +251,8 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
     const int col0 = (c - b * chunks_per_cloud) * TN;
 
     // ---- dgrad: dQ block = W^T (registers) * P chunk (LDS)
+    f32x16 accD[DK][DN];
     {
-      f32x16 accD[DK][DN];
 #pragma unroll
       for (int e = 0; e < DK; ++e)
 #pragma unroll
@@ -271,6 +300,25 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
       }
     }
 
+    // The BatchNorm-backward sums of the layer below, one accumulator row (q) of every dQ block
+    // at a time, slotted between the wgrad MFMA groups: this lane holds column nb*32 + l31 and
+    // rows 32*kbd + 4*lhi + (q&3) + 8*(q>>2) of the block.
+    auto stats_row = [&](int q) {
+      const int ro = (q & 3) + 8 * (q >> 2);
+#pragma unroll
+      for (int e = 0; e < DK; ++e) {
+        const int kbd = KBD >= 4 ? wave * DK + e : (wave >> 1);
+        const float4 rc = Rc[32 * kbd + 4 * lhi + ro];
+#pragma unroll
+        for (int n = 0; n < DN; ++n) {
+          const int nb = KBD >= 4 ? n : (wave & 1);
+          const float yv = Qc[(nb * 32 + l31) * LDQ + 32 * kbd + 4 * lhi + ro];
+          const float g = __fmaf_rn(yv, rc.x, rc.y) > 0.f ? accD[e][n][q] : 0.f;
+          st1[e][STATS ? q : 0] += g;
+          st2[e][STATS ? q : 0] = __fmaf_rn(g, (yv - rc.z) * rc.w, st2[e][STATS ? q : 0]);
+        }
+      }
+    };
     // ---- wgrad: dW blocks += P chunk * Q chunk^T (both LDS)
     {
       float ap[2][WU][WMB], bq[2][WU][WKB];
@@ -286,7 +334,8 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
 #pragma unroll
           for (int j = 0; j < WKB; ++j) {
             const int kb = MB >= 4 ? j : (wave / MB) + (4 / MB) * j;
-            bb[u][j] = Qc[n * LDQ + kb * 32 + l31];
+            const float raw = Qc[n * LDQ + kb * 32 + l31];
+            bb[u][j] = RAWQ ? fmaxf(__fmaf_rn(raw, fsc[j], fsh[j]), 0.f) : raw;
           }
         }
       };
@@ -304,6 +353,10 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
               accW[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[g & 1][u][i], bq[g & 1][u][j],
                                                                 accW[i][j], 0, 0, 0);
         between(DG + g);
+        if (STATS) {
+#pragma unroll
+          for (int q = g * 16 / WG; q < (g + 1) * 16 / WG; ++q) stats_row(q);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -334,6 +387,31 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
     __syncthreads();  // chunk c read by everyone, chunk c+1 staged by everyone
   }
 
+  if (STATS && stats_part != nullptr) {
+    // sum over the 32 columns held by the lanes of a half-wave, one partial per row and
+    // workgroup (two when two waves share a row block: KBD == 2)
+    constexpr int PPW = KBD >= 4 ? 1 : 2;
+    const int parts = (int)gridDim.x * PPW;
+    const int pidx = (int)blockIdx.x * PPW + (KBD >= 4 ? 0 : (wave & 1));
+#pragma unroll
+    for (int e = 0; e < DK; ++e) {
+      const int kbd = KBD >= 4 ? wave * DK + e : (wave >> 1);
+#pragma unroll
+      for (int q = 0; q < SQ; ++q) {
+        float a1 = st1[e][q], a2 = st2[e][q];
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+          a1 += __shfl_xor(a1, off, kWave);
+          a2 += __shfl_xor(a2, off, kWave);
+        }
+        if (l31 == 0) {
+          const int row = 32 * kbd + 4 * lhi + (q & 3) + 8 * (q >> 2);
+          stats_part[((size_t)row * parts + pidx) * 2] = a1;
+          stats_part[((size_t)row * parts + pidx) * 2 + 1] = a2;
+        }
+      }
+    }
+  }
   float *out = part + (size_t)blockIdx.x * M * k_total;
 #pragma unroll
   for (int i = 0; i < WMB; ++i) {
@@ -409,6 +487,16 @@ MLP_API int mlp_gemm_backward_fused_supported(int b, int m, int k, int r, int pm
   return 1;
 }
 
+// number of (s1, s2) partials per channel that mlp_gemm_backward_fused leaves in stats_part
+// (k, parts, 2) for the layer below (qmode 1 only; 0 otherwise)
+MLP_API int mlp_gemm_backward_fused_stats_parts(int b, int m, int k, int r) {
+  FusedShape s;
+  // the first set-abstraction level only: there the absorbed pass over (x, dq) costs ~95 us a
+  // layer; on the narrower levels the extra registers cost the GEMM more than the pass
+  if (!fused_shape(m, k, &s) || k != 64 || r % s.tn != 0) return 0;
+  return fused_workgroups(s, (long long)b * (r / s.tn)) * 2;
+}
+
 MLP_API size_t mlp_gemm_backward_fused_workspace_floats(int b, int m, int k, int r) {
   FusedShape s;
   if (!fused_shape(m, k, &s) || r % s.tn != 0) return 0;
@@ -423,7 +511,8 @@ MLP_API int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, 
                                     const float *scale, const float *shift, const float *mean,
                                     const float *invstd, const float *coef, int qmode,
                                     const float *x, const float *xscale, const float *xshift,
-                                    float *dq, float *dw, float *workspace, void *stream_) {
+                                    const float *xmean, const float *xinvstd, float *dq, float *dw,
+                                    float *workspace, float *stats_part, void *stream_) {
   if (!mlp_gemm_backward_fused_supported(b, m, k, r, pmode, qmode, ns)) return (int)hipErrorInvalidValue;
   FusedShape s;
   fused_shape(m, k, &s);
@@ -432,16 +521,19 @@ MLP_API int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, 
   const int total = b * cpc;
   const int g = fused_workgroups(s, total);
   OperandB P = {y, dz, scale, shift, mean, invstd, coef, argmax, ns, ns > 0 ? r / ns : 0};
-  OperandB Q = {x, nullptr, xscale, xshift, nullptr, nullptr, nullptr};
-#define FUSED(MB, KB, KBD, NB, PM, QM, OCC)                                                     \
-  hipLaunchKernelGGL((gemm_bwd_fused_kernel<MB, KB, KBD, NB, PM, QM, OCC>), dim3(g), dim3(256), \
-                     0, stream, k, r, total, cpc, s.xyz, P, Q, w, dq, workspace)
-  if (m == 64 && k == 64) FUSED(2, 2, 2, 2, OP_DY, OP_BNRELU, 2);
-  else if (m == 128 && k == 64) FUSED(4, 2, 2, 2, OP_POOLDY, OP_BNRELU, 1);
-  else if (m == 128 && k == 128) FUSED(4, 4, 4, 1, OP_DY, OP_BNRELU, 2);
-  else if (m == 256 && k == 128) FUSED(8, 4, 4, 1, OP_POOLDY, OP_BNRELU, 1);
-  else if (m == 128 && k == 131) FUSED(4, 5, 4, 1, OP_DY, OP_DIRECT, 1);
-  else FUSED(4, 9, 8, 1, OP_DY, OP_DIRECT, 1);
+  if (qmode == OP_BNRELU && (!xmean || !xinvstd)) return (int)hipErrorInvalidValue;
+  if (k != 64) stats_part = nullptr;
+  OperandB Q = {x, nullptr, xscale, xshift, xmean, xinvstd, nullptr};
+#define FUSED(MB, KB, KBD, NB, PM, QM, OCC, ST)                                                 \
+  hipLaunchKernelGGL((gemm_bwd_fused_kernel<MB, KB, KBD, NB, PM, QM, OCC, ST>), dim3(g),        \
+                     dim3(256), 0, stream, k, r, total, cpc, s.xyz, P, Q, w, dq, workspace,     \
+                     stats_part)
+  if (m == 64 && k == 64) FUSED(2, 2, 2, 2, OP_DY, OP_BNRELU, 2, true);
+  else if (m == 128 && k == 64) FUSED(4, 2, 2, 2, OP_POOLDY, OP_BNRELU, 1, true);
+  else if (m == 128 && k == 128) FUSED(4, 4, 4, 1, OP_DY, OP_BNRELU, 2, false);
+  else if (m == 256 && k == 128) FUSED(8, 4, 4, 1, OP_POOLDY, OP_BNRELU, 1, false);
+  else if (m == 128 && k == 131) FUSED(4, 5, 4, 1, OP_DY, OP_DIRECT, 1, false);
+  else FUSED(4, 9, 8, 1, OP_DY, OP_DIRECT, 1, false);
 #undef FUSED
   int rc = pn2_launch_status();
   if (rc) return rc;

@@ -264,11 +264,14 @@ def gemm_wgrad(m, k, x, xcoeff=None, dy=None, fly=None, pooled=None):
     return dw
 
 
-def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None):
-    """dgrad and wgrad of one layer in one pass: -> (dx (B,K,...), dw (M,K)), or None when the
-    layer's shape is outside the fused kernel (callers then use gemm_dgrad + gemm_wgrad).
+def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None):
+    """dgrad and wgrad of one layer in one pass: -> (dx (B,K,...), dw (M,K), below), or None when
+    the layer's shape is outside the fused kernel (callers then use gemm_dgrad + gemm_wgrad).
     x (B,K,...) direct or relu(bn(.)) via xcoeff=(scale, shift); the gradient operand on the fly
-    from fly / pooled as in gemm_dgrad."""
+    from fly / pooled as in gemm_dgrad.
+    xstats = (mean, invstd, gamma, training) of the layer that produced x (required with xcoeff):
+    `below` is then that layer's (dgamma, dbeta, coef), as bn_relu_backward_stats(x, dx, ...)
+    would return them -- the sums come out of the dgrad epilogue, no pass over (x, dx)."""
     m, k = w.shape
     _f32c(w, "w"); _f32c(x, "x")
     b = x.shape[0]
@@ -282,16 +285,32 @@ def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None):
     qmode = 0 if xcoeff is None else 1
     if not _lib.mlp_gemm_backward_fused_supported(b, m, k, r, pmode, qmode, ns):
         return None
+    if qmode == 1 and xstats is None:
+        raise RuntimeError("xstats=(mean, invstd, gamma, training) is required with xcoeff")
     xs, xh = xcoeff if xcoeff is not None else (None, None)
+    xmean, xinv, xgamma, xtraining = xstats if qmode == 1 else (None, None, None, False)
     dx = torch.empty_like(x)
     dw = torch.empty((m, k), dtype=torch.float32, device=x.device)
+    parts = int(_lib.mlp_gemm_backward_fused_stats_parts(b, m, k, r)) if qmode == 1 else 0
+    below = None
     with torch.cuda.device(x.device):
         ws = torch.empty(max(int(_lib.mlp_gemm_backward_fused_workspace_floats(b, m, k, r)), 1),
                          dtype=torch.float32, device=x.device)
+        sp = torch.empty((k, parts, 2), dtype=torch.float32, device=x.device) if parts else None
         _L.check(_lib.mlp_gemm_backward_fused(b, m, k, r, w.data_ptr(), pmode, y.data_ptr(),
                                               dz.data_ptr(), _ptr(argmax), ns, scale.data_ptr(),
                                               shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                               coef.data_ptr(), qmode, x.data_ptr(), _ptr(xs),
-                                              _ptr(xh), dx.data_ptr(), dw.data_ptr(), ws.data_ptr(),
-                                              _stream(x)), "mlp_gemm_backward_fused")
-    return dx, dw
+                                              _ptr(xh), _ptr(xmean), _ptr(xinv), dx.data_ptr(),
+                                              dw.data_ptr(), ws.data_ptr(), _ptr(sp), _stream(x)),
+                 "mlp_gemm_backward_fused")
+        if parts:
+            small = torch.empty((5, k), dtype=torch.float32, device=x.device)
+            _L.check(_lib.mlp_bn_backward_finalize(k, parts, float(b) * float(r),
+                                                   1 if xtraining else 0, sp.data_ptr(),
+                                                   xgamma.data_ptr(), xinv.data_ptr(),
+                                                   small[0].data_ptr(), small[1].data_ptr(),
+                                                   small[2:].data_ptr(), _stream(x)),
+                     "mlp_bn_backward_finalize")
+            below = (small[0], small[1], small[2:])
+    return dx, dw, below

@@ -189,7 +189,7 @@ class _FusedMLPChain(Function):
         dout = dout.contiguous()
         grads = [None] * (5 * n)
         need_dx = ctx.needs_input_grad[0]
-        dy_tensor, fly, pooled = None, None, None
+        dy_tensor, fly, pooled, below = None, None, None, None
         dz = dout
         for i in range(n - 1, -1, -1):
             w, gamma = params[5 * i], params[5 * i + 1]
@@ -204,17 +204,23 @@ class _FusedMLPChain(Function):
                 pooled = (ys[i], dz, extra[0], scale, shift, mean, invstd, coef)
             else:
                 pooled = None
-                dgamma, dbeta, coef = K.bn_relu_backward_stats(ys[i], dz, gamma, scale, shift, mean,
-                                                               invstd, training)
+                if below is not None:  # left behind by the fused backward GEMM of layer i+1
+                    dgamma, dbeta, coef = below
+                else:
+                    dgamma, dbeta, coef = K.bn_relu_backward_stats(ys[i], dz, gamma, scale, shift,
+                                                                   mean, invstd, training)
                 dy_tensor, fly = None, (ys[i], dz, scale, shift, mean, invstd, coef)
             grads[5 * i + 1], grads[5 * i + 2] = dgamma, dbeta
             m, k = w2.shape
             src = x if i == 0 else ys[i - 1]
             src_coeff = None if i == 0 else (coefs[i - 1][2], coefs[i - 1][3])
-            both = None
+            both, below = None, None
             if i > 0 or need_dx:  # both GEMMs from one pass over (y_i, dz) where the shape allows
-                both = K.gemm_backward_fused(w2, src, src_coeff, fly, pooled)
+                src_stats = None if i == 0 else (coefs[i - 1][0], coefs[i - 1][1],
+                                                 params[5 * (i - 1) + 1], training)
+                both = K.gemm_backward_fused(w2, src, src_coeff, fly, pooled, src_stats)
             if both is not None:
+                below = both[2]  # BatchNorm-backward sums of layer i-1 (None for the first layer)
                 grads[5 * i] = both[1].view_as(w)
                 if i == 0:
                     dx = both[0].view_as(x)

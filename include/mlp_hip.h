@@ -173,13 +173,27 @@ size_t mlp_gemm_backward_fused_workspace_floats(int b, int m, int k, int r);
 /* dq (b,k,r) = w^T * P[b] and dw (m,k) = sum_b P[b] * Q[b]^T (replaces conv2d backward-input AND
  * backward-weight, pytorch_utils.py:70-124).  P as in mlp_gemm_dgrad_nt (pmode 2: y, dz (b,m,r))
  * or mlp_gemm_dgrad_pooled_nt (pmode 3: y, dz = dpooled (b,m,r/ns), argmax); Q as in
- * mlp_gemm_wgrad (qmode 1: relu(x*xscale + xshift), qmode 0: x). */
+ * mlp_gemm_wgrad (qmode 1: relu(x*xscale + xshift), qmode 0: x).
+ * qmode 1 also needs xmean / xinvstd of the layer that produced x, and, for the k = 64 shapes when
+ * stats_part is not NULL, leaves that layer's BatchNorm-backward sums there: stats_part (k, parts, 2) =
+ * (sum g, sum g*xhat) with g = dq * [x*xscale + xshift > 0], parts =
+ * mlp_gemm_backward_fused_stats_parts() -- the input of mlp_bn_backward_finalize, in place of
+ * that layer's mlp_bn_relu_backward_stats pass over (x, dq). */
 int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, int pmode, const float *y,
                             const float *dz, const int *argmax, int ns, const float *scale,
                             const float *shift, const float *mean, const float *invstd,
                             const float *coef, int qmode, const float *x, const float *xscale,
-                            const float *xshift, float *dq, float *dw, float *workspace,
-                            void *stream);
+                            const float *xshift, const float *xmean, const float *xinvstd,
+                            float *dq, float *dw, float *workspace, float *stats_part, void *stream);
+/* partials per channel in stats_part; 0 when the layer leaves none (sizing helper for the
+ * BatchNorm backward of pytorch_utils.py:42-50) */
+int mlp_gemm_backward_fused_stats_parts(int b, int m, int k, int r);
+/* dgamma, dbeta and the (c,3) coefficients of dy from (s1, s2) partials (c, parts, 2) over `count`
+ * elements per channel (the reduction half of BatchNorm2d's backward, pytorch_utils.py:42-50;
+ * same outputs as mlp_bn_relu_backward_stats) */
+int mlp_bn_backward_finalize(int c, int parts, double count, int training, const float *partial,
+                             const float *gamma, const float *invstd, float *dgamma, float *dbeta,
+                             float *coef, void *stream);
 
 /* scratch (floats) for mlp_gemm_wgrad: per-slice partial dW tiles (replaces cuDNN's
  * workspace of conv2d backward-weight, pytorch_utils.py:70-124) */

@@ -236,16 +236,25 @@ def test_fused_backward_vs_two_gemms(b, m, k, groups, ns, pooled):
         dz = torch.randn(b, m, groups, ns, generator=g).to(DEV)
         _, _, coef = K.bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, True)
         kw = dict(fly=(y, dz, scale, shift, mean, invstd, coef))
-    xcoeff = None
+    xcoeff = xstats = None
     if k % 32 == 0:  # not a grouped network input: the previous layer's raw output
-        xcoeff = ((torch.rand(k, generator=g) + 0.5).to(DEV), (torch.randn(k, generator=g) * 0.3).to(DEV))
-    both = K.gemm_backward_fused(w, x, xcoeff, **kw)
+        xgamma = (torch.rand(k, generator=g) + 0.5).to(DEV)
+        xbeta = (torch.randn(k, generator=g) * 0.3).to(DEV)
+        xmean, xinv, xscale, xshift = K.bn_coefficients(x, xgamma, xbeta, torch.zeros(k, device=DEV),
+                                                        torch.ones(k, device=DEV), 0.1, 1e-5, True)
+        xcoeff, xstats = (xscale, xshift), (xmean, xinv, xgamma, True)
+    both = K.gemm_backward_fused(w, x, xcoeff, xstats=xstats, **kw)
     assert both is not None, "shape not routed to the fused kernel"
-    dx, dw = both
+    dx, dw, below = both
     want_dx = K.gemm_dgrad(w, **kw).view_as(x)
     want_dw = K.gemm_wgrad(m, k, x, xcoeff, **kw)
     close(dx, want_dx, 1e-5)
     close(dw, want_dw, 2e-5)
+    assert (below is not None) == (k == 64)  # the first set-abstraction level's layers
+    if below is not None:  # the layer below's BatchNorm-backward sums == its stats pass over (x, dx)
+        dgamma, dbeta, coef = K.bn_relu_backward_stats(x, want_dx.contiguous(), xgamma, xscale, xshift,
+                                                       xmean, xinv, True)
+        close(below[0], dgamma, 2e-5); close(below[1], dbeta, 2e-5); close(below[2], coef, 2e-5)
 
 
 def test_fused_backward_declines_other_shapes():

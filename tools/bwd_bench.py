@@ -1,5 +1,6 @@
 """Backward GEMMs of the set-abstraction layers at the train step's shapes: the fused one-pass
-kernel (mlp_gemm_backward_fused) against the two separate on-the-fly GEMMs.
+kernel (mlp_gemm_backward_fused, which also leaves the BatchNorm-backward sums of the layer below)
+against the two separate on-the-fly GEMMs plus that layer's statistics pass.
 
     python tools/bwd_bench.py [--json out.json]
 Per layer: microseconds, algorithmic bytes (fused: (2M+2K) floats per column; pooled: (M+2K)),
@@ -48,13 +49,23 @@ for name, m, k, groups, ns, pooled in LAYERS:
         dz = torch.randn(B, m, groups, ns, device=dev)
         _, _, coef = K.bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, True)
         kw = dict(fly=(y, dz, scale, shift, mean, invstd, coef))
-    xc = None if k % 32 else (torch.rand(k, device=dev) + 0.5, torch.randn(k, device=dev) * 0.3)
+    xc = xs = None
+    if k % 32 == 0:
+        xg, xb = torch.rand(k, device=dev) + 0.5, torch.randn(k, device=dev) * 0.3
+        xm, xi, xsc, xsh = K.bn_coefficients(x, xg, xb, torch.zeros(k, device=dev), torch.ones(k, device=dev),
+                                             0.1, 1e-5, True)
+        xc, xs = (xsc, xsh), (xm, xi, xg, True)
     cols = B * groups * ns
     byts = 4 * cols * ((m if pooled else 2 * m) + 2 * k)
     flops = 4 * m * k * cols
-    fused = bench.time_op(lambda: K.gemm_backward_fused(w, x, xc, **kw), iters=10)
+    fused = bench.time_op(lambda: K.gemm_backward_fused(w, x, xc, xstats=xs, **kw), iters=10)
     two = bench.time_op(lambda: (K.gemm_dgrad(w, **kw), K.gemm_wgrad(m, k, x, xc, **kw)), iters=10)
+    stats = 0.0
+    if xs is not None:  # the stats pass over (x, dx) of the layer below that the fused kernel absorbs
+        dxt = torch.randn_like(x)
+        stats = bench.time_op(lambda: K.bn_relu_backward_stats(x, dxt, xg, xsc, xsh, xm, xi, True), iters=10)
     res[name] = {"M": m, "K": k, "columns": cols, "fused_us": round(fused, 1), "two_gemms_us": round(two, 1),
+                 "stats_pass_below_us": round(stats, 1),
                  "hbm_frac": round(byts / (fused * 1e-6) / 8e12, 3),
                  "mfma_frac": round(flops / (fused * 1e-6) / 157e12, 3)}
     print(name, res[name], flush=True)
