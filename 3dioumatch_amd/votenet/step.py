@@ -133,10 +133,12 @@ class SupervisedStep(object):
         if os.environ.get("VOTENET_HIP_GRAPHS", "1") == "0":
             self.graphs = False
         lr_value = torch.tensor(float(lr), device=device) if on_gpu else lr
-        # one flat parameter: the fused implementation is ONE kernel per step (the default
-        # for-each form spends ~15 launches on it)
+        # holder of the hyper-parameters and of the state (torch's keys: step, exp_avg,
+        # exp_avg_sq); on the GPU the update itself is votenet_adam_step (see _apply)
         self.optimizer = torch.optim.Adam([self.flat_params], lr=lr_value, weight_decay=0,
-                                          capturable=on_gpu, fused=on_gpu)
+                                          capturable=on_gpu)
+        self._adam_scratch = None
+        self._lr_scalar = None
         self._side = None
         self._captured = None  # signature the graphs were captured for
         self._mask_cache = (None, None)
@@ -242,10 +244,45 @@ class SupervisedStep(object):
         if self.world > 1:
             torch.distributed.all_reduce(self.flat_grad)
 
-    def _apply(self):
-        if self.world > 1:
-            self.flat_grad.mul_(1.0 / self.world)
-        self.optimizer.step()
+    def _apply(self, teacher=None, ema_weight=None):
+        """Adam on the flat buffer (and, for the semi-supervised subclass, the teacher's EMA
+        update): one kernel of the gfx950 library on the GPU, torch's optimizer elsewhere.  The
+        state lives in self.optimizer.state under torch's own keys either way."""
+        if self.device.type != "cuda":
+            if self.world > 1:
+                self.flat_grad.mul_(1.0 / self.world)
+            self.optimizer.step()
+            if teacher is not None:
+                teacher.lerp_(self.flat_params.data, ema_weight)
+            return
+        import importlib
+        _L = importlib.import_module("3dioumatch_amd._lib")
+        group = self.optimizer.param_groups[0]
+        st = self.optimizer.state[self.flat_params]
+        if "exp_avg" not in st:
+            st["step"] = torch.zeros((), dtype=torch.float32, device=self.device)
+            st["exp_avg"] = torch.zeros_like(self.flat_params.data)
+            st["exp_avg_sq"] = torch.zeros_like(self.flat_params.data)
+        if self._adam_scratch is None:
+            self._adam_scratch = torch.zeros(2, dtype=torch.float32, device=self.device)
+        lr = group["lr"]
+        if not torch.is_tensor(lr):  # a float (set by a caller): keep a device scalar in step
+            if self._lr_scalar is None:
+                self._lr_scalar = torch.zeros((), dtype=torch.float32, device=self.device)
+            self._lr_scalar.fill_(float(lr))
+            lr = self._lr_scalar
+        if group.get("amsgrad") or group.get("maximize"):
+            raise RuntimeError("the flat Adam step implements neither amsgrad nor maximize")
+        beta1, beta2 = group["betas"]
+        with torch.cuda.device(self.device):
+            _L.check(_L.lib.votenet_adam_step(
+                self.flat_params.numel(), self.flat_params.data_ptr(), self.flat_grad.data_ptr(),
+                st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(),
+                lr.data_ptr(), float(beta1), float(beta2), float(group["eps"]),
+                float(group["weight_decay"]), 1.0 / self.world,
+                None if teacher is None else teacher.data_ptr(),
+                None if teacher is None else ema_weight.data_ptr(), self._adam_scratch.data_ptr(),
+                torch.cuda.current_stream(self.device).cuda_stream), "votenet_adam_step")
 
     def _expose_gradients(self):
         """Point every p.grad at its slice of the (averaged) flat gradient."""
@@ -556,8 +593,7 @@ class SemiSupervisedStep(SupervisedStep):
         self._ema_weight.fill_(1 - a)
 
     def _apply(self):
-        super()._apply()
-        self.flat_teacher.lerp_(self.flat_params.data, self._ema_weight)
+        super()._apply(self.flat_teacher, self._ema_weight)
 
 
 def flat_grads(module):

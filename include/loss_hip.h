@@ -78,6 +78,19 @@ int votenet_loss_forward_backward(const VnLossArgs *args, void *stream);
  * means of models/loss_helper_labeled.py:70-74, :118-123 and :283-297 */
 int votenet_loss_scratch_floats(const VnLossArgs *args);
 
+/* replaces optimizer.step() of torch.optim.Adam(net.parameters(), lr, weight_decay)
+ * (pretrain.py:186, :289; train.py:201, :339) on ONE flat parameter buffer, and -- with ema != NULL
+ * -- the teacher update that follows it in the semi-supervised stage (train.py:232-236
+ * update_ema_variables: teacher = alpha*teacher + (1-alpha)*student, *ema_weight = 1-alpha).
+ * p, g, m, v, ema: n floats, 16-byte aligned; step (count of steps so far, incremented), lr and
+ * ema_weight: device scalars (a captured graph of the launch replays with current values);
+ * g is read as g * grad_scale (the 1/world of a data-parallel mean) and, when grad_scale != 1,
+ * rewritten with that product; scratch: 2 floats. */
+int votenet_adam_step(long long n, float *p, float *g, float *m, float *v, float *step,
+                      const float *lr, double beta1, double beta2, double eps, double weight_decay,
+                      double grad_scale, float *ema, const float *ema_weight, float *scratch,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

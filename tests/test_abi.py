@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT, load_pkg
 
 HEADERS = ["pn2_hip.h", "iou3d_hip.h", "mlp_hip.h", "lhs_hip.h", "loss_hip.h"]
-DECL = re.compile(r"^(?:int|size_t|const char \*)\s*\*?\s*((?:pn2|iou3d|mlp|lhs|votenet_loss)_\w+)\s*\(", re.M)
+DECL = re.compile(r"^(?:int|size_t|const char \*)\s*\*?\s*((?:pn2|iou3d|mlp|lhs|votenet)_\w+)\s*\(", re.M)
 
 
 def declared(header):

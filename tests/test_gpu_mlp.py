@@ -351,3 +351,43 @@ def test_fused_head_chain_vs_torch(cin, mid, cout, shape, training):
             close(p1.grad, p2.grad, 5e-4)
         for (n1, b1), (n2, b2) in zip(m.named_buffers(), q.named_buffers()):
             close(b1.float(), b2.float(), 1e-5)
+
+
+@pytest.mark.parametrize("n,world,teacher", [(1000003, 1, False), (4096, 2, True), (5, 1, True)])
+def test_flat_adam_step_matches_torch(n, world, teacher):
+    """votenet_adam_step (Adam on one flat buffer, optional EMA teacher, gradient pre-scaled by
+    1/world) == torch.optim.Adam + lerp_ over several steps, lr changed in between."""
+    load_pkg()
+    L = importlib.import_module("3dioumatch_amd._lib")
+    g = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=g).to(DEV)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=2e-3)
+    p = p0.clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    step = torch.zeros((), device=DEV)
+    lr = torch.tensor(2e-3, device=DEV)
+    scratch = torch.zeros(2, device=DEV)
+    ema = p0.clone() if teacher else None
+    ema_ref = p0.clone()
+    w = torch.zeros((), device=DEV)
+    for it in range(4):
+        grad = (torch.randn(n, generator=g) * (10.0 ** (it - 2))).to(DEV)
+        if it == 2:
+            lr.fill_(5e-4)
+            opt.param_groups[0]["lr"] = 5e-4
+        w.fill_(1.0 - min(1 - 1 / (it + 1), 0.999))
+        ref.grad = grad / world
+        opt.step()
+        ema_ref.lerp_(ref.data, w)
+        L.check(L.lib.votenet_adam_step(n, p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                        step.data_ptr(), lr.data_ptr(), 0.9, 0.999, 1e-8, 0.0, 1.0 / world,
+                                        ema.data_ptr() if teacher else None, w.data_ptr() if teacher else None,
+                                        scratch.data_ptr(), torch.cuda.current_stream().cuda_stream), "adam")
+    assert float(step) == 4.0
+    close(grad, ref.grad, 1e-7)  # the mean is left where the sum was
+    close(p, ref.data, 2e-6)
+    close(m, opt.state[ref]["exp_avg"], 2e-6)
+    close(v, opt.state[ref]["exp_avg_sq"], 2e-6)
+    if teacher:
+        close(ema, ema_ref, 2e-6)
