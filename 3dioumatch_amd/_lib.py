@@ -94,6 +94,8 @@ _SIGNATURES = {
     "votenet_loss_decode": [_vp, _vp],
     "votenet_loss_forward_backward": [_vp, _vp],
     "votenet_loss_scratch_floats": [_vp],
+    "votenet_channel_normalize": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
+    "votenet_channel_normalize_grad": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "votenet_adam_step": [ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double,
                           ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _vp],
     "iou3d_corners_iou3d": [_c_int, _vp, _c_int, _vp, _vp, _vp],

@@ -15,6 +15,48 @@ from .backbone import Pointnet2Backbone
 from .heads import GridConv, ProposalModule, VotingModule
 
 
+
+class _UnitLength(torch.autograd.Function):
+    """features / ||features||_2 over the channel axis (models/votenet_iou_branch.py:103-104) as
+    one kernel each way (votenet_channel_normalize[_grad]) instead of ~30 tensor kernels."""
+
+    @staticmethod
+    def forward(ctx, x):
+        import importlib
+        _L = importlib.import_module("3dioumatch_amd._lib")
+        x = x.contiguous()
+        b, c, n = x.shape
+        y = torch.empty_like(x)
+        norm = torch.empty((b, n), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _L.check(_L.lib.votenet_channel_normalize(b, c, n, x.data_ptr(), y.data_ptr(), norm.data_ptr(),
+                                                      torch.cuda.current_stream(x.device).cuda_stream),
+                     "votenet_channel_normalize")
+        ctx.save_for_backward(y, norm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import importlib
+        _L = importlib.import_module("3dioumatch_amd._lib")
+        y, norm = ctx.saved_tensors
+        dy = dy.contiguous()
+        b, c, n = y.shape
+        dx = torch.empty_like(y)
+        with torch.cuda.device(y.device):
+            _L.check(_L.lib.votenet_channel_normalize_grad(b, c, n, y.data_ptr(), norm.data_ptr(),
+                                                           dy.data_ptr(), dx.data_ptr(),
+                                                           torch.cuda.current_stream(y.device).cuda_stream),
+                     "votenet_channel_normalize_grad")
+        return dx
+
+
+def unit_length_features(features):
+    if features.is_cuda and features.dtype == torch.float32 and features.dim() == 3:
+        return _UnitLength.apply(features)
+    return features.div(torch.norm(features, p=2, dim=1).unsqueeze(1))
+
+
 class VoteNet(nn.Module):
     def __init__(self, num_class, num_heading_bin, num_size_cluster, mean_size_arr, dataset_config,
                  input_feature_dim=0, num_proposal=128, vote_factor=1, sampling='vote_fps',
@@ -46,7 +88,7 @@ class VoteNet(nn.Module):
         end_points['seed_xyz'] = xyz
         end_points['seed_features'] = features
         xyz, features = self.vgen(xyz, features)
-        features = features.div(torch.norm(features, p=2, dim=1).unsqueeze(1))
+        features = unit_length_features(features)
         end_points['vote_xyz'] = xyz
         end_points['vote_features'] = features
         geometry = inputs.get('geometry')

@@ -91,6 +91,15 @@ int votenet_adam_step(long long n, float *p, float *g, float *m, float *v, float
                       double grad_scale, float *ema, const float *ema_weight, float *scratch,
                       void *stream);
 
+/* replaces features.div(torch.norm(features, p=2, dim=1).unsqueeze(1)) on the vote features
+ * (models/votenet_iou_branch.py:103-104): x (b,c,n) -> y = x / ||x||_2 over c, norm (b,n) */
+int votenet_channel_normalize(int b, int c, int n, const float *x, float *y, float *norm,
+                              void *stream);
+/* its backward (autograd of models/votenet_iou_branch.py:103-104):
+ * dx = (dy - y * sum_c(dy*y)) / norm, from the forward's y and norm */
+int votenet_channel_normalize_grad(int b, int c, int n, const float *y, const float *norm,
+                                   const float *dy, float *dx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

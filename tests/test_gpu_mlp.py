@@ -391,3 +391,21 @@ def test_flat_adam_step_matches_torch(n, world, teacher):
     close(v, opt.state[ref]["exp_avg_sq"], 2e-6)
     if teacher:
         close(ema, ema_ref, 2e-6)
+
+
+@pytest.mark.parametrize("shape", [(8, 256, 1024), (2, 7, 100), (1, 3, 1)])
+def test_unit_length_features_vs_torch(shape):
+    """votenet_channel_normalize[_grad] == features.div(torch.norm(features, p=2, dim=1).unsqueeze(1))
+    and its autograd backward (models/votenet_iou_branch.py:103-104)."""
+    load_pkg()
+    D = importlib.import_module("3dioumatch_amd.votenet.detector")
+    g = torch.Generator().manual_seed(sum(shape))
+    x1 = (torch.randn(shape, generator=g) * 3).to(DEV).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    y1 = D.unit_length_features(x1)
+    y2 = x2.div(torch.norm(x2, p=2, dim=1).unsqueeze(1))
+    close(y1, y2, 1e-6)
+    wgt = torch.randn(shape, generator=g).to(DEV)
+    (y1 * wgt).sum().backward()
+    (y2 * wgt).sum().backward()
+    close(x1.grad, x2.grad, 2e-6)

@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r2g
-timeout 900 python -m pytest tests/test_gpu_mlp.py tests/test_train_step.py tests/test_semi_step.py tests/test_ddp.py -q -m gpu -x -k "adam or train or semi or ddp or rank or graph" > gpurun_out/r2g/t1.log 2>&1; tail -n 3 gpurun_out/r2g/t1.log
+timeout 900 python -m pytest tests/test_gpu_mlp.py tests/test_train_step.py tests/test_semi_step.py -q -m gpu -x -k "unit_length or train or semi" > gpurun_out/r2g/t1.log 2>&1; tail -n 3 gpurun_out/r2g/t1.log
 timeout 600 python bench.py 2>&1 | tail -n 1 | cut -c1-260
-timeout 600 python bench.py --workload semi 2>&1 | tail -n 1 | cut -c1-260
