@@ -35,7 +35,7 @@
 
 namespace {
 
-template <int MB, int KB, int KBD, int NB, int PMODE, int QMODE, int OCC, bool STATS>
+template <int MB, int KB, int KBD, int NB, int PMODE, int QMODE, int OCC, bool STATS, bool DGRAD = true>
 __global__ void __launch_bounds__(256, OCC)
 gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, int xyz,
                       OperandB opp, OperandB opq, const float *__restrict__ w,
@@ -55,7 +55,7 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
   constexpr int DN = KBD >= 4 ? NB : 1;
   static_assert(KBD >= 4 ? KBD % 4 == 0 : (KBD == 2 && NB == 2), "dQ blocks must split over 4 waves");
   // MFMA groups of one chunk: DG of dgrad (DU reduction steps each), WG of wgrad (WU steps each)
-  constexpr int DU = 4, DG = (M / 2) / DU;
+  constexpr int DU = 4, DG = DGRAD ? (M / 2) / DU : 0;  // DGRAD false: the weight gradient only
   constexpr int WU = WMB * WKB >= 4 ? 1 : 2, WG = (TN / 2) / WU;
   // staging slices of one chunk per lane: a float4 (pair) of a P row, then of a Q row
   constexpr int NS = 4 * (PP + QP), NG = DG + WG;
@@ -64,6 +64,7 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
   __shared__ float Qs[2][TN * LDQ];
   // BatchNorm-backward sums of the layer BELOW (the one that produced Q) from the dQ blocks:
   // s1 = sum g, s2 = sum g * xhat, g = dQ * [y*sc + sh > 0], xhat = (y - mu) * is
+  static_assert(DGRAD || !STATS, "the sums come from the dQ blocks");
   static_assert(!STATS || QMODE == OP_BNRELU, "the sums are those of a BatchNorm+ReLU layer below");
   constexpr bool RAWQ = STATS;  // the Q tile then holds raw rows, rectified as fragments are read
   constexpr int SROWS = STATS ? 32 * KBD : 1;
@@ -116,15 +117,15 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
   const int lane_s = PMODE == OP_POOLDY ? seg_c % P.ns : 0;
 
   // W^T fragments of this wave's dQ row blocks: A operand of step s = W[2s + lhi][k0 + l31]
-  float wreg[DK][M / 2];
+  float wreg[DK][DGRAD ? M / 2 : 1];
 #pragma unroll
-  for (int e = 0; e < DK; ++e) {
+  for (int e = 0; e < (DGRAD ? DK : 0); ++e) {
     const int kbd = KBD >= 4 ? wave * DK + e : (wave >> 1);
     const float *wc = w + xyz + 32 * kbd + l31;
 #pragma unroll
     for (int s = 0; s < M / 2; ++s) wreg[e][s] = wc[(size_t)(2 * s + lhi) * k_total];
   }
-  for (int t = tid; t < 3 * M; t += 256) Wx[t] = xyz ? w[(size_t)(t % M) * k_total + t / M] : 0.f;
+  for (int t = tid; t < 3 * M; t += 256) Wx[t] = DGRAD && xyz ? w[(size_t)(t % M) * k_total + t / M] : 0.f;
 
   f32x16 accW[WMB][WKB];
 #pragma unroll
@@ -252,7 +253,7 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
 
     // ---- dgrad: dQ block = W^T (registers) * P chunk (LDS)
     f32x16 accD[DK][DN];
-    {
+    if (DGRAD) {
 #pragma unroll
       for (int e = 0; e < DK; ++e)
 #pragma unroll
@@ -362,7 +363,7 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
     }
 
     // ---- the three coordinate rows of dQ (TN == 32): dot products on the vector ALU
-    if (NB == 1 && xyz) {
+    if (DGRAD && NB == 1 && xyz) {
       const int n = tid & 31, g8 = tid >> 5;
       float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll 4
@@ -482,8 +483,11 @@ MLP_API int mlp_gemm_backward_fused_supported(int b, int m, int k, int r, int pm
   const bool first = s.xyz != 0;  // grouped input: the layer reads the network input directly
   if (first != (qmode == OP_DIRECT)) return 0;
   if (qmode != OP_DIRECT && qmode != OP_BNRELU) return 0;
-  const bool pooled_shape = (m == 128 && k == 64) || (m == 256 && k == 128);
-  if (pooled_shape != (pmode == OP_POOLDY)) return 0;
+  // instantiated (shape, gradient operand) pairs: the pooled last layers are (128,64), (256,128)
+  // and (128,128) (vote aggregation, grid features); (128,128) also occurs unpooled
+  const bool pooled_only = (m == 128 && k == 64) || (m == 256 && k == 128);
+  const bool either = m == 128 && k == 128;
+  if (!either && pooled_only != (pmode == OP_POOLDY)) return 0;
   return 1;
 }
 
@@ -516,6 +520,7 @@ MLP_API int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, 
   if (!mlp_gemm_backward_fused_supported(b, m, k, r, pmode, qmode, ns)) return (int)hipErrorInvalidValue;
   FusedShape s;
   fused_shape(m, k, &s);
+  if (dq == nullptr && !(m == 128 && k == 259)) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
   const int cpc = r / s.tn;
   const int total = b * cpc;
@@ -530,10 +535,14 @@ MLP_API int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, 
                      stats_part)
   if (m == 64 && k == 64) FUSED(2, 2, 2, 2, OP_DY, OP_BNRELU, 2, true);
   else if (m == 128 && k == 64) FUSED(4, 2, 2, 2, OP_POOLDY, OP_BNRELU, 1, true);
-  else if (m == 128 && k == 128) FUSED(4, 4, 4, 1, OP_DY, OP_BNRELU, 2, false);
+  else if (m == 128 && k == 128 && pmode == OP_DY) FUSED(4, 4, 4, 1, OP_DY, OP_BNRELU, 2, false);
+  else if (m == 128 && k == 128) FUSED(4, 4, 4, 1, OP_POOLDY, OP_BNRELU, 2, false);
   else if (m == 256 && k == 128) FUSED(8, 4, 4, 1, OP_POOLDY, OP_BNRELU, 1, false);
   else if (m == 128 && k == 131) FUSED(4, 5, 4, 1, OP_DY, OP_DIRECT, 1, false);
-  else FUSED(4, 9, 8, 1, OP_DY, OP_DIRECT, 1, false);
+  else if (dq != nullptr) FUSED(4, 9, 8, 1, OP_DY, OP_DIRECT, 1, false);
+  else  // the layer's input needs no gradient: the persistent weight-gradient half alone
+    hipLaunchKernelGGL((gemm_bwd_fused_kernel<4, 9, 8, 1, OP_DY, OP_DIRECT, 1, false, false>), dim3(g),
+                       dim3(256), 0, stream, k, r, total, cpc, s.xyz, P, Q, w, dq, workspace, stats_part);
 #undef FUSED
   int rc = pn2_launch_status();
   if (rc) return rc;

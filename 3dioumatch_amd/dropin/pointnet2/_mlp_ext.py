@@ -264,14 +264,15 @@ def gemm_wgrad(m, k, x, xcoeff=None, dy=None, fly=None, pooled=None):
     return dw
 
 
-def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None):
+def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None, need_dx=True):
     """dgrad and wgrad of one layer in one pass: -> (dx (B,K,...), dw (M,K), below), or None when
     the layer's shape is outside the fused kernel (callers then use gemm_dgrad + gemm_wgrad).
     x (B,K,...) direct or relu(bn(.)) via xcoeff=(scale, shift); the gradient operand on the fly
     from fly / pooled as in gemm_dgrad.
     xstats = (mean, invstd, gamma, training) of the layer that produced x (required with xcoeff):
     `below` is then that layer's (dgamma, dbeta, coef), as bn_relu_backward_stats(x, dx, ...)
-    would return them -- the sums come out of the dgrad epilogue, no pass over (x, dx)."""
+    would return them -- the sums come out of the dgrad epilogue, no pass over (x, dx).
+    need_dx=False (a first layer whose input needs no gradient): dx is None."""
     m, k = w.shape
     _f32c(w, "w"); _f32c(x, "x")
     b = x.shape[0]
@@ -285,11 +286,13 @@ def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None):
     qmode = 0 if xcoeff is None else 1
     if not _lib.mlp_gemm_backward_fused_supported(b, m, k, r, pmode, qmode, ns):
         return None
+    if not need_dx and (m, k) != (128, 259):  # the weight-gradient-only form exists for this shape
+        return None
     if qmode == 1 and xstats is None:
         raise RuntimeError("xstats=(mean, invstd, gamma, training) is required with xcoeff")
     xs, xh = xcoeff if xcoeff is not None else (None, None)
     xmean, xinv, xgamma, xtraining = xstats if qmode == 1 else (None, None, None, False)
-    dx = torch.empty_like(x)
+    dx = torch.empty_like(x) if need_dx else None
     dw = torch.empty((m, k), dtype=torch.float32, device=x.device)
     parts = int(_lib.mlp_gemm_backward_fused_stats_parts(b, m, k, r)) if qmode == 1 else 0
     below = None
@@ -301,7 +304,7 @@ def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None):
                                               dz.data_ptr(), _ptr(argmax), ns, scale.data_ptr(),
                                               shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                               coef.data_ptr(), qmode, x.data_ptr(), _ptr(xs),
-                                              _ptr(xh), _ptr(xmean), _ptr(xinv), dx.data_ptr(),
+                                              _ptr(xh), _ptr(xmean), _ptr(xinv), _ptr(dx),
                                               dw.data_ptr(), ws.data_ptr(), _ptr(sp), _stream(x)),
                  "mlp_gemm_backward_fused")
         if parts:

@@ -214,16 +214,17 @@ class _FusedMLPChain(Function):
             m, k = w2.shape
             src = x if i == 0 else ys[i - 1]
             src_coeff = None if i == 0 else (coefs[i - 1][2], coefs[i - 1][3])
-            both, below = None, None
-            if i > 0 or need_dx:  # both GEMMs from one pass over (y_i, dz) where the shape allows
-                src_stats = None if i == 0 else (coefs[i - 1][0], coefs[i - 1][1],
-                                                 params[5 * (i - 1) + 1], training)
-                both = K.gemm_backward_fused(w2, src, src_coeff, fly, pooled, src_stats)
+            # both GEMMs from one pass over (y_i, dz) where the shape allows
+            src_stats = None if i == 0 else (coefs[i - 1][0], coefs[i - 1][1],
+                                             params[5 * (i - 1) + 1], training)
+            both = K.gemm_backward_fused(w2, src, src_coeff, fly, pooled, src_stats,
+                                         need_dx=i > 0 or need_dx)
+            below = None
             if both is not None:
                 below = both[2]  # BatchNorm-backward sums of layer i-1 (None for the first layer)
                 grads[5 * i] = both[1].view_as(w)
                 if i == 0:
-                    dx = both[0].view_as(x)
+                    dx = both[0].view_as(x) if need_dx else None
                 else:
                     dz = both[0]
             elif i == 0:

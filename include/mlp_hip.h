@@ -161,7 +161,8 @@ int mlp_gemm_wgrad_pooled(int b, int m, int k, int groups, int ns, const float *
  * nn.Conv2d inside SharedMLP, :14-39) both consume the BatchNorm/ReLU backward of the incoming
  * gradient; run separately (mlp_gemm_dgrad_nt + mlp_gemm_wgrad above) both read the pair it is
  * formed from.  Covered: (m,k) in {(64,64), (128,64), (128,128), (256,128), (128,131), (128,259)},
- * r a multiple of 64 / 32, pmode 2 (from y, dz) or 3 (pooled last layer: (128,64) and (256,128)),
+ * r a multiple of 64 / 32, pmode 2 (from y, dz) or 3 (pooled last layer: (128,64), (256,128),
+ * (128,128)),
  * qmode 1 (x = raw output of the previous layer) or 0 (grouped network input: the k = 3+32j
  * shapes). */
 /* 1 when mlp_gemm_backward_fused covers the layer (replaces nothing by itself: dispatch helper
@@ -174,6 +175,8 @@ size_t mlp_gemm_backward_fused_workspace_floats(int b, int m, int k, int r);
  * backward-weight, pytorch_utils.py:70-124).  P as in mlp_gemm_dgrad_nt (pmode 2: y, dz (b,m,r))
  * or mlp_gemm_dgrad_pooled_nt (pmode 3: y, dz = dpooled (b,m,r/ns), argmax); Q as in
  * mlp_gemm_wgrad (qmode 1: relu(x*xscale + xshift), qmode 0: x).
+ * dq == NULL (only (128,259)): the weight gradient alone, for a first layer whose input needs no
+ * gradient.
  * qmode 1 also needs xmean / xinvstd of the layer that produced x, and, for the k = 64 shapes when
  * stats_part is not NULL, leaves that layer's BatchNorm-backward sums there: stats_part (k, parts, 2) =
  * (sum g, sum g*xhat) with g = dq * [x*xscale + xshift > 0], parts =

@@ -210,7 +210,8 @@ def test_pooled_operand_mode_vs_materialised(b, m, k, groups, ns):
 @pytest.mark.parametrize("b,m,k,groups,ns,pooled", [
     (2, 64, 64, 40, 64, False), (2, 128, 64, 36, 64, True), (3, 128, 128, 25, 32, False),
     (2, 256, 128, 33, 32, True), (2, 128, 131, 40, 32, False), (5, 128, 259, 26, 16, False),
-    (8, 128, 128, 512, 16, False), (1, 256, 128, 2048, 16, True)])
+    (8, 128, 128, 512, 16, False), (1, 256, 128, 2048, 16, True), (2, 128, 128, 64, 64, True),
+    (3, 128, 128, 256, 16, True)])
 def test_fused_backward_vs_two_gemms(b, m, k, groups, ns, pooled):
     """dgrad + wgrad of a layer from ONE pass over its activations (mlp_gemm_backward_fused) ==
     the two separate on-the-fly GEMMs, for every layer shape of the network: gradient operand from
@@ -250,6 +251,10 @@ def test_fused_backward_vs_two_gemms(b, m, k, groups, ns, pooled):
     want_dw = K.gemm_wgrad(m, k, x, xcoeff, **kw)
     close(dx, want_dx, 1e-5)
     close(dw, want_dw, 2e-5)
+    if (m, k) == (128, 259):  # the form for a first layer whose input needs no gradient
+        none, dw_only, _ = K.gemm_backward_fused(w, x, xcoeff, xstats=xstats, need_dx=False, **kw)
+        assert none is None
+        close(dw_only, want_dw, 2e-5)
     assert (below is not None) == (k == 64)  # the first set-abstraction level's layers
     if below is not None:  # the layer below's BatchNorm-backward sums == its stats pass over (x, dx)
         dgamma, dbeta, coef = K.bn_relu_backward_stats(x, want_dx.contiguous(), xgamma, xscale, xshift,
