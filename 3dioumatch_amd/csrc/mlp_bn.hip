@@ -333,6 +333,26 @@ bn_relu_pool_generic_kernel(int c, int m, int ns, const float *__restrict__ y,
   pooled[o] = best; argmax[o] = bk; ymax[o] = by;
 }
 
+// pooled = max over nsample of relu(y*sc + sh) from the per-group extrema of the raw y that the
+// forward GEMM left behind: the transform is monotone in y, so the winner is the group's maximum
+// (sc >= 0) or minimum (sc < 0); ext = 4 planes (max, min, argmax, argmin) of (b, c, groups)
+__global__ void __launch_bounds__(256)
+pool_from_extrema_kernel(int c, int groups, long long total, const float *__restrict__ ext,
+                         const float *__restrict__ scale, const float *__restrict__ shift,
+                         float *__restrict__ pooled, int *__restrict__ argmax,
+                         float *__restrict__ ymax) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int ch = (int)((i / groups) % c);
+  const float sc = scale[ch], sh = shift[ch];
+  const int *ei = reinterpret_cast<const int *>(ext);
+  const bool up = sc >= 0.f;
+  const float yw = up ? ext[i] : ext[total + i];
+  pooled[i] = fmaxf(yw * sc + sh, 0.f);
+  argmax[i] = up ? ei[2 * total + i] : ei[3 * total + i];
+  ymax[i] = yw;
+}
+
 // ---- backward sums: s1 = sum dzh, s2 = sum dzh * xhat, dzh = dz * [y*scale+shift > 0] --------
 __global__ void __launch_bounds__(kBnThreads)
 bn_relu_bwd_partial_kernel(int c, int r, int slices, const float *__restrict__ y,
@@ -638,6 +658,17 @@ MLP_API int mlp_bn_backward_finalize(int c, int parts, double count, int trainin
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn2_ceil_div(c, 256 / kWave)), dim3(256), 0,
                      (hipStream_t)stream_, c, parts, count, training, partial, gamma, invstd, dgamma,
                      dbeta, coef);
+  return pn2_launch_status();
+}
+
+// (pooled, argmax, ymax) of mlp_bn_relu_pool from the extrema planes of mlp_gemm_forward_stats_pool
+MLP_API int mlp_bn_pool_from_extrema(int b, int c, int groups, const float *ext, const float *scale,
+                                     const float *shift, float *pooled, int *argmax, float *ymax,
+                                     void *stream_) {
+  if (b <= 0 || c <= 0 || groups <= 0) return 0;
+  const long long total = (long long)b * c * groups;
+  hipLaunchKernelGGL(pool_from_extrema_kernel, dim3(pn2_ceil_div(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream_, c, groups, total, ext, scale, shift, pooled, argmax, ymax);
   return pn2_launch_status();
 }
 

@@ -167,15 +167,42 @@ __device__ __forceinline__ float half_wave_sum(float v) {
   return v;
 }
 
+// the same butterfly with max / min: lanes 16..31 (48..63) end up with the extreme of lanes
+// 0..31 (32..63); masked-out rows keep their own value (old = v)
+template <bool MAXOP>
+__device__ __forceinline__ float half_wave_extreme(float v) {
+#define HX_STEP(CTRL, RM)                                                                        \
+  {                                                                                              \
+    const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(                      \
+        __builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, RM, 0xf, false));         \
+    v = MAXOP ? fmaxf(v, o) : fminf(v, o);                                                       \
+  }
+  HX_STEP(0xB1, 0xf);
+  HX_STEP(0x4E, 0xf);
+  HX_STEP(0x141, 0xf);
+  HX_STEP(0x140, 0xf);
+  HX_STEP(0x142, 0xa);
+#undef HX_STEP
+  return v;
+}
+
 // A_VEC: the rows of A are 16-byte aligned (lda % 4 == 0 and an aligned base)
 // STATS: the epilogue also reduces every output row over the tile's columns to a
 //        (mean, M2) pair for the BatchNorm that follows (one per row, cloud and column tile, all
 //        tiles hold TN columns): the statistics pass no longer re-reads y from HBM
-template <int TM, int TN, int WM, int WN, int MODE, bool A_TRANS, bool A_VEC, bool STATS = false>
+// POOL:  (32 or 64 = nsample) the epilogue also leaves, per output row and group of POOL
+//        consecutive columns, the largest and the smallest raw value and where each first occurs.
+//        relu(y*sc + sh) is monotone in y for a given channel, so the max-pool over nsample that
+//        follows the BatchNorm (whose sc, sh are not known yet) is one of the two -- the pooling
+//        pass no longer re-reads y either.  ext: 4 planes (max, min, argmax, argmin) of
+//        (b, m_total, r / POOL).
+template <int TM, int TN, int WM, int WN, int MODE, bool A_TRANS, bool A_VEC, bool STATS = false,
+          int POOL = 0>
 __global__ void __launch_bounds__(256, (MODE <= OP_BNRELU && TM <= 128) ? 4 : 2)
 gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int lda,
                 unsigned a_bytes, OperandB opb, float *__restrict__ c, size_t b_stride_in,
-                size_t b_stride_out, float *__restrict__ stats = nullptr, int stat_channels = 0) {
+                size_t b_stride_out, float *__restrict__ stats = nullptr, int stat_channels = 0,
+                float *__restrict__ ext = nullptr, size_t ext_plane = 0) {
   constexpr int MB = TM / WM / 32, NB = TN / WN / 32;
   constexpr int LDA = TM + 4;       // [k][m] rows; 16-byte aligned rows, conflict-free fragments
   constexpr int AV = TM * KC / 4 / 256;  // 16-byte A pieces per lane and chunk
@@ -356,6 +383,59 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
       float *dst = stats + (((size_t)b * gridDim.x + blockIdx.x) * stat_channels + m0 + tid) * 2;
       dst[0] = mean;
       dst[1] = m2;
+    }
+  }
+  if constexpr (POOL != 0) {
+    static_assert(POOL == 0 || (NB == 2 && MB == 2 && (POOL == 32 || POOL == 64)),
+                  "a wave owns 64 x 64 of the tile");
+    // Transpose through LDS (the operand buffers are free now; the barrier that ended the K loop
+    // is behind every wave): the wave parks 32 rows x 64 columns of its accumulators, swizzled
+    // [row][col ^ row] so that both the column-wise writes and the row-wise scans are
+    // conflict-free, then lane (row = lane & 31, half = lane >> 5) scans 32 consecutive samples
+    // of its row for the largest / smallest value and their first positions.
+    constexpr int AS_FLOATS = 2 * KC * LDA;
+    float *park = AS_FLOATS >= 4 * 2048 ? &As[0][0] + wave * 2048
+                                        : (wave < 2 ? &As[0][0] + wave * 2048 : &Bs[0][0] + (wave - 2) * 2048);
+    static_assert(AS_FLOATS >= 2 * 2048 && 2 * KC * TN + (AS_FLOATS >= 4 * 2048 ? 4096 : 0) >= 4096,
+                  "operand buffers too small to park the accumulators");
+    const int half = lane >> 5, l31 = lane & 31;
+    const int groups = r / (POOL ? POOL : 1);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int rl = (q & 3) + 8 * (q >> 2) + 4 * half;
+          park[rl * 64 + ((j * 32 + l31) ^ rl)] = acc[i][j][q];
+        }
+      // (same wave wrote and reads: LDS operations of a wave complete in order)
+      float vmax = park[l31 * 64 + ((half * 32) ^ l31)], vmin = vmax;
+      int amax = 0, amin = 0;
+#pragma unroll
+      for (int s2 = 1; s2 < 32; ++s2) {
+        const float v = park[l31 * 64 + ((half * 32 + s2) ^ l31)];
+        if (v > vmax) { vmax = v; amax = s2; }
+        if (v < vmin) { vmin = v; amin = s2; }
+      }
+      if (POOL == 64) {  // the two halves of a row form one group: the lower half wins ties
+        const float omax = __shfl_xor(vmax, 32, kWave), omin = __shfl_xor(vmin, 32, kWave);
+        const int oamax = __shfl_xor(amax, 32, kWave), oamin = __shfl_xor(amin, 32, kWave);
+        if (half == 0) {
+          if (omax > vmax) { vmax = omax; amax = 32 + oamax; }
+          if (omin < vmin) { vmin = omin; amin = 32 + oamin; }
+        }
+      }
+      const int row = m0 + (wm * MB + i) * 32 + l31;
+      if (row < m_total && (POOL == 32 || half == 0)) {
+        const int grp = (r0 + wn * 64) / (POOL ? POOL : 1) + (POOL == 32 ? half : 0);
+        const size_t o = ((size_t)b * m_total + row) * groups + grp;
+        int *ei = reinterpret_cast<int *>(ext);
+        ext[o] = vmax;
+        ext[ext_plane + o] = vmin;
+        ei[2 * ext_plane + o] = amax;
+        ei[3 * ext_plane + o] = amin;
+      }
     }
   }
 }
@@ -776,6 +856,41 @@ MLP_API int mlp_gemm_forward_stats(int b, int m, int k, int r, const float *w, c
                                 (hipStream_t)stream_, pairs);
   return launch_nn<OP_BNRELU>(b, m, k, r, w, k, op, y, in_stride, out_stride, (hipStream_t)stream_,
                               pairs);
+}
+
+// 1 when mlp_gemm_forward_stats_pool covers the pooled last layer: statistics from the epilogue
+// available, one row tile (m = 128 or 256), nsample 32 or 64, 16-byte aligned weight rows
+MLP_API int mlp_gemm_forward_stats_pool_supported(int b, int m, int k, int r, int ns) {
+  const char *env = getenv("MLP_GEMM_EPILOGUE_POOL");
+  if (env && atoi(env) == 0) return 0;
+  if (mlp_gemm_forward_stats_parts(b, m, k, r, nullptr) == 0) return 0;
+  return (m == 128 || m == 256) && (ns == 32 || ns == 64) && r % ns == 0 && k % 4 == 0;
+}
+
+// mlp_gemm_forward_stats (mode 1: x = raw output of the previous layer) that also leaves, per
+// channel and group of ns columns, max / min / argmax / argmin of the raw output:
+// ext = 4 planes of b*m*(r/ns) 4-byte values
+MLP_API int mlp_gemm_forward_stats_pool(int b, int m, int k, int r, const float *w, const float *x,
+                                        const float *scale, const float *shift, float *y,
+                                        float *pairs, int ns, float *ext, void *stream_) {
+  if (!mlp_gemm_forward_stats_pool_supported(b, m, k, r, ns) || !pairs || !ext ||
+      (reinterpret_cast<size_t>(w) & 15) != 0)
+    return (int)hipErrorInvalidValue;
+  hipStream_t stream = (hipStream_t)stream_;
+  OperandB op = {x, nullptr, scale, shift, nullptr, nullptr, nullptr};
+  const size_t in_stride = (size_t)k * r, out_stride = (size_t)m * r;
+  const size_t plane = (size_t)b * m * (r / ns);
+  const unsigned a_bytes = (unsigned)(4 * (size_t)m * k);
+#define POOLED(TM, TN, WM, WN, NS)                                                                 \
+  hipLaunchKernelGGL((gemm_nn2_kernel<TM, TN, WM, WN, OP_BNRELU, false, true, true, NS>),          \
+                     dim3(r / TN, 1, b), dim3(256), 0, stream, m, k, r, w, k, a_bytes, op, y,     \
+                     in_stride, out_stride, pairs, m, ext, plane)
+  if (m == 256 && ns == 32) POOLED(256, 64, 4, 1, 32);
+  else if (m == 256) POOLED(256, 64, 4, 1, 64);
+  else if (ns == 32) POOLED(128, 128, 2, 2, 32);
+  else POOLED(128, 128, 2, 2, 64);
+#undef POOLED
+  return pn2_launch_status();
 }
 
 // dX (b,k,r) = W^T (k x m, given as wt row-major) * dY, with dY either given (mode 0: dy) or

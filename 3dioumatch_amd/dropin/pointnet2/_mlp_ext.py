@@ -144,10 +144,13 @@ def gemm_forward(w, x, coeff=None):
     return y
 
 
-def gemm_forward_bn(w, x, coeff, gamma, beta, running_mean, running_var, momentum, eps):
+def gemm_forward_bn(w, x, coeff, gamma, beta, running_mean, running_var, momentum, eps, pool=False):
     """Training-mode layer: y = gemm_forward(w, x, coeff) and the BatchNorm coefficients of y
     (mean, invstd, scale, shift), with the batch statistics reduced in the GEMM epilogue when the
-    shape allows (no second pass over y), else by bn_coefficients."""
+    shape allows (no second pass over y), else by bn_coefficients.
+    pool=True (x is (B,K,m,ns), the layer is followed by the max over nsample): returns a sixth
+    value, the extrema planes for pool_from_extrema -- or None when the shape has no such epilogue
+    and the caller pools with bn_relu_pool."""
     import ctypes
     _f32c(x, "x"); _f32c(w, "w")
     b, k = x.shape[0], x.shape[1]
@@ -158,7 +161,11 @@ def gemm_forward_bn(w, x, coeff, gamma, beta, running_mean, running_var, momentu
     if parts <= 0:
         y = gemm_forward(w, x, coeff)
         return (y,) + tuple(bn_coefficients(y, gamma, beta, running_mean, running_var, momentum,
-                                            eps, True))
+                                            eps, True)) + ((None,) if pool else ())
+    ns = x.shape[3] if (pool and x.dim() == 4) else 0
+    pooled = bool(ns) and coeff is not None and w.data_ptr() % 16 == 0 and \
+        bool(_lib.mlp_gemm_forward_stats_pool_supported(b, m, k, r, ns))
+    ext = torch.empty((4, b, m, r // ns), dtype=torch.float32, device=x.device) if pooled else None
     y = torch.empty((b, m) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
     pairs = torch.empty((parts, m, 2), dtype=torch.float32, device=x.device)
     out = torch.empty((4, m), dtype=torch.float32, device=x.device)
@@ -166,10 +173,17 @@ def gemm_forward_bn(w, x, coeff, gamma, beta, running_mean, running_var, momentu
                           device=x.device)
     scale, shift = coeff if coeff is not None else (None, None)
     with torch.cuda.device(x.device):
-        _L.check(_lib.mlp_gemm_forward_stats(b, m, k, r, w.data_ptr(), x.data_ptr(),
-                                             0 if coeff is None else 1, _ptr(scale), _ptr(shift),
-                                             y.data_ptr(), pairs.data_ptr(), _stream(x)),
-                 "mlp_gemm_forward_stats")
+        if pooled:
+            _L.check(_lib.mlp_gemm_forward_stats_pool(b, m, k, r, w.data_ptr(), x.data_ptr(),
+                                                      scale.data_ptr(), shift.data_ptr(),
+                                                      y.data_ptr(), pairs.data_ptr(), ns,
+                                                      ext.data_ptr(), _stream(x)),
+                     "mlp_gemm_forward_stats_pool")
+        else:
+            _L.check(_lib.mlp_gemm_forward_stats(b, m, k, r, w.data_ptr(), x.data_ptr(),
+                                                 0 if coeff is None else 1, _ptr(scale),
+                                                 _ptr(shift), y.data_ptr(), pairs.data_ptr(),
+                                                 _stream(x)), "mlp_gemm_forward_stats")
         rm = running_mean.data_ptr() if running_mean is not None else None
         rv = running_var.data_ptr() if running_var is not None else None
         _L.check(_lib.mlp_bn_finalize_pairs(m, parts, cols.value, pairs.data_ptr(),
@@ -178,7 +192,24 @@ def gemm_forward_bn(w, x, coeff, gamma, beta, running_mean, running_var, momentu
                                             out[1].data_ptr(), out[2].data_ptr(),
                                             out[3].data_ptr(), scratch.data_ptr(), _stream(x)),
                  "mlp_bn_finalize_pairs")
+    if pool:
+        return y, out[0], out[1], out[2], out[3], ext
     return y, out[0], out[1], out[2], out[3]
+
+
+def pool_from_extrema(ext, scale, shift):
+    """(pooled, argmax, ymax) as bn_relu_pool(y, scale, shift) would return them, from the extrema
+    planes (4,B,C,m) that gemm_forward_bn(pool=True) left behind: no pass over y."""
+    _, b, c, m = ext.shape
+    pooled = torch.empty((b, c, m), dtype=torch.float32, device=ext.device)
+    ymax = torch.empty_like(pooled)
+    argmax = torch.empty((b, c, m), dtype=torch.int32, device=ext.device)
+    with torch.cuda.device(ext.device):
+        _L.check(_lib.mlp_bn_pool_from_extrema(b, c, m, ext.data_ptr(), scale.data_ptr(),
+                                               shift.data_ptr(), pooled.data_ptr(),
+                                               argmax.data_ptr(), ymax.data_ptr(), _stream(ext)),
+                 "mlp_bn_pool_from_extrema")
+    return pooled, argmax, ymax
 
 
 def bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, training):

@@ -154,7 +154,12 @@ class _FusedMLPChain(Function):
         for i in range(n_layers):
             w, gamma, beta, rm, rv = params[5 * i:5 * i + 5]
             w2 = w.reshape(w.shape[0], -1)
-            if training:  # batch statistics come out of the GEMM epilogue where the shape allows
+            ext = None
+            if training and pool and i == n_layers - 1:
+                # ... and so do the per-group extrema the max over nsample needs
+                y, mean, invstd, scale, shift, ext = K.gemm_forward_bn(
+                    w2, cur, cur_coeff, gamma, beta, rm, rv, momenta[i], epss[i], pool=True)
+            elif training:  # batch statistics come out of the GEMM epilogue where the shape allows
                 y, mean, invstd, scale, shift = K.gemm_forward_bn(w2, cur, cur_coeff, gamma, beta,
                                                                   rm, rv, momenta[i], epss[i])
             else:
@@ -165,7 +170,10 @@ class _FusedMLPChain(Function):
             coefs.append((mean, invstd, scale, shift))
             cur, cur_coeff = y, (scale, shift)
         extra = []
-        if pool:
+        if pool and ext is not None:
+            out, argmax, ymax = K.pool_from_extrema(ext, cur_coeff[0], cur_coeff[1])
+            extra = [argmax, ymax]
+        elif pool:
             out, argmax, ymax = K.bn_relu_pool(cur, cur_coeff[0], cur_coeff[1])
             extra = [argmax, ymax]
         else:

@@ -156,6 +156,26 @@ int mlp_gemm_wgrad_pooled(int b, int m, int k, int groups, int ns, const float *
                           const float *coef, int qmode, const float *x, const float *xscale,
                           const float *xshift, float *dw, float *workspace, void *stream);
 
+/* ---- max over nsample without a second pass over the last layer's output ---------------------
+ * relu(y*scale + shift) is monotone in y per channel, so the max-pool over nsample that follows
+ * the last layer of an SA module (pointnet2_modules.py:256-262: F.max_pool2d over the nsample
+ * axis) is the transform of the group's largest (scale >= 0) or smallest raw value; the forward
+ * GEMM can leave both behind before scale / shift exist. */
+/* 1 when mlp_gemm_forward_stats_pool covers the layer: m 128 or 256, ns 32 or 64, k % 4 == 0 and
+ * the epilogue statistics available (dispatch helper for pointnet2_modules.py:256-262) */
+int mlp_gemm_forward_stats_pool_supported(int b, int m, int k, int r, int ns);
+/* mlp_gemm_forward_stats (mode 1) that also writes ext: 4 planes of (b, m, r/ns) -- max, min
+ * (float), argmax, argmin (int, first occurrence) of the raw output per channel and group of ns
+ * columns (replaces the read of y in the max-pool of pointnet2_modules.py:256-262) */
+int mlp_gemm_forward_stats_pool(int b, int m, int k, int r, const float *w, const float *x,
+                                const float *scale, const float *shift, float *y, float *pairs,
+                                int ns, float *ext, void *stream);
+/* pooled, argmax, ymax (b,c,groups) as mlp_bn_relu_pool returns them, from ext
+ * (replaces F.max_pool2d of pointnet2_modules.py:256-262 after BatchNorm + ReLU) */
+int mlp_bn_pool_from_extrema(int b, int c, int groups, const float *ext, const float *scale,
+                             const float *shift, float *pooled, int *argmax, float *ymax,
+                             void *stream);
+
 /* ---- dgrad + wgrad of one layer in one pass over its activations -----------------------------
  * The two backward GEMMs of a conv(1x1)+BN+ReLU layer (pytorch_utils.py:70-124: the autograd of
  * nn.Conv2d inside SharedMLP, :14-39) both consume the BatchNorm/ReLU backward of the incoming

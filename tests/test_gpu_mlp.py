@@ -414,3 +414,39 @@ def test_unit_length_features_vs_torch(shape):
     (y1 * wgt).sum().backward()
     (y2 * wgt).sum().backward()
     close(x1.grad, x2.grad, 2e-6)
+
+
+@pytest.mark.parametrize("b,m,k,groups,ns", [(5, 128, 64, 64, 64), (2, 256, 128, 512, 32), (1, 128, 128, 512, 64),
+                                             (3, 256, 128, 128, 64), (5, 128, 128, 128, 32)])
+def test_pool_from_gemm_epilogue_extrema(b, m, k, groups, ns):
+    """max over nsample of relu(bn(y)) from the per-group max / min of the raw GEMM output
+    (mlp_gemm_forward_stats_pool + mlp_bn_pool_from_extrema) == bn_relu_pool on y: pooled values
+    and winning pre-activations identical, arg-max identical wherever the winner is not rectified
+    to zero (there the gradient is zero whichever sample is named); channels with a negative
+    BatchNorm scale take the minimum.  Groups with repeated samples (ball-query padding) keep the
+    FIRST occurrence."""
+    load_pkg()
+    K = importlib.import_module("pointnet2._mlp_ext")
+    g = torch.Generator().manual_seed(m + k + groups + ns)
+    w = (torch.randn(m, k, generator=g) / k ** 0.5).to(DEV)
+    x = torch.randn(b, k, groups, ns, generator=g)
+    x[:, :, :, ns // 2:] = x[:, :, :, :1]  # padding: the first sample repeated
+    x = x.to(DEV)
+    xs, xh = (torch.rand(k, generator=g) + 0.5).to(DEV), (torch.randn(k, generator=g) * 0.3).to(DEV)
+    gamma = (torch.rand(m, generator=g) + 0.5)
+    gamma[::3] *= -1.0  # negative scales: the winner is the group's minimum
+    gamma = gamma.to(DEV)
+    beta = (torch.randn(m, generator=g) * 0.3).to(DEV)
+    rm, rv = torch.zeros(m, device=DEV), torch.ones(m, device=DEV)
+    y, mean, invstd, scale, shift, ext = K.gemm_forward_bn(w, x, (xs, xh), gamma, beta, rm, rv, 0.1, 1e-5,
+                                                           pool=True)
+    assert ext is not None, "shape not routed to the pooled epilogue"
+    pooled, argmax, ymax = K.pool_from_extrema(ext, scale, shift)
+    want_p, want_a, want_y = K.bn_relu_pool(y, scale, shift)
+    assert torch.equal(pooled, want_p)
+    live = want_p > 0
+    assert torch.equal(argmax[live], want_a[live])
+    assert torch.equal(ymax[live], want_y[live])
+    # the named sample always holds the named value
+    picked = torch.gather(y, 3, argmax.long().unsqueeze(3)).squeeze(3)
+    assert torch.equal(picked, ymax)
