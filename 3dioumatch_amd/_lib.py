@@ -78,7 +78,7 @@ _SIGNATURES = {
     "mlp_gemm_wgrad_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
     "mlp_gemm_forward_stats_pool_supported": [_c_int, _c_int, _c_int, _c_int, _c_int],
     "mlp_gemm_forward_stats_pool": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c_int,
-                                    _vp, _vp],
+                                    _vp, _vp, _vp],
     "mlp_bn_pool_from_extrema": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_gemm_backward_fused_supported": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int],
     "mlp_gemm_backward_fused_workspace_floats": [_c_int, _c_int, _c_int, _c_int],

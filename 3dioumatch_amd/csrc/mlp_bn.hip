@@ -333,9 +333,9 @@ bn_relu_pool_generic_kernel(int c, int m, int ns, const float *__restrict__ y,
   pooled[o] = best; argmax[o] = bk; ymax[o] = by;
 }
 
-// pooled = max over nsample of relu(y*sc + sh) from the per-group extrema of the raw y that the
-// forward GEMM left behind: the transform is monotone in y, so the winner is the group's maximum
-// (sc >= 0) or minimum (sc < 0); ext = 4 planes (max, min, argmax, argmin) of (b, c, groups)
+// pooled = max over nsample of relu(y*sc + sh) from the winning raw value per group that the
+// forward GEMM left behind (the transform is monotone in y; the GEMM picked the largest or the
+// smallest by the sign of gamma): ext = 2 planes (value, first index) of (b, c, groups)
 __global__ void __launch_bounds__(256)
 pool_from_extrema_kernel(int c, int groups, long long total, const float *__restrict__ ext,
                          const float *__restrict__ scale, const float *__restrict__ shift,
@@ -344,12 +344,9 @@ pool_from_extrema_kernel(int c, int groups, long long total, const float *__rest
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int ch = (int)((i / groups) % c);
-  const float sc = scale[ch], sh = shift[ch];
-  const int *ei = reinterpret_cast<const int *>(ext);
-  const bool up = sc >= 0.f;
-  const float yw = up ? ext[i] : ext[total + i];
-  pooled[i] = fmaxf(yw * sc + sh, 0.f);
-  argmax[i] = up ? ei[2 * total + i] : ei[3 * total + i];
+  const float yw = ext[i];
+  pooled[i] = fmaxf(yw * scale[ch] + shift[ch], 0.f);
+  argmax[i] = reinterpret_cast<const int *>(ext)[total + i];
   ymax[i] = yw;
 }
 

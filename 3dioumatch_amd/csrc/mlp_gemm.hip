@@ -190,11 +190,12 @@ __device__ __forceinline__ float half_wave_extreme(float v) {
 // STATS: the epilogue also reduces every output row over the tile's columns to a
 //        (mean, M2) pair for the BatchNorm that follows (one per row, cloud and column tile, all
 //        tiles hold TN columns): the statistics pass no longer re-reads y from HBM
-// POOL:  (32 or 64 = nsample) the epilogue also leaves, per output row and group of POOL
-//        consecutive columns, the largest and the smallest raw value and where each first occurs.
-//        relu(y*sc + sh) is monotone in y for a given channel, so the max-pool over nsample that
-//        follows the BatchNorm (whose sc, sh are not known yet) is one of the two -- the pooling
-//        pass no longer re-reads y either.  ext: 4 planes (max, min, argmax, argmin) of
+// POOL:  (16, 32 or 64 = nsample) the epilogue also leaves, per output row and group of POOL
+//        consecutive columns, the raw value that will win the max-pool over nsample and where
+//        it first occurs: relu(y*sc + sh) is monotone in y for a given channel -- increasing
+//        when gamma >= 0, decreasing otherwise (sc = gamma * invstd) -- so the winner is the
+//        group's largest or smallest raw value, known before the statistics are.  The pooling
+//        pass no longer re-reads y either.  ext: 2 planes (value, first index) of
 //        (b, m_total, r / POOL).
 template <int TM, int TN, int WM, int WN, int MODE, bool A_TRANS, bool A_VEC, bool STATS = false,
           int POOL = 0>
@@ -202,7 +203,8 @@ __global__ void __launch_bounds__(256, (MODE <= OP_BNRELU && TM <= 128) ? 4 : 2)
 gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int lda,
                 unsigned a_bytes, OperandB opb, float *__restrict__ c, size_t b_stride_in,
                 size_t b_stride_out, float *__restrict__ stats = nullptr, int stat_channels = 0,
-                float *__restrict__ ext = nullptr, size_t ext_plane = 0) {
+                float *__restrict__ ext = nullptr, size_t ext_plane = 0,
+                const float *__restrict__ pool_gamma = nullptr) {
   constexpr int MB = TM / WM / 32, NB = TN / WN / 32;
   constexpr int LDA = TM + 4;       // [k][m] rows; 16-byte aligned rows, conflict-free fragments
   constexpr int AV = TM * KC / 4 / 256;  // 16-byte A pieces per lane and chunk
@@ -386,55 +388,72 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
     }
   }
   if constexpr (POOL != 0) {
-    static_assert(POOL == 0 || (NB == 2 && MB == 2 && (POOL == 32 || POOL == 64)),
+    static_assert(NB == 2 && MB == 2 && (POOL == 16 || POOL == 32 || POOL == 64),
                   "a wave owns 64 x 64 of the tile");
+    // Which extreme wins is known before the statistics are: sign(scale) = sign(gamma).  Rows
+    // with a negative gamma are parked negated, so one scan for the maximum serves all.
     // Transpose through LDS (the operand buffers are free now; the barrier that ended the K loop
-    // is behind every wave): the wave parks 32 rows x 64 columns of its accumulators, swizzled
-    // [row][col ^ row] so that both the column-wise writes and the row-wise scans are
-    // conflict-free, then lane (row = lane & 31, half = lane >> 5) scans 32 consecutive samples
-    // of its row for the largest / smallest value and their first positions.
+    // is behind every wave): the wave parks 32 rows x 64 columns of its accumulators, 16-byte
+    // chunks swizzled [row][chunk ^ (row & 15)] (conflict-free for the column-wise 4-byte writes
+    // and for the row-wise 16-byte reads), then lane (row = lane & 31, half = lane >> 5) scans
+    // 32 consecutive samples of its row for the largest value and its first position.
     constexpr int AS_FLOATS = 2 * KC * LDA;
+    static_assert(AS_FLOATS >= 2 * 2048 && (AS_FLOATS >= 4 * 2048 || 2 * KC * TN >= 2 * 2048),
+                  "operand buffers too small to park the accumulators");
     float *park = AS_FLOATS >= 4 * 2048 ? &As[0][0] + wave * 2048
                                         : (wave < 2 ? &As[0][0] + wave * 2048 : &Bs[0][0] + (wave - 2) * 2048);
-    static_assert(AS_FLOATS >= 2 * 2048 && 2 * KC * TN + (AS_FLOATS >= 4 * 2048 ? 4096 : 0) >= 4096,
-                  "operand buffers too small to park the accumulators");
     const int half = lane >> 5, l31 = lane & 31;
-    const int groups = r / (POOL ? POOL : 1);
+    const int groups = r / POOL;
+    constexpr int GPL = 32 / (POOL < 32 ? POOL : 32);  // groups per lane: 2 for POOL == 16
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
+      const int rbase = m0 + (wm * MB + i) * 32;
 #pragma unroll
-      for (int j = 0; j < NB; ++j)
+      for (int q = 0; q < 16; ++q) {
+        const int cq = (q & 3) + 8 * (q >> 2);  // row of the block = cq + 4 * half
+        const int rowq = rbase + cq + 4 * half;
+        const bool neg = rowq < m_total && pool_gamma[rowq] < 0.f;
+        const int rsw = (cq & 15) ^ (half << 2);  // (row & 15) for cq + 4*half (bit 2 of cq is clear)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int rl = (q & 3) + 8 * (q >> 2) + 4 * half;
-          park[rl * 64 + ((j * 32 + l31) ^ rl)] = acc[i][j][q];
+        for (int j = 0; j < NB; ++j) {
+          const int col = j * 32 + l31;
+          const float v = acc[i][j][q];
+          park[(cq + 4 * half) * 64 + ((((col >> 2) ^ rsw) << 2) | (col & 3))] = neg ? -v : v;
         }
+      }
       // (same wave wrote and reads: LDS operations of a wave complete in order)
-      float vmax = park[l31 * 64 + ((half * 32) ^ l31)], vmin = vmax;
-      int amax = 0, amin = 0;
+      float best[GPL];
+      int at[GPL];
 #pragma unroll
-      for (int s2 = 1; s2 < 32; ++s2) {
-        const float v = park[l31 * 64 + ((half * 32 + s2) ^ l31)];
-        if (v > vmax) { vmax = v; amax = s2; }
-        if (v < vmin) { vmin = v; amin = s2; }
+      for (int gq = 0; gq < GPL; ++gq) { best[gq] = -__builtin_inff(); at[gq] = 0; }
+      const float4 *prow = reinterpret_cast<const float4 *>(park + l31 * 64);
+#pragma unroll
+      for (int c4 = 0; c4 < 8; ++c4) {
+        const float4 v4 = prow[(half * 8 + c4) ^ (l31 & 15)];
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int s2 = c4 * 4 + e;             // sample within the lane's 32
+          const int gq = GPL == 2 ? s2 / 16 : 0;  // its group within the lane
+          if (vv[e] > best[gq]) { best[gq] = vv[e]; at[gq] = GPL == 2 ? s2 % 16 : s2; }
+        }
       }
       if (POOL == 64) {  // the two halves of a row form one group: the lower half wins ties
-        const float omax = __shfl_xor(vmax, 32, kWave), omin = __shfl_xor(vmin, 32, kWave);
-        const int oamax = __shfl_xor(amax, 32, kWave), oamin = __shfl_xor(amin, 32, kWave);
-        if (half == 0) {
-          if (omax > vmax) { vmax = omax; amax = 32 + oamax; }
-          if (omin < vmin) { vmin = omin; amin = 32 + oamin; }
-        }
+        const float ob = __shfl_xor(best[0], 32, kWave);
+        const int oa = __shfl_xor(at[0], 32, kWave);
+        if (half == 0 && ob > best[0]) { best[0] = ob; at[0] = 32 + oa; }
       }
-      const int row = m0 + (wm * MB + i) * 32 + l31;
-      if (row < m_total && (POOL == 32 || half == 0)) {
-        const int grp = (r0 + wn * 64) / (POOL ? POOL : 1) + (POOL == 32 ? half : 0);
-        const size_t o = ((size_t)b * m_total + row) * groups + grp;
+      const int row = rbase + l31;
+      if (row < m_total && (POOL != 64 || half == 0)) {
+        const bool negr = pool_gamma[row] < 0.f;
+        const int g0 = (r0 + wn * 64) / POOL + (POOL == 64 ? 0 : half * GPL);
         int *ei = reinterpret_cast<int *>(ext);
-        ext[o] = vmax;
-        ext[ext_plane + o] = vmin;
-        ei[2 * ext_plane + o] = amax;
-        ei[3 * ext_plane + o] = amin;
+#pragma unroll
+        for (int gq = 0; gq < GPL; ++gq) {
+          const size_t o = ((size_t)b * m_total + row) * groups + g0 + gq;
+          ext[o] = negr ? -best[gq] : best[gq];
+          ei[ext_plane + o] = at[gq];
+        }
       }
     }
   }
@@ -864,16 +883,18 @@ MLP_API int mlp_gemm_forward_stats_pool_supported(int b, int m, int k, int r, in
   const char *env = getenv("MLP_GEMM_EPILOGUE_POOL");
   if (env && atoi(env) == 0) return 0;
   if (mlp_gemm_forward_stats_parts(b, m, k, r, nullptr) == 0) return 0;
-  return (m == 128 || m == 256) && (ns == 32 || ns == 64) && r % ns == 0 && k % 4 == 0;
+  return (m == 128 || m == 256) && (ns == 16 || ns == 32 || ns == 64) && r % ns == 0 && k % 4 == 0;
 }
 
 // mlp_gemm_forward_stats (mode 1: x = raw output of the previous layer) that also leaves, per
-// channel and group of ns columns, max / min / argmax / argmin of the raw output:
-// ext = 4 planes of b*m*(r/ns) 4-byte values
+// channel and group of ns columns, the raw output that wins the max-pool after BatchNorm (gamma:
+// the layer's BatchNorm weight, whose sign decides between largest and smallest) and its first
+// index: ext = 2 planes of b*m*(r/ns) 4-byte values
 MLP_API int mlp_gemm_forward_stats_pool(int b, int m, int k, int r, const float *w, const float *x,
                                         const float *scale, const float *shift, float *y,
-                                        float *pairs, int ns, float *ext, void *stream_) {
-  if (!mlp_gemm_forward_stats_pool_supported(b, m, k, r, ns) || !pairs || !ext ||
+                                        float *pairs, int ns, const float *gamma, float *ext,
+                                        void *stream_) {
+  if (!mlp_gemm_forward_stats_pool_supported(b, m, k, r, ns) || !pairs || !ext || !gamma ||
       (reinterpret_cast<size_t>(w) & 15) != 0)
     return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
@@ -884,9 +905,11 @@ MLP_API int mlp_gemm_forward_stats_pool(int b, int m, int k, int r, const float 
 #define POOLED(TM, TN, WM, WN, NS)                                                                 \
   hipLaunchKernelGGL((gemm_nn2_kernel<TM, TN, WM, WN, OP_BNRELU, false, true, true, NS>),          \
                      dim3(r / TN, 1, b), dim3(256), 0, stream, m, k, r, w, k, a_bytes, op, y,     \
-                     in_stride, out_stride, pairs, m, ext, plane)
-  if (m == 256 && ns == 32) POOLED(256, 64, 4, 1, 32);
+                     in_stride, out_stride, pairs, m, ext, plane, gamma)
+  if (m == 256 && ns == 16) POOLED(256, 64, 4, 1, 16);
+  else if (m == 256 && ns == 32) POOLED(256, 64, 4, 1, 32);
   else if (m == 256) POOLED(256, 64, 4, 1, 64);
+  else if (ns == 16) POOLED(128, 128, 2, 2, 16);
   else if (ns == 32) POOLED(128, 128, 2, 2, 32);
   else POOLED(128, 128, 2, 2, 64);
 #undef POOLED

@@ -165,7 +165,7 @@ def gemm_forward_bn(w, x, coeff, gamma, beta, running_mean, running_var, momentu
     ns = x.shape[3] if (pool and x.dim() == 4) else 0
     pooled = bool(ns) and coeff is not None and w.data_ptr() % 16 == 0 and \
         bool(_lib.mlp_gemm_forward_stats_pool_supported(b, m, k, r, ns))
-    ext = torch.empty((4, b, m, r // ns), dtype=torch.float32, device=x.device) if pooled else None
+    ext = torch.empty((2, b, m, r // ns), dtype=torch.float32, device=x.device) if pooled else None
     y = torch.empty((b, m) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
     pairs = torch.empty((parts, m, 2), dtype=torch.float32, device=x.device)
     out = torch.empty((4, m), dtype=torch.float32, device=x.device)
@@ -177,7 +177,7 @@ def gemm_forward_bn(w, x, coeff, gamma, beta, running_mean, running_var, momentu
             _L.check(_lib.mlp_gemm_forward_stats_pool(b, m, k, r, w.data_ptr(), x.data_ptr(),
                                                       scale.data_ptr(), shift.data_ptr(),
                                                       y.data_ptr(), pairs.data_ptr(), ns,
-                                                      ext.data_ptr(), _stream(x)),
+                                                      gamma.data_ptr(), ext.data_ptr(), _stream(x)),
                      "mlp_gemm_forward_stats_pool")
         else:
             _L.check(_lib.mlp_gemm_forward_stats(b, m, k, r, w.data_ptr(), x.data_ptr(),
@@ -199,7 +199,7 @@ def gemm_forward_bn(w, x, coeff, gamma, beta, running_mean, running_var, momentu
 
 def pool_from_extrema(ext, scale, shift):
     """(pooled, argmax, ymax) as bn_relu_pool(y, scale, shift) would return them, from the extrema
-    planes (4,B,C,m) that gemm_forward_bn(pool=True) left behind: no pass over y."""
+    planes (2,B,C,m) that gemm_forward_bn(pool=True) left behind: no pass over y."""
     _, b, c, m = ext.shape
     pooled = torch.empty((b, c, m), dtype=torch.float32, device=ext.device)
     ymax = torch.empty_like(pooled)

@@ -159,17 +159,19 @@ int mlp_gemm_wgrad_pooled(int b, int m, int k, int groups, int ns, const float *
 /* ---- max over nsample without a second pass over the last layer's output ---------------------
  * relu(y*scale + shift) is monotone in y per channel, so the max-pool over nsample that follows
  * the last layer of an SA module (pointnet2_modules.py:256-262: F.max_pool2d over the nsample
- * axis) is the transform of the group's largest (scale >= 0) or smallest raw value; the forward
- * GEMM can leave both behind before scale / shift exist. */
-/* 1 when mlp_gemm_forward_stats_pool covers the layer: m 128 or 256, ns 32 or 64, k % 4 == 0 and
- * the epilogue statistics available (dispatch helper for pointnet2_modules.py:256-262) */
+ * axis) is the transform of the group's largest (scale >= 0) or smallest raw value, and
+ * sign(scale) = sign(gamma) is known before the batch statistics are: the forward GEMM can leave
+ * the winner behind. */
+/* 1 when mlp_gemm_forward_stats_pool covers the layer: m 128 or 256, ns 16 / 32 / 64, k % 4 == 0
+ * and the epilogue statistics available (dispatch helper for pointnet2_modules.py:256-262) */
 int mlp_gemm_forward_stats_pool_supported(int b, int m, int k, int r, int ns);
-/* mlp_gemm_forward_stats (mode 1) that also writes ext: 4 planes of (b, m, r/ns) -- max, min
- * (float), argmax, argmin (int, first occurrence) of the raw output per channel and group of ns
- * columns (replaces the read of y in the max-pool of pointnet2_modules.py:256-262) */
+/* mlp_gemm_forward_stats (mode 1) that also writes ext: 2 planes of (b, m, r/ns) -- the raw output
+ * that wins the pool per channel and group of ns columns (the largest where gamma >= 0, the
+ * smallest where gamma < 0: gamma = the weight of the BatchNorm that follows) and its first
+ * index (replaces the read of y in the max-pool of pointnet2_modules.py:256-262) */
 int mlp_gemm_forward_stats_pool(int b, int m, int k, int r, const float *w, const float *x,
                                 const float *scale, const float *shift, float *y, float *pairs,
-                                int ns, float *ext, void *stream);
+                                int ns, const float *gamma, float *ext, void *stream);
 /* pooled, argmax, ymax (b,c,groups) as mlp_bn_relu_pool returns them, from ext
  * (replaces F.max_pool2d of pointnet2_modules.py:256-262 after BatchNorm + ReLU) */
 int mlp_bn_pool_from_extrema(int b, int c, int groups, const float *ext, const float *scale,

@@ -417,9 +417,10 @@ def test_unit_length_features_vs_torch(shape):
 
 
 @pytest.mark.parametrize("b,m,k,groups,ns", [(5, 128, 64, 64, 64), (2, 256, 128, 512, 32), (1, 128, 128, 512, 64),
-                                             (3, 256, 128, 128, 64), (5, 128, 128, 128, 32)])
+                                             (3, 256, 128, 128, 64), (5, 128, 128, 128, 32), (2, 256, 128, 1024, 16),
+                                             (3, 128, 128, 512, 16)])
 def test_pool_from_gemm_epilogue_extrema(b, m, k, groups, ns):
-    """max over nsample of relu(bn(y)) from the per-group max / min of the raw GEMM output
+    """max over nsample of relu(bn(y)) from the per-group winner of the raw GEMM output
     (mlp_gemm_forward_stats_pool + mlp_bn_pool_from_extrema) == bn_relu_pool on y: pooled values
     and winning pre-activations identical, arg-max identical wherever the winner is not rectified
     to zero (there the gradient is zero whichever sample is named); channels with a negative

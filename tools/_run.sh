@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2g
-timeout 900 python -m pytest tests/test_gpu_mlp.py tests/test_train_step.py tests/test_layers.py -q -m gpu -x -k "pool or fused_chain or train or layers" > gpurun_out/r2g/t1.log 2>&1; tail -n 3 gpurun_out/r2g/t1.log
-timeout 600 python bench.py 2>&1 | tail -n 1 | cut -c1-260
-MLP_GEMM_EPILOGUE_POOL=0 timeout 600 python bench.py --no-cpu-baseline 2>&1 | tail -n 1 | cut -c1-260
+mkdir -p gpurun_out/r2h
+export TMPDIR=/tmp
+rm -rf gpurun_out/r2h/prof
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2h/prof -o step -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r2h/bench_prof.log 2>&1
