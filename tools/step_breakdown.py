@@ -1,7 +1,7 @@
 """Per-step kernel breakdown from a rocprofv3 --kernel-trace csv of bench.py: the timed steps are
 delimited by the once-per-step loss_finalize kernel; prints time per kernel per step, busiest first.
 
-    python tools/step_breakdown.py <kernel_trace.csv> [steps=20] [top=40]
+    python tools/step_breakdown.py <kernel_trace.csv> [steps=20] [top=40] [out.csv]
 """
 import collections
 import csv
@@ -11,6 +11,7 @@ import sys
 path = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+out_csv = sys.argv[4] if len(sys.argv) > 4 else None
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 
@@ -36,3 +37,12 @@ print("span %.3f ms/step, kernel time summed over streams %.3f ms/step, %.0f ker
       % (span, busy, (hi - lo) / steps))
 for n, t in tot.most_common(top):
     print("%8.1f us %5.1f%% x%6.1f  %s" % (t / steps / 1e3, 100 * t / sum(tot.values()), cnt[n] / steps, n[:120]))
+
+if out_csv:
+    with open(out_csv, "w") as f:
+        f.write("kernel,launches_per_step,us_per_step,percent_of_kernel_time\n")
+        f.write('"(all kernels, both streams; profiler serialises them)",%.1f,%.1f,100.0\n'
+                % ((hi - lo) / steps, busy * 1e3))
+        for n, t in tot.most_common():
+            f.write('"%s",%.1f,%.1f,%.2f\n' % (n.replace('"', "'"), cnt[n] / steps, t / steps / 1e3,
+                                              100 * t / sum(tot.values())))
