@@ -119,20 +119,22 @@ lhs_nms_kernel(int n, const float *__restrict__ center, const double *__restrict
   if (live) picked[base + s_orig[lane]] = (int)((pick >> lane) & 1ull);
 }
 
-// The same greedy loop for 64 < n <= 256 (evaluation: every proposal of a scene takes part,
-// models/ap_helper.py:101-215): one 256-lane workgroup per scene, lane = box in ascending score
-// order, the alive / suppressed sets are four ballot words in LDS.
-__global__ void __launch_bounds__(256)
+// The same greedy loop for 64 < n <= T (evaluation: every proposal of a scene takes part,
+// models/ap_helper.py:101-215): one T-lane workgroup per scene (T = 256, or 1024 for scenes with
+// up to 1024 proposals), lane = box in ascending score order, the alive / suppressed sets are
+// T/64 ballot words in LDS.
+template <int T>
+__global__ void __launch_bounds__(T)
 nms_aabb_block_kernel(int n, const float *__restrict__ center, const double *__restrict__ size,
                       const double *__restrict__ heading, const float *__restrict__ score,
                       const long long *__restrict__ cls, double thresh, int old_type,
                       int same_class, int readmit, double area_eps, int *__restrict__ picked) {
-  __shared__ float s_score[256];
-  __shared__ Aabb s_box[256];
-  __shared__ double s_area[256];
-  __shared__ long long s_cls[256];
-  __shared__ int s_orig[256];
-  __shared__ unsigned long long s_alive[4], s_sup[4];
+  __shared__ float s_score[T];
+  __shared__ Aabb s_box[T];
+  __shared__ double s_area[T];
+  __shared__ long long s_cls[T];
+  __shared__ int s_orig[T];
+  __shared__ unsigned long long s_alive[T / 64], s_sup[T / 64];
   const int scene = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const size_t base = (size_t)scene * n;
   const bool live = tid < n;
@@ -169,7 +171,7 @@ nms_aabb_block_kernel(int n, const float *__restrict__ center, const double *__r
     __syncthreads();
     int i = -1;
 #pragma unroll
-    for (int q = 3; q >= 0; --q)
+    for (int q = T / 64 - 1; q >= 0; --q)
       if (i < 0 && s_alive[q]) i = q * 64 + 63 - __builtin_clzll(s_alive[q]);
     if (i < 0) break;  // uniform: every lane read the same words
     const Aabb bi = s_box[i];
@@ -201,7 +203,7 @@ nms_aabb_block_kernel(int n, const float *__restrict__ center, const double *__r
       if (readmit) {
         int total = 0, above = lane >= 63 ? 0 : __popcll(s_sup[w] >> (lane + 1));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < T / 64; ++q) {
           total += __popcll(s_sup[q]);
           if (q > w) above += __popcll(s_sup[q]);
         }
@@ -221,20 +223,24 @@ static int nms_aabb_launch(int scenes, int n, const float *center, const double 
                            double thresh, int old_type, int same_class, int readmit,
                            double area_eps, int *picked, hipStream_t stream) {
   if (scenes <= 0 || n <= 0) return 0;
-  if (n > 256) return (int)hipErrorInvalidValue;
+  if (n > 1024) return (int)hipErrorInvalidValue;
   if (n <= 64)
     hipLaunchKernelGGL(lhs_nms_kernel, dim3(scenes), dim3(64), 0, stream, n, center, size, heading,
                        score, cls, thresh, old_type, same_class, readmit, area_eps, picked);
+  else if (n <= 256)
+    hipLaunchKernelGGL(nms_aabb_block_kernel<256>, dim3(scenes), dim3(256), 0, stream, n, center,
+                       size, heading, score, cls, thresh, old_type, same_class, readmit, area_eps,
+                       picked);
   else
-    hipLaunchKernelGGL(nms_aabb_block_kernel, dim3(scenes), dim3(256), 0, stream, n, center, size,
-                       heading, score, cls, thresh, old_type, same_class, readmit, area_eps,
+    hipLaunchKernelGGL(nms_aabb_block_kernel<1024>, dim3(scenes), dim3(1024), 0, stream, n, center,
+                       size, heading, score, cls, thresh, old_type, same_class, readmit, area_eps,
                        picked);
   return pn2_launch_status();
 }
 
 // picked (scenes, n) int32 <- 1 for every box the reference's greedy axis-aligned 3-D NMS returns:
 // nms_3d_faster (same_class = 0) / nms_3d_faster_samecls (same_class = 1), utils/nms.py:77-166,
-// n <= 256 (the evaluation path, models/ap_helper.py:170-203)
+// n <= 1024 (the evaluation path, models/ap_helper.py:170-203)
 extern "C" __attribute__((visibility("default")))
 int lhs_nms3d_aabb(int scenes, int n, const float *center, const double *size,
                    const double *heading, const float *score, const long long *cls, double thresh,

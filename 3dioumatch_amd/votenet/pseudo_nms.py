@@ -38,15 +38,16 @@ def lhs_nms_samecls_gpu(center, size, heading, score, cls, thresh, old_type=Fals
 
 def nms3d_aabb_gpu(center, size, heading, score, cls, thresh, old_type=False, same_class=True):
     """The evaluation path's per-scene NMS (utils/nms.py nms_3d_faster / nms_3d_faster_samecls on
-    the camera-frame bounds of every proposal) -> picked (S,n) bool, n <= 256."""
+    the camera-frame bounds of every proposal) -> picked (S,n) bool, n <= 1024 (one workgroup per scene: 256 lanes up to 256 boxes,
+    1024 lanes beyond)."""
     for t, dt, name in ((center, torch.float32, "center"), (size, torch.float64, "size"),
                         (heading, torch.float64, "heading"), (score, torch.float32, "score"),
                         (cls, torch.int64, "cls")):
         if not t.is_cuda or t.dtype != dt:
             raise RuntimeError("%s must be a %s GPU tensor" % (name, dt))
     s, n = score.shape
-    if n > 256:
-        raise RuntimeError("nms3d_aabb: at most 256 boxes per scene")
+    if n > 1024:
+        raise RuntimeError("nms3d_aabb: at most 1024 boxes per scene")
     picked = torch.zeros((s, n), dtype=torch.int32, device=score.device)
     center, size, heading, score, cls = (t.contiguous() for t in (center, size, heading, score, cls))
     with torch.cuda.device(score.device):

@@ -18,7 +18,7 @@ int lhs_nms_samecls(int scenes, int n, const float *center, const double *size,
 /* replaces the per-scene numpy NMS of the evaluation path (models/ap_helper.py:170-203):
  * nms_3d_faster (same_class = 0, utils/nms.py:77-116) / nms_3d_faster_samecls (same_class = 1,
  * utils/nms.py:118-166) on the axis-aligned camera-frame bounds of get_3d_box
- * (utils/box_util.py:335-358).  Arguments as lhs_nms_samecls; n <= 256; picked (scenes,n) i32. */
+ * (utils/box_util.py:335-358).  Arguments as lhs_nms_samecls; n <= 1024; picked (scenes,n) i32. */
 int lhs_nms3d_aabb(int scenes, int n, const float *center, const double *size,
                    const double *heading, const float *score, const long long *cls, double thresh,
                    int old_type, int same_class, int *picked, void *stream);

@@ -784,8 +784,17 @@ def test_eval_nms_vs_reference_golden(oracle):
                                     torch.from_numpy(get("cls")[None]).cuda(), float(get("thresh")),
                                     bool(get("old")), bool(get("same")))
         np.testing.assert_array_equal(picked[0].cpu().numpy().astype(np.int32), get("pick"))
-    rng = np.random.default_rng(6)
-    s, n = 5, 256
+    for s, n in ((5, 256), (2, 257), (3, 700), (1, 1024)):
+        _check_aabb_nms_random(nms, oracle, s, n)
+    with pytest.raises(RuntimeError):
+        nms.nms3d_aabb_gpu(torch.zeros(1, 1025, 3, device=DEV), torch.ones(1, 1025, 3, device=DEV).double(),
+                           torch.zeros(1, 1025, device=DEV).double(), torch.zeros(1, 1025, device=DEV),
+                           torch.zeros(1, 1025, device=DEV).long(), 0.25)
+
+
+def _check_aabb_nms_random(nms, oracle, s, n):
+    t64 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64)).to(DEV)  # noqa: E731
+    rng = np.random.default_rng(6 + n)
     clump = rng.uniform(-2, 2, (s, 6, 3))
     center = (clump[np.arange(s)[:, None], rng.integers(0, 6, (s, n))] +
               rng.normal(0, 0.2, (s, n, 3))).astype(np.float32)
