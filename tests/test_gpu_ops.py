@@ -371,6 +371,27 @@ def test_three_nn_vs_oracle(ext, oracle, synth, b, n, m):
     assert np.array_equal(bits(d2.cpu().numpy()), bits(wd))
 
 
+@pytest.mark.parametrize("b,blocks,m,spread", [(2, 64, 1024, 0.4), (1, 33, 2048, 0.05), (3, 20, 256, 1.5),
+                                                (1, 16, 700, 0.0)])
+def test_three_nn_pruned_blocks_vs_oracle(ext, oracle, synth, b, blocks, m, spread):
+    """Queries that arrive in spatially coherent blocks of 128 (the grid points of a proposal box):
+    the kernel prunes the known set per block by a triangle-inequality bound -- results must stay
+    bit-identical to the full scan (indices incl. the first-wins tie rule, squared distances);
+    duplicate known points, a block of identical queries (spread 0), a ragged last block."""
+    rng = np.random.default_rng(blocks * 7 + m)
+    kn = synth.cloud_uniform(b, m, 3.0, seed=m + 2)
+    kn[:, m // 2] = kn[:, 0]
+    kn[:, m // 3] = kn[:, 1]
+    centres = rng.uniform(0.0, 3.0, (b, blocks, 1, 3))
+    unk = (centres + rng.uniform(-spread, spread, (b, blocks, 128, 3))).reshape(b, blocks * 128, 3)
+    unk = unk[:, :blocks * 128 - 37].astype(np.float32).copy()
+    unk[:, 5] = kn[:, 0]  # a query sitting exactly on a duplicated known point
+    wd, wi = oracle.three_nn(unk, kn)
+    d2, idx = ext.three_nn(dev(unk), dev(kn))
+    assert np.array_equal(idx.cpu().numpy(), wi)
+    assert np.array_equal(bits(d2.cpu().numpy()), bits(wd))
+
+
 def test_gridconv_three_nn_properties(ext, synth):
     """GridConv size (B=8, 32768 x 1024): distances sorted, indices valid, and exact against a
     torch fp32 top-3 on sampled queries."""
