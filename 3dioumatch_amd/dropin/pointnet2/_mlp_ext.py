@@ -4,6 +4,8 @@
 No reference counterpart: the reference runs nn.BatchNorm2d / nn.ReLU / F.max_pool2d here
 (pointnet2/pytorch_utils.py:14-124, pointnet2/pointnet2_modules.py:256-262).
 """
+import os
+
 import torch
 
 from pointnet2._ext import _L, _lib, _stream
@@ -348,3 +350,26 @@ def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None, n
                      "mlp_bn_backward_finalize")
             below = (small[0], small[1], small[2:])
     return dx, dw, below
+
+
+def wgrad_first4(w, x, fly):
+    """dw (64,4) of a first layer y = w x with a 4-channel input x (B,4,...) behind BatchNorm +
+    ReLU, from fly = (y, dz, scale, shift, mean, invstd, coef) as gemm_wgrad takes it -- y is
+    ignored: the ReLU gate is recomputed from x and everything else follows from the second
+    moments of x.  None when the shape is not (64, 4) or the columns are not a multiple of 4."""
+    m, k = w.shape
+    b = x.shape[0]
+    r = x.numel() // (b * x.shape[1])
+    if (m, k) != (64, 4) or x.shape[1] != 4 or r % 4 != 0 or os.environ.get("MLP_WGRAD_FIRST4", "1") == "0":
+        return None
+    _f32c(w, "w"); _f32c(x, "x")
+    _, dz, scale, shift, mean, invstd, coef = fly
+    _f32c(dz, "dz")
+    dw = torch.empty((m, k), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        ws = torch.empty(int(_lib.mlp_wgrad_first4_workspace_bytes(b, r)), dtype=torch.uint8, device=x.device)
+        _L.check(_lib.mlp_wgrad_first4(b, r, w.data_ptr(), x.data_ptr(), dz.data_ptr(), scale.data_ptr(),
+                                       shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                       coef.data_ptr(), dw.data_ptr(), ws.data_ptr(), _stream(x)),
+                 "mlp_wgrad_first4")
+    return dw

@@ -236,7 +236,10 @@ class _FusedMLPChain(Function):
                 else:
                     dz = both[0]
             elif i == 0:
-                grads[0 + 5 * i] = K.gemm_wgrad(m, k, x, None, dy_tensor, fly, pooled).view_as(w)
+                dw0 = K.wgrad_first4(w2, x, fly) if (fly is not None and not need_dx) else None
+                if dw0 is None:
+                    dw0 = K.gemm_wgrad(m, k, x, None, dy_tensor, fly, pooled)
+                grads[0 + 5 * i] = dw0.view_as(w)
                 dx = K.gemm_dgrad(w2, dy_tensor, fly, pooled).view_as(x) if need_dx else None
             else:
                 grads[5 * i] = K.gemm_wgrad(m, k, src, src_coeff, dy_tensor, fly, pooled).view_as(w)

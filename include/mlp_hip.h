@@ -220,6 +220,20 @@ int mlp_bn_backward_finalize(int c, int parts, double count, int training, const
                              const float *gamma, const float *invstd, float *dgamma, float *dbeta,
                              float *coef, void *stream);
 
+/* ---- weight gradient of a 4 -> 64 first layer without its output ------------------------------
+ * SA1's first layer (mlp [1+3, 64, ...], pointnet2_modules.py:230-262 / pytorch_utils.py:70-124):
+ * y = w x is a rank-4 function of x, so only the ReLU-gated part of the BatchNorm backward needs
+ * the big gradient tensor; the rest follows from the 4x4 second moments of x. */
+/* bytes of the workspace of mlp_wgrad_first4 (sizing helper for the backward-weight of
+ * pytorch_utils.py:70-124) */
+size_t mlp_wgrad_first4_workspace_bytes(int b, int r);
+/* dw (64,4) from x (b,4,r), dz (b,64,r) = gradient w.r.t. relu(bn(y)), and the layer's scale,
+ * shift, mean, invstd, coef (64,3) as mlp_bn_relu_backward_stats leaves them; y is not read
+ * (replaces conv2d backward-weight behind BatchNorm2d + ReLU, pytorch_utils.py:70-124) */
+int mlp_wgrad_first4(int b, int r, const float *w, const float *x, const float *dz,
+                     const float *scale, const float *shift, const float *mean, const float *invstd,
+                     const float *coef, float *dw, void *workspace, void *stream);
+
 /* scratch (floats) for mlp_gemm_wgrad: per-slice partial dW tiles (replaces cuDNN's
  * workspace of conv2d backward-weight, pytorch_utils.py:70-124) */
 size_t mlp_gemm_wgrad_workspace_floats(int b, int m, int k, int r);

@@ -451,3 +451,28 @@ def test_pool_from_gemm_epilogue_extrema(b, m, k, groups, ns):
     # the named sample always holds the named value
     picked = torch.gather(y, 3, argmax.long().unsqueeze(3)).squeeze(3)
     assert torch.equal(picked, ymax)
+
+
+@pytest.mark.parametrize("b,groups,ns,training", [(8, 256, 64, True), (2, 33, 4, True), (3, 100, 8, False)])
+def test_first_layer_weight_gradient_from_moments(b, groups, ns, training):
+    """mlp_wgrad_first4 (4 -> 64 first layer: gated sums over dz and x, the rest from the second
+    moments of x; the layer's output is never read) == the general on-the-fly wgrad over (y, dz)."""
+    load_pkg()
+    K = importlib.import_module("pointnet2._mlp_ext")
+    g = torch.Generator().manual_seed(groups + ns)
+    w = (torch.randn(64, 4, generator=g) * 0.5).to(DEV)
+    x = (torch.randn(b, 4, groups, ns, generator=g) * 2 + 0.7).to(DEV)
+    gamma = (torch.rand(64, generator=g) + 0.5)
+    gamma[::5] *= -1
+    gamma = gamma.to(DEV)
+    beta = (torch.randn(64, generator=g) * 0.3).to(DEV)
+    rm, rv = (torch.randn(64, generator=g) * 0.1).to(DEV), (torch.rand(64, generator=g) + 0.5).to(DEV)
+    y = K.gemm_forward(w, x, None)
+    mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, 0.1, 1e-5, training)
+    dz = torch.randn(b, 64, groups, ns, generator=g).to(DEV)
+    _, _, coef = K.bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, training)
+    fly = (y, dz, scale, shift, mean, invstd, coef)
+    got = K.wgrad_first4(w, x, fly)
+    assert got is not None
+    want = K.gemm_wgrad(64, 4, x, None, fly=fly)
+    close(got, want, 3e-5)
