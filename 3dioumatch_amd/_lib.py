@@ -81,12 +81,17 @@ _SIGNATURES = {
                                     _vp, _vp, _vp],
     "mlp_bn_pool_from_extrema": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_wgrad_first4_workspace_bytes": [_c_int, _c_int],
-    "mlp_wgrad_first4": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mlp_wgrad_first4": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mlp_first4_moments_doubles": [],
+    "mlp_first4_moments": [_c_int, _c_int, _vp, _vp, _vp],
+    "mlp_first4_bn": [_vp, ctypes.c_double, _vp, _vp, _vp, _c_float, _c_float, _vp, _vp, _vp, _vp, _vp, _vp,
+                      _vp],
+    "mlp_gemm_forward_stats_lin4": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_gemm_backward_fused_supported": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int],
     "mlp_gemm_backward_fused_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
-    "mlp_gemm_backward_fused": [_c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _c_int, _vp,
-                                _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                _vp],
+    "mlp_gemm_backward_fused": [_c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _c_int,
+                                _vp, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _vp, _vp],
     "mlp_gemm_backward_fused_stats_parts": [_c_int, _c_int, _c_int, _c_int],
     "mlp_bn_backward_finalize": [_c_int, _c_int, ctypes.c_double, _c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _vp],

@@ -65,7 +65,12 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
   // BatchNorm-backward sums of the layer BELOW (the one that produced Q) from the dQ blocks:
   // s1 = sum g, s2 = sum g * xhat, g = dQ * [y*sc + sh > 0], xhat = (y - mu) * is
   static_assert(DGRAD || !STATS, "the sums come from the dQ blocks");
-  static_assert(!STATS || QMODE == OP_BNRELU, "the sums are those of a BatchNorm+ReLU layer below");
+  static_assert(!STATS || QMODE == OP_BNRELU || QMODE == OP_LIN4,
+                "the sums are those of a BatchNorm+ReLU layer below");
+  // QLIN: the layer below is a 4 -> K first layer whose output is never stored; its rows are
+  // recomputed from the 4-channel input x4 (b,4,r) (raw: STATS is on, the tile holds raw rows)
+  constexpr bool QLIN = QMODE == OP_LIN4;
+  static_assert(!QLIN || (STATS && KB * 32 == 64), "recomputed rows: the 64-channel layer only");
   constexpr bool RAWQ = STATS;  // the Q tile then holds raw rows, rectified as fragments are read
   constexpr int SROWS = STATS ? 32 * KBD : 1;
   __shared__ float4 Rc[SROWS];       // per Q row: sc, sh, mu, is
@@ -94,8 +99,15 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
   for (int q = 0; q < QP; ++q) {
     const int row = seg_row + q * RPP;
     q_ok[q] = row < k_total;
-    qc[q] = load_row_coef<QMODE>(Q, q_ok[q] ? row : k_total - 1, true);
-    q_lane[q] = (size_t)(q_ok[q] ? row : k_total - 1) * r + seg_c;
+    qc[q] = load_row_coef<QLIN ? OP_BNRELU : QMODE>(Q, q_ok[q] ? row : k_total - 1, true);
+    q_lane[q] = QLIN ? (size_t)seg_c : (size_t)(q_ok[q] ? row : k_total - 1) * r + seg_c;
+  }
+  float4 qw[QP];  // QLIN: the first layer's weight row of each Q row this lane stages
+#pragma unroll
+  for (int q = 0; q < QP; ++q) {
+    const int row = seg_row + q * RPP;
+    qw[q] = QLIN && row < k_total ? *reinterpret_cast<const float4 *>(Q.lin_w + (size_t)row * 4)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (STATS) {
     for (int t = tid; t < SROWS; t += 256)
@@ -140,7 +152,7 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
   const int c_hi = c_lo + per < total_chunks ? c_lo + per : total_chunks;
 
   // raw operands of one chunk, in registers
-  float4 px[PP][4], pd[PP][4], qx[QP][4];
+  float4 px[PP][4], pd[PP][4], qx[QP][4][QLIN ? 4 : 1];
   int pwin[PP];
   float pdp[PP];
 #pragma unroll
@@ -152,7 +164,9 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
 #pragma unroll
   for (int q = 0; q < QP; ++q)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) qx[q][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int cc = 0; cc < (QLIN ? 4 : 1); ++cc) qx[q][i][cc] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // where chunk c lives (uniform values)
   struct ChunkAt { size_t p, q, grp; int s0; };
@@ -161,7 +175,7 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
     const int col0 = (c - b * chunks_per_cloud) * TN;
     ChunkAt at;
     at.p = (size_t)b * M * r + col0;
-    at.q = (size_t)b * k_total * r + col0;
+    at.q = (size_t)b * (QLIN ? 4 : k_total) * r + col0;
     at.grp = 0; at.s0 = 0;
     if (PMODE == OP_POOLDY) {
       const int g0 = col0 / P.ns;
@@ -184,7 +198,13 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
       }
     } else {
       const int q = (sl - 4 * PP) >> 2, i = (sl - 4 * PP) & 3;
-      qx[q][i] = *reinterpret_cast<const float4 *>(Q.x + at.q + q_lane[q] + 4 * i);
+      if constexpr (QLIN) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          qx[q][i][cc] = *reinterpret_cast<const float4 *>(Q.x + at.q + (size_t)cc * r + q_lane[q] + 4 * i);
+      } else {
+        qx[q][i][0] = *reinterpret_cast<const float4 *>(Q.x + at.q + q_lane[q] + 4 * i);
+      }
     }
   };
   // slice `sl` of the chunk held in the registers: transform -> LDS buffer `buf`
@@ -204,11 +224,21 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
       const int row = seg_row + q * RPP;
       if (q * RPP >= KP) return;                   // (static) pass beyond the padded tile
       if (KP % RPP != 0 && row >= KP) return;      // last, partial pass
-      const float xv[4] = {qx[q][i].x, qx[q][i].y, qx[q][i].z, qx[q][i].w};
+      float xv[4];
+      if constexpr (QLIN) {  // the first layer's raw output, recomputed
+        const float c0[4] = {qx[q][i][0].x, qx[q][i][0].y, qx[q][i][0].z, qx[q][i][0].w};
+        const float c1[4] = {qx[q][i][1].x, qx[q][i][1].y, qx[q][i][1].z, qx[q][i][1].w};
+        const float c2[4] = {qx[q][i][2].x, qx[q][i][2].y, qx[q][i][2].z, qx[q][i][2].w};
+        const float c3[4] = {qx[q][i][3].x, qx[q][i][3].y, qx[q][i][3].z, qx[q][i][3].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[e] = lin4(qw[q], c0[e], c1[e], c2[e], c3[e]);
+      } else {
+        xv[0] = qx[q][i][0].x; xv[1] = qx[q][i][0].y; xv[2] = qx[q][i][0].z; xv[3] = qx[q][i][0].w;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         Qs[buf][(seg_c + 4 * i + e) * LDQ + row] =
-            q_ok[q] ? (RAWQ ? xv[e] : transform<QMODE>(xv[e], 0.f, qc[q])) : 0.f;
+            q_ok[q] ? (RAWQ ? xv[e] : transform<QLIN ? OP_BNRELU : QMODE>(xv[e], 0.f, qc[q])) : 0.f;
     }
   };
 
@@ -480,6 +510,7 @@ MLP_API int mlp_gemm_backward_fused_supported(int b, int m, int k, int r, int pm
   if (pmode == OP_POOLDY && (ns <= 0 || ns % 16 != 0 || r % ns != 0 || (ns % s.tn != 0 && s.tn % ns != 0)))
     return 0;
   // instantiated operand combinations (the layers of the network)
+  if (qmode == OP_LIN4) return m == 64 && k == 64 && pmode == OP_DY;  // recomputed first layer below
   const bool first = s.xyz != 0;  // grouped input: the layer reads the network input directly
   if (first != (qmode == OP_DIRECT)) return 0;
   if (qmode != OP_DIRECT && qmode != OP_BNRELU) return 0;
@@ -515,8 +546,9 @@ MLP_API int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, 
                                     const float *scale, const float *shift, const float *mean,
                                     const float *invstd, const float *coef, int qmode,
                                     const float *x, const float *xscale, const float *xshift,
-                                    const float *xmean, const float *xinvstd, float *dq, float *dw,
-                                    float *workspace, float *stats_part, void *stream_) {
+                                    const float *xmean, const float *xinvstd, const float *xlin_w,
+                                    float *dq, float *dw, float *workspace, float *stats_part,
+                                    void *stream_) {
   if (!mlp_gemm_backward_fused_supported(b, m, k, r, pmode, qmode, ns)) return (int)hipErrorInvalidValue;
   FusedShape s;
   fused_shape(m, k, &s);
@@ -526,14 +558,16 @@ MLP_API int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, 
   const int total = b * cpc;
   const int g = fused_workgroups(s, total);
   OperandB P = {y, dz, scale, shift, mean, invstd, coef, argmax, ns, ns > 0 ? r / ns : 0};
-  if (qmode == OP_BNRELU && (!xmean || !xinvstd)) return (int)hipErrorInvalidValue;
+  if ((qmode == OP_BNRELU || qmode == OP_LIN4) && (!xmean || !xinvstd)) return (int)hipErrorInvalidValue;
+  if (qmode == OP_LIN4 && !xlin_w) return (int)hipErrorInvalidValue;
   if (k != 64) stats_part = nullptr;
-  OperandB Q = {x, nullptr, xscale, xshift, xmean, xinvstd, nullptr};
+  OperandB Q = {x, nullptr, xscale, xshift, xmean, xinvstd, nullptr, nullptr, 0, 0, xlin_w};
 #define FUSED(MB, KB, KBD, NB, PM, QM, OCC, ST)                                                 \
   hipLaunchKernelGGL((gemm_bwd_fused_kernel<MB, KB, KBD, NB, PM, QM, OCC, ST>), dim3(g),        \
                      dim3(256), 0, stream, k, r, total, cpc, s.xyz, P, Q, w, dq, workspace,     \
                      stats_part)
-  if (m == 64 && k == 64) FUSED(2, 2, 2, 2, OP_DY, OP_BNRELU, 2, true);
+  if (m == 64 && k == 64 && qmode == OP_LIN4) FUSED(2, 2, 2, 2, OP_DY, OP_LIN4, 2, true);
+  else if (m == 64 && k == 64) FUSED(2, 2, 2, 2, OP_DY, OP_BNRELU, 2, true);
   else if (m == 128 && k == 64) FUSED(4, 2, 2, 2, OP_POOLDY, OP_BNRELU, 1, true);
   else if (m == 128 && k == 128 && pmode == OP_DY) FUSED(4, 4, 4, 1, OP_DY, OP_BNRELU, 2, false);
   else if (m == 128 && k == 128) FUSED(4, 4, 4, 1, OP_POOLDY, OP_BNRELU, 2, false);

@@ -26,11 +26,6 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
   return __hiloint2double(hi, lo);
 }
 
-// y[k] = W[k] . x in one fixed order: every kernel that recomputes the layer's output uses this
-__device__ __forceinline__ float lin4(const float4 w, float x0, float x1, float x2, float x3) {
-  return __fmaf_rn(w.w, x3, __fmaf_rn(w.z, x2, __fmaf_rn(w.y, x1, w.x * x0)));
-}
-
 // G partials: 8 waves, wave w owns rows 8w .. 8w+7, a lane owns 4 consecutive columns per step
 constexpr int kF4Rpw = 8;  // rows per wave
 __global__ void __launch_bounds__(512, 2)
@@ -163,6 +158,55 @@ first4_combine_kernel(const float *__restrict__ gsum, const double *__restrict__
   dw[tid] = (float)(a * (g - c1 * x1 - c2 * (double)invstd[k] * (ws - (double)mean[k] * x1)));
 }
 
+// BatchNorm coefficients of y = W x from the moments of x (no pass over y, which is never
+// stored): mean_y = W mean_x, E[y^2] = w^T (S/N) w.  Same outputs and running-statistics update
+// as mlp_bn_finalize_pairs.  One workgroup; lane = channel.
+__global__ void __launch_bounds__(256)
+first4_bn_kernel(const double *__restrict__ mpart, double count, const float *__restrict__ w,
+                 const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                 float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
+                 float *__restrict__ mean_out, float *__restrict__ invstd_out,
+                 float *__restrict__ scale_out, float *__restrict__ shift_out) {
+  __shared__ double red[4][14];
+  __shared__ double mom[14];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int q = 0; q < 14; ++q) {
+    double v = mpart[(size_t)tid * 14 + q];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += shfl_xor_f64(v, off);
+    if (lane == 0) red[wave][q] = v;
+  }
+  __syncthreads();
+  if (tid < 14) mom[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  __syncthreads();
+  if (tid >= kF4Rows) return;
+  const int sidx[4][4] = {{4, 5, 6, 7}, {5, 8, 9, 10}, {6, 9, 11, 12}, {7, 10, 12, 13}};
+  const double wk[4] = {w[tid * 4], w[tid * 4 + 1], w[tid * 4 + 2], w[tid * 4 + 3]};
+  double mean = 0.0, ey2 = 0.0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    mean += wk[c] * mom[c];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) ey2 += wk[c] * wk[d] * mom[sidx[c][d]];
+  }
+  mean /= count;
+  double var = ey2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float fmean = (float)mean;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  mean_out[tid] = fmean;
+  invstd_out[tid] = invstd;
+  const float sc = gamma[tid] * invstd;
+  scale_out[tid] = sc;
+  shift_out[tid] = beta[tid] - fmean * sc;
+  if (running_mean != nullptr) {  // nn.BatchNorm: unbiased variance in the running estimate
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[tid] = (1.f - momentum) * running_mean[tid] + momentum * fmean;
+    running_var[tid] = (1.f - momentum) * running_var[tid] + momentum * (float)unbiased;
+  }
+}
+
 int first4_slices(int b, int r) {
   long long s = 512 / (b > 0 ? b : 1);  // two workgroups per CU, each streams many steps
   if (s < 1) s = 1;
@@ -177,7 +221,31 @@ constexpr int kF4MomentParts = 256;  // = lanes of the combine kernel
 
 #define MLP_API extern "C" __attribute__((visibility("default")))
 
-// workspace of mlp_wgrad_first4: G partials (floats), then the moment partials (doubles)
+// doubles of a moments buffer (256 partial rows of 14 sums)
+MLP_API int mlp_first4_moments_doubles(void) { return kF4MomentParts * 14; }
+
+// the 14 moments of x (b,4,r) -- 4 sums, 10 products -- as 256 partial rows of doubles
+MLP_API int mlp_first4_moments(int b, int r, const float *x, double *moments, void *stream_) {
+  if (b <= 0 || r <= 0) return 0;
+  if (!moments) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(first4_moments_kernel, dim3(kF4MomentParts), dim3(256), 0, (hipStream_t)stream_, r,
+                     (long long)b * r, x, moments);
+  return pn2_launch_status();
+}
+
+// training-mode BatchNorm coefficients (and running-statistics update) of y = w x, w (64,4), from
+// the moments of x over count = b*r columns; outputs as mlp_bn_finalize_pairs
+MLP_API int mlp_first4_bn(const double *moments, double count, const float *w, const float *gamma,
+                          const float *beta, float eps, float momentum, float *running_mean,
+                          float *running_var, float *mean, float *invstd, float *scale,
+                          float *shift, void *stream_) {
+  if (!moments || count <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(first4_bn_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, moments, count, w,
+                     gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  return pn2_launch_status();
+}
+
+// workspace of mlp_wgrad_first4: G partials + their sum (floats), then moment partials (doubles)
 MLP_API size_t mlp_wgrad_first4_workspace_bytes(int b, int r) {
   if (b <= 0 || r <= 0) return 0;
   const size_t g = sizeof(float) * ((size_t)b * first4_slices(b, r) + 1) * kF4Rows * 4;
@@ -186,11 +254,12 @@ MLP_API size_t mlp_wgrad_first4_workspace_bytes(int b, int r) {
 
 // dw (64,4) of the layer y = w x, x (b,4,r), behind BatchNorm + ReLU, from dz (b,64,r) = the
 // gradient w.r.t. relu(bn(y)) and the layer's (scale, shift, mean, invstd, coef (64,3)); y itself
-// is not read.  r % 4 == 0.
+// is not read.  r % 4 == 0.  moments: those of x from mlp_first4_moments (the forward's), or NULL
+// to compute them here.
 MLP_API int mlp_wgrad_first4(int b, int r, const float *w, const float *x, const float *dz,
                              const float *scale, const float *shift, const float *mean,
-                             const float *invstd, const float *coef, float *dw, void *workspace,
-                             void *stream_) {
+                             const float *invstd, const float *coef, const double *moments,
+                             float *dw, void *workspace, void *stream_) {
   if (b <= 0 || r <= 0) return 0;
   if (r % 4 != 0 || !workspace) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
@@ -202,11 +271,14 @@ MLP_API int mlp_wgrad_first4(int b, int r, const float *w, const float *x, const
   double *mpart = reinterpret_cast<double *>(static_cast<char *>(workspace) + gbytes);
   hipLaunchKernelGGL(first4_gated_kernel, dim3(slices, b), dim3(512), 0, stream, r, (int)per, w, x, dz,
                      scale, shift, gpart);
-  hipLaunchKernelGGL(first4_moments_kernel, dim3(kF4MomentParts), dim3(256), 0, stream, r,
-                     (long long)b * r, x, mpart);
+  if (moments == nullptr) {
+    hipLaunchKernelGGL(first4_moments_kernel, dim3(kF4MomentParts), dim3(256), 0, stream, r,
+                       (long long)b * r, x, mpart);
+    moments = mpart;
+  }
   int rc = mlp_reduce_partials(kF4Rows * 4, b * slices, gpart, gsum, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(first4_combine_kernel, dim3(1), dim3(256), 0, stream, gsum, mpart, w, mean, invstd,
+  hipLaunchKernelGGL(first4_combine_kernel, dim3(1), dim3(256), 0, stream, gsum, moments, w, mean, invstd,
                      coef, dw);
   return pn2_launch_status();
 }

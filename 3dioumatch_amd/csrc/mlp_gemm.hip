@@ -199,7 +199,7 @@ __device__ __forceinline__ float half_wave_extreme(float v) {
 //        (b, m_total, r / POOL).
 template <int TM, int TN, int WM, int WN, int MODE, bool A_TRANS, bool A_VEC, bool STATS = false,
           int POOL = 0>
-__global__ void __launch_bounds__(256, (MODE <= OP_BNRELU && TM <= 128) ? 4 : 2)
+__global__ void __launch_bounds__(256, ((MODE <= OP_BNRELU || MODE == OP_LIN4) && TM <= 128) ? 4 : 2)
 gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int lda,
                 unsigned a_bytes, OperandB opb, float *__restrict__ c, size_t b_stride_in,
                 size_t b_stride_out, float *__restrict__ stats = nullptr, int stat_channels = 0,
@@ -233,6 +233,20 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
   const int bkk = tid >> 4, bnn = (tid & 15) * SEG;
   float bx[SEG], bdz[SEG];
   RowCoef rc;
+  // OP_LIN4: the operand rows are relu(bn(W1 . x4)); this lane's SEG columns of the 4-channel
+  // input stay in registers for the whole K loop, a chunk only fetches W1 rows and coefficients
+  constexpr bool LIN = MODE == OP_LIN4;
+  float x4r[LIN ? 4 : 1][LIN ? SEG : 1];
+  float4 lw = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (LIN) {
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+      for (int i = 0; i < SEG; i += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(op.x + in_off + (size_t)cc * r + r0 + bnn + i);
+        x4r[cc][i] = v.x; x4r[cc][i + 1] = v.y; x4r[cc][i + 2] = v.z; x4r[cc][i + 3] = v.w;
+      }
+  }
   auto fetch = [&](int k0) {
     if (k0 + KC <= k_total) {  // full chunk: range-checked 16-byte loads, no exec masks
 #pragma unroll
@@ -273,10 +287,14 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
     const int gk = k0 + bkk;
     const bool row_ok = gk < k_total;
     // rows beyond K: zero coefficients AND zero data -> the staged operand is exactly zero
-    rc = load_row_coef<MODE>(op, gk, row_ok);
+    rc = load_row_coef<LIN ? OP_BNRELU : MODE>(op, gk, row_ok);
     if (!row_ok) { rc.sc = 0.f; rc.sh = 0.f; rc.a = 0.f; rc.q = 0.f; rc.p = 0.f; }
-    load_raw_segment<MODE, SEG>(op, in_off + (size_t)gk * r + r0 + bnn, r0 + bnn, r, true, row_ok,
-                                bx, bdz, b * k_total + gk);
+    if constexpr (LIN) {
+      lw = row_ok ? *reinterpret_cast<const float4 *>(op.lin_w + (size_t)gk * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      load_raw_segment<MODE, SEG>(op, in_off + (size_t)gk * r + r0 + bnn, r0 + bnn, r, true, row_ok,
+                                  bx, bdz, b * k_total + gk);
+    }
   };
   auto stash = [&](int buf) {
 #pragma unroll
@@ -292,10 +310,19 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
 #pragma unroll
     for (int i = 0; i < SEG; i += 4) {
       float4 v;
-      v.x = transform<MODE>(bx[i + 0], bdz[i + 0], rc);
-      v.y = transform<MODE>(bx[i + 1], bdz[i + 1], rc);
-      v.z = transform<MODE>(bx[i + 2], bdz[i + 2], rc);
-      v.w = transform<MODE>(bx[i + 3], bdz[i + 3], rc);
+      if constexpr (LIN) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = fmaxf(__fmaf_rn(lin4(lw, x4r[0][i + e], x4r[1][i + e], x4r[2][i + e], x4r[3][i + e]),
+                                 rc.sc, rc.sh), 0.f);
+        v = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        v.x = transform<MODE>(bx[i + 0], bdz[i + 0], rc);
+        v.y = transform<MODE>(bx[i + 1], bdz[i + 1], rc);
+        v.z = transform<MODE>(bx[i + 2], bdz[i + 2], rc);
+        v.w = transform<MODE>(bx[i + 3], bdz[i + 3], rc);
+      }
       *reinterpret_cast<float4 *>(&Bs[buf][bkk * TN + bnn + i]) = v;
     }
   };
@@ -913,6 +940,24 @@ MLP_API int mlp_gemm_forward_stats_pool(int b, int m, int k, int r, const float 
   else if (ns == 32) POOLED(128, 128, 2, 2, 32);
   else POOLED(128, 128, 2, 2, 64);
 #undef POOLED
+  return pn2_launch_status();
+}
+
+// mlp_gemm_forward_stats for the SECOND layer of a chain whose first layer has a 4-channel
+// input: the operand relu(bn(W1 x4)) is recomputed from x4 (b,4,r) -- the first layer's output
+// is never stored.  w (64,64), w1 (64,4), scale / shift (64) of the first layer's BatchNorm.
+MLP_API int mlp_gemm_forward_stats_lin4(int b, int r, const float *w, const float *x4,
+                                        const float *w1, const float *scale, const float *shift,
+                                        float *y, float *pairs, void *stream_) {
+  const int m = 64, k = 64;
+  if (b <= 0 || r <= 0) return 0;
+  if (!pairs || mlp_gemm_forward_stats_parts(b, m, k, r, nullptr) == 0 ||
+      (reinterpret_cast<size_t>(w) & 15) != 0 || (reinterpret_cast<size_t>(w1) & 15) != 0)
+    return (int)hipErrorInvalidValue;
+  OperandB op = {x4, nullptr, scale, shift, nullptr, nullptr, nullptr, nullptr, 0, 0, w1};
+  hipLaunchKernelGGL((gemm_nn2_kernel<64, 128, 2, 2, OP_LIN4, false, true, true>),
+                     dim3(r / 128, 1, b), dim3(256), 0, (hipStream_t)stream_, m, k, r, w, k,
+                     (unsigned)(4 * (size_t)m * k), op, y, (size_t)4 * r, (size_t)m * r, pairs, m);
   return pn2_launch_status();
 }
 

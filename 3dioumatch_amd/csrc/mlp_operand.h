@@ -10,7 +10,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
-enum OperandMode { OP_DIRECT = 0, OP_BNRELU = 1, OP_DY = 2, OP_POOLDY = 3 };
+enum OperandMode { OP_DIRECT = 0, OP_BNRELU = 1, OP_DY = 2, OP_POOLDY = 3, OP_LIN4 = 4 };
 
 struct OperandB {
   const float *x;        // OP_DIRECT / OP_BNRELU: the tensor; OP_DY: y
@@ -23,9 +23,18 @@ struct OperandB {
   const int *argmax;     // OP_POOLDY: (rows, r/ns) winning sample per group; dz holds dpooled
   int ns;                // OP_POOLDY: samples per group
   int groups;            // OP_POOLDY: r / ns (groups per row)
+  const float *lin_w;    // OP_LIN4: (rows, 4) weight of the 4 -> rows layer whose output the
+                         // operand stands for; x is then that layer's 4-channel input (b,4,r)
 };
 
 constexpr bool is_dy(int mode) { return mode == OP_DY || mode == OP_POOLDY; }
+
+// OP_LIN4: the output of a 4 -> rows first layer is never stored; whoever needs row k at column
+// n recomputes y[k][n] = W[k] . x[:, n] with THIS function (one fixed order, so that the ReLU
+// gate is the same bit pattern in the forward and in every backward kernel)
+__device__ __forceinline__ float lin4(const float4 w, float x0, float x1, float x2, float x3) {
+  return __fmaf_rn(w.w, x3, __fmaf_rn(w.z, x2, __fmaf_rn(w.y, x1, w.x * x0)));
+}
 
 // Per-row constants of an operand (loaded once per row, kept in registers).  The BatchNorm+ReLU
 // backward  a*(g - c1 - ((x - mu)*is)*c2),  g = [x*sc + sh > 0] ? dz : 0,  is affine in x next

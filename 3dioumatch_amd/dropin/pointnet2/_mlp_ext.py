@@ -297,7 +297,8 @@ def gemm_wgrad(m, k, x, xcoeff=None, dy=None, fly=None, pooled=None):
     return dw
 
 
-def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None, need_dx=True):
+def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None, need_dx=True,
+                        lin_w=None):
     """dgrad and wgrad of one layer in one pass: -> (dx (B,K,...), dw (M,K), below), or None when
     the layer's shape is outside the fused kernel (callers then use gemm_dgrad + gemm_wgrad).
     x (B,K,...) direct or relu(bn(.)) via xcoeff=(scale, shift); the gradient operand on the fly
@@ -305,29 +306,36 @@ def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None, n
     xstats = (mean, invstd, gamma, training) of the layer that produced x (required with xcoeff):
     `below` is then that layer's (dgamma, dbeta, coef), as bn_relu_backward_stats(x, dx, ...)
     would return them -- the sums come out of the dgrad epilogue, no pass over (x, dx).
-    need_dx=False (a first layer whose input needs no gradient): dx is None."""
+    need_dx=False (a first layer whose input needs no gradient): dx is None.
+    lin_w (64,4): the layer below is a 4 -> 64 first layer whose output was never stored; x is then
+    THAT layer's input (B,4,...), xcoeff / xstats its BatchNorm, and dx (B,64,...) the gradient
+    w.r.t. its activated output."""
     m, k = w.shape
     _f32c(w, "w"); _f32c(x, "x")
     b = x.shape[0]
-    r = x.numel() // (b * k)
+    r = x.numel() // (b * (4 if lin_w is not None else k))
     if pooled is not None:
         y, dz, argmax, scale, shift, mean, invstd, coef = pooled
         pmode, ns = 3, y.shape[3]
     else:
         y, dz, scale, shift, mean, invstd, coef = fly
         argmax, pmode, ns = None, 2, 0
-    qmode = 0 if xcoeff is None else 1
+    qmode = 4 if lin_w is not None else (0 if xcoeff is None else 1)
     if not _lib.mlp_gemm_backward_fused_supported(b, m, k, r, pmode, qmode, ns):
         return None
     if not need_dx and (m, k) != (128, 259):  # the weight-gradient-only form exists for this shape
         return None
-    if qmode == 1 and xstats is None:
+    if qmode != 0 and xstats is None:
         raise RuntimeError("xstats=(mean, invstd, gamma, training) is required with xcoeff")
     xs, xh = xcoeff if xcoeff is not None else (None, None)
-    xmean, xinv, xgamma, xtraining = xstats if qmode == 1 else (None, None, None, False)
-    dx = torch.empty_like(x) if need_dx else None
+    xmean, xinv, xgamma, xtraining = xstats if qmode != 0 else (None, None, None, False)
+    if lin_w is not None:
+        _f32c(lin_w, "lin_w")
+        dx = torch.empty((b, k) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    else:
+        dx = torch.empty_like(x) if need_dx else None
     dw = torch.empty((m, k), dtype=torch.float32, device=x.device)
-    parts = int(_lib.mlp_gemm_backward_fused_stats_parts(b, m, k, r)) if qmode == 1 else 0
+    parts = int(_lib.mlp_gemm_backward_fused_stats_parts(b, m, k, r)) if qmode != 0 else 0
     below = None
     with torch.cuda.device(x.device):
         ws = torch.empty(max(int(_lib.mlp_gemm_backward_fused_workspace_floats(b, m, k, r)), 1),
@@ -337,7 +345,7 @@ def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None, n
                                               dz.data_ptr(), _ptr(argmax), ns, scale.data_ptr(),
                                               shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                               coef.data_ptr(), qmode, x.data_ptr(), _ptr(xs),
-                                              _ptr(xh), _ptr(xmean), _ptr(xinv), _ptr(dx),
+                                              _ptr(xh), _ptr(xmean), _ptr(xinv), _ptr(lin_w), _ptr(dx),
                                               dw.data_ptr(), ws.data_ptr(), _ptr(sp), _stream(x)),
                  "mlp_gemm_backward_fused")
         if parts:
@@ -352,11 +360,12 @@ def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None, n
     return dx, dw, below
 
 
-def wgrad_first4(w, x, fly):
+def wgrad_first4(w, x, fly, moments=None):
     """dw (64,4) of a first layer y = w x with a 4-channel input x (B,4,...) behind BatchNorm +
     ReLU, from fly = (y, dz, scale, shift, mean, invstd, coef) as gemm_wgrad takes it -- y is
     ignored: the ReLU gate is recomputed from x and everything else follows from the second
-    moments of x.  None when the shape is not (64, 4) or the columns are not a multiple of 4."""
+    moments of x (`moments`: first4_moments(x) if the caller has them, e.g. from the forward).  None
+    when the shape is not (64, 4) or the columns are not a multiple of 4."""
     m, k = w.shape
     b = x.shape[0]
     r = x.numel() // (b * x.shape[1])
@@ -370,6 +379,74 @@ def wgrad_first4(w, x, fly):
         ws = torch.empty(int(_lib.mlp_wgrad_first4_workspace_bytes(b, r)), dtype=torch.uint8, device=x.device)
         _L.check(_lib.mlp_wgrad_first4(b, r, w.data_ptr(), x.data_ptr(), dz.data_ptr(), scale.data_ptr(),
                                        shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                       coef.data_ptr(), dw.data_ptr(), ws.data_ptr(), _stream(x)),
-                 "mlp_wgrad_first4")
+                                       coef.data_ptr(), _ptr(moments), dw.data_ptr(), ws.data_ptr(),
+                                       _stream(x)), "mlp_wgrad_first4")
     return dw
+
+
+def first4_moments(x):
+    """The 14 moments (4 sums, 10 products) of a 4-channel tensor x (B,4,...) as partial rows of
+    doubles: what BatchNorm statistics and weight gradients of a 4 -> 64 first layer need of x."""
+    _f32c(x, "x")
+    b = x.shape[0]
+    r = x.numel() // (b * 4)
+    mom = torch.empty(int(_lib.mlp_first4_moments_doubles()), dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        _L.check(_lib.mlp_first4_moments(b, r, x.data_ptr(), mom.data_ptr(), _stream(x)), "mlp_first4_moments")
+    return mom
+
+
+def first4_bn(moments, count, w, gamma, beta, running_mean, running_var, momentum, eps):
+    """Training-mode BatchNorm coefficients (mean, invstd, scale, shift) of y = w x for w (64,4),
+    from the moments of x over `count` columns -- y itself is never formed; running statistics are
+    updated like bn_coefficients does."""
+    _f32c(w, "w")
+    out = torch.empty((4, 64), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _L.check(_lib.mlp_first4_bn(moments.data_ptr(), float(count), w.data_ptr(), gamma.data_ptr(),
+                                    beta.data_ptr(), float(eps), float(momentum), _ptr(running_mean),
+                                    _ptr(running_var), out[0].data_ptr(), out[1].data_ptr(),
+                                    out[2].data_ptr(), out[3].data_ptr(), _stream(w)), "mlp_first4_bn")
+    return out[0], out[1], out[2], out[3]
+
+
+def lin4_supported(w0, w1, x):
+    """Can the first layer (w0 (64,4) on x (B,4,...)) stay virtual, i.e. be recomputed inside the
+    kernels of the second layer (w1 (64,64))?"""
+    if os.environ.get("MLP_FIRST4_VIRTUAL", "1") == "0":
+        return False
+    if tuple(w0.shape) != (64, 4) or tuple(w1.shape) != (64, 64) or x.shape[1] != 4:
+        return False
+    b = x.shape[0]
+    r = x.numel() // (b * 4)
+    return (w0.data_ptr() % 16 == 0 and w1.data_ptr() % 16 == 0
+            and int(_lib.mlp_gemm_forward_stats_parts(b, 64, 64, r, None)) > 0
+            and bool(_lib.mlp_gemm_backward_fused_supported(b, 64, 64, r, 2, 4, 0)))
+
+
+def gemm_forward_bn_lin4(w, x4, w1, coeff1, gamma, beta, running_mean, running_var, momentum, eps):
+    """gemm_forward_bn for the second layer (w (64,64)) when the first (w1 (64,4), BatchNorm
+    coefficients coeff1 = (scale, shift)) is virtual: its activated output is recomputed from x4."""
+    import ctypes
+    _f32c(x4, "x4"); _f32c(w, "w"); _f32c(w1, "w1")
+    b = x4.shape[0]
+    r = x4.numel() // (b * 4)
+    m = 64
+    cols = ctypes.c_int(0)
+    parts = int(_lib.mlp_gemm_forward_stats_parts(b, m, 64, r, ctypes.byref(cols)))
+    y = torch.empty((b, m) + tuple(x4.shape[2:]), dtype=torch.float32, device=x4.device)
+    pairs = torch.empty((parts, m, 2), dtype=torch.float32, device=x4.device)
+    out = torch.empty((4, m), dtype=torch.float32, device=x4.device)
+    scratch = torch.empty(int(_lib.mlp_bn_finalize_pairs_scratch_bytes(m)), dtype=torch.uint8,
+                          device=x4.device)
+    with torch.cuda.device(x4.device):
+        _L.check(_lib.mlp_gemm_forward_stats_lin4(b, r, w.data_ptr(), x4.data_ptr(), w1.data_ptr(),
+                                                  coeff1[0].data_ptr(), coeff1[1].data_ptr(),
+                                                  y.data_ptr(), pairs.data_ptr(), _stream(x4)),
+                 "mlp_gemm_forward_stats_lin4")
+        _L.check(_lib.mlp_bn_finalize_pairs(m, parts, cols.value, pairs.data_ptr(), gamma.data_ptr(),
+                                            beta.data_ptr(), float(eps), float(momentum),
+                                            _ptr(running_mean), _ptr(running_var), out[0].data_ptr(),
+                                            out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+                                            scratch.data_ptr(), _stream(x4)), "mlp_bn_finalize_pairs")
+    return y, out[0], out[1], out[2], out[3]

@@ -151,10 +151,34 @@ class _FusedMLPChain(Function):
         x = x.contiguous()
         ys, coefs = [], []
         cur, cur_coeff = x, None
+        # A 4 -> 64 first layer followed by a 64 -> 64 layer (SA1) stays VIRTUAL: its output is a
+        # rank-4 function of x, so its BatchNorm statistics follow from the second moments of x
+        # and every kernel that needs a row of it recomputes that row (four FMAs per element)
+        # instead of a 268 MB tensor being written once and read three times.
+        moments = None
+        virtual0 = (training and n_layers >= 3 and x.dim() == 4 and not ctx.needs_input_grad[0]
+                    and K.lin4_supported(params[0].reshape(params[0].shape[0], -1),
+                                         params[5].reshape(params[5].shape[0], -1), x))
         for i in range(n_layers):
             w, gamma, beta, rm, rv = params[5 * i:5 * i + 5]
             w2 = w.reshape(w.shape[0], -1)
             ext = None
+            if virtual0 and i == 0:
+                moments = K.first4_moments(x)
+                mean, invstd, scale, shift = K.first4_bn(moments, x.numel() // 4, w2, gamma, beta, rm, rv,
+                                                         momenta[0], epss[0])
+                ys.append(x.new_empty(0))  # never materialised
+                coefs.append((mean, invstd, scale, shift))
+                cur, cur_coeff = None, (scale, shift)
+                continue
+            if virtual0 and i == 1:
+                w0 = params[0].reshape(params[0].shape[0], -1)
+                y, mean, invstd, scale, shift = K.gemm_forward_bn_lin4(w2, x, w0, cur_coeff, gamma, beta,
+                                                                       rm, rv, momenta[1], epss[1])
+                ys.append(y)
+                coefs.append((mean, invstd, scale, shift))
+                cur, cur_coeff = y, (scale, shift)
+                continue
             if training and pool and i == n_layers - 1:
                 # ... and so do the per-group extrema the max over nsample needs
                 y, mean, invstd, scale, shift, ext = K.gemm_forward_bn(
@@ -181,6 +205,7 @@ class _FusedMLPChain(Function):
         flat = [t for c in coefs for t in c]
         ctx.save_for_backward(x, *ys, *flat, *extra, *params)
         ctx.n_layers, ctx.pool, ctx.training = n_layers, pool, training
+        ctx.moments = moments  # not None: the first layer is virtual (ys[0] is a placeholder)
         return out
 
     @staticmethod
@@ -214,19 +239,26 @@ class _FusedMLPChain(Function):
                 pooled = None
                 if below is not None:  # left behind by the fused backward GEMM of layer i+1
                     dgamma, dbeta, coef = below
+                elif i == 0 and ctx.moments is not None:
+                    raise RuntimeError("the virtual first layer's BatchNorm sums must come from the "
+                                       "fused backward kernel of the second layer")
                 else:
                     dgamma, dbeta, coef = K.bn_relu_backward_stats(ys[i], dz, gamma, scale, shift,
                                                                    mean, invstd, training)
                 dy_tensor, fly = None, (ys[i], dz, scale, shift, mean, invstd, coef)
             grads[5 * i + 1], grads[5 * i + 2] = dgamma, dbeta
             m, k = w2.shape
-            src = x if i == 0 else ys[i - 1]
+            virtual0 = ctx.moments is not None
+            src = x if (i == 0 or (i == 1 and virtual0)) else ys[i - 1]
             src_coeff = None if i == 0 else (coefs[i - 1][2], coefs[i - 1][3])
+            lin_w = params[0].reshape(params[0].shape[0], -1) if (i == 1 and virtual0) else None
             # both GEMMs from one pass over (y_i, dz) where the shape allows
             src_stats = None if i == 0 else (coefs[i - 1][0], coefs[i - 1][1],
                                              params[5 * (i - 1) + 1], training)
             both = K.gemm_backward_fused(w2, src, src_coeff, fly, pooled, src_stats,
-                                         need_dx=i > 0 or need_dx)
+                                         need_dx=i > 0 or need_dx, lin_w=lin_w)
+            if lin_w is not None and both is None:
+                raise RuntimeError("the virtual first layer needs the fused backward kernel of the second")
             below = None
             if both is not None:
                 below = both[2]  # BatchNorm-backward sums of layer i-1 (None for the first layer)
@@ -236,7 +268,9 @@ class _FusedMLPChain(Function):
                 else:
                     dz = both[0]
             elif i == 0:
-                dw0 = K.wgrad_first4(w2, x, fly) if (fly is not None and not need_dx) else None
+                dw0 = K.wgrad_first4(w2, x, fly, ctx.moments) if (fly is not None and not need_dx) else None
+                if dw0 is None and virtual0:
+                    raise RuntimeError("the virtual first layer needs mlp_wgrad_first4")
                 if dw0 is None:
                     dw0 = K.gemm_wgrad(m, k, x, None, dy_tensor, fly, pooled)
                 grads[0 + 5 * i] = dw0.view_as(w)

@@ -196,7 +196,9 @@ size_t mlp_gemm_backward_fused_workspace_floats(int b, int m, int k, int r);
 /* dq (b,k,r) = w^T * P[b] and dw (m,k) = sum_b P[b] * Q[b]^T (replaces conv2d backward-input AND
  * backward-weight, pytorch_utils.py:70-124).  P as in mlp_gemm_dgrad_nt (pmode 2: y, dz (b,m,r))
  * or mlp_gemm_dgrad_pooled_nt (pmode 3: y, dz = dpooled (b,m,r/ns), argmax); Q as in
- * mlp_gemm_wgrad (qmode 1: relu(x*xscale + xshift), qmode 0: x).
+ * mlp_gemm_wgrad (qmode 1: relu(x*xscale + xshift), qmode 0: x; qmode 4, (64,64) only: the layer
+ * below is a 4 -> 64 first layer whose output is not stored -- x is ITS input (b,4,r), xlin_w its
+ * weight (64,4), and Q = relu((xlin_w . x)*xscale + xshift) is recomputed).
  * dq == NULL (only (128,259)): the weight gradient alone, for a first layer whose input needs no
  * gradient.
  * qmode 1 also needs xmean / xinvstd of the layer that produced x, and, for the k = 64 shapes when
@@ -209,7 +211,8 @@ int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, int pmod
                             const float *shift, const float *mean, const float *invstd,
                             const float *coef, int qmode, const float *x, const float *xscale,
                             const float *xshift, const float *xmean, const float *xinvstd,
-                            float *dq, float *dw, float *workspace, float *stats_part, void *stream);
+                            const float *xlin_w, float *dq, float *dw, float *workspace,
+                            float *stats_part, void *stream);
 /* partials per channel in stats_part; 0 when the layer leaves none (sizing helper for the
  * BatchNorm backward of pytorch_utils.py:42-50) */
 int mlp_gemm_backward_fused_stats_parts(int b, int m, int k, int r);
@@ -224,15 +227,36 @@ int mlp_bn_backward_finalize(int c, int parts, double count, int training, const
  * SA1's first layer (mlp [1+3, 64, ...], pointnet2_modules.py:230-262 / pytorch_utils.py:70-124):
  * y = w x is a rank-4 function of x, so only the ReLU-gated part of the BatchNorm backward needs
  * the big gradient tensor; the rest follows from the 4x4 second moments of x. */
+/* doubles in a moments buffer (sizing helper for the BatchNorm2d of pytorch_utils.py:42-50) */
+int mlp_first4_moments_doubles(void);
+/* the 4 sums and 10 products of x (b,4,r) as partial rows of doubles (input of the two entry
+ * points below; replaces the statistics pass of BatchNorm2d over the first layer's output,
+ * pytorch_utils.py:42-50) */
+int mlp_first4_moments(int b, int r, const float *x, double *moments, void *stream);
+/* training-mode BatchNorm2d (pytorch_utils.py:42-50) of y = w x, w (64,4), from the moments of x
+ * over count = b*r columns: mean, invstd, scale, shift (64) and the running-statistics update, as
+ * mlp_bn_finalize_pairs -- without y */
+int mlp_first4_bn(const double *moments, double count, const float *w, const float *gamma,
+                  const float *beta, float eps, float momentum, float *running_mean,
+                  float *running_var, float *mean, float *invstd, float *scale, float *shift,
+                  void *stream);
+/* mlp_gemm_forward_stats for the SECOND layer (64 -> 64) of such a chain: the operand
+ * relu(bn(w1 x4)) is recomputed from x4 (b,4,r); the first layer's output is never stored
+ * (replaces conv + BatchNorm + ReLU + conv of pytorch_utils.py:14-39 for SA1's first two layers) */
+int mlp_gemm_forward_stats_lin4(int b, int r, const float *w, const float *x4, const float *w1,
+                                const float *scale, const float *shift, float *y, float *pairs,
+                                void *stream);
 /* bytes of the workspace of mlp_wgrad_first4 (sizing helper for the backward-weight of
  * pytorch_utils.py:70-124) */
 size_t mlp_wgrad_first4_workspace_bytes(int b, int r);
 /* dw (64,4) from x (b,4,r), dz (b,64,r) = gradient w.r.t. relu(bn(y)), and the layer's scale,
- * shift, mean, invstd, coef (64,3) as mlp_bn_relu_backward_stats leaves them; y is not read
+ * shift, mean, invstd, coef (64,3) as mlp_bn_relu_backward_stats leaves them; y is not read;
+ * moments = those of x (mlp_first4_moments) or NULL to compute them here
  * (replaces conv2d backward-weight behind BatchNorm2d + ReLU, pytorch_utils.py:70-124) */
 int mlp_wgrad_first4(int b, int r, const float *w, const float *x, const float *dz,
                      const float *scale, const float *shift, const float *mean, const float *invstd,
-                     const float *coef, float *dw, void *workspace, void *stream);
+                     const float *coef, const double *moments, float *dw, void *workspace,
+                     void *stream);
 
 /* scratch (floats) for mlp_gemm_wgrad: per-slice partial dW tiles (replaces cuDNN's
  * workspace of conv2d backward-weight, pytorch_utils.py:70-124) */

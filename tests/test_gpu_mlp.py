@@ -476,3 +476,51 @@ def test_first_layer_weight_gradient_from_moments(b, groups, ns, training):
     assert got is not None
     want = K.gemm_wgrad(64, 4, x, None, fly=fly)
     close(got, want, 3e-5)
+
+
+@pytest.mark.parametrize("pool", [True, False])
+def test_virtual_first_layer_chain_vs_sequential(pool, monkeypatch):
+    """SA1's chain 4 -> 64 -> 64 -> 128 with the first layer VIRTUAL (its output never stored:
+    BatchNorm statistics from the second moments of the input, its rows recomputed inside the
+    second layer's forward and backward kernels, its weight gradient from gated sums + moments)
+    == the same chain with the layer materialised, and == nn.Sequential: outputs, every parameter
+    gradient, running statistics."""
+    P = _mods()
+    K = importlib.import_module("pointnet2._mlp_ext")
+    torch.manual_seed(3)
+    widths, shape = [4, 64, 64, 128], (8, 4, 256, 64)
+    mlp = P.SharedMLP(list(widths), bn=True).to(DEV)
+    for layer in mlp:
+        bn = next(layer.bn.children())
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.weight.data[::7] *= -1
+        bn.bias.data.normal_(0, 0.3)
+    twin = P.SharedMLP(list(widths), bn=True).to(DEV)
+    twin.load_state_dict(mlp.state_dict())
+    ref = P.SharedMLP(list(widths), bn=True).to(DEV)
+    ref.load_state_dict(mlp.state_dict())
+    x = (torch.randn(shape, device=DEV) * 1.5 + 0.4)
+    assert K.lin4_supported(mlp[0].conv.weight.reshape(64, 4), mlp[1].conv.weight.reshape(64, 64), x)
+    calls = []
+    real = K.first4_moments
+    monkeypatch.setattr(K, "first4_moments", lambda t: (calls.append(1), real(t))[1])
+    out = mlp.forward_pooled(x) if pool else mlp(x)
+    assert calls, "the first layer was materialised"
+    monkeypatch.setenv("MLP_FIRST4_VIRTUAL", "0")
+    out2 = twin.forward_pooled(x) if pool else twin(x)
+    z = torch.nn.Sequential.forward(ref, x)
+    want = torch.max(z, dim=3)[0] if pool else z
+    close(out, out2, 1e-5)
+    close(out, want, 2e-4)
+    wgt = torch.randn_like(want)
+    (out * wgt).sum().backward()
+    (out2 * wgt).sum().backward()
+    (want * wgt).sum().backward()
+    for (n1, p1), (n2, p2), (n3, p3) in zip(mlp.named_parameters(), twin.named_parameters(),
+                                            ref.named_parameters()):
+        rel = float((p1.grad - p2.grad).norm() / (p2.grad.norm() + 1e-12))
+        assert rel < 2e-3, (n1, rel)   # virtual vs materialised: same kernels downstream
+        rel = float((p1.grad - p3.grad).norm() / (p3.grad.norm() + 1e-12))
+        assert rel < 3e-2, (n1, rel)   # vs torch (mask flips at rounding level, as in the chain test)
+    for (n1, b1), (n2, b2) in zip(mlp.named_buffers(), ref.named_buffers()):
+        close(b1.float(), b2.float(), 2e-4)
