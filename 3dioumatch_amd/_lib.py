@@ -25,6 +25,7 @@ _SIGNATURES = {
     "pn2_three_nn": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "pn2_three_interpolate": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "pn2_three_interpolate_grad": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "pn2_multi_copy": [_c_int, _vp, ctypes.c_longlong, _vp],
     "pn2_group_inverse_supported": [_c_int, _c_int, _c_int],
     "pn2_group_inverse_entries": [_c_int, _c_int],
     "pn2_group_inverse_build": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp],

@@ -264,4 +264,40 @@ PN2_API int pn2_gather_points_grad(int b, int c, int n, int npoints, const float
   return pn2_launch_status();
 }
 
+// ---- many small device-to-device copies in ONE launch -----------------------------------------
+// The train step stages a batch (inputs + its prefetched index chain: ~46 tensors, 11 MB) from a
+// prefetch slot into the buffers its captured graphs read; as 46 copy launches that is ~100 us of
+// launch boundaries per step.  table: n rows of (src, dst, bytes) as 64-bit values on the device.
+namespace {
+__global__ void __launch_bounds__(256)
+multi_copy_kernel(const unsigned long long *__restrict__ table) {
+  const unsigned long long *row = table + (size_t)blockIdx.y * 3;
+  const char *src = reinterpret_cast<const char *>(row[0]);
+  char *dst = reinterpret_cast<char *>(row[1]);
+  const unsigned long long bytes = row[2];
+  const unsigned long long off0 = (unsigned long long)blockIdx.x * 32768ull;
+  if (off0 >= bytes) return;
+  const bool vec = ((row[0] | row[1]) & 15ull) == 0;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const unsigned long long off = off0 + ((unsigned long long)it * 256 + threadIdx.x) * 16ull;
+    if (off >= bytes) break;
+    if (vec && off + 16 <= bytes) {
+      *reinterpret_cast<uint4 *>(dst + off) = *reinterpret_cast<const uint4 *>(src + off);
+    } else {
+      const unsigned long long end = off + 16 < bytes ? off + 16 : bytes;
+      for (unsigned long long q = off; q < end; ++q) dst[q] = src[q];
+    }
+  }
+}
+}  // namespace
+
+PN2_API int pn2_multi_copy(int n, const void *table, long long max_bytes, void *stream_) {
+  if (n <= 0 || max_bytes <= 0) return 0;
+  if (!table || n > 65535) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)((max_bytes + 32767) / 32768), n), dim3(256), 0,
+                     (hipStream_t)stream_, static_cast<const unsigned long long *>(table));
+  return pn2_launch_status();
+}
+
 PN2_API const char *pn2_error_string(int code) { return hipGetErrorString((hipError_t)code); }

@@ -463,10 +463,36 @@ class SupervisedStep(object):
         self._copy_dst = [self._cur[k] for k in self._keys] + \
             [self._cur_geometry[k] for k in self._geo_keys]
         for slot in self._slots:
+            slot["copy_table"] = None  # pointer table of _stage_copies: rebuilt for the new buffers
             slot["copy_src"] = [slot["inputs"][k] for k in self._keys] + \
                 [slot["geometry"][k] for k in self._geo_keys]
         torch.cuda.synchronize(dev)
         self._captured = sig
+
+    def _stage_copies(self, slot):
+        """slot -> the buffers G1 reads: one launch for all ~46 tensors (a table of pointers that
+        never change after capture), torch's per-tensor copies where there is no GPU."""
+        if self.device.type != "cuda":
+            torch._foreach_copy_(self._copy_dst, slot["copy_src"])
+            return
+        if slot.get("copy_table") is None:
+            rows, biggest = [], 0
+            for d, s_ in zip(self._copy_dst, slot["copy_src"]):
+                if not (d.is_contiguous() and s_.is_contiguous() and d.dtype == s_.dtype
+                        and d.numel() == s_.numel()):
+                    raise RuntimeError("staging buffers must be contiguous twins")
+                nbytes = d.numel() * d.element_size()
+                rows.append([s_.data_ptr(), d.data_ptr(), nbytes])
+                biggest = max(biggest, nbytes)
+            slot["copy_table"] = torch.tensor(rows, dtype=torch.int64, device=self.device)
+            slot["copy_biggest"] = biggest
+        import importlib
+        _L = importlib.import_module("3dioumatch_amd._lib")
+        with torch.cuda.device(self.device):
+            _L.check(_L.lib.pn2_multi_copy(len(self._copy_dst), slot["copy_table"].data_ptr(),
+                                           slot["copy_biggest"],
+                                           torch.cuda.current_stream(self.device).cuda_stream),
+                     "pn2_multi_copy")
 
     def _replay(self, batch):
         main = torch.cuda.current_stream(self.device)
@@ -481,7 +507,7 @@ class SupervisedStep(object):
             self._stage(slot, batch)
             slot["graph"].replay()
         slot["token"] = -1
-        torch._foreach_copy_(self._copy_dst, slot["copy_src"])
+        self._stage_copies(slot)
         self._g1.replay()
         self._exchange_gradients()
         self._before_apply()

@@ -192,6 +192,12 @@ int pn2_group_points_grad_sorted(int b, int c, int n, int npoints, int nsample,
                                  const float *grad_out, int c_total, int channel0,
                                  const unsigned *inv, float *grad_points, void *stream);
 
+/* n device-to-device copies in one launch; table: n rows of (src, dst, bytes) as 64-bit values
+ * in device memory, max_bytes the largest row (no reference counterpart: the reference feeds
+ * each batch to the network directly, train.py:305-371 / pretrain.py:260-300; here a prefetched
+ * batch is staged into the buffers the captured graphs read) */
+int pn2_multi_copy(int n, const void *table, long long max_bytes, void *stream);
+
 /* Human-readable text for a non-zero return value (hipGetErrorString); stands in for the
  * message the reference prints before exit(-1) in CUDA_CHECK_ERRORS (cuda_utils.h:35-44). */
 const char *pn2_error_string(int code);

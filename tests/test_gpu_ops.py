@@ -831,3 +831,25 @@ def _check_aabb_nms_random(nms, oracle, s, n):
             aabb = oracle.camera_aabb(center[i], size[i], heading[i])
             want = oracle.nms3d_aabb(aabb, score[i], cls[i], 0.25, False, same)
             np.testing.assert_array_equal(got[i].astype(np.int32), want)
+
+
+def test_multi_copy_one_launch():
+    """pn2_multi_copy: many device-to-device copies from a pointer table in one launch -- sizes
+    that are no multiple of 16 bytes, a misaligned pair (byte path), an empty row."""
+    import importlib
+    L = importlib.import_module("3dioumatch_amd._lib")
+    g = torch.Generator().manual_seed(0)
+    sizes = [1, 3, 4, 17, 1000, 32768 // 4, 32768 // 4 + 5, 1234567, 0]
+    srcs = [torch.randn(max(n, 1), generator=g).to(DEV)[:n] for n in sizes]
+    dsts = [torch.full((max(n, 1),), -1.0, device=DEV)[:n] for n in sizes]
+    big_src = torch.randn(4099, generator=g).to(DEV)
+    big_dst = torch.zeros(4099, device=DEV)
+    srcs.append(big_src[1:4097])   # 4 bytes off 16-byte alignment
+    dsts.append(big_dst[2:4098])
+    rows = [[s.data_ptr(), d.data_ptr(), s.numel() * 4] for s, d in zip(srcs, dsts)]
+    table = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    L.check(L.lib.pn2_multi_copy(len(rows), table.data_ptr(), max(r[2] for r in rows),
+                                 torch.cuda.current_stream().cuda_stream), "pn2_multi_copy")
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(s, d)
+    assert float(big_dst[0]) == 0.0 and float(big_dst[1]) == 0.0 and float(big_dst[-1]) == 0.0
