@@ -39,6 +39,7 @@
 //
 // The order in which LDS atomics fill a cell is irrelevant: selection and ordering are by index.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 #include "ball_common.h"
 #include "grid_common.h"
@@ -237,7 +238,8 @@ template <int MAXH>
 struct alignas(16) WaveLds {
   float4 list[MAXH];          // records (x, y, z, index) of the hits, in arrival order
   unsigned tmp[MAXH];         // indices grouped by bucket (order inside a bucket: arrival)
-  unsigned char perm[MAXH];   // perm[rank] = list position of the hit with that rank
+  // perm[rank] = list position of the hit with that rank (a byte up to 256 hits)
+  typename std::conditional<(MAXH > 256), unsigned short, unsigned char>::type perm[MAXH];
   int cnt[kWave];             // hits per index bucket
   int off[kWave];             // exclusive prefix of cnt
 };
@@ -257,7 +259,8 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
   return v;
 }
 
-// MAXH : capacity of the hit list (<= 256; denser balls: in-launch brute force); nsample <= MAXH / 2
+// MAXH : capacity of the hit list (192 / 256 / 512; denser balls: in-launch brute force);
+//        nsample <= 64 (192), 128 (256), 256 (512)
 // WPB  : waves (= centroids in flight) per workgroup
 // GROUP: also write the grouped (b, ctot, m, ns) tensor
 // ABL  : 0 = the operator; 1 / 2 = timing ablations (no ranking / no candidate tests), used by
@@ -280,9 +283,9 @@ grid_query_kernel(int n, int m, int wg_per_cloud, unsigned wpc_recip, float radi
                   unsigned bucket_mul, const float *__restrict__ new_xyz,
                   const float *__restrict__ xyz, const int *__restrict__ start,
                   const float4 *__restrict__ rec, int *__restrict__ idx, GroupOut g) {
-  static_assert(MAXH <= 256, "perm holds list positions in a byte");
+  static_assert(MAXH <= 512, "hit list capacity");
   constexpr int TMAX = MAXH / kWave;
-  constexpr int NH = MAXH >= 4 * kWave ? 2 : 1;  // nsample <= 64 * NH
+  constexpr int NH = MAXH >= 8 * kWave ? 4 : (MAXH >= 4 * kWave ? 2 : 1);  // nsample <= 64 * NH
   constexpr int CPW = 1;
   __shared__ WaveLds<MAXH> lds[WPB];
   // 1-D grid, XCD-contiguous: cloud = id / wg_per_cloud (one division per workgroup)
@@ -443,7 +446,7 @@ grid_query_kernel(int n, int m, int wg_per_cloud, unsigned wpc_recip, float radi
             int rank = o;
 #pragma clang loop vectorize(disable) unroll(disable)
             for (int u = 0; u < sz; ++u) rank += L.tmp[o + u] < key[t] ? 1 : 0;
-            if (rank < have) L.perm[rank] = (unsigned char)(t * kWave + lane);
+            if (rank < have) L.perm[rank] = (decltype(L.perm[0] + 0))(t * kWave + lane);
           }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -494,7 +497,7 @@ grid_query_kernel(int n, int m, int wg_per_cloud, unsigned wpc_recip, float radi
 
 size_t pn2_ball_query_grid_workspace(int b, int n, int m, int nsample) {
   (void)m;
-  if (n < 4096 || n > kGridMaxPoints || nsample > 2 * kWave) return 0;
+  if (n < 4096 || n > kGridMaxPoints || nsample > 4 * kWave) return 0;
   return grid_ws_layout(nullptr, b, n).bytes;
 }
 
@@ -555,7 +558,8 @@ static int grid_run(int b, int n, int m, float radius, int nsample, const float 
   // four waves per workgroup, tools/pair_bench.py --sweep); PN2_GRID_WPB=4 selects the latter
   const char *wpb_env = getenv("PN2_GRID_WPB");
   const int wpb = wpb_env ? atoi(wpb_env) : 1;
-  if (nsample > kWave) { if (group) GRID_QUERY(256, true, 0); else GRID_QUERY(256, false, 0); }
+  if (nsample > 2 * kWave) { if (group) GRID_QUERY(512, true, 0); else GRID_QUERY(512, false, 0); }
+  else if (nsample > kWave) { if (group) GRID_QUERY(256, true, 0); else GRID_QUERY(256, false, 0); }
   else if (!group) GRID_QUERY(192, false, 0);
   else if (abl == 1) GRID_QUERY_W(192, 4, true, 1);
   else if (abl == 2) GRID_QUERY_W(192, 4, true, 2);

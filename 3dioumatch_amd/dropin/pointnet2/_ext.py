@@ -377,7 +377,7 @@ def query_and_group(new_xyz, xyz, features, radius, nsample, normalize_xyz, idx=
                                            _stream(new_xyz)), "group_concat")
         return idx, out
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
-    if grid is not None and nsample <= 128:
+    if grid is not None and nsample <= 256:
         grid.check(xyz, radius)
         with torch.cuda.device(new_xyz.device):
             _L.check(_lib.pn2_query_and_group_prebuilt(b, n, m, c, float(radius), nsample,

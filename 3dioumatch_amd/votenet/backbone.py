@@ -59,7 +59,7 @@ class Pointnet2Backbone(nn.Module):
                                                        inds).transpose(1, 2).contiguous()
             geometry["sa%d_inds" % i] = inds
             geometry["sa%d_new_xyz" % i] = new_xyz
-            if lists is not None and sa.nsample <= 128:
+            if lists is not None and sa.nsample <= 256:
                 geometry["sa%d_ball_idx" % i] = pointnet2_utils._ext.ball_query_prebuilt(
                     new_xyz, xyz, sa.radius, sa.nsample, lists)
             else:

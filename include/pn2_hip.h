@@ -145,7 +145,7 @@ int pn2_grid_build(int b, int n, float radius, const float *xyz, void *grid, siz
 
 /* pn2_ball_query on prebuilt cell lists (same radius as at build time): replaces
  * query_ball_point_kernel_wrapper (ball_query.cpp:9-11, ball_query_gpu.cu:14-59), same result;
- * nsample <= 128 */
+ * nsample <= 256 */
 int pn2_ball_query_prebuilt(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                             const float *xyz, int *idx, const void *grid, size_t grid_bytes,
                             void *stream);

@@ -645,13 +645,13 @@ def test_ballquery_cell_list_tier_edge_cases(ext, oracle_omp, synth, case):
     assert np.all(got[:, -1] == 0)
 
 
-@pytest.mark.parametrize("case", ["plain", "c0", "c12", "ns_100", "dense_hits", "negative",
-                                  "aliasing", "clumps", "ragged"])
+@pytest.mark.parametrize("case", ["plain", "c0", "c12", "ns_100", "ns_200", "ns_256_dense", "dense_hits",
+                                  "negative", "aliasing", "clumps", "ragged"])
 def test_query_and_group_fused_cell_list(ext, oracle_omp, synth, case):
     """The fused ball query + gather kernel of the cell-list tier (n >= 4096): idx, gathered
     features (bit-exact) and relative xyz against the reference composition
     (pointnet2_utils.py:335-358) done with the oracle -- with 0 / 1 / 12 feature channels (more
-    than 8 go through the channel-parallel gather), 64 < nsample <= 128, balls with > 384 hits
+    than 8 go through the channel-parallel gather), 64 < nsample <= 256, balls with more hits than the list holds
     (in-launch brute force, then the gather), the lattice seam (negative coordinates put
     centroids in cells 0 and 31), aliasing, clumps, and n / m that are not multiples of 4."""
     g = np.random.default_rng(17)
@@ -663,6 +663,10 @@ def test_query_and_group_fused_cell_list(ext, oracle_omp, synth, case):
         c = 12
     elif case == "ns_100":
         ns, r = 100, 0.3
+    elif case == "ns_200":      # 128 < nsample <= 256: the 512-entry hit list
+        ns, r = 200, 0.4
+    elif case == "ns_256_dense":  # more than 512 hits in most balls: in-launch brute force
+        ns, r = 256, 0.65
     elif case == "dense_hits":
         r = 0.6
     elif case == "negative":
