@@ -263,6 +263,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("BENCH_SHARE_GPU") == "1":
+        local_rank = 0  # every rank on cuda:0: exercises the N > 1 code path on a one-GPU box
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
