@@ -293,6 +293,20 @@ def grid_supported(b, n):
     return int(_lib.pn2_grid_bytes(int(b), int(n))) > 0
 
 
+def grid_query_variant(variant=-1, cpg=0):
+    """Tool / test hook (include/pn2_hip.h pn2_grid_query_variant): 0 = grouped query kernel with
+    `cpg` centroids per wave, 1 = the round-2 kernel.  Returns (previous variant, previous cpg)."""
+    prev = int(_lib.pn2_grid_query_variant(int(variant), int(cpg)))
+    return prev // 16, prev % 16
+
+
+def grid_query_profile(buffer):
+    """Tool hook: int64 device tensor (8 values per wave) for the stage clocks of the grouped query
+    kernel (flag bit 2 of grid_query_variant), or None to switch it off."""
+    _L.check(_lib.pn2_grid_query_profile(None if buffer is None else buffer.data_ptr()),
+             "grid_query_profile")
+
+
 def build_grid(xyz, radius):
     """CellLists of xyz (B,N,3) for `radius` (the stand-alone two-kernel build)."""
     _chk_f32(xyz, "xyz")

@@ -157,6 +157,17 @@ int pn2_query_and_group_prebuilt(int b, int n, int m, int c, float radius, int n
                                  const float *features, int *idx, float *out, const void *grid,
                                  size_t grid_bytes, void *stream);
 
+/* Tool / test hook: which kernel answers the cell-list queries.  variant 0 = the grouped kernel
+ * (a wave owns `cpg` consecutive centroids: 2, 4 or 7), variant 1 = the round-2 kernel (one wave
+ * and one workgroup per centroid); a negative variant / other cpg leaves that setting alone.
+ * Returns previous variant * 16 + previous cpg.  Both implement ball_query_gpu.cu:14-49. */
+int pn2_grid_query_variant(int variant, int cpg);
+
+/* Tool hook: device buffer (8 x uint64 per wave) that receives the stage clocks of the grouped
+ * query kernel when flag bit 2 is set through pn2_grid_query_variant (variant = flags << 4);
+ * NULL switches it off.  Instrumentation of the replacement of ball_query_gpu.cu:14-59 only. */
+int pn2_grid_query_profile(void *buffer);
+
 /* 1 if pn2_furthest_point_sampling_grid can leave cell lists behind for clouds of n points
  * (bucketed tier, 8192 <= n <= 65535); the reference's kernel has no such by-product
  * (sampling_gpu.cu:75-178) */

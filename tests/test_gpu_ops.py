@@ -704,6 +704,46 @@ def test_query_and_group_fused_cell_list(ext, oracle_omp, synth, case):
     assert torch.equal(idx2, idx)
 
 
+@pytest.mark.parametrize("variant,cpg", [(1, 0), (0, 2), (0, 4), (0, 7), (0x80, 2), (0xa0, 4)])
+def test_cell_list_query_kernel_variants(ext, oracle_omp, synth, variant, cpg):
+    """Both query kernels of the cell-list tier (the grouped kernel at 2 / 4 / 7 centroids per
+    wave, with / without the prefetched rows (flag 0x80) and streaming stores (0x20), and the
+    round-2 one-wave-per-centroid kernel behind pn2_grid_query_variant) against the
+    oracle on the shapes where their special paths trigger: ragged m (last group partly empty),
+    the lattice seam with occupied wrapped cells (negative coordinates), rows of more than 64
+    candidates and balls with more hits than the list holds (dense clump), an empty ball, nsample
+    64 / 100 / 200, and the fused gather."""
+    g = np.random.default_rng(29)
+    prev = ext.grid_query_variant(variant, cpg)
+    try:
+        for case, (n, m, r, ns) in {"ragged": (4099, 203, 0.2, 33), "seam": (6000, 301, 0.2, 64),
+                                    "clump": (6000, 300, 0.2, 64), "ns100": (6000, 150, 0.3, 100),
+                                    "ns200": (6000, 150, 0.4, 200)}.items():
+            b = 2
+            xyz = synth.cloud_uniform(b, n, 2.0, seed=61)
+            if case == "seam":
+                xyz = xyz - 1.0
+                xyz[1] *= -3.0
+            elif case == "clump":
+                xyz[0, :500] = 0.5 + g.random((500, 3), dtype=np.float32) * 0.05
+                xyz[1, :3000] = 0.7 + g.random((3000, 3), dtype=np.float32) * 0.05
+            cen = xyz[:, g.permutation(n)[:m]].copy()
+            cen[:, -1] = 1000.0                                # empty ball -> zero row
+            feats = g.standard_normal((b, 2, n)).astype(np.float32)
+            want = oracle_omp.ball_query(cen, xyz, r, ns)
+            got = ext.ball_query(dev(cen), dev(xyz), r, ns)
+            assert np.array_equal(got.cpu().numpy(), want), (case, np.argwhere(got.cpu().numpy() != want)[:5])
+            idx, out = ext.query_and_group(dev(cen), dev(xyz), dev(feats), r, ns, False)
+            assert torch.equal(idx, got), case
+            out = out.cpu().numpy()
+            assert np.array_equal(bits(out[:, 3:]), bits(oracle_omp.group_points(feats, want))), case
+            gx = oracle_omp.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), want)
+            gx = gx - cen.transpose(0, 2, 1)[..., None]
+            assert np.array_equal(bits(out[:, :3]), bits(gx.astype(np.float32))), case
+    finally:
+        ext.grid_query_variant(*prev)
+
+
 @pytest.mark.parametrize("case", ["uniform", "skipped_points", "negative", "ns_100", "small_m"])
 def test_cell_lists_from_fps_and_standalone(ext, oracle_omp, synth, case):
     """Cell lists as an object (include/pn2_hip.h pn2_grid_*): built by the two-kernel build or

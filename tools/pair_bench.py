@@ -70,12 +70,12 @@ if plain:
         api()
         fused()
         layer()
-    if "--ablate" in sys.argv:  # counter passes of the timing ablations (kernel names differ)
-        for a in ("1", "2"):
-            os.environ["PN2_GRID_ABLATE"] = a
+    if "--variants" in sys.argv:  # counter passes of the other query kernels (names differ)
+        for variant, cpg in ((1, 0), (0, 2), (0, 7)):
+            ext.grid_query_variant(variant, cpg)
             for _ in range(iters):
-                fused()
-        os.environ.pop("PN2_GRID_ABLATE")
+                layer()
+        ext.grid_query_variant(0, 4)
     torch.cuda.synchronize()
     print("pair_bench done (plain)")
 else:
@@ -85,17 +85,56 @@ else:
         us = bench.time_op(fn, iters=iters, warm=3)
         res[name + "_us"] = round(us, 2)
         res[name + "_frac_of_8TBs"] = round(bench.PAIR_BYTES / (us * 1e-6) / 8e12, 4)
-    if "--sweep" in sys.argv:  # tuning switches / timing ablations of the cell-list kernels
+    if "--stages" in sys.argv:  # per-wave stage clocks of the grouped query kernel (s_memtime)
+        stages = {}
+        names = ("descriptors", "rows_wait+tests+list", "next_loads_issue", "ranking",
+                 "slots+gather+stores_issue", "tail", "wave_total")
+        for cpg, fl in ((4, 0x40), (2, 0x40), (2, 0xc0)):
+            waves = B * ((M + 4 * cpg - 1) // (4 * cpg)) * 4
+            buf = torch.zeros(waves * 8, dtype=torch.int64, device=dev)
+            ext.grid_query_profile(buf)
+            ext.grid_query_variant(fl, cpg)
+            layer()
+            torch.cuda.synchronize()
+            ext.grid_query_variant(0, 4)
+            ext.grid_query_profile(None)
+            t = buf.view(waves, 8).cpu().double()
+            live = t[:, 6] > 0
+            t = t[live]
+            stages["cpg%d%s" % (cpg, "_nopf" if fl & 0x80 else "")] = {
+                "waves": int(live.sum()), "clock": "s_memtime ticks (shader cycles)",
+                "mean_ticks": {nm: round(float(t[:, k].mean()), 1) for k, nm in enumerate(names)},
+                "max_wave_total": float(t[:, 6].max())}
+        res["stages"] = stages
+        exp = {}
+        keep = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)  # must outlive the graph capture
+        for nm, fl in (("prof_kernel_baseline", 0x40), ("five_of_nine_row_loads", 0x50),
+                       ("nine_loads_of_one_row", 0x140)):
+            ext.grid_query_profile(keep)
+            ext.grid_query_variant(fl, 4)
+            exp[nm + "_us"] = round(bench.time_op(layer, iters=iters, warm=2), 2)
+        ext.grid_query_variant(0, 4)
+        ext.grid_query_profile(None)
+        res["timing_experiments_wrong_results"] = exp
+    if "--sweep" in sys.argv:  # kernel variants of the cell-list query (pn2_grid_query_variant)
         sweep = {}
-        for t in ("1", "4"):
-            os.environ["PN2_GRID_WPB"] = t
-            sweep["layer_wpb%s_us" % t] = round(bench.time_op(layer, iters=iters, warm=2), 2)
-        os.environ.pop("PN2_GRID_WPB")
-        for a, what in (("1", "no_ordering_network"), ("2", "no_candidate_tests")):
-            os.environ["PN2_GRID_ABLATE"] = a
-            sweep["fused_%s_us" % what] = round(bench.time_op(fused, iters=iters, warm=2), 2)
-        os.environ.pop("PN2_GRID_ABLATE")
         idx = ext.ball_query(new_xyz, xyz, R, NS)
+        def layer_nofeat():
+            ext.query_and_group(new_xyz, xyz, None, R, NS, True, None, LISTS)
+
+        for name, (variant, cpg) in (("round2_kernel", (1, 0)), ("grouped_cpg2", (0, 2)),
+                                     ("grouped_cpg4", (0, 4)), ("grouped_cpg4_nt", (0x20, 4)),
+                                     ("grouped_cpg2_nopf_8waves", (0x80, 2)),
+                                     ("grouped_cpg4_nopf_8waves", (0x80, 4)),
+                                     ("grouped_cpg2_nopf_8waves_nt", (0xa0, 2))):
+            ext.grid_query_variant(variant, cpg)
+            got_idx, got = ext.query_and_group(new_xyz, xyz, feat, R, NS, True, None, LISTS)
+            sweep[name + "_idx_equal"] = bool(torch.equal(got_idx, idx))
+            sweep[name + "_layer_us"] = round(bench.time_op(layer, iters=iters, warm=2), 2)
+            sweep[name + "_layer_nofeat_us"] = round(bench.time_op(layer_nofeat, iters=iters, warm=2), 2)
+            sweep[name + "_query_only_us"] = round(bench.time_op(
+                lambda: ext.ball_query_prebuilt(new_xyz, xyz, R, NS, LISTS), iters=iters, warm=2), 2)
+        ext.grid_query_variant(0, 4)
         sweep["ball_query_us"] = round(bench.time_op(lambda: ext.ball_query(new_xyz, xyz, R, NS), iters=iters), 2)
         sweep["group_xyz_us"] = round(bench.time_op(lambda: ext.group_points(flipped, idx), iters=iters), 2)
         sweep["group_feat_us"] = round(bench.time_op(lambda: ext.group_points(feat, idx), iters=iters), 2)
