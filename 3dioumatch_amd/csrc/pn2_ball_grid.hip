@@ -881,7 +881,8 @@ grid_query2_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side
   }
 }
 
-int g_query_variant = 1;  // 0 = grid_query2_kernel, 1 = the round-2 kernel (tools / A-B tests)
+int g_query_variant = 2;  // 0 = grouped kernel, 1 = round-2 kernel (one wave per centroid), 2 = tile
+                          // kernel where a plan exists (pn2_ball_tile.hip), else the round-2 kernel
 int g_query_cpg = 4;      // centroids per wave of grid_query2_kernel (2, 4 or 7)
 int g_query_flags = 0;    // bit 1: streaming stores;
                           // bit 2: per-wave stage clocks into g_query_prof
@@ -892,7 +893,7 @@ unsigned long long *g_query_prof = nullptr;  // 8 values per wave (tools/pair_be
 // test / tool hook: which query kernel answers (see g_query_variant); returns the previous value
 PN2_API int pn2_grid_query_variant(int variant, int cpg) {
   const int prev = g_query_variant * 16 + g_query_cpg;
-  if (variant >= 0) { g_query_variant = variant & 1; g_query_flags = variant >> 4; }
+  if (variant >= 0) { g_query_variant = variant & 3; g_query_flags = variant >> 4; }
   if (cpg == 2 || cpg == 4 || cpg == 7) g_query_cpg = cpg;
   return prev;
 }
@@ -903,10 +904,21 @@ PN2_API int pn2_grid_query_profile(void *buffer) {
   return 0;
 }
 
+// tile form (pn2_ball_tile.hip)
+size_t pn2_tile_plan_ints(int b, int m);
+int pn2_tile_plan_supported(int n, int m, int nsample);
+int pn2_tile_plan_launch(int b, int m, float radius, const float *new_xyz, int *plan, hipStream_t stream);
+int pn2_tile_query_launch(int b, int n, int m, int c_gather, int ctot, float radius, int nsample,
+                          int normalize_xyz, int flags, const float *new_xyz, const float *xyz,
+                          const float *features, int *idx, float *out, void *grid_ws,
+                          const int *plan, unsigned long long *prof, hipStream_t stream);
+
+// cell lists + (where the tile form applies) the query plan behind them
 size_t pn2_ball_query_grid_workspace(int b, int n, int m, int nsample) {
-  (void)m;
   if (n < 4096 || n > kGridMaxPoints || nsample > 4 * kWave) return 0;
-  return grid_ws_layout(nullptr, b, n).bytes;
+  size_t bytes = grid_ws_layout(nullptr, b, n).bytes;
+  if (pn2_tile_plan_supported(n, m, nsample)) bytes += sizeof(int) * pn2_tile_plan_ints(b, m);
+  return bytes;
 }
 
 size_t pn2_grid_layout_bytes(int b, int n) {
@@ -929,12 +941,16 @@ int pn2_grid_build_launch(int b, int n, float radius, const float *xyz, void *wo
 
 // Answer the queries on the cell lists in `workspace` (built here unless `prebuilt`); with
 // group != nullptr the fused kernel also writes the grouped tensor.
+// `plan`: the query plan of these centroids (tile form), or nullptr.  Self-contained calls
+// (!prebuilt) with room behind the cell lists build it themselves.
 static int grid_run(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                     const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
-                    hipStream_t stream, const GroupOut *group, bool prebuilt, int *handled) {
+                    hipStream_t stream, const GroupOut *group, bool prebuilt, const int *plan,
+                    int *handled) {
   *handled = 0;
-  const size_t need = pn2_ball_query_grid_workspace(b, n, m, nsample);
-  if (need == 0 || workspace == nullptr || workspace_bytes < need) return 0;
+  if (n < 4096 || n > kGridMaxPoints || nsample > 4 * kWave) return 0;
+  const size_t need = grid_ws_layout(nullptr, b, n).bytes;
+  if (workspace == nullptr || workspace_bytes < need) return 0;
   if (!(radius > 1e-6f) || !(radius < 1e6f)) return 0;  // also rejects NaN
   const GridWs ws = grid_ws_layout(workspace, b, n);
   const float inv_side = grid_inv_side(radius);
@@ -942,12 +958,27 @@ static int grid_run(int b, int n, int m, float radius, int nsample, const float 
     const int rc = pn2_grid_build_launch(b, n, radius, xyz, workspace, stream);
     if (rc != 0) return rc;
   }
-  const float radius2 = radius * radius;  // fp32 product, as ball_query_gpu.cu:27
   GroupOut g = {nullptr, nullptr, 0, 3, 0, 1.f};
   if (group) g = *group;
+  if (g_query_variant == 2 && pn2_tile_plan_supported(n, m, nsample)) {
+    if (plan == nullptr && !prebuilt &&
+        workspace_bytes >= need + sizeof(int) * pn2_tile_plan_ints(b, m)) {
+      int *own = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + need);
+      const int rc = pn2_tile_plan_launch(b, m, radius, new_xyz, own, stream);
+      if (rc != 0) return rc;
+      plan = own;
+    }
+    if (plan != nullptr) {
+      *handled = 1;
+      return pn2_tile_query_launch(b, n, m, g.c, g.ctot, radius, nsample, g.normalize, g_query_flags,
+                                   new_xyz, xyz, g.features, idx, g.out, workspace, plan, g_query_prof,
+                                   stream);
+    }
+  }
+  const float radius2 = radius * radius;  // fp32 product, as ball_query_gpu.cu:27
   // bucket of an index = floor(index * 64 / n), as a multiply-high
   const unsigned bucket_mul = (unsigned)(((unsigned long long)64 << 32) / (unsigned long long)n);
-  if (g_query_variant == 1) {  // the round-2 kernel: one wave and one workgroup per centroid
+  if (g_query_variant != 0) {  // the round-2 kernel: one wave and one workgroup per centroid
 #define GRID_QUERY1(MAXH, GROUP)                                                                   \
   do {                                                                                             \
     const unsigned recip = (unsigned)(((1ull << 32) + m - 1) / m);                                 \
@@ -997,9 +1028,9 @@ static int grid_run(int b, int n, int m, float radius, int nsample, const float 
 
 int pn2_ball_query_grid_try(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                             const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
-                            hipStream_t stream, int prebuilt, int *handled) {
+                            hipStream_t stream, int prebuilt, const int *plan, int *handled) {
   return grid_run(b, n, m, radius, nsample, new_xyz, xyz, idx, workspace, workspace_bytes, stream,
-                  nullptr, prebuilt != 0, handled);
+                  nullptr, prebuilt != 0, plan, handled);
 }
 
 // fused ball query + gathers of QueryAndGroup (pointnet2_utils.py:335-358) on the cell lists
@@ -1008,9 +1039,9 @@ int pn2_query_group_grid_try(int b, int n, int m, int c_gather, int ctot, float 
                              int nsample, int normalize_xyz, const float *new_xyz,
                              const float *xyz, const float *features, int *idx, float *out,
                              void *workspace, size_t workspace_bytes, hipStream_t stream,
-                             int prebuilt, int *handled) {
+                             int prebuilt, const int *plan, int *handled) {
   // torch divides by a scalar as x * (1/r)
   GroupOut g = {features, out, c_gather, ctot, normalize_xyz, 1.0f / radius};
   return grid_run(b, n, m, radius, nsample, new_xyz, xyz, idx, workspace, workspace_bytes, stream,
-                  &g, prebuilt != 0, handled);
+                  &g, prebuilt != 0, plan, handled);
 }

@@ -279,8 +279,17 @@ class CellLists(object):
     """Cell lists of one (B,N,3) cloud for ball queries of one radius (include/pn2_hip.h
     pn2_grid_*): built once, queried by ball_query / query_and_group via `grid=`."""
 
-    def __init__(self, buf, b, n, radius):
+    def __init__(self, buf, b, n, radius, plan=None, plan_m=0):
         self.buf, self.b, self.n, self.radius = buf, b, n, float(radius)
+        # query plan (include/pn2_hip.h pn2_query_plan_*): the centroids the sampling kernel
+        # picked, sorted by lattice tile -- for queries of exactly those plan_m centroids
+        self.plan, self.plan_m = plan, int(plan_m)
+
+    def plan_for(self, m, nsample):
+        """the plan, if it was made for m centroids and the tile kernel covers nsample"""
+        if self.plan is not None and self.plan_m == int(m) and int(nsample) <= 64:
+            return self.plan
+        return None
 
     def check(self, xyz, radius):
         if tuple(xyz.shape[:2]) != (self.b, self.n) or float(radius) != self.radius:
@@ -340,12 +349,31 @@ def furthest_point_sampling_with_grid(points, nsamples, radius):
         ws = torch.empty(max(need, 1), dtype=torch.uint8, device=points.device)
         gbytes = int(_lib.pn2_grid_bytes(b, n))
         gbuf = torch.empty(gbytes, dtype=torch.uint8, device=points.device)
-        _L.check(_lib.pn2_furthest_point_sampling_grid(b, n, nsamples, points.data_ptr(),
-                                                       out.data_ptr(), ws.data_ptr(), need,
-                                                       float(radius), gbuf.data_ptr(), gbytes,
-                                                       _stream(points)),
-                 "furthest_point_sampling_grid")
-    return out, CellLists(gbuf, b, n, radius)
+        pints = int(_lib.pn2_query_plan_ints(b, n, nsamples, 64))
+        plan = torch.empty(pints, dtype=torch.int32, device=points.device) if pints else None
+        _L.check(_lib.pn2_furthest_point_sampling_grid_plan(
+            b, n, nsamples, points.data_ptr(), out.data_ptr(), ws.data_ptr(), need, float(radius),
+            gbuf.data_ptr(), gbytes, None if plan is None else plan.data_ptr(), _stream(points)),
+            "furthest_point_sampling_grid")
+    return out, CellLists(gbuf, b, n, radius, plan, nsamples)
+
+
+def build_query_plan(new_xyz, xyz, radius, nsample, grid):
+    """Attach to `grid` (CellLists of xyz for radius) the query plan of the centroids new_xyz
+    (one small kernel); returns grid.  No-op where the tile kernel does not apply."""
+    _chk_f32(new_xyz, "new_xyz"); _chk_dev(new_xyz, (xyz, "xyz"))
+    grid.check(xyz, radius)
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    pints = int(_lib.pn2_query_plan_ints(b, n, m, int(nsample)))
+    if pints:
+        plan = torch.empty(pints, dtype=torch.int32, device=new_xyz.device)
+        with torch.cuda.device(new_xyz.device):
+            _L.check(_lib.pn2_query_plan_build(b, n, m, float(radius), int(nsample),
+                                               new_xyz.data_ptr(), plan.data_ptr(),
+                                               _stream(new_xyz)), "query_plan_build")
+        grid.plan, grid.plan_m = plan, m
+    return grid
 
 
 def ball_query_prebuilt(new_xyz, xyz, radius, nsample, grid):
@@ -355,6 +383,15 @@ def ball_query_prebuilt(new_xyz, xyz, radius, nsample, grid):
     b, n, _ = xyz.shape
     m = new_xyz.shape[1]
     idx = torch.empty((b, m, int(nsample)), dtype=torch.int32, device=new_xyz.device)
+    plan = grid.plan_for(m, nsample)
+    if plan is not None:
+        with torch.cuda.device(new_xyz.device):
+            _L.check(_lib.pn2_ball_query_planned(b, n, m, float(radius), int(nsample),
+                                                 new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr(),
+                                                 grid.buf.data_ptr(), grid.buf.numel(),
+                                                 plan.data_ptr(), _stream(new_xyz)),
+                     "ball_query_planned")
+        return idx
     with torch.cuda.device(new_xyz.device):
         _L.check(_lib.pn2_ball_query_prebuilt(b, n, m, float(radius), int(nsample),
                                               new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr(),
@@ -393,6 +430,17 @@ def query_and_group(new_xyz, xyz, features, radius, nsample, normalize_xyz, idx=
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
     if grid is not None and nsample <= 256:
         grid.check(xyz, radius)
+        plan = grid.plan_for(m, nsample)
+        if plan is not None:
+            with torch.cuda.device(new_xyz.device):
+                _L.check(_lib.pn2_query_and_group_planned(b, n, m, c, float(radius), nsample,
+                                                          1 if normalize_xyz else 0,
+                                                          new_xyz.data_ptr(), xyz.data_ptr(), fptr,
+                                                          idx.data_ptr(), out.data_ptr(),
+                                                          grid.buf.data_ptr(), grid.buf.numel(),
+                                                          plan.data_ptr(), _stream(new_xyz)),
+                         "query_and_group_planned")
+            return idx, out
         with torch.cuda.device(new_xyz.device):
             _L.check(_lib.pn2_query_and_group_prebuilt(b, n, m, c, float(radius), nsample,
                                                        1 if normalize_xyz else 0,

@@ -704,7 +704,7 @@ def test_query_and_group_fused_cell_list(ext, oracle_omp, synth, case):
     assert torch.equal(idx2, idx)
 
 
-@pytest.mark.parametrize("variant,cpg", [(1, 0), (0, 2), (0, 4), (0, 7), (0x80, 2), (0xa0, 4)])
+@pytest.mark.parametrize("variant,cpg", [(2, 4), (0x22, 4), (1, 0), (0, 2), (0, 4), (0, 7), (0x80, 2), (0xa0, 4)])
 def test_cell_list_query_kernel_variants(ext, oracle_omp, synth, variant, cpg):
     """Both query kernels of the cell-list tier (the grouped kernel at 2 / 4 / 7 centroids per
     wave, with / without the prefetched rows (flag 0x80) and streaming stores (0x20), and the

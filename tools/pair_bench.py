@@ -71,11 +71,11 @@ if plain:
         fused()
         layer()
     if "--variants" in sys.argv:  # counter passes of the other query kernels (names differ)
-        for variant, cpg in ((1, 0), (0, 2), (0, 7)):
+        for variant, cpg in ((1, 0), (0, 4)):
             ext.grid_query_variant(variant, cpg)
             for _ in range(iters):
                 layer()
-        ext.grid_query_variant(0, 4)
+        ext.grid_query_variant(2, 4)
     torch.cuda.synchronize()
     print("pair_bench done (plain)")
 else:
@@ -87,21 +87,44 @@ else:
         res[name + "_frac_of_8TBs"] = round(bench.PAIR_BYTES / (us * 1e-6) / 8e12, 4)
     if "--stages" in sys.argv:  # per-wave stage clocks of the grouped query kernel (s_memtime)
         stages = {}
-        names = ("descriptors", "rows_wait+tests+list", "next_loads_issue", "ranking",
-                 "slots+gather+stores_issue", "tail", "wave_total")
-        for cpg, fl in ((4, 0x40), (2, 0x40), (2, 0xc0)):
-            waves = B * ((M + 4 * cpg - 1) // (4 * cpg)) * 4
+        for cpg, fl in ((0, 0x42), (4, 0x40)):
+            waves = B * ((M + 4 * cpg - 1) // (4 * cpg)) * 4 if cpg else 1024 * 8
+            names = ("descriptors", "rows_wait+tests+list", "next_loads_issue", "ranking",
+                     "slots+gather+stores_issue", "tail", "wave_total")
+            if cpg == 0:
+                names = ("tile_record+cell_offsets", "halo_copy+barrier", "ranges+tests+list", "ranking",
+                         "slots+gather+stores_issue", "end_barrier", "wave_total")
             buf = torch.zeros(waves * 8, dtype=torch.int64, device=dev)
             ext.grid_query_profile(buf)
-            ext.grid_query_variant(fl, cpg)
+            ext.grid_query_variant(fl, cpg or 4)
             layer()
             torch.cuda.synchronize()
-            ext.grid_query_variant(0, 4)
+            ext.grid_query_variant(2, 4)
             ext.grid_query_profile(None)
             t = buf.view(waves, 8).cpu().double()
+            if cpg == 0:  # waves 0 and 7 of every workgroup separately
+                raw = buf.view(waves, 8)[:, 7].cpu()
+                tiles, cen, gen = raw & 0xffff, (raw >> 16) & 0xffff, (raw >> 32) & 0xffff
+                tot = t[:, 6]
+                wg_tot = tot.view(-1, 8).max(dim=1).values
+                wg_cen = cen.view(-1, 8).sum(dim=1)
+                wg_gen = gen.view(-1, 8).sum(dim=1)
+                wg_tiles = tiles.view(-1, 8)[:, 0]
+                order_ = torch.argsort(wg_tot)
+                pick = [int(order_[int(q * (len(order_) - 1))]) for q in (0.0, 0.25, 0.5, 0.75, 0.9, 0.99, 1.0)]
+                stages["tile_workgroups_by_time"] = [
+                    {"quantile": q, "ticks": float(wg_tot[i]), "tiles": int(wg_tiles[i]),
+                     "centroids": int(wg_cen[i]), "general_path": int(wg_gen[i])}
+                    for q, i in zip((0.0, 0.25, 0.5, 0.75, 0.9, 0.99, 1.0), pick)]
+                stages["tile_totals"] = {"tiles": int(wg_tiles.sum()), "centroids": int(cen.sum()),
+                                         "general_path": int(gen.sum())}
+                for wv in (0, 7):
+                    tw = t[wv::8]
+                    stages["tile_wave%d" % wv] = {nm: round(float(tw[:, k].mean()), 1)
+                                                  for k, nm in enumerate(names)}
             live = t[:, 6] > 0
             t = t[live]
-            stages["cpg%d%s" % (cpg, "_nopf" if fl & 0x80 else "")] = {
+            stages[("cpg%d" % cpg) if cpg else "tile"] = {
                 "waves": int(live.sum()), "clock": "s_memtime ticks (shader cycles)",
                 "mean_ticks": {nm: round(float(t[:, k].mean()), 1) for k, nm in enumerate(names)},
                 "max_wave_total": float(t[:, 6].max())}
@@ -113,7 +136,7 @@ else:
             ext.grid_query_profile(keep)
             ext.grid_query_variant(fl, 4)
             exp[nm + "_us"] = round(bench.time_op(layer, iters=iters, warm=2), 2)
-        ext.grid_query_variant(0, 4)
+        ext.grid_query_variant(2, 4)
         ext.grid_query_profile(None)
         res["timing_experiments_wrong_results"] = exp
     if "--sweep" in sys.argv:  # kernel variants of the cell-list query (pn2_grid_query_variant)
@@ -122,7 +145,8 @@ else:
         def layer_nofeat():
             ext.query_and_group(new_xyz, xyz, None, R, NS, True, None, LISTS)
 
-        for name, (variant, cpg) in (("round2_kernel", (1, 0)), ("grouped_cpg2", (0, 2)),
+        for name, (variant, cpg) in (("tile", (2, 4)), ("tile_nt", (0x22, 4)),
+                                     ("round2_kernel", (1, 0)), ("grouped_cpg2", (0, 2)),
                                      ("grouped_cpg4", (0, 4)), ("grouped_cpg4_nt", (0x20, 4)),
                                      ("grouped_cpg2_nopf_8waves", (0x80, 2)),
                                      ("grouped_cpg4_nopf_8waves", (0x80, 4)),
@@ -134,7 +158,7 @@ else:
             sweep[name + "_layer_nofeat_us"] = round(bench.time_op(layer_nofeat, iters=iters, warm=2), 2)
             sweep[name + "_query_only_us"] = round(bench.time_op(
                 lambda: ext.ball_query_prebuilt(new_xyz, xyz, R, NS, LISTS), iters=iters, warm=2), 2)
-        ext.grid_query_variant(0, 4)
+        ext.grid_query_variant(2, 4)
         sweep["ball_query_us"] = round(bench.time_op(lambda: ext.ball_query(new_xyz, xyz, R, NS), iters=iters), 2)
         sweep["group_xyz_us"] = round(bench.time_op(lambda: ext.group_points(flipped, idx), iters=iters), 2)
         sweep["group_feat_us"] = round(bench.time_op(lambda: ext.group_points(feat, idx), iters=iters), 2)
