@@ -46,7 +46,7 @@ _SIGNATURES = {
     "pn2_grid_query_variant": [_c_int, _c_int],
     "pn2_grid_query_profile": [_vp],
     "pn2_query_plan_ints": [_c_int, _c_int, _c_int, _c_int],
-    "pn2_query_plan_build": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _vp],
+    "pn2_query_plan_build": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _sz, _vp, _vp],
     "pn2_ball_query_planned": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp, _sz, _vp, _vp],
     "pn2_query_and_group_planned": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _vp,
                                     _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp],

@@ -42,6 +42,7 @@
 #include <type_traits>
 #include "ball_common.h"
 #include "grid_common.h"
+#include "query_desc.h"
 
 namespace {
 
@@ -881,8 +882,170 @@ grid_query2_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side
   }
 }
 
-int g_query_variant = 2;  // 0 = grouped kernel, 1 = round-2 kernel (one wave per centroid), 2 = tile
-                          // kernel where a plan exists (pn2_ball_tile.hip), else the round-2 kernel
+// =================================================================================================
+// grid_query_desc_kernel -- one wave per centroid like grid_query_kernel, but on DESCRIPTORS
+// (query_desc.h): the centroid's coordinates and its nine row ranges arrive with one scalar load,
+// so the chain of dependent memory round trips per centroid -- what bounds these kernels,
+// profiles/r3_pair_* -- loses its first two links (centroid, CSR offsets); and with one feature
+// channel the gather is issued for every HIT before the ranking and rides under it instead of
+// following it.  nsample <= 64.
+template <bool GROUP>
+__global__ void __launch_bounds__(kWave)
+grid_query_desc_kernel(int n, int m, float radius2, float inv_side, int nsample,
+                       unsigned bucket_mul, int flags, const float *__restrict__ new_xyz,
+                       const float *__restrict__ xyz, const int *__restrict__ start,
+                       const float4 *__restrict__ rec, const int *__restrict__ desc_all,
+                       int *__restrict__ idx, GroupOut g) {
+  constexpr int MAXH = 192;
+  __shared__ GroupLds<MAXH, 1> L;
+  const int wg = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);  // = cloud * m + centroid
+  const int b = wg / m, j = wg - b * m;
+  const int lane = lane_id();
+  const bool nt = (flags & 2) != 0;
+  const int *d = desc_all + (size_t)wg * kDescInts;  // uniform address: scalar loads
+  const float *ctr = new_xyz + (size_t)wg * 3;
+  const float *pts = xyz + (size_t)b * n * 3;
+  const int *st = start + (size_t)b * kStartStride;
+  const float4 *cloud = rec + (size_t)b * n;
+  const size_t plane = (size_t)m * nsample;
+  int *row = idx + (size_t)wg * nsample;
+
+  const float cx = __builtin_bit_cast(float, d[0]), cy = __builtin_bit_cast(float, d[1]);
+  const float cz = __builtin_bit_cast(float, d[2]);
+  float4 q[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) q[r] = cloud[d[4 + r] + lane];  // (the record array is padded)
+  int len[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) len[r] = d[13 + r];
+  // the descriptors are trusted for speed, not for correctness: a centroid that is not the one
+  // they were made for takes the general path
+  const bool stale = __builtin_bit_cast(int, ctr[0]) != d[0] || __builtin_bit_cast(int, ctr[1]) != d[1] ||
+                     __builtin_bit_cast(int, ctr[2]) != d[2];
+  const bool slow = d[3] != 0;
+  int total = test_rows<MAXH>(L, q, len, cx, cy, cz, radius2, lane);
+  float4 rr;
+  float feat0 = 0.f;
+  bool have_feat = false;
+  if (!(stale || slow || total > MAXH || total == 0)) {
+    const int have = total < nsample ? total : nsample;
+    constexpr int TMAX = MAXH / kWave;
+    // one feature channel: fetch it for every hit now, the loads ride under the ranking
+    float fh[TMAX] = {0.f, 0.f, 0.f};
+    const bool early = GROUP && g.c == 1;
+    if (early) {
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        const int e = t * kWave + lane;
+        if (e < total)
+          fh[t] = g.features[(size_t)b * n + __builtin_bit_cast(unsigned, L.list[e].w)];
+      }
+    }
+    rank_hits<MAXH>(L, total, have, bucket_mul, lane);
+    if (early) {  // tmp is free again: feature of list entry e
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        const int e = t * kWave + lane;
+        if (e < total) L.tmp[e] = __builtin_bit_cast(unsigned, fh[t]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    const int e = L.perm[lane < have ? lane : 0];  // tail: first hit
+    rr = L.list[e];
+    if (early) { feat0 = __builtin_bit_cast(float, L.tmp[e]); have_feat = true; }
+    if (lane < nsample) put(row + lane, __builtin_bit_cast(int, rr.w), nt);
+  } else {
+    // ---- general path: every special case of a ball, from the centroid itself ------------------
+    const float gcx = ctr[0], gcy = ctr[1], gcz = ctr[2];
+    const int gx = __builtin_amdgcn_readfirstlane(cell_coord(gcx, inv_side)) & (kG - 1);
+    const int gy = __builtin_amdgcn_readfirstlane(cell_coord(gcy, inv_side));
+    const int gz = __builtin_amdgcn_readfirstlane(cell_coord(gcz, inv_side));
+    const int xa = gx > 0 ? gx - 1 : 0, xb = gx < kG - 1 ? gx + 1 : kG - 1;
+    total = 0;
+    auto scan_range = [&](int from, int to) {
+      for (int p0 = from; p0 < to; p0 += kWave) {
+        const int p = p0 + lane;
+        float4 qq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < to) qq = cloud[p];
+        const bool h = p < to && sqdist3(gcx, gcy, gcz, qq.x, qq.y, qq.z) < radius2;
+        const unsigned long long hm = __builtin_amdgcn_ballot_w64(h);
+        const int pos = total + mask_rank(hm);
+        if (h && pos < MAXH) L.list[pos] = qq;
+        total += __popcll(hm);
+      }
+    };
+#pragma unroll 1
+    for (int r = 0; r < 9; ++r) {
+      const int rowbase = (((gz + r / 3 - 1) & (kG - 1)) * kG + ((gy + r % 3 - 1) & (kG - 1))) * kG;
+      scan_range(st[rowbase + xa], st[rowbase + xb + 1]);
+      if (gx == 0 || gx == kG - 1) {
+        const int wc = rowbase + (gx == 0 ? kG - 1 : 0);
+        scan_range(st[wc], st[wc + 1]);
+      }
+    }
+    if (total > MAXH) {  // very dense ball: exact brute-force scan for this centroid
+      ball_query_wave_scan<1>(pts, n, ctr, 1, radius2, nsample, row);
+      if (GROUP) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // this wave's stores -> its loads
+        const int v = lane < nsample ? row[lane] : 0;
+        rr = make_float4(pts[v * 3 + 0], pts[v * 3 + 1], pts[v * 3 + 2], __builtin_bit_cast(float, v));
+      }
+    } else if (total > 0) {
+      const int have = total < nsample ? total : nsample;
+      rank_hits<MAXH>(L, total, have, bucket_mul, lane);
+      rr = L.list[L.perm[lane < have ? lane : 0]];
+      if (lane < nsample) row[lane] = __builtin_bit_cast(int, rr.w);
+    } else {  // no hit: the reference's zero-initialised row -> point 0 everywhere
+      if (lane < nsample) row[lane] = 0;
+      rr = make_float4(pts[0], pts[1], pts[2], 0.f);
+    }
+    if (GROUP && lane < nsample) {  // (relative to the centroid the caller passed)
+      float *ob = g.out + (size_t)b * g.ctot * plane + (size_t)j * nsample;
+      float rx = __fsub_rn(rr.x, gcx), ry = __fsub_rn(rr.y, gcy), rz = __fsub_rn(rr.z, gcz);
+      if (g.normalize) {
+        rx = __fmul_rn(rx, g.inv_radius); ry = __fmul_rn(ry, g.inv_radius); rz = __fmul_rn(rz, g.inv_radius);
+      }
+      ob[lane] = rx;
+      ob[plane + lane] = ry;
+      ob[2 * plane + lane] = rz;
+      const unsigned v = __builtin_bit_cast(unsigned, rr.w);
+      for (int l = 0; l < g.c; ++l)
+        ob[(size_t)(3 + l) * plane + lane] = g.features[((size_t)b * g.c + l) * n + v];
+    }
+    return;
+  }
+  if (GROUP && lane < nsample) {
+    float *ob = g.out + (size_t)b * g.ctot * plane + (size_t)j * nsample;
+    float rx = __fsub_rn(rr.x, cx), ry = __fsub_rn(rr.y, cy), rz = __fsub_rn(rr.z, cz);
+    if (g.normalize) {
+      rx = __fmul_rn(rx, g.inv_radius); ry = __fmul_rn(ry, g.inv_radius); rz = __fmul_rn(rz, g.inv_radius);
+    }
+    put(ob + lane, rx, nt);
+    put(ob + plane + lane, ry, nt);
+    put(ob + 2 * plane + lane, rz, nt);
+    const unsigned v = __builtin_bit_cast(unsigned, rr.w);
+    if (have_feat) {
+      put(ob + 3 * plane + lane, feat0, nt);
+    } else {
+      for (int l = 0; l < g.c; ++l)
+        put(ob + (size_t)(3 + l) * plane + lane, g.features[((size_t)b * g.c + l) * n + v], nt);
+    }
+  }
+}
+
+// descriptors of arbitrary centroids (query_desc.h); one workgroup per cloud
+__global__ void __launch_bounds__(kDescThreads)
+grid_desc_kernel(int m, float inv_side, const float *__restrict__ new_xyz,
+                 const int *__restrict__ start, int *__restrict__ desc) {
+  const float *c = new_xyz + (size_t)blockIdx.x * m * 3;
+  desc_build(m, inv_side,
+             [&](int j, float &x, float &y, float &z) { x = c[j * 3]; y = c[j * 3 + 1]; z = c[j * 3 + 2]; },
+             start + (size_t)blockIdx.x * kStartStride, desc + (size_t)blockIdx.x * m * kDescInts);
+}
+
+int g_query_variant = 2;  // 0 = grouped kernel, 1 = round-2 kernel (one wave per centroid), 2 = the
+                          // descriptor kernel where descriptors exist, else the round-2 kernel
 int g_query_cpg = 4;      // centroids per wave of grid_query2_kernel (2, 4 or 7)
 int g_query_flags = 0;    // bit 1: streaming stores;
                           // bit 2: per-wave stage clocks into g_query_prof
@@ -904,21 +1067,26 @@ PN2_API int pn2_grid_query_profile(void *buffer) {
   return 0;
 }
 
-// tile form (pn2_ball_tile.hip)
-size_t pn2_tile_plan_ints(int b, int m);
-int pn2_tile_plan_supported(int n, int m, int nsample);
-int pn2_tile_plan_launch(int b, int m, float radius, const float *new_xyz, int *plan, hipStream_t stream);
-int pn2_tile_query_launch(int b, int n, int m, int c_gather, int ctot, float radius, int nsample,
-                          int normalize_xyz, int flags, const float *new_xyz, const float *xyz,
-                          const float *features, int *idx, float *out, void *grid_ws,
-                          const int *plan, unsigned long long *prof, hipStream_t stream);
+// ints of the descriptors of b x m centroids (0: the descriptor kernel does not cover the shape)
+size_t pn2_query_desc_ints(int b, int n, int m, int nsample) {
+  if (n < 4096 || n > kGridMaxPoints || m < 1 || nsample < 1 || nsample > kWave ||
+      (long long)b * m >= (1ll << 30))
+    return 0;
+  return (size_t)b * m * kDescInts;
+}
 
-// cell lists + (where the tile form applies) the query plan behind them
+int pn2_query_desc_launch(int b, int n, int m, float radius, const float *new_xyz,
+                          const void *grid_ws, int *desc, hipStream_t stream) {
+  const GridWs ws = grid_ws_layout(const_cast<void *>(grid_ws), b, n);
+  hipLaunchKernelGGL(grid_desc_kernel, dim3(b), dim3(kDescThreads), 0, stream, m,
+                     grid_inv_side(radius), new_xyz, ws.start, desc);
+  return pn2_launch_status();
+}
+
 size_t pn2_ball_query_grid_workspace(int b, int n, int m, int nsample) {
+  (void)m;
   if (n < 4096 || n > kGridMaxPoints || nsample > 4 * kWave) return 0;
-  size_t bytes = grid_ws_layout(nullptr, b, n).bytes;
-  if (pn2_tile_plan_supported(n, m, nsample)) bytes += sizeof(int) * pn2_tile_plan_ints(b, m);
-  return bytes;
+  return grid_ws_layout(nullptr, b, n).bytes;
 }
 
 size_t pn2_grid_layout_bytes(int b, int n) {
@@ -941,8 +1109,7 @@ int pn2_grid_build_launch(int b, int n, float radius, const float *xyz, void *wo
 
 // Answer the queries on the cell lists in `workspace` (built here unless `prebuilt`); with
 // group != nullptr the fused kernel also writes the grouped tensor.
-// `plan`: the query plan of these centroids (tile form), or nullptr.  Self-contained calls
-// (!prebuilt) with room behind the cell lists build it themselves.
+// `plan`: the descriptors of these centroids (query_desc.h), or nullptr.
 static int grid_run(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                     const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
                     hipStream_t stream, const GroupOut *group, bool prebuilt, const int *plan,
@@ -960,24 +1127,21 @@ static int grid_run(int b, int n, int m, float radius, int nsample, const float 
   }
   GroupOut g = {nullptr, nullptr, 0, 3, 0, 1.f};
   if (group) g = *group;
-  if (g_query_variant == 2 && pn2_tile_plan_supported(n, m, nsample)) {
-    if (plan == nullptr && !prebuilt &&
-        workspace_bytes >= need + sizeof(int) * pn2_tile_plan_ints(b, m)) {
-      int *own = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + need);
-      const int rc = pn2_tile_plan_launch(b, m, radius, new_xyz, own, stream);
-      if (rc != 0) return rc;
-      plan = own;
-    }
-    if (plan != nullptr) {
-      *handled = 1;
-      return pn2_tile_query_launch(b, n, m, g.c, g.ctot, radius, nsample, g.normalize, g_query_flags,
-                                   new_xyz, xyz, g.features, idx, g.out, workspace, plan, g_query_prof,
-                                   stream);
-    }
-  }
   const float radius2 = radius * radius;  // fp32 product, as ball_query_gpu.cu:27
   // bucket of an index = floor(index * 64 / n), as a multiply-high
   const unsigned bucket_mul = (unsigned)(((unsigned long long)64 << 32) / (unsigned long long)n);
+  if (g_query_variant == 2 && plan != nullptr && pn2_query_desc_ints(b, n, m, nsample) != 0) {
+    if (group)
+      hipLaunchKernelGGL(grid_query_desc_kernel<true>, dim3(m * b), dim3(kWave), 0, stream, n, m,
+                         radius2, inv_side, nsample, bucket_mul, g_query_flags, new_xyz, xyz, ws.start,
+                         ws.rec, plan, idx, g);
+    else
+      hipLaunchKernelGGL(grid_query_desc_kernel<false>, dim3(m * b), dim3(kWave), 0, stream, n, m,
+                         radius2, inv_side, nsample, bucket_mul, g_query_flags, new_xyz, xyz, ws.start,
+                         ws.rec, plan, idx, g);
+    *handled = 1;
+    return pn2_launch_status();
+  }
   if (g_query_variant != 0) {  // the round-2 kernel: one wave and one workgroup per centroid
 #define GRID_QUERY1(MAXH, GROUP)                                                                   \
   do {                                                                                             \

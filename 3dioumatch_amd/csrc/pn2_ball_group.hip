@@ -455,9 +455,9 @@ int pn2_query_group_grid_try(int b, int n, int m, int c_gather, int ctot, float 
                              const float *xyz, const float *features, int *idx, float *out,
                              void *workspace, size_t workspace_bytes, hipStream_t stream,
                              int prebuilt, const int *plan, int *handled);
-size_t pn2_tile_plan_ints(int b, int m);
-int pn2_tile_plan_supported(int n, int m, int nsample);
-int pn2_tile_plan_launch(int b, int m, float radius, const float *new_xyz, int *plan, hipStream_t stream);
+size_t pn2_query_desc_ints(int b, int n, int m, int nsample);
+int pn2_query_desc_launch(int b, int n, int m, float radius, const float *new_xyz,
+                          const void *grid_ws, int *desc, hipStream_t stream);
 size_t pn2_ball_query_grid_workspace(int b, int n, int m, int nsample);
 size_t pn2_grid_layout_bytes(int b, int n);
 int pn2_grid_build_launch(int b, int n, float radius, const float *xyz, void *workspace,
@@ -693,17 +693,19 @@ PN2_API int pn2_query_and_group_prebuilt(int b, int n, int m, int c, float radiu
                               idx, out, const_cast<void *>(grid), grid_bytes, 1, nullptr, stream_);
 }
 
-// ---- query plans (tile form of the cell-list query, pn2_ball_tile.hip) -------------------------
+// ---- query plans: per-centroid descriptors of the cell-list query (csrc/query_desc.h) ----------
 PN2_API size_t pn2_query_plan_ints(int b, int n, int m, int nsample) {
-  return pn2_tile_plan_supported(n, m, nsample) ? pn2_tile_plan_ints(b, m) : 0;
+  return pn2_query_desc_ints(b, n, m, nsample);
 }
 
 PN2_API int pn2_query_plan_build(int b, int n, int m, float radius, int nsample,
-                                 const float *new_xyz, int *plan, void *stream_) {
+                                 const float *new_xyz, const void *grid, size_t grid_bytes,
+                                 int *plan, void *stream_) {
   if (b <= 0) return 0;
-  if (!pn2_tile_plan_supported(n, m, nsample) || !plan || !(radius > 1e-6f) || !(radius < 1e6f))
+  if (pn2_query_desc_ints(b, n, m, nsample) == 0 || !plan || !grid ||
+      grid_bytes < pn2_grid_layout_bytes(b, n) || !(radius > 1e-6f) || !(radius < 1e6f))
     return (int)hipErrorInvalidValue;
-  return pn2_tile_plan_launch(b, m, radius, new_xyz, plan, (hipStream_t)stream_);
+  return pn2_query_desc_launch(b, n, m, radius, new_xyz, grid, plan, (hipStream_t)stream_);
 }
 
 PN2_API int pn2_ball_query_planned(int b, int n, int m, float radius, int nsample,
@@ -711,7 +713,7 @@ PN2_API int pn2_ball_query_planned(int b, int n, int m, float radius, int nsampl
                                    const void *grid, size_t grid_bytes, const int *plan,
                                    void *stream_) {
   if (b <= 0 || m <= 0 || nsample <= 0) return 0;
-  if (!plan || !pn2_tile_plan_supported(n, m, nsample)) return (int)hipErrorInvalidValue;
+  if (!plan || pn2_query_desc_ints(b, n, m, nsample) == 0) return (int)hipErrorInvalidValue;
   int handled = 0;
   const int rc = pn2_ball_query_grid_try(b, n, m, radius, nsample, new_xyz, xyz, idx,
                                          const_cast<void *>(grid), grid_bytes,
@@ -725,7 +727,7 @@ PN2_API int pn2_query_and_group_planned(int b, int n, int m, int c, float radius
                                         const float *features, int *idx, float *out,
                                         const void *grid, size_t grid_bytes, const int *plan,
                                         void *stream_) {
-  if (!plan || !pn2_tile_plan_supported(n, m, nsample)) return (int)hipErrorInvalidValue;
+  if (!plan || pn2_query_desc_ints(b, n, m, nsample) == 0) return (int)hipErrorInvalidValue;
   return query_and_group_impl(b, n, m, c, radius, nsample, normalize_xyz, new_xyz, xyz, features,
                               idx, out, const_cast<void *>(grid), grid_bytes, 1, plan, stream_);
 }

@@ -30,7 +30,7 @@
 #include "common.h"
 #include "fps_common.h"
 #include "grid_common.h"
-#include "tile_plan.h"
+#include "query_desc.h"
 
 namespace {
 
@@ -103,7 +103,7 @@ fps_bucket_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
                   float4 *__restrict__ scratch, int *__restrict__ idxs, float grid_inv_side,
                   int *__restrict__ grid_start, float4 *__restrict__ grid_rec,
                   int *__restrict__ plan) {
-  static_assert(kThreads == grid::kPlanThreads && kCells >= grid::kTiles, "plan_build's shape");
+  static_assert(kThreads == grid::kDescThreads, "desc_build's shape");
   __shared__ int cell_cnt[kCells];                 // histogram, then scatter cursors
   __shared__ float red[kWaves * 8];
   __shared__ __attribute__((aligned(16))) float slots[2][kWaves * 8];
@@ -251,18 +251,18 @@ fps_bucket_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
   if (tid == 0) out[0] = 0;
   __syncthreads();  // scratch writes of this workgroup are visible to its own waves
 
-  // By-product for the layer's ball query (pn2_ball_tile.hip): the sampled centroids sorted by
-  // lattice tile -- this workgroup has just picked them.
+  // By-product for the layer's ball query (query_desc.h): the descriptors of the sampled centroids
+  // -- this workgroup has just picked them and built the cell lists they will be looked up in.
   auto leave_plan = [&]() {
     if (plan == nullptr) return;
-    __syncthreads();  // out[] is complete (written by this workgroup's lanes)
-    grid::plan_build(m, grid_inv_side,
+    __syncthreads();  // out[] and the cell lists of this cloud are complete (written by this workgroup)
+    grid::desc_build(m, grid_inv_side,
                      [&](int j, float &x, float &y, float &z) {
                        const int k = out[j];
                        x = pts[k * 3 + 0]; y = pts[k * 3 + 1]; z = pts[k * 3 + 2];
                      },
-                     cell_cnt, reinterpret_cast<int *>(red),
-                     plan + (size_t)blockIdx.x * (4 + 3 * (size_t)m));
+                     grid_start + (size_t)blockIdx.x * grid::kStartStride,
+                     plan + (size_t)blockIdx.x * m * grid::kDescInts);
   };
   if (n_valid == 0) {  // every point skipped: the reference keeps returning index 0
     for (int j = 1 + tid; j < m; j += kThreads) out[j] = 0;

@@ -236,7 +236,6 @@ PN2_API int pn2_furthest_point_sampling_grid_plan(int b, int n, int m, const flo
                                                   void *grid, size_t grid_bytes, int *plan,
                                                   void *stream_) {
   if (b <= 0 || m <= 0) return 0;
-  if (plan != nullptr && m > 65535) return (int)hipErrorInvalidValue;
   if (!pn2_fps_grid_supported(n) || !grid || grid_bytes < pn2_grid_layout_bytes(b, n) ||
       !(grid_radius > 1e-6f) || !(grid_radius < 1e6f))
     return (int)hipErrorInvalidValue;

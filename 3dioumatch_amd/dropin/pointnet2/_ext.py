@@ -281,12 +281,12 @@ class CellLists(object):
 
     def __init__(self, buf, b, n, radius, plan=None, plan_m=0):
         self.buf, self.b, self.n, self.radius = buf, b, n, float(radius)
-        # query plan (include/pn2_hip.h pn2_query_plan_*): the centroids the sampling kernel
-        # picked, sorted by lattice tile -- for queries of exactly those plan_m centroids
+        # query plan (include/pn2_hip.h pn2_query_plan_*): descriptors of the plan_m centroids the
+        # sampling kernel picked -- for queries of exactly those centroids
         self.plan, self.plan_m = plan, int(plan_m)
 
     def plan_for(self, m, nsample):
-        """the plan, if it was made for m centroids and the tile kernel covers nsample"""
+        """the plan, if it was made for m centroids and the descriptor kernel covers nsample"""
         if self.plan is not None and self.plan_m == int(m) and int(nsample) <= 64:
             return self.plan
         return None
@@ -360,7 +360,7 @@ def furthest_point_sampling_with_grid(points, nsamples, radius):
 
 def build_query_plan(new_xyz, xyz, radius, nsample, grid):
     """Attach to `grid` (CellLists of xyz for radius) the query plan of the centroids new_xyz
-    (one small kernel); returns grid.  No-op where the tile kernel does not apply."""
+    (one small kernel); returns grid.  No-op where the descriptor kernel does not apply."""
     _chk_f32(new_xyz, "new_xyz"); _chk_dev(new_xyz, (xyz, "xyz"))
     grid.check(xyz, radius)
     b, n, _ = xyz.shape
@@ -370,7 +370,8 @@ def build_query_plan(new_xyz, xyz, radius, nsample, grid):
         plan = torch.empty(pints, dtype=torch.int32, device=new_xyz.device)
         with torch.cuda.device(new_xyz.device):
             _L.check(_lib.pn2_query_plan_build(b, n, m, float(radius), int(nsample),
-                                               new_xyz.data_ptr(), plan.data_ptr(),
+                                               new_xyz.data_ptr(), grid.buf.data_ptr(),
+                                               grid.buf.numel(), plan.data_ptr(),
                                                _stream(new_xyz)), "query_plan_build")
         grid.plan, grid.plan_m = plan, m
     return grid

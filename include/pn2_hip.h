@@ -157,23 +157,25 @@ int pn2_query_and_group_prebuilt(int b, int n, int m, int c, float radius, int n
                                  const float *features, int *idx, float *out, const void *grid,
                                  size_t grid_bytes, void *stream);
 
-/* ---- query plans: the tile form of the cell-list query (no reference counterpart; replaces the
- * per-centroid scan of ball_query_gpu.cu:24-47 by one staged neighbourhood per 2x2x2 cells) ------
- * A plan is the list of the m centroids counting-sorted by lattice tile.  With a plan the query
- * kernel stages the ~1000 candidate records around a tile in LDS once and answers all of the
- * tile's centroids from there.  nsample <= 64, 4096 <= n <= 131072, m <= 65535. */
+/* ---- query plans: per-centroid descriptors of the cell-list query (no reference counterpart;
+ * the reference's kernel reads the centroid and scans the whole cloud, ball_query_gpu.cu:24-47) --
+ * The cell-list query kernels are bound by their chain of dependent memory round trips per
+ * centroid (centroid -> CSR offsets -> candidate rows -> ... ).  A plan holds, per centroid, its
+ * coordinates and its nine row ranges (24 ints), computed where the centroids are born (the tail
+ * of the sampling kernel) or by pn2_query_plan_build: the query starts at the candidate rows.
+ * nsample <= 64, 4096 <= n <= 131072. */
 
 /* ints of a plan for b clouds of m centroids (0: shape not covered); sizing helper for the
  * replacement of query_ball_point_kernel_wrapper (ball_query.cpp:9-11) */
 size_t pn2_query_plan_ints(int b, int n, int m, int nsample);
 
-/* build the plan of new_xyz (b,m,3) for cell lists of `radius` (one small kernel); the centroid
- * argument of query_ball_point_kernel_wrapper (ball_query.cpp:9-11) */
+/* build the plan of new_xyz (b,m,3) on the cell lists `grid` of `radius` (one small kernel); the
+ * centroid argument of query_ball_point_kernel_wrapper (ball_query.cpp:9-11) */
 int pn2_query_plan_build(int b, int n, int m, float radius, int nsample, const float *new_xyz,
-                         int *plan, void *stream);
+                         const void *grid, size_t grid_bytes, int *plan, void *stream);
 
-/* pn2_ball_query_prebuilt with the plan of exactly these centroids (a stale plan is detected per
- * centroid and costs speed, not correctness): replaces query_ball_point_kernel_wrapper
+/* pn2_ball_query_prebuilt with the plan of these centroids (a centroid whose coordinates differ
+ * from its descriptor is detected and answered the general way: speed, not correctness): replaces query_ball_point_kernel_wrapper
  * (ball_query.cpp:9-11, ball_query_gpu.cu:14-59), same result */
 int pn2_ball_query_planned(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                            const float *xyz, int *idx, const void *grid, size_t grid_bytes,
@@ -195,7 +197,7 @@ int pn2_furthest_point_sampling_grid_plan(int b, int n, int m, const float *data
 
 /* Tool / test hook: which kernel answers the cell-list queries.  variant 0 = the grouped kernel
  * (a wave owns `cpg` consecutive centroids: 2, 4 or 7), variant 1 = the round-2 kernel (one wave
- * and one workgroup per centroid), variant 2 (default) = the tile kernel wherever a plan exists,
+ * and one workgroup per centroid), variant 2 (default) = the descriptor kernel wherever a plan exists,
  * else variant 1; bits 4.. of `variant` are experiment flags; a negative variant / other cpg
  * leaves that setting alone.
  * Returns previous variant * 16 + previous cpg.  Both implement ball_query_gpu.cu:14-49. */

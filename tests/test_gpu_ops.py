@@ -744,6 +744,41 @@ def test_cell_list_query_kernel_variants(ext, oracle_omp, synth, variant, cpg):
         ext.grid_query_variant(*prev)
 
 
+def test_query_plans_fresh_stale_and_standalone(ext, oracle_omp, synth):
+    """Query plans (include/pn2_hip.h pn2_query_plan_*: per-centroid descriptors).  The plan the
+    sampling kernel leaves behind answers queries of the sampled centroids; a plan built for other
+    centroids (stale) must cost speed only -- every centroid whose coordinates differ from its
+    descriptor takes the general path; a plan built by pn2_query_plan_build for arbitrary
+    centroids (seam, dense clump, empty ball) matches the oracle too."""
+    g = np.random.default_rng(31)
+    b, n, m, r, ns = 2, 9000, 500, 0.2, 48
+    xyz = synth.cloud_uniform(b, n, 2.0, seed=71) - 0.7       # occupied cells on both sides of the seam
+    xyz[0, :600] = 0.3 + g.random((600, 3), dtype=np.float32) * 0.06   # rows longer than 64, > 192 hits
+    d_xyz = dev(xyz)
+    feats = g.standard_normal((b, 1, n)).astype(np.float32)
+    inds, lists = ext.furthest_point_sampling_with_grid(d_xyz, m, r)
+    assert lists.plan is not None and lists.plan_m == m
+    new_xyz = ext.gather_points(d_xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+
+    def check(cen, grid):
+        want = oracle_omp.ball_query(cen.cpu().numpy(), xyz, r, ns)
+        got = ext.ball_query_prebuilt(cen, d_xyz, r, ns, grid)
+        assert np.array_equal(got.cpu().numpy(), want), np.argwhere(got.cpu().numpy() != want)[:5]
+        idx, out = ext.query_and_group(cen, d_xyz, dev(feats), r, ns, True, None, grid)
+        assert torch.equal(idx, got)
+        out = out.cpu().numpy()
+        assert np.array_equal(bits(out[:, 3:]), bits(oracle_omp.group_points(feats, want)))
+        gx = oracle_omp.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), want)
+        gx = (gx - cen.cpu().numpy().transpose(0, 2, 1)[..., None]) * (np.float32(1.0) / np.float32(r))
+        assert np.array_equal(bits(out[:, :3]), bits(gx.astype(np.float32)))
+
+    check(new_xyz, lists)                                      # fresh plan
+    other = dev(xyz[:, g.permutation(n)[:m]].copy())
+    other[:, -1] = 1000.0                                      # empty ball
+    check(other, lists)                                        # stale plan: same m, other centroids
+    check(other, ext.build_query_plan(other, d_xyz, r, ns, ext.build_grid(d_xyz, r)))
+
+
 @pytest.mark.parametrize("case", ["uniform", "skipped_points", "negative", "ns_100", "small_m"])
 def test_cell_lists_from_fps_and_standalone(ext, oracle_omp, synth, case):
     """Cell lists as an object (include/pn2_hip.h pn2_grid_*): built by the two-kernel build or
