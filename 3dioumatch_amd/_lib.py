@@ -43,15 +43,6 @@ _SIGNATURES = {
     "pn2_query_and_group_prebuilt": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _vp,
                                      _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "pn2_fps_grid_supported": [_c_int],
-    "pn2_grid_query_variant": [_c_int, _c_int],
-    "pn2_grid_query_profile": [_vp],
-    "pn2_query_plan_ints": [_c_int, _c_int, _c_int, _c_int],
-    "pn2_query_plan_build": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _sz, _vp, _vp],
-    "pn2_ball_query_planned": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp, _sz, _vp, _vp],
-    "pn2_query_and_group_planned": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _vp,
-                                    _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp],
-    "pn2_furthest_point_sampling_grid_plan": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _sz, _c_float,
-                                              _vp, _sz, _vp, _vp],
     "pn2_furthest_point_sampling_grid": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _sz, _c_float, _vp,
                                          _sz, _vp],
     "pn2_error_string": [_c_int],
@@ -126,7 +117,7 @@ _SIGNATURES = {
     "iou3d_nms": [_vp, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp],
     "iou3d_boxes_iou_bev_cpu": [_c_int, _vp, _c_int, _vp, _vp],
 }
-_RESTYPE = {"pn2_query_plan_ints": _sz, "pn2_ball_query_workspace_bytes": _sz, "pn2_grid_bytes": _sz, "pn2_fps_workspace_bytes": _sz, "mlp_bn_workspace_floats": _sz, "mlp_gemm_wgrad_workspace_floats": _sz, "mlp_wgrad_first4_workspace_bytes": _sz, "mlp_gemm_backward_fused_workspace_floats": _sz, "mlp_bn_finalize_pairs_scratch_bytes": _sz, "pn2_error_string": ctypes.c_char_p}
+_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_grid_bytes": _sz, "pn2_fps_workspace_bytes": _sz, "mlp_bn_workspace_floats": _sz, "mlp_gemm_wgrad_workspace_floats": _sz, "mlp_wgrad_first4_workspace_bytes": _sz, "mlp_gemm_backward_fused_workspace_floats": _sz, "mlp_bn_finalize_pairs_scratch_bytes": _sz, "pn2_error_string": ctypes.c_char_p}
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -38,8 +38,7 @@ inline GridWs grid_ws_layout(void *base, int b, int n) {
   auto take = [&](size_t bytes) { char *q = p + off; off += (bytes + 255) & ~(size_t)255; return q; };
   w.start = reinterpret_cast<int *>(take(sizeof(int) * (size_t)b * kStartStride));
   w.segoff = reinterpret_cast<int *>(take(sizeof(int) * (size_t)b * kChunks * kSegOff));
-  // + 64 records: the query kernel loads whole 64-record rows without clamping the tail
-  w.rec = reinterpret_cast<float4 *>(take(sizeof(float4) * ((size_t)b * n + kWave)));
+  w.rec = reinterpret_cast<float4 *>(take(sizeof(float4) * (size_t)b * n));
   w.seg = reinterpret_cast<float4 *>(take(sizeof(float4) * (size_t)b * kChunks * grid_chunk_points(n)));
   w.bytes = off;
   return w;

@@ -449,15 +449,12 @@ int channel_groups(int c, int per_thread) {
 
 int pn2_ball_query_grid_try(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                             const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
-                            hipStream_t stream, int prebuilt, const int *plan, int *handled);
+                            hipStream_t stream, int prebuilt, int *handled);
 int pn2_query_group_grid_try(int b, int n, int m, int c_gather, int ctot, float radius,
                              int nsample, int normalize_xyz, const float *new_xyz,
                              const float *xyz, const float *features, int *idx, float *out,
                              void *workspace, size_t workspace_bytes, hipStream_t stream,
-                             int prebuilt, const int *plan, int *handled);
-size_t pn2_query_desc_ints(int b, int n, int m, int nsample);
-int pn2_query_desc_launch(int b, int n, int m, float radius, const float *new_xyz,
-                          const void *grid_ws, int *desc, hipStream_t stream);
+                             int prebuilt, int *handled);
 size_t pn2_ball_query_grid_workspace(int b, int n, int m, int nsample);
 size_t pn2_grid_layout_bytes(int b, int n);
 int pn2_grid_build_launch(int b, int n, float radius, const float *xyz, void *workspace,
@@ -477,7 +474,7 @@ PN2_API int pn2_ball_query(int b, int n, int m, float radius, int nsample, const
   }
   int handled = 0;
   const int rc = pn2_ball_query_grid_try(b, n, m, radius, nsample, new_xyz, xyz, idx, workspace,
-                                         workspace_bytes, stream, 0, nullptr, &handled);
+                                         workspace_bytes, stream, 0, &handled);
   if (rc != 0 || handled) return rc;
 
   const float radius2 = radius * radius;  // fp32 product, as ball_query_gpu.cu:27
@@ -625,8 +622,7 @@ constexpr int kFusedGatherChannels = 8;
 static int query_and_group_impl(int b, int n, int m, int c, float radius, int nsample,
                                 int normalize_xyz, const float *new_xyz, const float *xyz,
                                 const float *features, int *idx, float *out, void *workspace,
-                                size_t workspace_bytes, int prebuilt, const int *plan,
-                                void *stream_) {
+                                size_t workspace_bytes, int prebuilt, void *stream_) {
   if (b <= 0 || m <= 0 || nsample <= 0) return 0;
   if (c > 0 && !features) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
@@ -635,7 +631,7 @@ static int query_and_group_impl(int b, int n, int m, int c, float radius, int ns
     const int cg = c <= kFusedGatherChannels ? c : 0;
     int rc = pn2_query_group_grid_try(b, n, m, cg, 3 + c, radius, nsample, normalize_xyz, new_xyz,
                                       xyz, features, idx, out, workspace, workspace_bytes, stream,
-                                      prebuilt, plan, &handled);
+                                      prebuilt, &handled);
     if (rc != 0) return rc;
     if (handled) {
       if (cg == c) return 0;
@@ -656,7 +652,7 @@ PN2_API int pn2_query_and_group(int b, int n, int m, int c, float radius, int ns
                                 const float *features, int *idx, float *out, void *workspace,
                                 size_t workspace_bytes, void *stream_) {
   return query_and_group_impl(b, n, m, c, radius, nsample, normalize_xyz, new_xyz, xyz, features,
-                              idx, out, workspace, workspace_bytes, 0, nullptr, stream_);
+                              idx, out, workspace, workspace_bytes, 0, stream_);
 }
 
 // ---- cell lists as an object: built once (by pn2_grid_build or as a by-product of
@@ -679,7 +675,7 @@ PN2_API int pn2_ball_query_prebuilt(int b, int n, int m, float radius, int nsamp
   int handled = 0;
   const int rc = pn2_ball_query_grid_try(b, n, m, radius, nsample, new_xyz, xyz, idx,
                                          const_cast<void *>(grid), grid_bytes,
-                                         (hipStream_t)stream_, 1, nullptr, &handled);
+                                         (hipStream_t)stream_, 1, &handled);
   if (rc != 0) return rc;
   return handled ? 0 : (int)hipErrorInvalidValue;
 }
@@ -690,46 +686,7 @@ PN2_API int pn2_query_and_group_prebuilt(int b, int n, int m, int c, float radiu
                                          float *out, const void *grid, size_t grid_bytes,
                                          void *stream_) {
   return query_and_group_impl(b, n, m, c, radius, nsample, normalize_xyz, new_xyz, xyz, features,
-                              idx, out, const_cast<void *>(grid), grid_bytes, 1, nullptr, stream_);
-}
-
-// ---- query plans: per-centroid descriptors of the cell-list query (csrc/query_desc.h) ----------
-PN2_API size_t pn2_query_plan_ints(int b, int n, int m, int nsample) {
-  return pn2_query_desc_ints(b, n, m, nsample);
-}
-
-PN2_API int pn2_query_plan_build(int b, int n, int m, float radius, int nsample,
-                                 const float *new_xyz, const void *grid, size_t grid_bytes,
-                                 int *plan, void *stream_) {
-  if (b <= 0) return 0;
-  if (pn2_query_desc_ints(b, n, m, nsample) == 0 || !plan || !grid ||
-      grid_bytes < pn2_grid_layout_bytes(b, n) || !(radius > 1e-6f) || !(radius < 1e6f))
-    return (int)hipErrorInvalidValue;
-  return pn2_query_desc_launch(b, n, m, radius, new_xyz, grid, plan, (hipStream_t)stream_);
-}
-
-PN2_API int pn2_ball_query_planned(int b, int n, int m, float radius, int nsample,
-                                   const float *new_xyz, const float *xyz, int *idx,
-                                   const void *grid, size_t grid_bytes, const int *plan,
-                                   void *stream_) {
-  if (b <= 0 || m <= 0 || nsample <= 0) return 0;
-  if (!plan || pn2_query_desc_ints(b, n, m, nsample) == 0) return (int)hipErrorInvalidValue;
-  int handled = 0;
-  const int rc = pn2_ball_query_grid_try(b, n, m, radius, nsample, new_xyz, xyz, idx,
-                                         const_cast<void *>(grid), grid_bytes,
-                                         (hipStream_t)stream_, 1, plan, &handled);
-  if (rc != 0) return rc;
-  return handled ? 0 : (int)hipErrorInvalidValue;
-}
-
-PN2_API int pn2_query_and_group_planned(int b, int n, int m, int c, float radius, int nsample,
-                                        int normalize_xyz, const float *new_xyz, const float *xyz,
-                                        const float *features, int *idx, float *out,
-                                        const void *grid, size_t grid_bytes, const int *plan,
-                                        void *stream_) {
-  if (!plan || pn2_query_desc_ints(b, n, m, nsample) == 0) return (int)hipErrorInvalidValue;
-  return query_and_group_impl(b, n, m, c, radius, nsample, normalize_xyz, new_xyz, xyz, features,
-                              idx, out, const_cast<void *>(grid), grid_bytes, 1, plan, stream_);
+                              idx, out, const_cast<void *>(grid), grid_bytes, 1, stream_);
 }
 
 // ---- inverse index of an index array (group_points_gpu.cu:48-69 does a same-address atomic per

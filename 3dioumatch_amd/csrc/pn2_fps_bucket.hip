@@ -30,7 +30,6 @@
 #include "common.h"
 #include "fps_common.h"
 #include "grid_common.h"
-#include "query_desc.h"
 
 namespace {
 
@@ -101,9 +100,7 @@ template <int NBW>
 __global__ void __launch_bounds__(kThreads)
 fps_bucket_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
                   float4 *__restrict__ scratch, int *__restrict__ idxs, float grid_inv_side,
-                  int *__restrict__ grid_start, float4 *__restrict__ grid_rec,
-                  int *__restrict__ plan) {
-  static_assert(kThreads == grid::kDescThreads, "desc_build's shape");
+                  int *__restrict__ grid_start, float4 *__restrict__ grid_rec) {
   __shared__ int cell_cnt[kCells];                 // histogram, then scatter cursors
   __shared__ float red[kWaves * 8];
   __shared__ __attribute__((aligned(16))) float slots[2][kWaves * 8];
@@ -251,22 +248,8 @@ fps_bucket_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
   if (tid == 0) out[0] = 0;
   __syncthreads();  // scratch writes of this workgroup are visible to its own waves
 
-  // By-product for the layer's ball query (query_desc.h): the descriptors of the sampled centroids
-  // -- this workgroup has just picked them and built the cell lists they will be looked up in.
-  auto leave_plan = [&]() {
-    if (plan == nullptr) return;
-    __syncthreads();  // out[] and the cell lists of this cloud are complete (written by this workgroup)
-    grid::desc_build(m, grid_inv_side,
-                     [&](int j, float &x, float &y, float &z) {
-                       const int k = out[j];
-                       x = pts[k * 3 + 0]; y = pts[k * 3 + 1]; z = pts[k * 3 + 2];
-                     },
-                     grid_start + (size_t)blockIdx.x * grid::kStartStride,
-                     plan + (size_t)blockIdx.x * m * grid::kDescInts);
-  };
   if (n_valid == 0) {  // every point skipped: the reference keeps returning index 0
     for (int j = 1 + tid; j < m; j += kThreads) out[j] = 0;
-    leave_plan();
     return;
   }
 
@@ -349,7 +332,6 @@ fps_bucket_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
     if (p.idx == 0) { x1 = pts[0]; y1 = pts[1]; z1 = pts[2]; } else { x1 = p.x; y1 = p.y; z1 = p.z; }
     if (tid == 0) out[j] = p.idx;
   }
-  leave_plan();
 }
 
 }  // namespace
@@ -372,7 +354,7 @@ int pn2_fps_bucket_grid_max_points() { return 65535; }
 
 int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, void *scratch,
                        size_t scratch_bytes, int *idxs, hipStream_t stream, int *handled,
-                       float grid_radius, void *grid, int *plan) {
+                       float grid_radius, void *grid) {
   *handled = 0;
   if (n > kBucketMaxPoints || scratch == nullptr) return 0;
   if (scratch_bytes < pn2_fps_bucket_scratch_bytes(b, n)) return 0;
@@ -387,12 +369,10 @@ int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, vo
     g_start = ws.start;
     g_rec = ws.rec;
     g_inv = grid::grid_inv_side(grid_radius);
-  } else if (plan != nullptr) {
-    return (int)hipErrorInvalidValue;  // a plan is for the cell lists of the same radius
   }
 #define FPS_BUCKET(T)                                                                         \
   hipLaunchKernelGGL((fps_bucket_kernel<T>), dim3(b), dim3(kThreads), 0, stream, n, m, log2bs, \
-                     dataset, sc, idxs, g_inv, g_start, g_rec, plan)
+                     dataset, sc, idxs, g_inv, g_start, g_rec)
   if (nbw <= 8) FPS_BUCKET(8);
   else if (nbw <= 16) FPS_BUCKET(16);
   else if (nbw <= 24) FPS_BUCKET(24);

@@ -145,7 +145,7 @@ int pn2_fps_bucket_grid_max_points();
 size_t pn2_grid_layout_bytes(int b, int n);
 int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, void *scratch,
                        size_t scratch_bytes, int *idxs, hipStream_t stream, int *handled,
-                       float grid_radius, void *grid, int *plan);
+                       float grid_radius, void *grid);
 
 // clouds with at least this many points use the bucketed (spatially pruned) tier when a
 // workspace is supplied; overridable for experiments with PN2_FPS_BUCKET_MIN_N
@@ -178,7 +178,7 @@ PN2_API int pn2_furthest_point_sampling_ws(int b, int n, int m, const float *dat
   if (n >= fps_bucket_min_n()) {
     int handled = 0;
     const int rc = pn2_fps_bucket_try(b, n, m, log2bs, dataset, workspace, workspace_bytes, idxs,
-                                      stream, &handled, 0.f, nullptr, nullptr);
+                                      stream, &handled, 0.f, nullptr);
     if (rc != 0 || handled) return rc;
   }
 #define FPS_REG(T, P)                                                                     \
@@ -214,27 +214,10 @@ PN2_API int pn2_fps_grid_supported(int n) {
          pn2_grid_layout_bytes(1, n) != 0;
 }
 
-// (plan: optional pn2_query_plan_ints() ints -- the sampled centroids sorted by lattice tile, for
-//  pn2_query_and_group_planned / pn2_ball_query_planned with nsample <= 64)
-PN2_API int pn2_furthest_point_sampling_grid_plan(int b, int n, int m, const float *dataset,
-                                                  int *idxs, void *workspace,
-                                                  size_t workspace_bytes, float grid_radius,
-                                                  void *grid, size_t grid_bytes, int *plan,
-                                                  void *stream_);
-
 PN2_API int pn2_furthest_point_sampling_grid(int b, int n, int m, const float *dataset, int *idxs,
                                              void *workspace, size_t workspace_bytes,
                                              float grid_radius, void *grid, size_t grid_bytes,
                                              void *stream_) {
-  return pn2_furthest_point_sampling_grid_plan(b, n, m, dataset, idxs, workspace, workspace_bytes,
-                                               grid_radius, grid, grid_bytes, nullptr, stream_);
-}
-
-PN2_API int pn2_furthest_point_sampling_grid_plan(int b, int n, int m, const float *dataset,
-                                                  int *idxs, void *workspace,
-                                                  size_t workspace_bytes, float grid_radius,
-                                                  void *grid, size_t grid_bytes, int *plan,
-                                                  void *stream_) {
   if (b <= 0 || m <= 0) return 0;
   if (!pn2_fps_grid_supported(n) || !grid || grid_bytes < pn2_grid_layout_bytes(b, n) ||
       !(grid_radius > 1e-6f) || !(grid_radius < 1e6f))
@@ -242,7 +225,7 @@ PN2_API int pn2_furthest_point_sampling_grid_plan(int b, int n, int m, const flo
   int handled = 0;
   const int rc = pn2_fps_bucket_try(b, n, m, ref_log2_block(n), dataset, workspace,
                                     workspace_bytes, idxs, (hipStream_t)stream_, &handled,
-                                    grid_radius, grid, plan);
+                                    grid_radius, grid);
   if (rc != 0) return rc;
   return handled ? 0 : (int)hipErrorInvalidValue;  // (workspace too small for the bucketed tier)
 }

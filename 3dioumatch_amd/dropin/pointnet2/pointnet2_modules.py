@@ -142,11 +142,14 @@ class PointnetSAModuleVotes(nn.Module):
             return torch.sum(feats * rbf.unsqueeze(1), -1) / float(self.nsample)
         raise ValueError("unknown pooling %r" % (self.pooling,))
 
-    def forward(self, xyz, features=None, inds=None, ball_idx=None, new_xyz=None, ball_inv=None):
+    def forward(self, xyz, features=None, inds=None, ball_idx=None, new_xyz=None, ball_inv=None,
+                grouped=None):
         """ball_idx / new_xyz / ball_inv: optional precomputed ball-query indices
         (B,npoint,nsample) int32, centroid coordinates (B,npoint,3) for the centroids `inds`, and
         the inverse index of ball_idx (_ext.group_inverse) -- all depend on coordinates only; see
-        votenet/step.py."""
+        votenet/step.py.  grouped: the layer's whole grouped tensor (B, 3+C, npoint, nsample),
+        precomputed by the fused query + gather kernel for a layer whose features are network
+        inputs (no gradient flows into them); requires inds and new_xyz."""
         if inds is not None:
             assert inds.shape[1] == self.npoint
         lists = None
@@ -161,6 +164,12 @@ class PointnetSAModuleVotes(nn.Module):
                 new_xyz, inds = _sample_centroids(xyz, self.npoint, inds)
         else:
             new_xyz = None
+        if grouped is not None:
+            if new_xyz is None or inds is None or self.pooling != 'max' or self.ret_unique_cnt or \
+                    (features is not None and features.requires_grad):
+                raise RuntimeError("a precomputed grouped tensor needs inds, new_xyz, max pooling "
+                                   "and input features without gradient")
+            return new_xyz, self.mlp_module.forward_pooled(grouped), inds
         if ball_idx is not None and isinstance(self.grouper, pointnet2_utils.QueryAndGroup):
             grouped = self.grouper(xyz, new_xyz, features, ball_idx, None, ball_inv)
         elif lists is not None:

@@ -46,9 +46,12 @@ class Pointnet2Backbone(nn.Module):
         for the NEXT batch on a side stream while the current step trains (votenet/step.py),
         which takes the strictly serial FPS rounds (a handful of busy CUs) off the critical
         path.  Returns {"sa<i>_inds", "sa<i>_ball_idx"} (int32), the centroid coordinates
-        "sa<i>_new_xyz" and the interpolation ("fp<j>_idx", "fp<j>_weight") of the two FP layers."""
+        "sa<i>_new_xyz" and the interpolation ("fp<j>_idx", "fp<j>_weight") of the two FP layers.
+        The first layer's features are network INPUTS as well, so on large clouds its whole
+        grouped tensor "sa1_grouped" (B, 3+C, npoint, nsample) comes out of the same ONE kernel
+        that answers its ball queries (the north-star pair of bench.py's roofline)."""
         from pointnet2 import pointnet2_utils
-        xyz = pointcloud[..., 0:3].contiguous()
+        xyz, in_features = self._break_up_pc(pointcloud)
         geometry = {}
         for i in range(1, 5):
             sa = getattr(self, "sa%d" % i)
@@ -59,7 +62,12 @@ class Pointnet2Backbone(nn.Module):
                                                        inds).transpose(1, 2).contiguous()
             geometry["sa%d_inds" % i] = inds
             geometry["sa%d_new_xyz" % i] = new_xyz
-            if lists is not None and sa.nsample <= 256:
+            if i == 1 and lists is not None and sa.nsample <= 256 and sa.use_xyz and \
+                    sa.pooling == 'max' and (in_features is None or in_features.shape[1] <= 8):
+                idx, grouped = pointnet2_utils._ext.query_and_group(
+                    new_xyz, xyz, in_features, sa.radius, sa.nsample, sa.normalize_xyz, None, lists)
+                geometry["sa1_ball_idx"], geometry["sa1_grouped"] = idx, grouped
+            elif lists is not None and sa.nsample <= 256:
                 geometry["sa%d_ball_idx" % i] = pointnet2_utils._ext.ball_query_prebuilt(
                     new_xyz, xyz, sa.radius, sa.nsample, lists)
             else:
@@ -88,8 +96,9 @@ class Pointnet2Backbone(nn.Module):
             ball = geometry.get("sa%d_ball_idx" % i) if geometry is not None else None
             centroids = geometry.get("sa%d_new_xyz" % i) if geometry is not None else None
             inverse = geometry.get("sa%d_ball_inv" % i) if geometry is not None else None
+            grouped = geometry.get("sa%d_grouped" % i) if geometry is not None else None
             xyz, features, inds = getattr(self, "sa%d" % i)(xyz, features, given, ball, centroids,
-                                                            inverse)
+                                                            inverse, grouped)
             end_points["sa%d_xyz" % i] = xyz
             end_points["sa%d_features" % i] = features
             if i <= 2:

@@ -157,57 +157,6 @@ int pn2_query_and_group_prebuilt(int b, int n, int m, int c, float radius, int n
                                  const float *features, int *idx, float *out, const void *grid,
                                  size_t grid_bytes, void *stream);
 
-/* ---- query plans: per-centroid descriptors of the cell-list query (no reference counterpart;
- * the reference's kernel reads the centroid and scans the whole cloud, ball_query_gpu.cu:24-47) --
- * The cell-list query kernels are bound by their chain of dependent memory round trips per
- * centroid (centroid -> CSR offsets -> candidate rows -> ... ).  A plan holds, per centroid, its
- * coordinates and its nine row ranges (24 ints), computed where the centroids are born (the tail
- * of the sampling kernel) or by pn2_query_plan_build: the query starts at the candidate rows.
- * nsample <= 64, 4096 <= n <= 131072. */
-
-/* ints of a plan for b clouds of m centroids (0: shape not covered); sizing helper for the
- * replacement of query_ball_point_kernel_wrapper (ball_query.cpp:9-11) */
-size_t pn2_query_plan_ints(int b, int n, int m, int nsample);
-
-/* build the plan of new_xyz (b,m,3) on the cell lists `grid` of `radius` (one small kernel); the
- * centroid argument of query_ball_point_kernel_wrapper (ball_query.cpp:9-11) */
-int pn2_query_plan_build(int b, int n, int m, float radius, int nsample, const float *new_xyz,
-                         const void *grid, size_t grid_bytes, int *plan, void *stream);
-
-/* pn2_ball_query_prebuilt with the plan of these centroids (a centroid whose coordinates differ
- * from its descriptor is detected and answered the general way: speed, not correctness): replaces query_ball_point_kernel_wrapper
- * (ball_query.cpp:9-11, ball_query_gpu.cu:14-59), same result */
-int pn2_ball_query_planned(int b, int n, int m, float radius, int nsample, const float *new_xyz,
-                           const float *xyz, int *idx, const void *grid, size_t grid_bytes,
-                           const int *plan, void *stream);
-
-/* pn2_query_and_group_prebuilt with a plan: ONE kernel for the ball query and the gathers of
- * QueryAndGroup.forward (pointnet2_utils.py:335-358) */
-int pn2_query_and_group_planned(int b, int n, int m, int c, float radius, int nsample,
-                                int normalize_xyz, const float *new_xyz, const float *xyz,
-                                const float *features, int *idx, float *out, const void *grid,
-                                size_t grid_bytes, const int *plan, void *stream);
-
-/* pn2_furthest_point_sampling_grid (furthest_point_sampling_kernel_wrapper, sampling.cpp:16-18)
- * that also leaves the plan of the centroids it has just picked (plan may be NULL) */
-int pn2_furthest_point_sampling_grid_plan(int b, int n, int m, const float *dataset, int *idxs,
-                                          void *workspace, size_t workspace_bytes,
-                                          float grid_radius, void *grid, size_t grid_bytes,
-                                          int *plan, void *stream);
-
-/* Tool / test hook: which kernel answers the cell-list queries.  variant 0 = the grouped kernel
- * (a wave owns `cpg` consecutive centroids: 2, 4 or 7), variant 1 = the round-2 kernel (one wave
- * and one workgroup per centroid), variant 2 (default) = the descriptor kernel wherever a plan exists,
- * else variant 1; bits 4.. of `variant` are experiment flags; a negative variant / other cpg
- * leaves that setting alone.
- * Returns previous variant * 16 + previous cpg.  Both implement ball_query_gpu.cu:14-49. */
-int pn2_grid_query_variant(int variant, int cpg);
-
-/* Tool hook: device buffer (8 x uint64 per wave) that receives the stage clocks of the grouped
- * query kernel when flag bit 2 is set through pn2_grid_query_variant (variant = flags << 4);
- * NULL switches it off.  Instrumentation of the replacement of ball_query_gpu.cu:14-59 only. */
-int pn2_grid_query_profile(void *buffer);
-
 /* 1 if pn2_furthest_point_sampling_grid can leave cell lists behind for clouds of n points
  * (bucketed tier, 8192 <= n <= 65535); the reference's kernel has no such by-product
  * (sampling_gpu.cu:75-178) */

@@ -36,9 +36,14 @@ def test_bench_default_line_has_roofline_and_cpu_baseline():
     # the pair's algorithmic bytes -- it never re-reads the index array and reads 16-byte records
     assert roof["traffic"] is None or (roof["traffic_source"] and 0 < roof["traffic"] < 2 * roof["algorithmic_bytes"])
     forms = roof["forms"]
-    assert set(forms) == {"layer", "self_contained", "reference_api_3_calls"}
+    assert set(forms) == {"layer", "self_contained", "reference_api_3_calls",
+                          "reference_api_3_calls_cached_lists"}
     assert abs(forms["layer"]["us"] - roof["duration_us"]) < 1e-6
     assert forms["layer"]["us"] < forms["self_contained"]["us"] < forms["reference_api_3_calls"]["us"]
+    # with the cloud's cell lists found in _ext's cache the three reference calls skip the build
+    assert forms["layer"]["us"] < forms["reference_api_3_calls_cached_lists"]["us"] < \
+        forms["reference_api_3_calls"]["us"]
+    assert d["time_op_eager_fallbacks"] == []
     assert d["ms_per_step_no_prefetch"] > d["ms_per_step"]
     kernels = d["kernels"]
     for name in ("fps_40000_2048", "ball_query_sa1", "group_xyz_sa1", "group_feat_sa1",

@@ -704,79 +704,50 @@ def test_query_and_group_fused_cell_list(ext, oracle_omp, synth, case):
     assert torch.equal(idx2, idx)
 
 
-@pytest.mark.parametrize("variant,cpg", [(2, 4), (0x22, 4), (1, 0), (0, 2), (0, 4), (0, 7), (0x80, 2), (0xa0, 4)])
-def test_cell_list_query_kernel_variants(ext, oracle_omp, synth, variant, cpg):
-    """Both query kernels of the cell-list tier (the grouped kernel at 2 / 4 / 7 centroids per
-    wave, with / without the prefetched rows (flag 0x80) and streaming stores (0x20), and the
-    round-2 one-wave-per-centroid kernel behind pn2_grid_query_variant) against the
-    oracle on the shapes where their special paths trigger: ragged m (last group partly empty),
-    the lattice seam with occupied wrapped cells (negative coordinates), rows of more than 64
-    candidates and balls with more hits than the list holds (dense clump), an empty ball, nsample
-    64 / 100 / 200, and the fused gather."""
-    g = np.random.default_rng(29)
-    prev = ext.grid_query_variant(variant, cpg)
-    try:
-        for case, (n, m, r, ns) in {"ragged": (4099, 203, 0.2, 33), "seam": (6000, 301, 0.2, 64),
-                                    "clump": (6000, 300, 0.2, 64), "ns100": (6000, 150, 0.3, 100),
-                                    "ns200": (6000, 150, 0.4, 200)}.items():
-            b = 2
-            xyz = synth.cloud_uniform(b, n, 2.0, seed=61)
-            if case == "seam":
-                xyz = xyz - 1.0
-                xyz[1] *= -3.0
-            elif case == "clump":
-                xyz[0, :500] = 0.5 + g.random((500, 3), dtype=np.float32) * 0.05
-                xyz[1, :3000] = 0.7 + g.random((3000, 3), dtype=np.float32) * 0.05
-            cen = xyz[:, g.permutation(n)[:m]].copy()
-            cen[:, -1] = 1000.0                                # empty ball -> zero row
-            feats = g.standard_normal((b, 2, n)).astype(np.float32)
-            want = oracle_omp.ball_query(cen, xyz, r, ns)
-            got = ext.ball_query(dev(cen), dev(xyz), r, ns)
-            assert np.array_equal(got.cpu().numpy(), want), (case, np.argwhere(got.cpu().numpy() != want)[:5])
-            idx, out = ext.query_and_group(dev(cen), dev(xyz), dev(feats), r, ns, False)
-            assert torch.equal(idx, got), case
-            out = out.cpu().numpy()
-            assert np.array_equal(bits(out[:, 3:]), bits(oracle_omp.group_points(feats, want))), case
-            gx = oracle_omp.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), want)
-            gx = gx - cen.transpose(0, 2, 1)[..., None]
-            assert np.array_equal(bits(out[:, :3]), bits(gx.astype(np.float32))), case
-    finally:
-        ext.grid_query_variant(*prev)
-
-
-def test_query_plans_fresh_stale_and_standalone(ext, oracle_omp, synth):
-    """Query plans (include/pn2_hip.h pn2_query_plan_*: per-centroid descriptors).  The plan the
-    sampling kernel leaves behind answers queries of the sampled centroids; a plan built for other
-    centroids (stale) must cost speed only -- every centroid whose coordinates differ from its
-    descriptor takes the general path; a plan built by pn2_query_plan_build for arbitrary
-    centroids (seam, dense clump, empty ball) matches the oracle too."""
-    g = np.random.default_rng(31)
-    b, n, m, r, ns = 2, 9000, 500, 0.2, 48
-    xyz = synth.cloud_uniform(b, n, 2.0, seed=71) - 0.7       # occupied cells on both sides of the seam
-    xyz[0, :600] = 0.3 + g.random((600, 3), dtype=np.float32) * 0.06   # rows longer than 64, > 192 hits
-    d_xyz = dev(xyz)
-    feats = g.standard_normal((b, 1, n)).astype(np.float32)
-    inds, lists = ext.furthest_point_sampling_with_grid(d_xyz, m, r)
-    assert lists.plan is not None and lists.plan_m == m
-    new_xyz = ext.gather_points(d_xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
-
-    def check(cen, grid):
-        want = oracle_omp.ball_query(cen.cpu().numpy(), xyz, r, ns)
-        got = ext.ball_query_prebuilt(cen, d_xyz, r, ns, grid)
-        assert np.array_equal(got.cpu().numpy(), want), np.argwhere(got.cpu().numpy() != want)[:5]
-        idx, out = ext.query_and_group(cen, d_xyz, dev(feats), r, ns, True, None, grid)
-        assert torch.equal(idx, got)
-        out = out.cpu().numpy()
-        assert np.array_equal(bits(out[:, 3:]), bits(oracle_omp.group_points(feats, want)))
-        gx = oracle_omp.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), want)
-        gx = (gx - cen.cpu().numpy().transpose(0, 2, 1)[..., None]) * (np.float32(1.0) / np.float32(r))
-        assert np.array_equal(bits(out[:, :3]), bits(gx.astype(np.float32)))
-
-    check(new_xyz, lists)                                      # fresh plan
-    other = dev(xyz[:, g.permutation(n)[:m]].copy())
-    other[:, -1] = 1000.0                                      # empty ball
-    check(other, lists)                                        # stale plan: same m, other centroids
-    check(other, ext.build_query_plan(other, d_xyz, r, ns, ext.build_grid(d_xyz, r)))
+def test_cell_list_cache_behind_the_reference_surface(ext, oracle_omp, synth):
+    """The reference's layer calls furthest_point_sampling(xyz, npoint) and then
+    ball_query(new_xyz, xyz, r, ns) on the same cloud (pointnet2_modules.py:236-250); the pybind
+    surface cannot pass cell lists between the two, so _ext keeps them per cloud tensor.  A hit
+    must be exactly what a fresh build answers, and a cloud that changed (in place, or a new tensor
+    that may reuse the address) must never hit."""
+    b, n, m, r, ns = 2, 9000, 256, 0.25, 32
+    xyz_np = synth.cloud_uniform(b, n, 2.0, seed=91)
+    xyz = dev(xyz_np)
+    stats = ext.cache_stats
+    inds = ext.furthest_point_sampling(xyz, m)
+    new_xyz = ext.gather_points(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+    h0, m0, l0 = stats["hits"], stats["misses"], stats["left_by_sampling"]
+    a = ext.ball_query(new_xyz, xyz, r, ns)                      # miss (or lists left by sampling)
+    bq = ext.ball_query(new_xyz, xyz, r, ns)                     # hit
+    assert stats["hits"] >= h0 + 1 and torch.equal(a, bq)
+    assert np.array_equal(a.cpu().numpy(), oracle_omp.ball_query(new_xyz.cpu().numpy(), xyz_np, r, ns))
+    # the radius is now known for clouds of this size: sampling a NEW cloud leaves its lists behind
+    xyz2_np = synth.cloud_uniform(b, n, 2.0, seed=92)
+    xyz2 = dev(xyz2_np)
+    inds2 = ext.furthest_point_sampling(xyz2, m)
+    assert stats["left_by_sampling"] == l0 + 1
+    assert np.array_equal(inds2.cpu().numpy(), oracle_omp.furthest_point_sampling(xyz2_np, m))
+    new2 = ext.gather_points(xyz2.transpose(1, 2).contiguous(), inds2).transpose(1, 2).contiguous()
+    h1, m1 = stats["hits"], stats["misses"]
+    c = ext.ball_query(new2, xyz2, r, ns)
+    assert stats["hits"] == h1 + 1 and stats["misses"] == m1
+    assert np.array_equal(c.cpu().numpy(), oracle_omp.ball_query(new2.cpu().numpy(), xyz2_np, r, ns))
+    # in-place change: the version moves, the stale lists must not be used
+    xyz2.mul_(0.5)
+    m2 = stats["misses"]
+    d = ext.ball_query(new2, xyz2, r, ns)
+    assert stats["misses"] == m2 + 1
+    assert np.array_equal(d.cpu().numpy(), oracle_omp.ball_query(new2.cpu().numpy(), xyz2_np * np.float32(0.5), r, ns))
+    # another radius on the same cloud: its own lists
+    e = ext.ball_query(new2, xyz2, 0.4, ns)
+    assert np.array_equal(e.cpu().numpy(), oracle_omp.ball_query(new2.cpu().numpy(), xyz2_np * np.float32(0.5), 0.4, ns))
+    # entries die with their cloud
+    key = id(xyz2)
+    assert key in ext._LISTS
+    del xyz2
+    import gc
+    gc.collect()
+    assert key not in ext._LISTS
 
 
 @pytest.mark.parametrize("case", ["uniform", "skipped_points", "negative", "ns_100", "small_m"])

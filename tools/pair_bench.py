@@ -70,12 +70,12 @@ if plain:
         api()
         fused()
         layer()
-    if "--variants" in sys.argv:  # counter passes of the other query kernels (names differ)
-        for variant, cpg in ((1, 0), (0, 4)):
-            ext.grid_query_variant(variant, cpg)
+    if "--ablate" in sys.argv:  # counter passes of the timing ablations (kernel names differ)
+        for a in ("1", "2"):
+            os.environ["PN2_GRID_ABLATE"] = a
             for _ in range(iters):
-                layer()
-        ext.grid_query_variant(2, 4)
+                fused()
+        os.environ.pop("PN2_GRID_ABLATE")
     torch.cuda.synchronize()
     print("pair_bench done (plain)")
 else:
@@ -85,80 +85,17 @@ else:
         us = bench.time_op(fn, iters=iters, warm=3)
         res[name + "_us"] = round(us, 2)
         res[name + "_frac_of_8TBs"] = round(bench.PAIR_BYTES / (us * 1e-6) / 8e12, 4)
-    if "--stages" in sys.argv:  # per-wave stage clocks of the grouped query kernel (s_memtime)
-        stages = {}
-        for cpg, fl in ((0, 0x42), (4, 0x40)):
-            waves = B * ((M + 4 * cpg - 1) // (4 * cpg)) * 4 if cpg else 1024 * 8
-            names = ("descriptors", "rows_wait+tests+list", "next_loads_issue", "ranking",
-                     "slots+gather+stores_issue", "tail", "wave_total")
-            if cpg == 0:
-                names = ("tile_record+cell_offsets", "halo_copy+barrier", "ranges+tests+list", "ranking",
-                         "slots+gather+stores_issue", "end_barrier", "wave_total")
-            buf = torch.zeros(waves * 8, dtype=torch.int64, device=dev)
-            ext.grid_query_profile(buf)
-            ext.grid_query_variant(fl, cpg or 4)
-            layer()
-            torch.cuda.synchronize()
-            ext.grid_query_variant(2, 4)
-            ext.grid_query_profile(None)
-            t = buf.view(waves, 8).cpu().double()
-            if cpg == 0:  # waves 0 and 7 of every workgroup separately
-                raw = buf.view(waves, 8)[:, 7].cpu()
-                tiles, cen, gen = raw & 0xffff, (raw >> 16) & 0xffff, (raw >> 32) & 0xffff
-                tot = t[:, 6]
-                wg_tot = tot.view(-1, 8).max(dim=1).values
-                wg_cen = cen.view(-1, 8).sum(dim=1)
-                wg_gen = gen.view(-1, 8).sum(dim=1)
-                wg_tiles = tiles.view(-1, 8)[:, 0]
-                order_ = torch.argsort(wg_tot)
-                pick = [int(order_[int(q * (len(order_) - 1))]) for q in (0.0, 0.25, 0.5, 0.75, 0.9, 0.99, 1.0)]
-                stages["tile_workgroups_by_time"] = [
-                    {"quantile": q, "ticks": float(wg_tot[i]), "tiles": int(wg_tiles[i]),
-                     "centroids": int(wg_cen[i]), "general_path": int(wg_gen[i])}
-                    for q, i in zip((0.0, 0.25, 0.5, 0.75, 0.9, 0.99, 1.0), pick)]
-                stages["tile_totals"] = {"tiles": int(wg_tiles.sum()), "centroids": int(cen.sum()),
-                                         "general_path": int(gen.sum())}
-                for wv in (0, 7):
-                    tw = t[wv::8]
-                    stages["tile_wave%d" % wv] = {nm: round(float(tw[:, k].mean()), 1)
-                                                  for k, nm in enumerate(names)}
-            live = t[:, 6] > 0
-            t = t[live]
-            stages[("cpg%d" % cpg) if cpg else "tile"] = {
-                "waves": int(live.sum()), "clock": "s_memtime ticks (shader cycles)",
-                "mean_ticks": {nm: round(float(t[:, k].mean()), 1) for k, nm in enumerate(names)},
-                "max_wave_total": float(t[:, 6].max())}
-        res["stages"] = stages
-        exp = {}
-        keep = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)  # must outlive the graph capture
-        for nm, fl in (("prof_kernel_baseline", 0x40), ("five_of_nine_row_loads", 0x50),
-                       ("nine_loads_of_one_row", 0x140)):
-            ext.grid_query_profile(keep)
-            ext.grid_query_variant(fl, 4)
-            exp[nm + "_us"] = round(bench.time_op(layer, iters=iters, warm=2), 2)
-        ext.grid_query_variant(2, 4)
-        ext.grid_query_profile(None)
-        res["timing_experiments_wrong_results"] = exp
-    if "--sweep" in sys.argv:  # kernel variants of the cell-list query (pn2_grid_query_variant)
+    if "--sweep" in sys.argv:  # tuning switches / timing ablations of the cell-list kernels
         sweep = {}
+        for t in ("1", "4"):
+            os.environ["PN2_GRID_WPB"] = t
+            sweep["layer_wpb%s_us" % t] = round(bench.time_op(layer, iters=iters, warm=2), 2)
+        os.environ.pop("PN2_GRID_WPB")
+        for a, what in (("1", "no_ordering_network"), ("2", "no_candidate_tests")):
+            os.environ["PN2_GRID_ABLATE"] = a
+            sweep["fused_%s_us" % what] = round(bench.time_op(fused, iters=iters, warm=2), 2)
+        os.environ.pop("PN2_GRID_ABLATE")
         idx = ext.ball_query(new_xyz, xyz, R, NS)
-        def layer_nofeat():
-            ext.query_and_group(new_xyz, xyz, None, R, NS, True, None, LISTS)
-
-        for name, (variant, cpg) in (("tile", (2, 4)), ("tile_nt", (0x22, 4)),
-                                     ("round2_kernel", (1, 0)), ("grouped_cpg2", (0, 2)),
-                                     ("grouped_cpg4", (0, 4)), ("grouped_cpg4_nt", (0x20, 4)),
-                                     ("grouped_cpg2_nopf_8waves", (0x80, 2)),
-                                     ("grouped_cpg4_nopf_8waves", (0x80, 4)),
-                                     ("grouped_cpg2_nopf_8waves_nt", (0xa0, 2))):
-            ext.grid_query_variant(variant, cpg)
-            got_idx, got = ext.query_and_group(new_xyz, xyz, feat, R, NS, True, None, LISTS)
-            sweep[name + "_idx_equal"] = bool(torch.equal(got_idx, idx))
-            sweep[name + "_layer_us"] = round(bench.time_op(layer, iters=iters, warm=2), 2)
-            sweep[name + "_layer_nofeat_us"] = round(bench.time_op(layer_nofeat, iters=iters, warm=2), 2)
-            sweep[name + "_query_only_us"] = round(bench.time_op(
-                lambda: ext.ball_query_prebuilt(new_xyz, xyz, R, NS, LISTS), iters=iters, warm=2), 2)
-        ext.grid_query_variant(2, 4)
         sweep["ball_query_us"] = round(bench.time_op(lambda: ext.ball_query(new_xyz, xyz, R, NS), iters=iters), 2)
         sweep["group_xyz_us"] = round(bench.time_op(lambda: ext.group_points(flipped, idx), iters=iters), 2)
         sweep["group_feat_us"] = round(bench.time_op(lambda: ext.group_points(feat, idx), iters=iters), 2)
