@@ -18,6 +18,7 @@ want torch's DistributedDataParallel around the module (the custom forward is re
 nn.Module.__call__, `model(batch, mode="jitter")`, so that DDP's hooks fire).
 """
 import os
+import weakref
 import sys
 
 import numpy as np
@@ -138,10 +139,14 @@ class SupervisedStep(object):
         self.optimizer = torch.optim.Adam([self.flat_params], lr=lr_value, weight_decay=0,
                                           capturable=on_gpu)
         self._adam_scratch = None
-        self._lr_scalar = None
+        # the learning rate the Adam kernel reads: a device scalar that never moves, refreshed
+        # from param_groups[0]["lr"] (tensor OR float) eagerly before every update, so a caller
+        # that assigns a float -- the reference's adjust_learning_rate does -- is honoured under
+        # graph replay too
+        self._lr_scalar = torch.zeros((), dtype=torch.float32, device=device) if on_gpu else None
         self._side = None
         self._captured = None  # signature the graphs were captured for
-        self._mask_cache = (None, None)
+        self._mask_cache = (None, None, None)
         self._token = 0
         self.global_step = 0
 
@@ -200,6 +205,10 @@ class SupervisedStep(object):
         for i, p in enumerate(self._params):
             n = p.numel()
             entry = state[i] if i in state else state[str(i)]
+            for k in ("exp_avg", "exp_avg_sq"):
+                if tuple(entry[k].shape) != tuple(p.shape):
+                    raise ValueError("optimizer state %d: %s has shape %s, the parameter %s"
+                                     % (i, k, tuple(entry[k].shape), tuple(p.shape)))
             st["exp_avg"][off:off + n].copy_(entry["exp_avg"].reshape(-1))
             st["exp_avg_sq"][off:off + n].copy_(entry["exp_avg_sq"].reshape(-1))
             steps.append(float(entry["step"]))
@@ -210,9 +219,16 @@ class SupervisedStep(object):
             st["step"].fill_(steps[0])
         else:
             st["step"] = steps[0]
+        saved = state_dict["param_groups"][0]
         for k in ("betas", "eps", "weight_decay", "amsgrad"):
-            if k in state_dict["param_groups"][0]:
-                self.optimizer.param_groups[0][k] = state_dict["param_groups"][0][k]
+            if k in saved:
+                self.optimizer.param_groups[0][k] = saved[k]
+        if "lr" in saved:  # torch's optimizer.load_state_dict restores the rate as well
+            cur = self.optimizer.param_groups[0]["lr"]
+            if torch.is_tensor(cur):
+                cur.fill_(float(saved["lr"]))
+            else:
+                self.optimizer.param_groups[0]["lr"] = float(saved["lr"])
 
     # ---------------------------------------------------------------- the step, eagerly
     def _forward_backward(self, batch):
@@ -239,9 +255,13 @@ class SupervisedStep(object):
                 self.flat_grad[off:off + p.numel()].copy_(p.grad.reshape(-1))
             off += p.numel()
 
+    # run the gradient collective even when world_size == 1 (a one-rank process group): lets a
+    # single-GPU box exercise RCCL's init, the all-reduce and its ordering between the graphs
+    exchange_always = False
+
     def _exchange_gradients(self):
         """Data parallelism: the mean of the per-rank gradients, one collective per step."""
-        if self.world > 1:
+        if self.world > 1 or self.exchange_always:
             torch.distributed.all_reduce(self.flat_grad)
 
     def _apply(self, teacher=None, ema_weight=None):
@@ -265,12 +285,7 @@ class SupervisedStep(object):
             st["exp_avg_sq"] = torch.zeros_like(self.flat_params.data)
         if self._adam_scratch is None:
             self._adam_scratch = torch.zeros(2, dtype=torch.float32, device=self.device)
-        lr = group["lr"]
-        if not torch.is_tensor(lr):  # a float (set by a caller): keep a device scalar in step
-            if self._lr_scalar is None:
-                self._lr_scalar = torch.zeros((), dtype=torch.float32, device=self.device)
-            self._lr_scalar.fill_(float(lr))
-            lr = self._lr_scalar
+        lr = self._lr_scalar  # refreshed by _refresh_lr() before this call (never inside a capture)
         if group.get("amsgrad") or group.get("maximize"):
             raise RuntimeError("the flat Adam step implements neither amsgrad nor maximize")
         beta1, beta2 = group["betas"]
@@ -309,9 +324,20 @@ class SupervisedStep(object):
         """Every tensor a step mutates besides the optimizer state (restored after capture)."""
         return [b for b in self.net.buffers()] + [self.flat_params.data]
 
+    def _refresh_lr(self):
+        """param_groups[0]["lr"] -> the device scalar the (possibly captured) Adam kernel reads."""
+        if self._lr_scalar is None:
+            return
+        lr = self.optimizer.param_groups[0]["lr"]
+        if torch.is_tensor(lr):
+            self._lr_scalar.copy_(lr, non_blocking=True)
+        else:
+            self._lr_scalar.fill_(float(lr))
+
     def _before_apply(self):
         """Eager host-side work between the backward graph and the update graph."""
         self.global_step += 1
+        self._refresh_lr()
 
     # ---------------------------------------------------------------- geometry prefetch
     def prefetch_geometry(self, batch):
@@ -355,16 +381,20 @@ class SupervisedStep(object):
         the labeled loss indexes, how many are labeled), so they are part of the capture
         signature.  A loader should hand over a host copy (`supervised_mask_host`, any sequence of
         0/1) next to the device tensor; otherwise the device tensor is read back -- once per
-        distinct (storage, version), so a resident mask costs one synchronisation in total."""
+        tensor object and in-place version, so a resident mask costs one synchronisation in total
+        and a fresh mask per batch one per step."""
         mask = batch.get("supervised_mask")
         if mask is None:
             return None
         host = batch.get("supervised_mask_host")
         if host is None:
-            key = (mask.data_ptr(), mask._version, tuple(mask.shape), str(mask.device))
-            if self._mask_cache[0] != key:
-                self._mask_cache = (key, tuple(int(v) for v in mask.detach().cpu().reshape(-1).tolist()))
-            host = self._mask_cache[1]
+            # the same tensor OBJECT at the same in-place version (never its address: a fresh
+            # mask per batch may land on a recycled one)
+            ref, version, cached = self._mask_cache
+            if ref is None or ref() is not mask or version != mask._version:
+                cached = tuple(int(v) for v in mask.detach().cpu().reshape(-1).tolist())
+                self._mask_cache = (weakref.ref(mask), mask._version, cached)
+            host = cached
         return tuple(int(v) != 0 for v in host)
 
     def _signature(self, batch):
@@ -396,15 +426,17 @@ class SupervisedStep(object):
 
     def _capture(self, batch, sig):
         dev = self.device
+        self._refresh_lr()  # the warm-up updates below read the device scalar
         torch.cuda.synchronize(dev)
         src = _tensor_items(batch)
         src.pop("supervised_inds", None)
         self._keys = sorted(src)
         # two staging slots (inputs + index chain of a prefetched batch) and the buffers G1 reads
-        self._slots = [{"inputs": {k: src[k].clone() for k in self._keys}, "token": -1,
+        self._slots = [{"inputs": {k: src[k].clone(memory_format=torch.contiguous_format)
+                                   for k in self._keys}, "token": -1,
                         "ready": torch.cuda.Event()} for _ in range(2)]
         self._turn = 0
-        self._cur = {k: src[k].clone() for k in self._keys}
+        self._cur = {k: src[k].clone(memory_format=torch.contiguous_format) for k in self._keys}
         # which samples are supervised is part of the captured control flow (host-side nonzero)
         host_info = self._host_info(src)
 
@@ -615,6 +647,7 @@ class SemiSupervisedStep(SupervisedStep):
 
     def _before_apply(self):
         self.global_step += 1
+        self._refresh_lr()
         a = min(1 - 1 / (self.global_step + 1), self.ema_decay)  # train.py:285-289
         self._ema_weight.fill_(1 - a)
 

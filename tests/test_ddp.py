@@ -251,6 +251,7 @@ def _gpu_graph_worker(rank, world, port, out_dir, semi):
     torch.manual_seed(100 + rank)
     single(batch(0))
     out["single_grad"] = single.flat_grad.detach().cpu().numpy().copy()
+    out["sizes"] = np.array([p.numel() for p in single._params], dtype=np.int64)
     np.savez(os.path.join(out_dir, "g%d.npz" % rank), **out)
     dist.barrier()
     dist.destroy_process_group()
@@ -281,4 +282,66 @@ def test_graph_step_two_ranks_share_one_gpu(tmp_path, semi):
     assert rel(r[0]["graph_params"], r[0]["eager_params"]) < 1e-2
     want = (r[0]["single_grad"] + r[1]["single_grad"]) / 2
     assert rel(r[0]["graph_grad"], want) < 1e-4, rel(r[0]["graph_grad"], want)
+    # ... and for EVERY parameter tensor, not only in the global norm: a wrong 1/world (or a tensor
+    # left out of the exchange) on a small tensor would be a 100 % error there and invisible above
+    worst, off, floor = 0.0, 0, 1e-4 * np.linalg.norm(want)
+    for n_el in r[0]["sizes"]:
+        g_t, w_t = r[0]["graph_grad"][off:off + n_el], want[off:off + n_el]
+        worst = max(worst, np.linalg.norm(g_t - w_t) / (np.linalg.norm(w_t) + floor))
+        off += int(n_el)
+    assert off == want.size and worst < 2e-2, worst
     assert np.isfinite(r[0]["graph_loss"]) and r[0]["graph_loss"] != r[1]["graph_loss"]
+
+
+# ------------------------------------------------------------ RCCL itself, on one GPU
+def _rccl_worker(rank, world, port, out_dir):
+    """A ONE-rank `nccl` (= RCCL) process group on cuda:0: init with device_id, the flat-gradient
+    all-reduce on RCCL's stream between the replays of the backward graph and the update graph."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    load_pkg()
+    V = importlib.import_module("3dioumatch_amd.votenet")
+    data = importlib.import_module("3dioumatch_amd.votenet.data")
+    cfg = V.scannet_config()
+    batch = lambda s: data.make_batch(2, 4096, cfg, seed=400 + s, num_objects=5, device=dev)  # noqa: E731
+    out = {}
+    for name, with_group in (("plain", False), ("rccl", True)):
+        if with_group:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        runner = V.SupervisedStep(cfg, dev, world_size=1, num_proposal=K, graphs=True)
+        runner.exchange_always = with_group
+        torch.manual_seed(7)
+        losses = []
+        for s in range(5):
+            loss, _ = runner(batch(s))
+            losses.append(float(loss))
+        assert bool(runner.graphs), "graph capture fell back to eager"
+        torch.cuda.synchronize(dev)
+        out[name + "_params"] = runner.flat_params.detach().cpu().numpy().copy()
+        out[name + "_losses"] = np.array(losses)
+    out["backend"] = np.array([ord(c) for c in dist.get_backend()])
+    np.savez(os.path.join(out_dir, "rccl.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_graph_step_with_a_one_rank_rccl_group(tmp_path):
+    """RCCL on this stack before an 8-GPU node ever sees it: process-group init, the gradient
+    all-reduce between G1 and G2 (five replays), finite losses, and -- the collective over one
+    rank being the identity -- parameters equal to the run without a process group (up to the
+    order of atomic sums: a few Adam steps of sign noise, as in the two-rank test)."""
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_rccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "rccl.npz")
+    assert "".join(chr(c) for c in r["backend"]) == "nccl"
+    assert np.all(np.isfinite(r["rccl_losses"])) and np.all(np.isfinite(r["plain_losses"]))
+    assert np.abs(r["rccl_losses"][0] - r["plain_losses"][0]) <= 1e-4 * abs(r["plain_losses"][0])
+    assert np.abs(r["rccl_params"] - r["plain_params"]).max() <= 5 * 3 * 1e-3
+    rel = np.linalg.norm(r["rccl_params"] - r["plain_params"]) / np.linalg.norm(r["plain_params"])
+    assert rel < 1e-2, rel

@@ -87,7 +87,8 @@ def test_supervised_step_matches_reference(use_gpu, tag, oracle_omp):
     for k in ("objectness_label", "object_assignment"):
         flipped |= end_points[k].cpu().numpy() != g["%s_%s" % (tag, k)]
     n_flips = int(flipped.sum())
-    assert n_flips <= (0.03 * B * K if use_gpu else 0), ("label flips", n_flips)
+    # (observed on the GPU over rounds 1-3: 0 of B*K on both datasets; one is allowed)
+    assert n_flips <= (1 if use_gpu else 0), ("label flips", n_flips)
     for k in ("center", "objectness_scores", "iou_scores"):
         want = g["%s_%s" % (tag, k)]
         got = end_points[k].detach().cpu().numpy()
@@ -296,6 +297,19 @@ def test_graph_recapture_on_shape_or_schedule_change(oracle_omp):
     assert runner._g1 is not second and bool(torch.isfinite(loss))
     moved = float((step_params(runner) - before).abs().max())
     assert 0 < moved <= 3.5e-4                      # lr 1e-4 now: far below a 1e-3 step (Adam ratio <= ~3.2)
+    # the reference's adjust_learning_rate assigns a FLOAT to param_groups (train.py / pretrain.py):
+    # honoured under replay too -- the rate the captured Adam kernel reads is refreshed every step
+    third = runner._g1
+    runner.optimizer.param_groups[0]["lr"] = 1e-5
+    before = step_params(runner)
+    loss, _ = runner(mk(B + 1, N + 512, 54))
+    assert runner._g1 is third and bool(torch.isfinite(loss))   # no re-capture for a new rate
+    moved = float((step_params(runner) - before).abs().max())
+    assert 0 < moved <= 3.5e-5
+    # a fresh supervised_mask tensor per batch is read per object, never looked up by address
+    facts = [runner._mask_facts({"supervised_mask": torch.tensor(v, device=dev)})
+             for v in ([1, 0, 1], [0, 1, 1], [1, 0, 1])]
+    assert facts[0] == (True, False, True) and facts[1] == (False, True, True) and facts[2] == facts[0]
 
 
 def step_params(runner):
