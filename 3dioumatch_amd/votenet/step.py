@@ -93,6 +93,9 @@ def _tensor_items(batch):
     return {k: v for k, v in batch.items() if torch.is_tensor(v)}
 
 
+_SIDE_STREAMS = {}  # (device type, index) -> the prefetch stream shared by all runners
+
+
 class SupervisedStep(object):
     """One optimisation step on a labeled batch (dict of tensors already on `device`).
 
@@ -349,7 +352,14 @@ class SupervisedStep(object):
             batch["geometry"] = self._compute_geometry(batch)
             return
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            # ONE side stream per device for every runner of the process: HIP maps streams onto a
+            # few hardware queues, and a third runner's fresh stream was seen to share the main
+            # stream's queue (its index chain no longer overlapped the dense kernels: 16.8 ->
+            # 27.3 ms per semi-supervised step inside bench.py's multi-workload run)
+            key = (self.device.type, self.device.index)
+            if key not in _SIDE_STREAMS:
+                _SIDE_STREAMS[key] = torch.cuda.Stream(device=self.device)
+            self._side = _SIDE_STREAMS[key]
         main = torch.cuda.current_stream(self.device)
         if self.graphs and self._ensure_captured(batch):
             slot = self._slots[self._turn]

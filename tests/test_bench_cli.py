@@ -44,6 +44,11 @@ def test_bench_default_line_has_roofline_and_cpu_baseline():
     assert forms["layer"]["us"] < forms["reference_api_3_calls_cached_lists"]["us"] < \
         forms["reference_api_3_calls"]["us"]
     assert d["time_op_eager_fallbacks"] == []
+    # BASELINE configs[2] and configs[3] ride in the same line (short passes outside the timed region)
+    for name, scenes in (("sunrgbd", 16), ("semi", 12)):
+        w = d["workloads"][name]
+        assert w["per_gpu_batch"] == scenes and w["hip_graphs"] is True and w["value"] > 0
+        assert abs(w["value"] - scenes * 1000.0 / w["ms_per_step"]) <= 0.02 * w["value"]
     assert d["ms_per_step_no_prefetch"] > d["ms_per_step"]
     kernels = d["kernels"]
     for name in ("fps_40000_2048", "ball_query_sa1", "group_xyz_sa1", "group_feat_sa1",
@@ -59,6 +64,7 @@ def test_bench_default_line_has_roofline_and_cpu_baseline():
 @pytest.mark.parametrize("workload,scenes", [("semi", 12), ("sunrgbd", 16)])
 def test_bench_other_workloads(workload, scenes):
     d = _run("--workload", workload, "--no-kernels", "--no-cpu-baseline")
+    assert "workloads" not in d
     assert REQUIRED <= set(d) and d["config"]["per_gpu_batch"] == scenes
     assert d["config"]["hip_graphs"] is True and d["value"] > 0
 
