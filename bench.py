@@ -189,6 +189,23 @@ def kernel_table(device):
     with ext.lists_cached_during_capture():
         forms["reference_api_3_calls_cached_lists"] = time_op(api)
     hbm("query_and_group_sa1_fused_kernel", forms["layer"], PAIR_BYTES)
+    # the same kernel with its inputs and outputs rotating through 12 distinct sets (12 x 26 MB >
+    # the 256 MB Infinity Cache): back-to-back replays on ONE set find their 7 MB of reads in
+    # L2 / MALL, which flatters a fraction quoted against HBM
+    sets = []
+    for q in range(12):
+        xq = torch.from_numpy(synth.cloud_uniform(B, NPTS, synth.cube_side(NPTS, 0.2, 64), seed=10 + q)).to(device)
+        iq, lq = ext.furthest_point_sampling_with_grid(xq, m1, 0.2)
+        nq = ext.gather_points(xq.transpose(1, 2).contiguous(), iq).transpose(1, 2).contiguous()
+        sets.append((nq, xq, torch.rand(B, 1, NPTS, device=device), lq))
+    keep = []
+
+    def rotating():
+        for nq, xq, fq, lq in sets:
+            keep.append(ext.query_and_group(nq, xq, fq, 0.2, ns1, True, None, lq))
+
+    forms["layer_rotating_inputs"] = time_op(rotating, iters=2, warm=1, name="pair_rotating") / len(sets)
+    del keep[:]
     g4 = torch.rand(B, 4, m1, ns1, device=device)
     hbm("group_grad_sa1_c4", time_op(lambda: ext.group_points_grad(g4, idx, NPTS)),
         4 * B * 4 * m1 * ns1 + 4 * B * m1 * ns1 + 4 * B * 4 * NPTS)

@@ -37,7 +37,9 @@ def test_bench_default_line_has_roofline_and_cpu_baseline():
     assert roof["traffic"] is None or (roof["traffic_source"] and 0 < roof["traffic"] < 2 * roof["algorithmic_bytes"])
     forms = roof["forms"]
     assert set(forms) == {"layer", "self_contained", "reference_api_3_calls",
-                          "reference_api_3_calls_cached_lists"}
+                          "reference_api_3_calls_cached_lists", "layer_rotating_inputs"}
+    # (replays on one input set find their reads in L2 / MALL; twelve rotating sets do not)
+    assert 0.8 * forms["layer"]["us"] < forms["layer_rotating_inputs"]["us"] < 2.5 * forms["layer"]["us"]
     assert abs(forms["layer"]["us"] - roof["duration_us"]) < 1e-6
     assert forms["layer"]["us"] < forms["self_contained"]["us"] < forms["reference_api_3_calls"]["us"]
     # with the cloud's cell lists found in _ext's cache the three reference calls skip the build
