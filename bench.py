@@ -399,10 +399,21 @@ def main():
             # WRITE_SIZE in separate runs, gfx950 correction of the guide applied): measured by
             # tools/pair_bench.py --plain under the profiler, NOT by this run
             traffic, source = None, None
-            pmc = os.path.join(ROOT, "profiles", "r2_pair_pmc.json")
+            pmc = os.path.join(ROOT, "profiles", "r3_pair_pmc.json")
             if os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get("traffic_bytes_fused_kernel")
-                source = "profiles/r2_pair_pmc.json (separate rocprofv3 --pmc passes)"
+                source = "profiles/r3_pair_pmc.json (separate rocprofv3 --pmc passes)"
+            # VALU utilisation of the VALU-bound operators, from the committed
+            # counter pass of tools/op_bench.py (tools/valu_util.py), not from this run
+            vu = os.path.join(ROOT, "profiles", "r3_ops_valu_util.json")
+            if os.path.exists(vu):
+                busy = {k: v["valu_busy"] for k, v in json.load(open(vu))["kernels"].items()}
+                for op_name, kern in (("iou3d_2048x512", "pair_matrix_kernel<2>"),
+                                      ("three_nn_gridconv", "three_nn_kernel"),
+                                      ("ball_query_sa2", "ball_query_bf_kernel<2>")):
+                    if op_name in table and kern in busy:
+                        table[op_name]["valu_busy"] = busy[kern]
+                        table[op_name]["valu_busy_source"] = "profiles/r3_ops_valu_util.json (%s)" % kern
             out["roofline"] = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

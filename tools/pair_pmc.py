@@ -4,7 +4,7 @@
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d W -o pair -- python tools/pair_bench.py 5 --plain
     rocprofv3 --kernel-trace --stats    --output-format csv -d S -o pair -- python tools/pair_bench.py 10 --plain
     python tools/pair_pmc.py F/pair_counter_collection.csv W/pair_counter_collection.csv \
-        S/pair_kernel_stats.csv profiles/r2_pair_pmc.json
+        S/pair_kernel_stats.csv profiles/r3_pair_pmc.json
 
 Counters are collected in their own passes (MI355X_MICROARCH.md, HBM section).  Units: the counter
 values are KiB; on gfx950 FETCH_SIZE reports HALF of the bytes of wide coalesced reads, so
@@ -20,8 +20,8 @@ PAIR_BYTES = 38516736
 KERNELS = {  # substring -> role
     "grid_split_kernel": "cell-list build, pass 1 (split by z-layer)",
     "grid_bin_kernel": "cell-list build, pass 2 (CSR rows of a layer)",
-    "grid_query_kernel<192, 1, true, 0>": "fused ball query + gathers (the dominant kernel)",
-    "grid_query_kernel<192, 1, false, 0>": "ball query only (reference operator surface)",
+    "grid_query_kernel<192, 1, true>": "fused ball query + gathers (the dominant kernel)",
+    "grid_query_kernel<192, 1, false>": "ball query only (reference operator surface)",
     "group_points_lds_kernel": "group_points (reference operator surface), two launches per pair",
 }
 
@@ -53,7 +53,7 @@ def main():
                                "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
                                "hbm_bytes_corrected": int((2 * f + w) * 1024),
                                "avg_us_under_profiler": None if d is None else round(d, 2)})
-    fused = next((k for k in out["kernels"] if "true, 0" in k["kernel"]), None)
+    fused = next((k for k in out["kernels"] if "1, true>" in k["kernel"]), None)
     if fused:
         out["traffic_bytes_fused_kernel"] = fused["hbm_bytes_corrected"]
         out["traffic_over_algorithmic"] = round(fused["hbm_bytes_corrected"] / PAIR_BYTES, 3)

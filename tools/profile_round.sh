@@ -1,0 +1,34 @@
+#!/bin/bash
+# Every rocprofv3 summary of a round, at HEAD (run on the GPU box from the repo root):
+#     bash tools/profile_round.sh r3
+# writes gpurun_out/<tag>_profiles/*, to be copied into profiles/.  Counter passes are separate
+# runs (MI355X_MICROARCH.md); every pass is bounded by `timeout`.
+TAG=${1:-r3}
+export TMPDIR=/tmp
+ROOT=$(pwd)
+O=$ROOT/gpurun_out/${TAG}_profiles; mkdir -p $O
+P=/tmp/prof_$TAG; rm -rf $P; mkdir -p $P
+run() { name=$1; shift; timeout 240 "$@" > $O/$name.log 2>&1; echo "$name rc=$?"; }
+# -- the step, timed steps only
+run step rocprofv3 --kernel-trace --stats --output-format csv -d $P/step -o step -- python bench.py --steps 20 --warmup 5 --no-kernels --no-cpu-baseline --no-workloads
+python tools/step_breakdown.py $P/step/step_kernel_trace.csv 20 400 $O/${TAG}_train_step_timed_summary.csv > $O/step_breakdown.txt 2>&1
+run semi rocprofv3 --kernel-trace --stats --output-format csv -d $P/semi -o step -- python bench.py --workload semi --steps 20 --warmup 5 --no-kernels --no-cpu-baseline
+python tools/step_breakdown.py $P/semi/step_kernel_trace.csv 20 400 $O/${TAG}_semi_step_timed_summary.csv > $O/semi_breakdown.txt 2>&1
+# -- the north-star pair
+run pair_stats rocprofv3 --kernel-trace --stats --output-format csv -d $P/pair -o pair -- python tools/pair_bench.py 10 --plain
+cp $P/pair/pair_kernel_stats.csv $O/${TAG}_pair_kernel_stats.csv
+run pair_fetch rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pf -o pair -- python tools/pair_bench.py 5 --plain
+run pair_write rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pw -o pair -- python tools/pair_bench.py 5 --plain
+python tools/pair_pmc.py $P/pf/pair_counter_collection.csv $P/pw/pair_counter_collection.csv $P/pair/pair_kernel_stats.csv $O/${TAG}_pair_pmc.json > $O/pair_pmc.txt 2>&1
+run pair_sq rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $P/psq -o pair -- python tools/pair_bench.py 3 --plain
+run pair_mem rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TD_TD_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum SQ_BUSY_CYCLES SQ_LDS_IDX_ACTIVE --output-format csv -d $P/pmem -o pair -- python tools/pair_bench.py 3 --plain
+python tools/pmc_table.py $O/${TAG}_pair_sq_counters.csv --filter grid_ $P/psq/pair_counter_collection.csv $P/pmem/pair_counter_collection.csv > /dev/null 2>&1
+# -- VALU-bound operators
+run ops_valu rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d $P/ops -o ops -- python tools/op_bench.py 3
+python tools/valu_util.py $P/ops/ops_counter_collection.csv $O/${TAG}_ops_valu_util.json > $O/ops_valu.txt 2>&1
+# -- shared-MLP GEMMs
+run gemm_util rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $P/gemm -o g -- python tools/gemm_bench.py
+python tools/mfma_util.py $P/gemm/g_counter_collection.csv $O/${TAG}_gemm_mfma_util.csv > /dev/null 2>&1
+run bwd_util rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $P/bwd -o g -- python tools/bwd_bench.py
+python tools/mfma_util.py $P/bwd/g_counter_collection.csv $O/${TAG}_bwd_mfma_util.csv > /dev/null 2>&1
+ls -la $O | head -40
