@@ -25,6 +25,7 @@ _SIGNATURES = {
     "pn2_three_nn": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "pn2_three_interpolate": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "pn2_three_interpolate_grad": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "pn2_three_nn_weights": [ctypes.c_longlong, _vp, _vp, _vp],
     "pn2_multi_copy": [_c_int, _vp, ctypes.c_longlong, _vp],
     "pn2_group_inverse_supported": [_c_int, _c_int, _c_int],
     "pn2_group_inverse_entries": [_c_int, _c_int],
@@ -106,6 +107,7 @@ _SIGNATURES = {
     "votenet_loss_decode": [_vp, _vp],
     "votenet_loss_forward_backward": [_vp, _vp],
     "votenet_loss_scratch_floats": [_vp],
+    "votenet_gridconv_points": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "votenet_channel_normalize": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
     "votenet_channel_normalize_grad": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "votenet_adam_step": [ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double,

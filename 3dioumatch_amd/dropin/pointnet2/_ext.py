@@ -241,6 +241,20 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     return out
 
 
+def three_nn_weights(dist2):
+    """dist2 (B,n,3) squared distances as returned by three_nn -> (B,n,3) normalised inverse-distance
+    weights 1 / (sqrt(d2) + 1e-8) / sum: the five tensor kernels of pointnet2_modules.py:395-398 /
+    grid_conv_module.py:94-98 (and the sqrt of pointnet2_utils.py:147) in one."""
+    _chk_f32(dist2, "dist2")
+    if not dist2.is_cuda:
+        raise RuntimeError("CPU not supported")
+    out = torch.empty_like(dist2)
+    with torch.cuda.device(dist2.device):
+        _L.check(_lib.pn2_three_nn_weights(dist2.numel() // 3, dist2.data_ptr(), out.data_ptr(),
+                                           _stream(dist2)), "three_nn_weights")
+    return out
+
+
 def group_inverse(idx, n):
     """Inverse of a grouping index array idx (B,m,ns) i32 with values < n: the positions of each
     cloud sorted by the point they refer to, packed (point << 16 | position) -> (B, entries) int32

@@ -223,9 +223,7 @@ class PointnetFPModule(nn.Module):
     def interpolation(unknown, known):
         """(idx (B,n,3) int32, weight (B,n,3)): the three nearest known points of every unknown
         point and their normalised inverse distances -- coordinates only."""
-        dist, idx = pointnet2_utils.three_nn(unknown, known)
-        recip = 1.0 / (dist + 1e-8)
-        return idx, recip / torch.sum(recip, dim=2, keepdim=True)
+        return pointnet2_utils.three_nn_with_weights(unknown, known)
 
     def forward(self, unknown, known, unknow_feats, known_feats, interpolation=None):
         if known is None:

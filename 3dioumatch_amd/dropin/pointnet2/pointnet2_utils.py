@@ -69,6 +69,21 @@ class ThreeNN(Function):
 three_nn = ThreeNN.apply
 
 
+def three_nn_with_weights(unknown, known):
+    """(idx (B,n,3) int32, weight (B,n,3)): the three nearest known points of every unknown point
+    and their normalised inverse distances 1 / (dist + 1e-8) / sum -- coordinates only, nothing
+    differentiable (pointnet2_modules.py:393-398, grid_conv_module.py:87-98).  One kernel behind
+    the search where the extension has it (the stand-in of the CPU tests has not)."""
+    fused = getattr(_ext, "three_nn_weights", None)
+    if fused is not None and unknown.is_cuda:
+        with torch.no_grad():
+            dist2, idx = _ext.three_nn(unknown.detach(), known.detach())
+            return idx, fused(dist2)
+    dist, idx = three_nn(unknown, known)
+    recip = 1.0 / (dist + 1e-8)
+    return idx, (recip / torch.sum(recip, dim=2, keepdim=True)).contiguous()
+
+
 class ThreeInterpolate(Function):
     @staticmethod
     def forward(ctx, features, idx, weight):

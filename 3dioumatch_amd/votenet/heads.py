@@ -128,6 +128,16 @@ def rot_z(t):
     return torch.stack([c, s, zero, -s, c, zero, zero, zero, one], dim=-1).view(*t.shape, 3, 3)
 
 
+def _fused_front_end():
+    """the C-ABI library when it has the GridConv front-end kernel (GPU builds), else None"""
+    import importlib
+    try:
+        _L = importlib.import_module("3dioumatch_amd._lib")
+    except Exception:  # noqa: BLE001  (CPU-only test environments without the library)
+        return None
+    return _L if hasattr(_L.lib, "votenet_gridconv_points") else None
+
+
 class GridConv(nn.Module):
     """IoU branch: a 4x4x4 grid inside each box, features interpolated from the 3 nearest
     seeds, shared MLP, max-pool, IoU head."""
@@ -154,6 +164,16 @@ class GridConv(nn.Module):
         self.bn1_iou = nn.BatchNorm1d(128)
         self.bn2_iou = nn.BatchNorm1d(128)
 
+    def _unit_grid(self, device):
+        """(64, 3) unit grid, x slowest / z fastest (grid_conv_module.py:64-75), made once per device"""
+        key = str(device)
+        cache = self.__dict__.setdefault("_unit_cache", {})
+        if key not in cache:
+            step = torch.linspace(-1, 1, self.GRID, device=device)
+            cache[key] = torch.stack(torch.meshgrid(step, step, step, indexing='ij'),
+                                     dim=-1).view(self.GRID ** 3, 3).contiguous()
+        return cache[key]
+
     def _origin(self, end_points):
         if self.query_feats == 'vote':
             return end_points['vote_xyz'], end_points['vote_features']
@@ -170,9 +190,31 @@ class GridConv(nn.Module):
         b, k = size.shape[:2]
         g = self.GRID
         g3 = g * g * g
-        step = torch.linspace(-1, 1, g, device=size.device)
-        # unit grid, x slowest / z fastest: (g3, 3)
-        unit = torch.stack(torch.meshgrid(step, step, step, indexing='ij'), dim=-1).view(g3, 3)
+        no_grad_path = not (torch.is_grad_enabled() and
+                            (center.requires_grad or size.requires_grad or heading.requires_grad))
+        if no_grad_path and origin_features.is_cuda and _fused_front_end() is not None:
+            # training / inference without test-time IoU optimisation: grid points + relative
+            # coordinates from ONE kernel (written straight into channels 0..2 of the tensor the
+            # shared MLP reads), the interpolation weights from one kernel behind three_nn, the
+            # interpolation into channels 3.. -- grid_conv_module.py:64-107 was ~20 tensor kernels
+            _L = _fused_front_end()
+            c = origin_features.shape[1]
+            feats = torch.empty((b, 3 + c, k * g3), dtype=torch.float32, device=size.device)
+            whole = torch.empty((b, k * g3, 3), dtype=torch.float32, device=size.device)
+            ctr, sz, hd = center.detach().contiguous(), size.detach().contiguous(), heading.detach().contiguous()
+            with torch.cuda.device(size.device):
+                _L.check(_L.lib.votenet_gridconv_points(
+                    b, k, 3 + c, self._unit_grid(size.device).data_ptr(), ctr.data_ptr(), sz.data_ptr(),
+                    hd.data_ptr(), whole.data_ptr(), feats.data_ptr(),
+                    torch.cuda.current_stream(size.device).cuda_stream), "votenet_gridconv_points")
+            idx, weight = pointnet2_utils.three_nn_with_weights(whole, origin_xyz)
+            pointnet2_utils._ext.three_interpolate_into(origin_features, idx, weight, feats, 3)
+            iou_features = self.mlp_before_iou.forward_pooled(feats.view(b, -1, k, g3))
+            net = head_chain(iou_features, self.conv1_iou, self.bn1_iou, self.conv2_iou, self.bn2_iou,
+                             self.conv3_iou)
+            end_points['iou_scores'] = net.transpose(2, 1)[:, :, -self.iou_size:]
+            return end_points
+        unit = self._unit_grid(size.device)
         local = unit.view(1, 1, g3, 3) * size.unsqueeze(2)  # (B, K, 64, 3): half-sizes scale it
         # local @ rot_z(heading)^T, written out (a 3x3 rotation about z is two multiply-adds per
         # coordinate; the reference's torch.bmm, grid_conv_module.py:78-79, launches a BLAS kernel)

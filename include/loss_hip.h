@@ -100,6 +100,15 @@ int votenet_channel_normalize(int b, int c, int n, const float *x, float *y, flo
 int votenet_channel_normalize_grad(int b, int c, int n, const float *y, const float *norm,
                                    const float *dy, float *dx, void *stream);
 
+/* the 4x4x4 grid points of every proposal box and their box-relative coordinates: replaces the
+ * linspace / repeat / cat, rot_gpu + torch.bmm and the centre additions of
+ * models/grid_conv_module.py:64-83 and the subtraction of :91.  unit (64,3) = the unit grid
+ * (x slowest, z fastest); center, size (b,k,3), heading (b,k) -> whole (b,k*64,3), and the
+ * relative coordinates into channels 0..2 of feats (b,ctot,k*64) */
+int votenet_gridconv_points(int b, int k, int ctot, const float *unit, const float *center,
+                            const float *size, const float *heading, float *whole, float *feats,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -192,6 +192,12 @@ int pn2_group_points_grad_sorted(int b, int c, int n, int npoints, int nsample,
                                  const float *grad_out, int c_total, int channel0,
                                  const unsigned *inv, float *grad_points, void *stream);
 
+/* normalised inverse-distance weights of the three nearest neighbours: replaces
+ * weight = 1 / (dist + 1e-8); weight / sum(weight) of models/grid_conv_module.py:94-98 and
+ * pointnet2_modules.py:395-398 (and the sqrt of pointnet2_utils.py:147); dist2 (n,3) as returned
+ * by pn2_three_nn -> weight (n,3) */
+int pn2_three_nn_weights(long long n, const float *dist2, float *weight, void *stream);
+
 /* n device-to-device copies in one launch; table: n rows of (src, dst, bytes) as 64-bit values
  * in device memory, max_bytes the largest row (no reference counterpart: the reference feeds
  * each batch to the network directly, train.py:305-371 / pretrain.py:260-300; here a prefetched
