@@ -107,6 +107,7 @@ _SIGNATURES = {
     "votenet_loss_decode": [_vp, _vp],
     "votenet_loss_forward_backward": [_vp, _vp],
     "votenet_loss_scratch_floats": [_vp],
+    "votenet_bbox_jitter": [_c_int, _c_int, _c_int, _c_int] + [_vp] * 15,
     "votenet_gridconv_points": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "votenet_channel_normalize": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
     "votenet_channel_normalize_grad": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],

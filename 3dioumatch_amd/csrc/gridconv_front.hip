@@ -58,7 +58,91 @@ three_nn_weights_kernel(long long n, const float *__restrict__ dist2, float *__r
   o[2] = __fdiv_rn(w2, sum);
 }
 
+// ---- decoded boxes of the proposals + one jittered copy of each --------------------------------
+// What it replaces: VoteNet.calculate_bbox + the jitter of forward_with_pred_jitter
+// (models/votenet_iou_branch.py:111-137, :157-172) in the TRAINING forward, where nothing flows back
+// through these tensors (they feed the detached IoU branch and the IoU labels): two argmax, two
+// gathers, index_select, the size / angle arithmetic, where, two randn-scaled offsets, clamp, clone
+// and three cats -- ~25 tensor kernels.  One lane per proposal; every operation of the tensor
+// formulation in its order, each rounded to fp32; the two noise tensors are drawn by torch (same
+// generator stream as the reference).  arg-max = first maximum.
+__global__ void __launch_bounds__(256)
+bbox_jitter_kernel(int total, int k, int ns, int nh, float angle_per_class,
+                   const float *__restrict__ center, const float *__restrict__ size_scores,
+                   const float *__restrict__ size_residuals,
+                   const float *__restrict__ heading_scores,
+                   const float *__restrict__ heading_residuals, const float *__restrict__ mean_size,
+                   const float *__restrict__ noise_c, const float *__restrict__ noise_s,
+                   float *__restrict__ size, float *__restrict__ heading,
+                   float *__restrict__ all_center, float *__restrict__ all_size,
+                   float *__restrict__ all_heading, float *__restrict__ jitter_size2) {
+  const int t = blockIdx.x * 256 + threadIdx.x;  // cloud * k + proposal
+  if (t >= total) return;
+  const int b = t / k, kk = t - b * k;
+  const float *ss = size_scores + (size_t)t * ns;
+  int sc = 0;
+  float best = ss[0];
+  for (int q = 1; q < ns; ++q)
+    if (ss[q] > best) { best = ss[q]; sc = q; }
+  float sz[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float v = __fdiv_rn(__fadd_rn(mean_size[sc * 3 + d], size_residuals[((size_t)t * ns + sc) * 3 + d]), 2.0f);
+    sz[d] = v < 0.f ? 1e-6f : v;
+  }
+  float hd = 0.f;
+  if (nh > 1) {
+    const float *hs = heading_scores + (size_t)t * nh;
+    int hc = 0;
+    float hb = hs[0];
+    for (int q = 1; q < nh; ++q)
+      if (hs[q] > hb) { hb = hs[q]; hc = q; }
+    hd = __fadd_rn(__fmul_rn((float)hc, angle_per_class), heading_residuals[(size_t)t * nh + hc]);
+    const float kPi = 3.14159265358979323846f, kTwoPi = 6.28318530717958647692f;
+    hd = __fsub_rn(hd, __fmul_rn(hd > kPi ? 1.0f : 0.0f, kTwoPi));
+  }
+  const size_t o1 = ((size_t)b * 2 * k + kk) * 3, o2 = ((size_t)b * 2 * k + k + kk) * 3;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float c = center[(size_t)t * 3 + d];
+    size[(size_t)t * 3 + d] = sz[d];
+    const float cj = __fadd_rn(c, __fmul_rn(__fmul_rn(sz[d], noise_c[(size_t)t * 3 + d]), 0.3f));
+    float sj = __fadd_rn(sz[d], __fmul_rn(__fmul_rn(sz[d], noise_s[(size_t)t * 3 + d]), 0.3f));
+    sj = sj < 1e-8f ? 1e-8f : sj;
+    all_center[o1 + d] = c;
+    all_center[o2 + d] = cj;
+    all_size[o1 + d] = sz[d];
+    all_size[o2 + d] = sj;
+    jitter_size2[(size_t)t * 3 + d] = __fmul_rn(sj, 2.0f);
+  }
+  heading[t] = hd;
+  all_heading[(size_t)b * 2 * k + kk] = hd;
+  all_heading[(size_t)b * 2 * k + k + kk] = hd;
+}
+
 }  // namespace
+
+// proposals of b clouds x k: decoded (size, heading), the (b,2k,*) tensors [predicted | jittered]
+// the IoU branch consumes, and 2 * jittered size (the `jitter_size` entry of the end points)
+PN2_API int votenet_bbox_jitter(int b, int k, int ns, int nh, const float *center,
+                                const float *size_scores, const float *size_residuals,
+                                const float *heading_scores, const float *heading_residuals,
+                                const float *mean_size, const float *noise_c, const float *noise_s,
+                                float *size, float *heading, float *all_center, float *all_size,
+                                float *all_heading, float *jitter_size2, void *stream_) {
+  if (b <= 0 || k <= 0) return 0;
+  if (ns < 1 || nh < 1 || !center || !size_scores || !size_residuals || !mean_size || !noise_c ||
+      !noise_s || !size || !heading || !all_center || !all_size || !all_heading || !jitter_size2 ||
+      (nh > 1 && (!heading_scores || !heading_residuals)))
+    return (int)hipErrorInvalidValue;
+  const int total = b * k;
+  const float angle_per_class = (float)(2.0 * 3.14159265358979323846 / (double)nh);
+  hipLaunchKernelGGL(bbox_jitter_kernel, dim3(pn2_ceil_div(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream_, total, k, ns, nh, angle_per_class, center, size_scores,
+                     size_residuals, heading_scores, heading_residuals, mean_size, noise_c, noise_s,
+                     size, heading, all_center, all_size, all_heading, jitter_size2);
+  return pn2_launch_status();
+}
 
 // center, size (b,k,3), heading (b,k), unit (64,3) -> whole (b,k*64,3) and channels 0..2 of
 // feats (b,ctot,k*64)

@@ -185,7 +185,7 @@ def furthest_point_sampling(points, nsamples):
             _remember_lists(points, hint, lists)
             cache_stats["left_by_sampling"] += 1
         return out
-    out = torch.zeros((b, nsamples), dtype=torch.int32, device=points.device)
+    out = torch.empty((b, nsamples), dtype=torch.int32, device=points.device)  # every index is written
     with torch.cuda.device(points.device):
         need = int(_lib.pn2_fps_workspace_bytes(b, n, nsamples))
         # private scratch per call (the reference allocates its `temp` per call as well)
@@ -426,7 +426,7 @@ def furthest_point_sampling_with_grid(points, nsamples, radius):
     nsamples = int(nsamples)
     if not _lib.pn2_fps_grid_supported(n):
         return furthest_point_sampling(points, nsamples), None
-    out = torch.zeros((b, nsamples), dtype=torch.int32, device=points.device)
+    out = torch.empty((b, nsamples), dtype=torch.int32, device=points.device)  # every index is written
     with torch.cuda.device(points.device):
         need = int(_lib.pn2_fps_workspace_bytes(b, n, nsamples))
         ws = torch.empty(max(need, 1), dtype=torch.uint8, device=points.device)

@@ -147,6 +147,9 @@ class VoteNet(nn.Module):
         """Predicted boxes + one jittered copy of each go through the IoU branch together
         (votenet_iou_branch.py:157-181): K -> 2K boxes."""
         end_points = self.forward_backbone(inputs)
+        fused = self._bbox_jitter_fused(end_points)
+        if fused is not None:
+            return fused
         center, size, heading = self.calculate_bbox(end_points)
         k = heading.shape[1]
         center_jitter = center + size * torch.randn(size.shape, device=size.device) * 0.3
@@ -163,6 +166,50 @@ class VoteNet(nn.Module):
         end_points['jitter_center'] = center_jitter
         end_points['jitter_size'] = size_jitter * 2
         end_points['jitter_heading'] = heading_jitter
+        return end_points
+
+    def _bbox_jitter_fused(self, end_points):
+        """calculate_bbox + the jitter as ONE kernel (votenet_bbox_jitter) on the GPU: nothing flows
+        back through these tensors in the training forward (they feed the detached IoU branch and
+        the IoU labels).  Returns the completed end_points, or None where the kernel is not there."""
+        center = end_points['center']
+        if not center.is_cuda:
+            return None
+        from .heads import _fused_front_end
+        _L = _fused_front_end()
+        if _L is None or not hasattr(_L.lib, "votenet_bbox_jitter"):
+            return None
+        size_scores, size_residuals = end_points['size_scores'], end_points['size_residuals']
+        b, k, ns = size_scores.shape
+        nh = self.num_heading_bin
+        dev = center.device
+        # the two draws of the reference, in its order (votenet_iou_branch.py:161-162)
+        noise_c = torch.randn((b, k, 3), device=dev)
+        noise_s = torch.randn((b, k, 3), device=dev)
+        c = center.detach().contiguous()
+        ss, sr = size_scores.detach().contiguous(), size_residuals.detach().contiguous()
+        hs = end_points['heading_scores'].detach().contiguous()
+        hr = end_points['heading_residuals'].detach().contiguous()
+        size = torch.empty((b, k, 3), dtype=torch.float32, device=dev)
+        heading = torch.empty((b, k), dtype=torch.float32, device=dev)
+        all_center = torch.empty((b, 2 * k, 3), dtype=torch.float32, device=dev)
+        all_size = torch.empty((b, 2 * k, 3), dtype=torch.float32, device=dev)
+        all_heading = torch.empty((b, 2 * k), dtype=torch.float32, device=dev)
+        jitter_size2 = torch.empty((b, k, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _L.check(_L.lib.votenet_bbox_jitter(
+                b, k, ns, nh, c.data_ptr(), ss.data_ptr(), sr.data_ptr(), hs.data_ptr(), hr.data_ptr(),
+                self._mean_size.data_ptr(), noise_c.data_ptr(), noise_s.data_ptr(), size.data_ptr(),
+                heading.data_ptr(), all_center.data_ptr(), all_size.data_ptr(), all_heading.data_ptr(),
+                jitter_size2.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                "votenet_bbox_jitter")
+        end_points['size'], end_points['heading'] = size, heading
+        end_points = self.grid_conv(all_center, all_size, all_heading, end_points)
+        end_points['iou_scores'], end_points['iou_scores_jitter'] = torch.split(
+            end_points['iou_scores'], [k, end_points['iou_scores'].shape[1] - k], dim=1)
+        end_points['jitter_center'] = all_center[:, k:]
+        end_points['jitter_size'] = jitter_size2
+        end_points['jitter_heading'] = all_heading[:, k:]
         return end_points
 
     def forward_onlyiou_faster(self, end_points, center, size, heading):

@@ -100,6 +100,19 @@ int votenet_channel_normalize(int b, int c, int n, const float *x, float *y, flo
 int votenet_channel_normalize_grad(int b, int c, int n, const float *y, const float *norm,
                                    const float *dy, float *dx, void *stream);
 
+/* decoded boxes of the proposals + one jittered copy of each, training forward (no gradient flows
+ * through them): replaces VoteNet.calculate_bbox and the jitter of forward_with_pred_jitter,
+ * models/votenet_iou_branch.py:111-137 and :157-172.  center (b,k,3), size_scores (b,k,ns),
+ * size_residuals (b,k,ns,3), heading_scores / heading_residuals (b,k,nh), mean_size (ns,3),
+ * noise_c / noise_s (b,k,3) standard normal draws -> size (b,k,3) (half sizes), heading (b,k),
+ * all_center / all_size (b,2k,3), all_heading (b,2k) = [predicted | jittered], jitter_size2 (b,k,3) */
+int votenet_bbox_jitter(int b, int k, int ns, int nh, const float *center, const float *size_scores,
+                        const float *size_residuals, const float *heading_scores,
+                        const float *heading_residuals, const float *mean_size,
+                        const float *noise_c, const float *noise_s, float *size, float *heading,
+                        float *all_center, float *all_size, float *all_heading, float *jitter_size2,
+                        void *stream);
+
 /* the 4x4x4 grid points of every proposal box and their box-relative coordinates: replaces the
  * linspace / repeat / cat, rot_gpu + torch.bmm and the centre additions of
  * models/grid_conv_module.py:64-83 and the subtraction of :91.  unit (64,3) = the unit grid
