@@ -8,12 +8,12 @@
 
 // STORES: 0 = one dword per wave; 5 = five 64-lane dword stores (256 B each, five planes);
 //         2 = one 64-lane dwordx4 store (four planes, 16 lanes x 16 B each) + one dword store
-template <int BYTES, int STORES = 0>
-__global__ void __launch_bounds__(64)
+template <int BYTES, int STORES = 0, int WPB = 1>
+__global__ void __launch_bounds__(64 * WPB)
 td_rate_kernel(const char *__restrict__ base, unsigned cloud_bytes, int m, int rows,
                float *__restrict__ out) {
-  const int wg = blockIdx.x, b = wg / m, j = wg - b * m;
-  const int lane = threadIdx.x;
+  const int wg = blockIdx.x * WPB + (threadIdx.x >> 6), b = wg / m, j = wg - b * m;
+  const int lane = threadIdx.x & 63;
   const char *cloud = base + (size_t)b * cloud_bytes;
   unsigned h = (unsigned)j * 2654435761u + 12345u;
   float acc = 0.f;
@@ -27,7 +27,7 @@ td_rate_kernel(const char *__restrict__ base, unsigned cloud_bytes, int m, int r
     else { acc += *reinterpret_cast<const float *>(p); }
   }
   if (STORES == 5) {
-    const size_t plane = (size_t)gridDim.x * 64;
+    const size_t plane = (size_t)gridDim.x * WPB * 64;
     for (int p = 0; p < 5; ++p) out[p * plane + (size_t)wg * 64 + lane] = acc + p;
     return;
   }
@@ -53,5 +53,7 @@ int td_rate_launch(int bytes, const void *base, unsigned cloud_bytes, int b, int
   else if (bytes == 4) hipLaunchKernelGGL(td_rate_kernel<4>, dim3(b * m), dim3(64), 0, s, p, cloud_bytes, m, rows, out);
   else if (bytes == 165) hipLaunchKernelGGL((td_rate_kernel<16, 5>), dim3(b * m), dim3(64), 0, s, p, cloud_bytes, m, rows, out);
   else if (bytes == 162) hipLaunchKernelGGL((td_rate_kernel<16, 2>), dim3(b * m), dim3(64), 0, s, p, cloud_bytes, m, rows, out);
+  else if (bytes == 1654) hipLaunchKernelGGL((td_rate_kernel<16, 5, 4>), dim3(b * m / 4), dim3(256), 0, s, p, cloud_bytes, m, rows, out);
+  else if (bytes == 16516) hipLaunchKernelGGL((td_rate_kernel<16, 5, 16>), dim3(b * m / 16), dim3(1024), 0, s, p, cloud_bytes, m, rows, out);
   return (int)hipGetLastError();
 }

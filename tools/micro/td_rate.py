@@ -37,10 +37,23 @@ for rows in (9, 18, 36):
             assert rc == 0
         us = bench.time_op(run, iters=20, warm=3)
         res["rows%d_bytes%d_us" % (rows, nbytes)] = round(us, 2)
-for tag, code in (("five_dword_stores", 165), ("one_dwordx4_plus_one_dword_store", 162)):
+for tag, code in (("five_dword_stores", 165), ("one_dwordx4_plus_one_dword_store", 162),
+                  ("five_dword_stores_4_waves_per_workgroup", 1654),
+                  ("five_dword_stores_16_waves_per_workgroup", 16516)):
     def run():
         rc = lib.td_rate_launch(code, data.data_ptr(), cloud_bytes, B, M, 9, out.data_ptr(),
                                 torch.cuda.current_stream().cuda_stream)
         assert rc == 0
     res["rows9_bytes16_%s_us" % tag] = round(bench.time_op(run, iters=20, warm=3), 2)
+    if code >= 1654:  # the fixed part alone: no row loads
+        def run0():
+            rc = lib.td_rate_launch(code, data.data_ptr(), cloud_bytes, B, M, 0, out.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+        res["rows0_%s_us" % tag] = round(bench.time_op(run0, iters=20, warm=3), 2)
+def run00():
+    rc = lib.td_rate_launch(165, data.data_ptr(), cloud_bytes, B, M, 0, out.data_ptr(),
+                            torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+res["rows0_five_dword_stores_us"] = round(bench.time_op(run00, iters=20, warm=3), 2)
 print(json.dumps(res))
