@@ -32,33 +32,69 @@ constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kRowHalfMirror = 0x141, kRowMi
 // __builtin_bit_cast applied directly to an element of the returned vector folds both
 // elements into element 0 (clang 22 / ROCm 7.2), silently dropping half of the exchange.
 template <bool HALF>
-__device__ __forceinline__ void swap_rows(unsigned v, unsigned &r0, unsigned &r1) {
+__device__ __forceinline__ void swap_rows(unsigned a, unsigned b, unsigned &r0, unsigned &r1) {
+  // HALF: r0 = (a.lo32, b.lo32), r1 = (a.hi32, b.hi32);  else: r0 takes b's even rows into its odd
+  // rows: r0 = (a.row0, b.row0, a.row2, b.row2), r1 = (a.row1, b.row1, a.row3, b.row3)
   if (HALF) {
-    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
     r0 = r[0]; r1 = r[1];
   } else {
-    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
     r0 = r[0]; r1 = r[1];
   }
 }
+template <bool HALF>
+__device__ __forceinline__ void swap_rows(unsigned v, unsigned &r0, unsigned &r1) {
+  swap_rows<HALF>(v, v, r0, r1);
+}
 
+// One reduction step = ONE instruction: v_max_f32 / v_min_f32 with the DPP-permuted operand
+// (the compiler's own form is v_mov_dpp + v_cmp + v_cndmask: three dependent instructions of
+// ~8 clocks each, and FPS rounds are nothing but dependent chains).  s_nop 1 covers the
+// VALU-write -> DPP-read hazard, which the compiler cannot see inside an asm statement.
+#define FPS_DPP_OP(OP, V, CTRL) \
+  asm("s_nop 1\n\t" OP " %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(V) : "v"(V))
+
+// max over the first LANES lanes' groups: LANES = 8 -> every lane gets the max of its aligned
+// group of 8, 16 -> of its row, 64 -> of the wave
+template <int LANES = 64>
 __device__ __forceinline__ float wave_max_f32(float v) {
-#define FPS_STEP(CTRL) { const float o = __builtin_bit_cast(float, dpp_mov<CTRL>(__builtin_bit_cast(unsigned, v))); v = o > v ? o : v; }
-  FPS_STEP(kQuadXor1) FPS_STEP(kQuadXor2) FPS_STEP(kRowHalfMirror) FPS_STEP(kRowMirror)
-#undef FPS_STEP
+  FPS_DPP_OP("v_max_f32_dpp", v, "quad_perm:[1,0,3,2]");
+  FPS_DPP_OP("v_max_f32_dpp", v, "quad_perm:[2,3,0,1]");
+  FPS_DPP_OP("v_max_f32_dpp", v, "row_half_mirror");
+  if (LANES > 8) FPS_DPP_OP("v_max_f32_dpp", v, "row_mirror");
+  if (LANES > 16) {
+    unsigned r0, r1;
+    swap_rows<false>(__builtin_bit_cast(unsigned, v), r0, r1);
+    float f0 = __builtin_bit_cast(float, r0), f1 = __builtin_bit_cast(float, r1);
+    asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(f0), "v"(f1));
+    swap_rows<true>(__builtin_bit_cast(unsigned, v), r0, r1);
+    f0 = __builtin_bit_cast(float, r0); f1 = __builtin_bit_cast(float, r1);
+    asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(f0), "v"(f1));
+  }
+  return v;
+}
+
+__device__ __forceinline__ float wave_min_f32(float v) {
+  FPS_DPP_OP("v_min_f32_dpp", v, "quad_perm:[1,0,3,2]");
+  FPS_DPP_OP("v_min_f32_dpp", v, "quad_perm:[2,3,0,1]");
+  FPS_DPP_OP("v_min_f32_dpp", v, "row_half_mirror");
+  FPS_DPP_OP("v_min_f32_dpp", v, "row_mirror");
   unsigned r0, r1;
   swap_rows<false>(__builtin_bit_cast(unsigned, v), r0, r1);
   float f0 = __builtin_bit_cast(float, r0), f1 = __builtin_bit_cast(float, r1);
-  v = f0 > f1 ? f0 : f1;
+  asm("v_min_f32 %0, %1, %2" : "=v"(v) : "v"(f0), "v"(f1));
   swap_rows<true>(__builtin_bit_cast(unsigned, v), r0, r1);
   f0 = __builtin_bit_cast(float, r0); f1 = __builtin_bit_cast(float, r1);
-  return f0 > f1 ? f0 : f1;
+  asm("v_min_f32 %0, %1, %2" : "=v"(v) : "v"(f0), "v"(f1));
+  return v;
 }
 
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-#define FPS_STEP(CTRL) { const unsigned o = dpp_mov<CTRL>(v); v = o < v ? o : v; }
-  FPS_STEP(kQuadXor1) FPS_STEP(kQuadXor2) FPS_STEP(kRowHalfMirror) FPS_STEP(kRowMirror)
-#undef FPS_STEP
+  FPS_DPP_OP("v_min_u32_dpp", v, "quad_perm:[1,0,3,2]");
+  FPS_DPP_OP("v_min_u32_dpp", v, "quad_perm:[2,3,0,1]");
+  FPS_DPP_OP("v_min_u32_dpp", v, "row_half_mirror");
+  FPS_DPP_OP("v_min_u32_dpp", v, "row_mirror");
   unsigned r0, r1;
   swap_rows<false>(v, r0, r1);
   v = r0 < r1 ? r0 : r1;
@@ -66,19 +102,50 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
   return r0 < r1 ? r0 : r1;
 }
 
-// Lane (wave-uniform) holding the best candidate under the reference's order: largest value,
-// ties broken by the smallest key.  The common case (a unique maximum) needs one float
-// reduction and one ballot; only real ties pay for the key reduction.
-__device__ __forceinline__ int wave_argmax_lane(float v, int idx, int log2bs) {
-  const float m = wave_max_f32(v);
-  const unsigned long long tie = __ballot(v == m);
-  if (__popcll(tie) <= 1) return tie ? __builtin_ctzll(tie) : 0;
-  const unsigned key = (v == m) ? fps_key(idx, log2bs) : 0xFFFFFFFFu;
+// Among the lanes of `tie` (all holding the maximum), the one the reference's reduction tree
+// keeps: smallest key.  Rare path (exact ties of fp32 distances).
+__device__ __forceinline__ int wave_tie_break(unsigned long long tie, int idx, int log2bs) {
+  const bool in = (tie >> lane_id()) & 1ull;
+  const unsigned key = in ? fps_key(idx, log2bs) : 0xFFFFFFFFu;
   const unsigned mk = wave_min_u32(key);
   return __builtin_ctzll(__ballot(key == mk));
 }
 
+// Lane (wave-uniform) holding the best candidate under the reference's order: largest value,
+// ties broken by the smallest key.  The common case (a unique maximum) needs one float
+// reduction and one ballot; only real ties pay for the key reduction.  LANES < 64: only the
+// first LANES lanes hold candidates.
+template <int LANES = 64>
+__device__ __forceinline__ int wave_argmax_lane(float v, int idx, int log2bs) {
+  const float m = wave_max_f32<LANES>(v);
+  unsigned long long tie = __ballot(v == m);
+  if (LANES < 64) tie &= (1ull << LANES) - 1ull;
+  if (__popcll(tie) <= 1) return tie ? __builtin_ctzll(tie) : 0;
+  return wave_tie_break(tie, idx, log2bs);
+}
+
 struct FpsPick { int idx; float x, y, z; };
+
+// After the barrier: wave w's candidate sits in slot[w*8 .. w*8+4] = (value, idx, x, y, z); every
+// lane returns the workgroup's pick (largest value, ties by the reference's key).
+template <int NW>
+__device__ __forceinline__ FpsPick fps_pick_collect(const float *slot, int log2bs) {
+  const int lane = lane_id();
+  float sv = -2.0f, sx = 0.f, sy = 0.f, sz = 0.f;  // -2 < every real candidate (>= -1)
+  int si = 0;
+  if (lane < NW) {
+    const float4 a = *reinterpret_cast<const float4 *>(slot + lane * 8);
+    sv = a.x; si = __builtin_bit_cast(int, a.y); sx = a.z; sy = a.w;
+    sz = slot[lane * 8 + 4];
+  }
+  const int best = wave_argmax_lane<(NW <= 8 ? 8 : NW <= 16 ? 16 : 64)>(sv, si, log2bs);
+  FpsPick p;
+  p.idx = __builtin_amdgcn_readlane(si, best);
+  p.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sx), best));
+  p.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sy), best));
+  p.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sz), best));
+  return p;
+}
 
 // One candidate per lane (value v, point index idx, its coordinates) -> the workgroup's pick,
 // known to every lane together with its coordinates (so the next round needs no dependent
@@ -97,20 +164,7 @@ __device__ __forceinline__ FpsPick fps_block_pick(float v, int idx, float x, flo
     slot[w * 8 + 4] = z;
   }
   __syncthreads();
-  float sv = -2.0f, sx = 0.f, sy = 0.f, sz = 0.f;  // -2 < every real candidate (>= -1)
-  int si = 0;
-  if (lane < NW) {
-    const float4 a = *reinterpret_cast<const float4 *>(slot + lane * 8);
-    sv = a.x; si = __builtin_bit_cast(int, a.y); sx = a.z; sy = a.w;
-    sz = slot[lane * 8 + 4];
-  }
-  const int best = wave_argmax_lane(sv, si, log2bs);
-  FpsPick p;
-  p.idx = __builtin_amdgcn_readlane(si, best);
-  p.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sx), best));
-  p.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sy), best));
-  p.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sz), best));
-  return p;
+  return fps_pick_collect<NW>(slot, log2bs);
 }
 
 __device__ __forceinline__ bool fps_skipped(float x, float y, float z) {

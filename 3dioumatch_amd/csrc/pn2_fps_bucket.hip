@@ -1,5 +1,5 @@
 // 3dioumatch_amd/csrc/pn2_fps_bucket.hip -- exact furthest point sampling for LARGE clouds
-// (SA1: 40 000 -> 2048) in one workgroup per cloud, with spatial pruning.
+// (SA1: 40 000 -> 2048), one workgroup per cloud, with spatial pruning.
 //
 // Why: FPS is m-1 strictly dependent rounds.  The reference (sampling_gpu.cu:75-178) and the
 // streaming tier of pn2_sampling.hip re-read every point every round (N*16 bytes per round
@@ -7,21 +7,34 @@
 // sample only lowers the running distance of points that are closer to it than their current
 // distance, and those are spatially clustered.  So:
 //
-//   * once per call the cloud is counting-sorted by a coarse Morton cell (16^3 cells, LDS
-//     histogram + LDS atomic cursors) into a scratch array of (x, y, z, original index), and
-//     cut into BUCKETS of 64 consecutive sorted points.  Bucket b belongs to wave b % 16;
-//     lane l of that wave holds point l of the bucket, and keeps ITS running distance in a
-//     register for the whole call (NBW buckets per wave -> NBW registers per lane);
-//   * lane j of a wave also holds the metadata of the wave's j-th bucket: tight bounding box,
-//     current maximum running distance and the point that attains it (index + coordinates);
-//   * a round = (1) every lane tests its bucket: if the squared distance from the new sample
+//   * SETUP kernel (1024 lanes per cloud): the cloud is counting-sorted by a coarse Morton cell
+//     (16^3 cells, LDS histogram + LDS atomic cursors) into a scratch array of (x, y, z,
+//     original index) and cut into BUCKETS of 64 consecutive sorted points.  A second workgroup
+//     per cloud builds, on request, the ball-query cell lists of the same cloud (grid_common.h);
+//   * ROUNDS kernel (W = 4 or 8 waves per cloud -- ONE or TWO waves per SIMD, see below).
+//     Bucket b belongs to wave b % W; lane l of that wave holds point l of the bucket and keeps
+//     ITS running distance in a register for the whole call: the wave's buckets are a register
+//     file of up to 160 entries per lane, addressed with a wave-uniform index (s_set_gpr_idx);
+//   * lane j of a wave also holds the metadata of the wave's buckets j, 64 + j, 128 + j: tight
+//     bounding box, current maximum running distance and the point that attains it;
+//   * a round = (1) every lane tests its buckets: if the squared distance from the new sample
 //     to the bounding box (shrunk by 1e-6 relative, to stay conservative under fp32 rounding)
 //     is not below the bucket's maximum, no point of the bucket can change -> skip;
-//     (2) the wave visits only the ballot-selected buckets: one coalesced 1 KiB load, the
-//     reference's exact fp32 update, a 64-lane argmax (DPP / permlane, fps_common.h);
-//     (3) argmax over the per-bucket maxima of the wave, then across the 16 waves through LDS
+//     (2) the wave walks the set bits of the ballots: the 1 KiB loads of up to four visited
+//     buckets are issued together, then each gets the reference's exact fp32 update and a
+//     64-lane argmax (DPP / permlane, fps_common.h);
+//     (3) argmax over the per-bucket maxima of the wave, then across the W waves through LDS
 //     with one barrier (fps_block_pick).
-//   After a few dozen rounds only ~1 bucket per wave is touched per round.
+//   After a few dozen rounds ~15 of the 625 buckets of a 40 000-point cloud are touched per round.
+//
+// Why few waves: a round is a latency chain, not a throughput problem.  Measured with per-round
+// clocks (tools/micro/fps_probe.py, profiles/r3_fps_round_clocks.json) the previous form --
+// 16 waves, the wave's 40 buckets as 40 unrolled wave-uniform branches -- spent 1400 of its
+// 5000 clocks per round walking the branch ladder (84 KB of code, 40 taken branches), 1900 in
+// the pick (every one of the 16 waves repeats the final argmax; four waves share a SIMD's
+// issue slot) and 750 per visited bucket with the loads serialised.  One wave per SIMD runs
+// the same dependent chain without contention, a visited-bit walk costs nothing for the
+// buckets that are skipped, and the loads overlap.
 //
 // Exactness: skipping is a no-op by construction (min(d, t) == t for every point of a skipped
 // bucket), the update arithmetic is the reference's, and ties are resolved by the reference's
@@ -31,6 +44,18 @@
 #include "fps_common.h"
 #include "grid_common.h"
 
+#ifdef FPS_PROBE  // tools/micro/fps_probe.py: per-round clocks and visit counts of cloud 0
+__device__ unsigned long long fps_probe_t[2048 * 16 * 16];
+__device__ unsigned char fps_probe_v[2048 * 16];
+#define FPS_STAMP(I)                                                              \
+  if (blockIdx.x == 0 && j < 2048) {                                              \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                   \
+    if (lane == 0) fps_probe_t[(j * 16 + w) * 16 + (I)] = t_;                     \
+  }
+#else
+#define FPS_STAMP(I)
+#endif
+
 namespace {
 
 using namespace fps;
@@ -39,23 +64,6 @@ constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / kWave;  // 16
 constexpr int kGrid = 16;                 // cells per axis
 constexpr int kCells = kGrid * kGrid * kGrid;
-
-// (NOT -wave_max_f32(-v): clang 22 / ROCm 7.2 folds the negations into source modifiers of the
-//  v_cndmask_b32 selects of the DPP steps and the result came out wrong for negative inputs --
-//  bounding boxes of clouds with negative coordinates were too tight, buckets were pruned that
-//  still held the farthest point: regression test test_fps_negative_coordinates)
-__device__ __forceinline__ float wave_min_f32(float v) {
-#define FPS_MIN_STEP(CTRL) { const float o = __builtin_bit_cast(float, dpp_mov<CTRL>(__builtin_bit_cast(unsigned, v))); v = o < v ? o : v; }
-  FPS_MIN_STEP(kQuadXor1) FPS_MIN_STEP(kQuadXor2) FPS_MIN_STEP(kRowHalfMirror) FPS_MIN_STEP(kRowMirror)
-#undef FPS_MIN_STEP
-  unsigned r0, r1;
-  swap_rows<false>(__builtin_bit_cast(unsigned, v), r0, r1);
-  float f0 = __builtin_bit_cast(float, r0), f1 = __builtin_bit_cast(float, r1);
-  v = f0 < f1 ? f0 : f1;
-  swap_rows<true>(__builtin_bit_cast(unsigned, v), r0, r1);
-  f0 = __builtin_bit_cast(float, r0); f1 = __builtin_bit_cast(float, r1);
-  return f0 < f1 ? f0 : f1;
-}
 
 __device__ __forceinline__ unsigned spread4(unsigned v) {  // abcd -> 00a00b00c00d
   v &= 0xF;
@@ -84,43 +92,23 @@ __device__ __forceinline__ float box_dist2(float px, float py, float pz, float l
   return dx * dx + dy * dy + dz * dz;
 }
 
-// My point of the wave's jj-th bucket.  The byte offset is rebuilt at every use from one
-// lane offset and one compile-time constant hidden behind empty asm statements; otherwise the
-// compiler hoists NBW loop-invariant 64-bit addresses out of the round loop and spends two
-// VGPRs per bucket on them (spilling at NBW >= 40).
-__device__ __forceinline__ float4 load_bucket(const float4 *wave_base, int jj, unsigned lane_off) {
-  unsigned so = (unsigned)jj * (kWaves * kWave * (unsigned)sizeof(float4));
-  asm volatile("" : "+s"(so));
-  asm volatile("" : "+v"(lane_off));
-  const char *p = reinterpret_cast<const char *>(wave_base) + so;
-  return *reinterpret_cast<const float4 *>(p + lane_off);
-}
-
-template <int NBW>
+// ---- setup: sort the cloud into buckets (blockIdx.y == 0) / build its cell lists (== 1) -----
 __global__ void __launch_bounds__(kThreads)
-fps_bucket_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
-                  float4 *__restrict__ scratch, int *__restrict__ idxs, float grid_inv_side,
-                  int *__restrict__ grid_start, float4 *__restrict__ grid_rec) {
-  __shared__ int cell_cnt[kCells];                 // histogram, then scatter cursors
-  __shared__ float red[kWaves * 8];
-  __shared__ __attribute__((aligned(16))) float slots[2][kWaves * 8];
-  __shared__ float box[8];                         // lo[3], inv[3]
-  __shared__ int s_valid;
-
+fps_bucket_setup_kernel(int n, size_t cloud_stride, const float *__restrict__ dataset,
+                        float4 *__restrict__ rec_all, int *__restrict__ pidx_all,
+                        float *__restrict__ bbox_all, int *__restrict__ n_valid_out,
+                        float grid_inv_side, int *__restrict__ grid_start,
+                        float4 *__restrict__ grid_rec) {
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int w = tid / kWave;
   const float *pts = dataset + (size_t)blockIdx.x * n * 3;
-  float4 *sp = scratch + (size_t)blockIdx.x * (kThreads * NBW);
-  int *out = idxs + (size_t)blockIdx.x * m;
 
-  // ---- G: by-product -- the ball-query cell lists of this cloud (grid_common.h) -------------
-  // The set-abstraction layer that samples this cloud queries balls in it right afterwards.
-  // This workgroup streams the cloud anyway (and has ~6 ms of serial rounds ahead of it), so it
-  // also counting-sorts the points by lattice cell: 32768 16-bit counters packed in 64 KB of LDS
-  // (n < 65536 on this path), scan, scatter.  The separate two-kernel build of the ball query
-  // (15 us on all CUs) disappears from the layer.
-  if (grid_start != nullptr) {
+  // ---- G: the ball-query cell lists of this cloud (grid_common.h) -------------------------
+  // The set-abstraction layer that samples this cloud queries balls in it right afterwards:
+  // 32768 16-bit counters packed in 64 KB of LDS (n < 65536 on this path), scan, scatter.  The
+  // separate two-kernel build of the ball query disappears from the layer.
+  if (blockIdx.y == 1) {
     __shared__ unsigned gcnt[grid::kCells / 2];
     __shared__ int g_wave_tot[kWaves];
     for (int t = tid; t < grid::kCells / 2; t += kThreads) gcnt[t] = 0u;
@@ -168,8 +156,16 @@ fps_bucket_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
       const unsigned old = atomicAdd(&gcnt[cell >> 1], 1u << sh);
       rec[(old >> sh) & 0xFFFFu] = make_float4(x, y, z, __builtin_bit_cast(float, k));
     }
-    __syncthreads();
+    return;
   }
+
+  __shared__ int cell_cnt[kCells];                 // histogram, then scatter cursors
+  __shared__ float red[kWaves * 8];
+  __shared__ float box[8];                         // lo[3], inv[3]
+  __shared__ int s_valid;
+  float4 *sp = rec_all + (size_t)blockIdx.x * cloud_stride;      // (x, y, z, running distance)
+  int *spi = pidx_all + (size_t)blockIdx.x * cloud_stride;        // original index
+  float *sbox = bbox_all + (size_t)blockIdx.x * (cloud_stride / kWave) * 8;
 
   // ---- P0: bounding box of the participating points --------------------------------------
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
@@ -240,126 +236,304 @@ fps_bucket_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
     const float x = pts[k * 3 + 0], y = pts[k * 3 + 1], z = pts[k * 3 + 2];
     if (!fps_skipped(x, y, z)) {
       const int pos = atomicAdd(&cell_cnt[morton_cell(x, y, z, box, box + 3)], 1);
-      sp[pos] = make_float4(x, y, z, __builtin_bit_cast(float, k));
+      sp[pos] = make_float4(x, y, z, 1e10f);
+      spi[pos] = k;
     }
   }
-  for (int t = n_valid + tid; t < n_buckets * kWave; t += kThreads)
-    sp[t] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, -1));
-  if (tid == 0) out[0] = 0;
+  for (int t = n_valid + tid; t < n_buckets * kWave; t += kThreads) {
+    sp[t] = make_float4(0.f, 0.f, 0.f, -1.0f);   // below every real distance: never picked
+    spi[t] = -1;
+  }
+  if (tid == 0) n_valid_out[blockIdx.x] = n_valid;
   __syncthreads();  // scratch writes of this workgroup are visible to its own waves
 
+  // ---- P4: tight bounding box of every bucket ---------------------------------------------
+  for (int bkt = w; bkt < n_buckets; bkt += kWaves) {
+    const float4 q = sp[bkt * kWave + lane];
+    const bool real = q.w >= 0.f;
+    const float lx = wave_min_f32(real ? q.x : 3.0e38f), hx = wave_max_f32(real ? q.x : -3.0e38f);
+    const float ly = wave_min_f32(real ? q.y : 3.0e38f), hy = wave_max_f32(real ? q.y : -3.0e38f);
+    const float lz = wave_min_f32(real ? q.z : 3.0e38f), hz = wave_max_f32(real ? q.z : -3.0e38f);
+    if (lane == 0) {
+      *reinterpret_cast<float4 *>(sbox + bkt * 8) = make_float4(lx, ly, lz, hx);
+      *reinterpret_cast<float2 *>(sbox + bkt * 8 + 4) = make_float2(hy, hz);
+    }
+  }
+}
+
+// ---- rounds ---------------------------------------------------------------------------------
+// W waves; bucket b belongs to wave b % W and is the wave's bucket jj = b / W; lane jj % 64 holds
+// its bounding box and current maximum in metadata set jj / 64 (META sets); the point that
+// attains the maximum (x, y, z, index) sits in LDS, written by the lane that owns that point.
+//
+// A round is one dependent chain, and on this machine a dependent VALU instruction costs 8
+// clocks, a DPP one 16, a VALU -> SGPR -> VALU round trip 32, any branch ~20, an LDS round trip
+// ~110 and an L2 hit ~220 (tools/micro/lat_probe.py, profiles/r3_instruction_costs.json).  So:
+//   * up to FOUR visited buckets are updated together: their 1 KiB loads are in flight at the
+//     same time and their four 64-lane maxima come out of ONE reduction tree (two permlane
+//     swaps leave a quarter of each bucket in each 16-lane row, then four DPP steps) instead
+//     of four trees; when fewer than four remain the last one is repeated -- the update is
+//     idempotent;
+//   * no value is moved between lanes: the lane that holds a bucket's farthest point writes it
+//     to LDS itself, the bucket's maximum reaches its metadata lane as a scalar;
+//   * exact ties (between points of a bucket, buckets of a wave or waves) are detected with one
+//     popcount each and resolved on a slow path by the reference's reduction-tree key.
+template <int W, int META>
+__global__ void __launch_bounds__(W * kWave)
+fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
+                         const float *__restrict__ dataset, float4 *__restrict__ rec_all,
+                         const int *__restrict__ pidx_all, const float *__restrict__ bbox_all,
+                         const int *__restrict__ n_valid_in, int *__restrict__ idxs) {
+  __shared__ __attribute__((aligned(16))) float slots[2][W * 8];
+  // by bucket id: (x, y, z, index) of its farthest point; then one scratch entry per lane, the
+  // target of the lanes that have nothing to write (a select on the address instead of a branch
+  // on exec: branches cost ~20 clocks each here)
+  __shared__ float4 far_pt[W * META * kWave + W * kWave];
+  const int far_nowhere = W * META * kWave + (int)threadIdx.x;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int w = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const float *pts = dataset + (size_t)blockIdx.x * n * 3;
+  int *out = idxs + (size_t)blockIdx.x * m;
+  const int n_valid = n_valid_in[blockIdx.x];
+  const int n_buckets = (n_valid + kWave - 1) / kWave;
+  if (tid == 0) out[0] = 0;
   if (n_valid == 0) {  // every point skipped: the reference keeps returning index 0
-    for (int j = 1 + tid; j < m; j += kThreads) out[j] = 0;
+    for (int j = 1 + tid; j < m; j += W * kWave) out[j] = 0;
     return;
   }
+  // my point of the wave's jj-th bucket: uniform base + jj * (W KiB) + one lane offset
+  char *rec_base = reinterpret_cast<char *>(rec_all + (size_t)blockIdx.x * cloud_stride);
+  const char *pidx_base = reinterpret_cast<const char *>(pidx_all + (size_t)blockIdx.x * cloud_stride);
+  const unsigned rec_off = (unsigned)(w * kWave + lane) * (unsigned)sizeof(float4);
+  const unsigned pidx_off = (unsigned)(w * kWave + lane) * (unsigned)sizeof(int);
+#define FPS_REC(JJ) (reinterpret_cast<float4 *>(rec_base + (size_t)(unsigned)(JJ) * (W * kWave * sizeof(float4)) + rec_off))
+#define FPS_PIDX(JJ) (*reinterpret_cast<const int *>(pidx_base + (size_t)(unsigned)(JJ) * (W * kWave * sizeof(int)) + pidx_off))
 
-  // ---- P4: per-bucket state ---------------------------------------------------------------
-  // bucket jj of the wave <-> metadata set jj / 64 of lane jj % 64 (one set up to 4096 points
-  // per wave, two sets beyond: 65 536 < N <= 81 920)
-  constexpr int META = (NBW + kWave - 1) / kWave;
-  const float4 *wave_base = sp + w * kWave;          // bucket (w + 16 jj) starts 16 KiB * jj later
-  const unsigned lane_off = (unsigned)lane * (unsigned)sizeof(float4);
-  float td[NBW];                       // running distance of MY point of bucket jj
-  float blx[META], bly[META], blz[META], bhx[META], bhy[META], bhz[META];  // bucket `lane` of set s
-  float bval[META], bx[META], by[META], bz[META];
-  int bidx[META];
+  // ---- per-bucket state: bucket jj of the wave <-> metadata set jj / 64 of lane jj % 64 ------
+  float blx[META], bly[META], blz[META], bhx[META], bhy[META], bhz[META], bval[META];
+  {
+    const float *sbox = bbox_all + (size_t)blockIdx.x * (cloud_stride / kWave) * 8;
 #pragma unroll
-  for (int s = 0; s < META; ++s) {
-    blx[s] = bly[s] = blz[s] = bhx[s] = bhy[s] = bhz[s] = 0.f;
-    bval[s] = -2.0f; bx[s] = by[s] = bz[s] = 0.f; bidx[s] = 0;
-  }
-#pragma clang loop unroll(full)
-  for (int jj = 0; jj < NBW; ++jj) {
-    const int bid = w + kWaves * jj;
-    td[jj] = -1.0f;
-    if (bid < n_buckets) {  // wave-uniform
-      const float4 q = load_bucket(wave_base, jj, lane_off);
-      const bool real = __builtin_bit_cast(int, q.w) >= 0;
-      td[jj] = real ? 1e10f : -1.0f;
-      const float lx = wave_min_f32(real ? q.x : 3.0e38f), hx = wave_max_f32(real ? q.x : -3.0e38f);
-      const float ly = wave_min_f32(real ? q.y : 3.0e38f), hy = wave_max_f32(real ? q.y : -3.0e38f);
-      const float lz = wave_min_f32(real ? q.z : 3.0e38f), hz = wave_max_f32(real ? q.z : -3.0e38f);
-      if (lane == jj % kWave) {
-        blx[jj / kWave] = lx; bly[jj / kWave] = ly; blz[jj / kWave] = lz;
-        bhx[jj / kWave] = hx; bhy[jj / kWave] = hy; bhz[jj / kWave] = hz;
-        bval[jj / kWave] = 1e10f;  // forces the first round to visit the bucket
+    for (int s = 0; s < META; ++s) {
+      blx[s] = bly[s] = blz[s] = bhx[s] = bhy[s] = bhz[s] = 0.f;
+      bval[s] = -2.0f;
+      const int bid = w + W * (s * kWave + lane);
+      if (bid < n_buckets) {
+        const float4 a = *reinterpret_cast<const float4 *>(sbox + bid * 8);
+        const float2 c = *reinterpret_cast<const float2 *>(sbox + bid * 8 + 4);
+        blx[s] = a.x; bly[s] = a.y; blz[s] = a.z; bhx[s] = a.w; bhy[s] = c.x; bhz[s] = c.y;
+        bval[s] = 1e10f;  // forces the first round to visit the bucket
       }
     }
   }
 
   // ---- rounds -----------------------------------------------------------------------------
-  float x1 = pts[0], y1 = pts[1], z1 = pts[2];
+  const float p0x = pts[0], p0y = pts[1], p0z = pts[2];
+  float x1 = p0x, y1 = p0y, z1 = p0z;
   for (int j = 1; j < m; ++j) {
+    FPS_STAMP(0)
+    FPS_STAMP(1)
+#ifdef FPS_PROBE
+    int probe_visits = 0;
+    bool probe_first = true;
+#endif
     // (1) which of my wave's buckets can change?  lane jj % 64 answers for bucket jj
     unsigned long long visit[META];
 #pragma unroll
     for (int s = 0; s < META; ++s) {
       const float lb = box_dist2(x1, y1, z1, blx[s], bly[s], blz[s], bhx[s], bhy[s], bhz[s]);
       visit[s] = __ballot(bval[s] > -2.0f && lb * 0.999999f < bval[s]);
+#ifdef FPS_PROBE
+      probe_visits += __popcll(visit[s]);
+#endif
     }
-    // (2) update the selected buckets
-#pragma clang loop unroll(full)
-    for (int jj = 0; jj < NBW; ++jj) {
-      if ((visit[jj / kWave] >> (jj % kWave)) & 1ull) {  // wave-uniform
-        const float4 q = load_bucket(wave_base, jj, lane_off);
-        const float d = sqdist3(q.x, q.y, q.z, x1, y1, z1);
-        const float d2 = fminf(d, td[jj]);
-        td[jj] = d2;
-        const int qi = __builtin_bit_cast(int, q.w);
-        const int win = wave_argmax_lane(d2, qi, log2bs);
-        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d2), win));
-        const int vi = __builtin_amdgcn_readlane(qi, win);
-        const float vx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.x), win));
-        const float vy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.y), win));
-        const float vz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.z), win));
-        if (lane == jj % kWave) {
-          bval[jj / kWave] = v; bidx[jj / kWave] = vi;
-          bx[jj / kWave] = vx; by[jj / kWave] = vy; bz[jj / kWave] = vz;
+    FPS_STAMP(2)
+    // (2) update the selected buckets, four at a time
+#pragma unroll
+    for (int s = 0; s < META; ++s) {
+      unsigned long long vm = visit[s];
+      while (vm) {
+        int bk[4];
+        bk[0] = __builtin_ctzll(vm);
+        vm &= vm - 1ull;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+          bk[k] = vm ? (int)__builtin_ctzll(vm) : bk[k - 1];
+          vm = vm ? (vm & (vm - 1ull)) : 0ull;
         }
+        float4 q[4];
+        int qi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          q[k] = *FPS_REC(s * kWave + bk[k]);
+          qi[k] = FPS_PIDX(s * kWave + bk[k]);
+        }
+#ifdef FPS_PROBE
+        if (probe_first) { FPS_STAMP(3) }
+#endif
+        float d2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float d = sqdist3(q[k].x, q[k].y, q[k].z, x1, y1, z1);
+          d2[k] = fminf(d, q[k].w);
+          FPS_REC(s * kWave + bk[k])->w = d2[k];
+        }
+#ifdef FPS_PROBE
+        if (probe_first) { FPS_STAMP(4) }
+#endif
+        // four maxima from one tree: rows 0..3 of r end up holding the maximum of bucket 0, 2, 1, 3
+        float r;
+        {
+          unsigned a0, a1, c0, c1;
+          swap_rows<true>(__builtin_bit_cast(unsigned, d2[0]), __builtin_bit_cast(unsigned, d2[1]), a0, a1);
+          swap_rows<true>(__builtin_bit_cast(unsigned, d2[2]), __builtin_bit_cast(unsigned, d2[3]), c0, c1);
+          float m01, m23;
+          {
+            const float f0 = __builtin_bit_cast(float, a0), f1 = __builtin_bit_cast(float, a1);
+            asm("v_max_f32 %0, %1, %2" : "=v"(m01) : "v"(f0), "v"(f1));
+            const float g0 = __builtin_bit_cast(float, c0), g1 = __builtin_bit_cast(float, c1);
+            asm("v_max_f32 %0, %1, %2" : "=v"(m23) : "v"(g0), "v"(g1));
+          }
+          swap_rows<false>(__builtin_bit_cast(unsigned, m01), __builtin_bit_cast(unsigned, m23), a0, a1);
+          const float f0 = __builtin_bit_cast(float, a0), f1 = __builtin_bit_cast(float, a1);
+          asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(f0), "v"(f1));
+          FPS_DPP_OP("v_max_f32_dpp", r, "quad_perm:[1,0,3,2]");
+          FPS_DPP_OP("v_max_f32_dpp", r, "quad_perm:[2,3,0,1]");
+          FPS_DPP_OP("v_max_f32_dpp", r, "row_half_mirror");
+          FPS_DPP_OP("v_max_f32_dpp", r, "row_mirror");
+        }
+        float mx[4];
+        mx[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 0));
+        mx[2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 16));
+        mx[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 32));
+        mx[3] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 48));
+        unsigned long long tie[4];
+        int holders = 0;   // lanes holding a maximum: 4 unless some bucket has an exact tie
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          tie[k] = __ballot(d2[k] == mx[k]);
+          holders += __popcll(tie[k]);
+        }
+        int win[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) win[k] = __builtin_ctzll(tie[k]);
+        if (__builtin_expect(holders > 4, 0)) {  // exact ties inside a bucket: the reference's order decides
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (tie[k] & (tie[k] - 1ull)) win[k] = wave_tie_break(tie[k], qi[k], log2bs);
+        }
+#ifdef FPS_PROBE
+        if (probe_first) { FPS_STAMP(5) }
+#endif
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          far_pt[lane == win[k] ? w + W * (s * kWave + bk[k]) : far_nowhere] =
+              make_float4(q[k].x, q[k].y, q[k].z, __builtin_bit_cast(float, qi[k]));
+          bval[s] = lane == bk[k] ? mx[k] : bval[s];
+        }
+#ifdef FPS_PROBE
+        if (probe_first) { FPS_STAMP(6) }
+        probe_first = false;
+#endif
       }
     }
-    // (3) best bucket of the lane's sets (value, then the reference's tie order), of the wave,
-    //     then of the workgroup
-    float cv = bval[0], cx = bx[0], cy = by[0], cz = bz[0];
-    int ci = bidx[0];
+    FPS_STAMP(7)
+#ifdef FPS_PROBE
+    if (blockIdx.x == 0 && lane == 0 && j < 2048)
+      fps_probe_v[j * 16 + w] = (unsigned char)(probe_visits > 255 ? 255 : probe_visits);
+#endif
+    // (3) the wave's farthest bucket, then the workgroup's
+    float cv = bval[0];
 #pragma unroll
-    for (int s = 1; s < META; ++s) {
-      const bool better = bval[s] > cv ||
-                          (bval[s] == cv && fps_key(bidx[s], log2bs) < fps_key(ci, log2bs));
-      if (better) { cv = bval[s]; ci = bidx[s]; cx = bx[s]; cy = by[s]; cz = bz[s]; }
+    for (int s = 1; s < META; ++s) cv = fmaxf(cv, bval[s]);
+    const float wm = wave_max_f32(cv);
+    FPS_STAMP(8)
+    unsigned long long eq[META];
+    int total = 0;
+#pragma unroll
+    for (int s = 0; s < META; ++s) {
+      eq[s] = __ballot(bval[s] == wm);
+      total += __popcll(eq[s]);
     }
-    const FpsPick p = fps_block_pick<kWaves>(cv, ci, cx, cy, cz, slots[j & 1], log2bs);
-    if (p.idx == 0) { x1 = pts[0]; y1 = pts[1]; z1 = pts[2]; } else { x1 = p.x; y1 = p.y; z1 = p.z; }
+    int best_jj = 0;  // wave-uniform: the wave's bucket holding its farthest point
+#pragma unroll
+    for (int s = META - 1; s >= 0; --s)
+      if (eq[s]) best_jj = s * kWave + (int)__builtin_ctzll(eq[s]);
+    if (__builtin_expect(total > 1, 0)) {  // equal maxima in several buckets: smallest key wins
+      unsigned key = 0xFFFFFFFFu;
+      int kjj = 0;
+#pragma unroll
+      for (int s = 0; s < META; ++s) {
+        if (bval[s] == wm) {
+          const int jj = s * kWave + lane;
+          const unsigned kk = fps_key(__builtin_bit_cast(int, far_pt[w + W * jj].w), log2bs);
+          if (kk < key) { key = kk; kjj = jj; }
+        }
+      }
+      const unsigned mk = wave_min_u32(key);
+      best_jj = __builtin_amdgcn_readlane(kjj, __builtin_ctzll(__ballot(key == mk)));
+    }
+    FPS_STAMP(9)
+    {
+      const float4 c = far_pt[w + W * best_jj];   // one address: broadcast read
+      if (lane == 0) {
+        float *slot = slots[j & 1] + w * 8;
+        *reinterpret_cast<float4 *>(slot) = make_float4(wm, c.w, c.x, c.y);
+        slot[4] = c.z;
+      }
+    }
+    __syncthreads();
+    FPS_STAMP(10)
+    const FpsPick p = fps_pick_collect<W>(slots[j & 1], log2bs);
+    FPS_STAMP(11)
+    const bool first = p.idx == 0;   // (the reference re-reads point 0 itself, skipped or not)
+    x1 = first ? p0x : p.x; y1 = first ? p0y : p.y; z1 = first ? p0z : p.z;
     if (tid == 0) out[j] = p.idx;
+    FPS_STAMP(12)
   }
+#undef FPS_REC
+#undef FPS_PIDX
 }
 
 }  // namespace
 
-// largest cloud the bucketed tier accepts: 16 waves x 80 buckets x 64 points (the running
-// distances are one VGPR per owned point: 80 of the 128 a 1024-lane workgroup may use)
-constexpr int kBucketMaxPoints = kThreads * 80;
+#ifndef FPS_BUCKET_WAVES
+#define FPS_BUCKET_WAVES 8
+#endif
 
-size_t pn2_fps_bucket_scratch_bytes(int b, int n) {
-  if (n > kBucketMaxPoints) return 0;
-  const int nbw = (n + kThreads - 1) / kThreads;
-  int tier = 8;
-  while (tier < nbw) tier += 8;
-  return sizeof(float4) * (size_t)b * kThreads * tier;
+// largest cloud the bucketed tier accepts: W waves x 3 metadata sets x 64 buckets x 64 points
+constexpr int kBucketMaxPoints = FPS_BUCKET_WAVES * 3 * kWave * kWave;
+
+static size_t fps_bucket_cloud_stride(int n) {  // point slots per cloud: whole buckets
+  return (size_t)((n + kWave - 1) / kWave) * kWave;
 }
 
-// returns 0 and sets *handled when the bucketed kernel was launched
-// largest cloud whose cell lists the kernel can emit (16-bit scatter cursors)
+// per cloud: (x, y, z, distance) + index per slot, 8 floats of bounding box per bucket; then
+// one int per cloud
+size_t pn2_fps_bucket_scratch_bytes(int b, int n) {
+  if (n > kBucketMaxPoints) return 0;
+  const size_t stride = fps_bucket_cloud_stride(n);
+  return (size_t)b * stride * (sizeof(float4) + sizeof(int)) + (size_t)b * (stride / kWave) * 8 * sizeof(float) +
+         sizeof(int) * (((size_t)b + 63) & ~(size_t)63);
+}
+
+// largest cloud whose cell lists the setup kernel can emit (16-bit scatter cursors)
 int pn2_fps_bucket_grid_max_points() { return 65535; }
 
+// returns 0 and sets *handled when the bucketed kernels were launched
 int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, void *scratch,
                        size_t scratch_bytes, int *idxs, hipStream_t stream, int *handled,
                        float grid_radius, void *grid) {
   *handled = 0;
   if (n > kBucketMaxPoints || scratch == nullptr) return 0;
   if (scratch_bytes < pn2_fps_bucket_scratch_bytes(b, n)) return 0;
-  const int nbw = (n + kThreads - 1) / kThreads;
-  float4 *sc = reinterpret_cast<float4 *>(scratch);
+  const size_t stride = fps_bucket_cloud_stride(n);
+  float4 *rec = reinterpret_cast<float4 *>(scratch);
+  int *pidx = reinterpret_cast<int *>(rec + (size_t)b * stride);
+  float *bbox = reinterpret_cast<float *>(pidx + (size_t)b * stride);
+  int *n_valid = reinterpret_cast<int *>(bbox + (size_t)b * (stride / kWave) * 8);
   int *g_start = nullptr;
   float4 *g_rec = nullptr;
   float g_inv = 0.f;
@@ -370,20 +544,17 @@ int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, vo
     g_rec = ws.rec;
     g_inv = grid::grid_inv_side(grid_radius);
   }
-#define FPS_BUCKET(T)                                                                         \
-  hipLaunchKernelGGL((fps_bucket_kernel<T>), dim3(b), dim3(kThreads), 0, stream, n, m, log2bs, \
-                     dataset, sc, idxs, g_inv, g_start, g_rec)
-  if (nbw <= 8) FPS_BUCKET(8);
-  else if (nbw <= 16) FPS_BUCKET(16);
-  else if (nbw <= 24) FPS_BUCKET(24);
-  else if (nbw <= 32) FPS_BUCKET(32);
-  else if (nbw <= 40) FPS_BUCKET(40);
-  else if (nbw <= 48) FPS_BUCKET(48);
-  else if (nbw <= 56) FPS_BUCKET(56);
-  else if (nbw <= 64) FPS_BUCKET(64);
-  else if (nbw <= 72) FPS_BUCKET(72);
-  else FPS_BUCKET(80);
-#undef FPS_BUCKET
+  hipLaunchKernelGGL(fps_bucket_setup_kernel, dim3(b, grid != nullptr ? 2 : 1), dim3(kThreads), 0, stream,
+                     n, stride, dataset, rec, pidx, bbox, n_valid, g_inv, g_start, g_rec);
+  constexpr int WV = FPS_BUCKET_WAVES;
+  const int per_wave = ((int)(stride / kWave) + WV - 1) / WV;   // buckets per wave
+#define FPS_ROUNDS(META)                                                                       \
+  hipLaunchKernelGGL((fps_bucket_rounds_kernel<WV, META>), dim3(b), dim3(WV * kWave), 0, \
+                     stream, n, m, log2bs, stride, dataset, rec, pidx, bbox, n_valid, idxs)
+  if (per_wave <= kWave) FPS_ROUNDS(1);
+  else if (per_wave <= 2 * kWave) FPS_ROUNDS(2);
+  else FPS_ROUNDS(3);
+#undef FPS_ROUNDS
   *handled = 1;
   return pn2_launch_status();
 }
