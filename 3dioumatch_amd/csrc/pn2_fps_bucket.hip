@@ -56,9 +56,29 @@ __device__ unsigned char fps_probe_v[2048 * 16];
 #define FPS_STAMP(I)
 #endif
 
+// Raw buffer access (descriptor + per-lane offset + SCALAR offset).  Declared against the LLVM
+// intrinsics: __builtin_amdgcn_raw_buffer_load_b128 of clang 22 / ROCm 7.2 returns element 0 in
+// all four lanes of its result.
+typedef int fps_i32x4 __attribute__((ext_vector_type(4)));
+typedef float fps_f32x4 __attribute__((ext_vector_type(4)));
+__device__ fps_f32x4 fps_buffer_load_x4(fps_i32x4 rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ void fps_buffer_store_f32(float data, fps_i32x4 rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.store.f32");
+
 namespace {
 
 using namespace fps;
+
+__device__ __forceinline__ fps_i32x4 buffer_rsrc(const void *p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  fps_i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu));   // stride 0: raw buffer
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;                                                               // 32-bit data format
+  return r;
+}
 
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / kWave;  // 16
@@ -264,38 +284,45 @@ fps_bucket_setup_kernel(int n, size_t cloud_stride, const float *__restrict__ da
 // ---- rounds ---------------------------------------------------------------------------------
 // W waves; bucket b belongs to wave b % W and is the wave's bucket jj = b / W; lane jj % 64 holds
 // its bounding box and current maximum in metadata set jj / 64 (META sets); the point that
-// attains the maximum (x, y, z, index) sits in LDS, written by the lane that owns that point.
+// attains the maximum (x, y, z, position in the sorted array) sits in LDS, written by the lane
+// that owns that point.  Original indices are not touched during the rounds: the picks are
+// recorded as positions and translated at the end (exact ties, which need the reference's
+// index-based key, look the indices up on a slow path).
 //
 // A round is one dependent chain, and on this machine a dependent VALU instruction costs 8
 // clocks, a DPP one 16, a VALU -> SGPR -> VALU round trip 32, any branch ~20, an LDS round trip
-// ~110 and an L2 hit ~220 (tools/micro/lat_probe.py, profiles/r3_instruction_costs.json).  So:
-//   * up to FOUR visited buckets are updated together: their 1 KiB loads are in flight at the
-//     same time and their four 64-lane maxima come out of ONE reduction tree (two permlane
-//     swaps leave a quarter of each bucket in each 16-lane row, then four DPP steps) instead
-//     of four trees; when fewer than four remain the last one is repeated -- the update is
-//     idempotent;
+// ~110, an L2 hit ~220, and a vector-memory instruction occupies the CU's one address unit for
+// 8..32 clocks (tools/micro/lat_probe.py, profiles/r3_instruction_costs.json).  So:
+//   * up to G visited buckets are updated together: their 1 KiB loads are in flight at the same
+//     time and their 64-lane maxima come out of ONE reduction tree (permlane swaps leave a part
+//     of each bucket in each 16-lane row, then four DPP steps); when fewer than G remain the
+//     last one is repeated -- the update is idempotent;
+//   * addresses are buffer descriptor + per-lane offset + a SCALAR bucket offset: no VALU
+//     address arithmetic;
 //   * no value is moved between lanes: the lane that holds a bucket's farthest point writes it
 //     to LDS itself, the bucket's maximum reaches its metadata lane as a scalar;
+//   * the waves exchange (maximum, bucket id) only -- 8 bytes per wave -- and then read the
+//     winner's coordinates from LDS;
 //   * exact ties (between points of a bucket, buckets of a wave or waves) are detected with one
-//     popcount each and resolved on a slow path by the reference's reduction-tree key.
-template <int W, int META>
+//     count each and resolved on a slow path by the reference's reduction-tree key.
+template <int W, int META, int G>
 __global__ void __launch_bounds__(W * kWave)
 fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
                          const float *__restrict__ dataset, float4 *__restrict__ rec_all,
                          const int *__restrict__ pidx_all, const float *__restrict__ bbox_all,
                          const int *__restrict__ n_valid_in, int *__restrict__ idxs) {
-  __shared__ __attribute__((aligned(16))) float slots[2][W * 8];
-  // by bucket id: (x, y, z, index) of its farthest point; then one scratch entry per lane, the
-  // target of the lanes that have nothing to write (a select on the address instead of a branch
-  // on exec: branches cost ~20 clocks each here)
+  static_assert(G == 2 || G == 4, "group of 2 or 4 buckets");
+  __shared__ __attribute__((aligned(16))) int2 slots[2][W];   // (bits of the wave's maximum, bucket id)
+  // by bucket id: (x, y, z, position) of its farthest point; then one scratch entry per lane, the
+  // target of the lanes that have nothing to write (a select on the address instead of a branch)
   __shared__ float4 far_pt[W * META * kWave + W * kWave];
-  const int far_nowhere = W * META * kWave + (int)threadIdx.x;
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int w = __builtin_amdgcn_readfirstlane(tid / kWave);
-  const float *pts = dataset + (size_t)blockIdx.x * n * 3;
+  const int far_nowhere = W * META * kWave + tid;
   int *out = idxs + (size_t)blockIdx.x * m;
+  const int *pidx = pidx_all + (size_t)blockIdx.x * cloud_stride;
   const int n_valid = n_valid_in[blockIdx.x];
   const int n_buckets = (n_valid + kWave - 1) / kWave;
   if (tid == 0) out[0] = 0;
@@ -303,13 +330,11 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
     for (int j = 1 + tid; j < m; j += W * kWave) out[j] = 0;
     return;
   }
-  // my point of the wave's jj-th bucket: uniform base + jj * (W KiB) + one lane offset
-  char *rec_base = reinterpret_cast<char *>(rec_all + (size_t)blockIdx.x * cloud_stride);
-  const char *pidx_base = reinterpret_cast<const char *>(pidx_all + (size_t)blockIdx.x * cloud_stride);
-  const unsigned rec_off = (unsigned)(w * kWave + lane) * (unsigned)sizeof(float4);
-  const unsigned pidx_off = (unsigned)(w * kWave + lane) * (unsigned)sizeof(int);
-#define FPS_REC(JJ) (reinterpret_cast<float4 *>(rec_base + (size_t)(unsigned)(JJ) * (W * kWave * sizeof(float4)) + rec_off))
-#define FPS_PIDX(JJ) (*reinterpret_cast<const int *>(pidx_base + (size_t)(unsigned)(JJ) * (W * kWave * sizeof(int)) + pidx_off))
+  // my point of the wave's jj-th bucket: descriptor + lane offset + jj * (W KiB)
+  const fps_i32x4 rec_rs = buffer_rsrc(rec_all + (size_t)blockIdx.x * cloud_stride,
+                                       (unsigned)(cloud_stride * sizeof(float4)));
+  const int rec_off = (w * kWave + lane) * (int)sizeof(float4);
+  constexpr int kBucketStep = W * kWave * (int)sizeof(float4);
 
   // ---- per-bucket state: bucket jj of the wave <-> metadata set jj / 64 of lane jj % 64 ------
   float blx[META], bly[META], blz[META], bhx[META], bhy[META], bhz[META], bval[META];
@@ -330,8 +355,8 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
   }
 
   // ---- rounds -----------------------------------------------------------------------------
-  const float p0x = pts[0], p0y = pts[1], p0z = pts[2];
-  float x1 = p0x, y1 = p0y, z1 = p0z;
+  const float *pts = dataset + (size_t)blockIdx.x * n * 3;
+  float x1 = pts[0], y1 = pts[1], z1 = pts[2];
   for (int j = 1; j < m; ++j) {
     FPS_STAMP(0)
     FPS_STAMP(1)
@@ -344,55 +369,58 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
 #pragma unroll
     for (int s = 0; s < META; ++s) {
       const float lb = box_dist2(x1, y1, z1, blx[s], bly[s], blz[s], bhx[s], bhy[s], bhz[s]);
-      visit[s] = __ballot(bval[s] > -2.0f && lb * 0.999999f < bval[s]);
+      visit[s] = __ballot(lb * 0.999999f < bval[s]);   // (absent buckets: bval = -2 < 0 <= lb)
 #ifdef FPS_PROBE
       probe_visits += __popcll(visit[s]);
 #endif
     }
     FPS_STAMP(2)
-    // (2) update the selected buckets, four at a time
+    // (2) update the selected buckets, G at a time
 #pragma unroll
     for (int s = 0; s < META; ++s) {
       unsigned long long vm = visit[s];
       while (vm) {
-        int bk[4];
+        int bk[G];
         bk[0] = __builtin_ctzll(vm);
         vm &= vm - 1ull;
 #pragma unroll
-        for (int k = 1; k < 4; ++k) {
+        for (int k = 1; k < G; ++k) {
           bk[k] = vm ? (int)__builtin_ctzll(vm) : bk[k - 1];
           vm = vm ? (vm & (vm - 1ull)) : 0ull;
         }
-        float4 q[4];
-        int qi[4];
+        fps_f32x4 q[G];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          q[k] = *FPS_REC(s * kWave + bk[k]);
-          qi[k] = FPS_PIDX(s * kWave + bk[k]);
-        }
+        for (int k = 0; k < G; ++k)
+          q[k] = fps_buffer_load_x4(rec_rs, rec_off, (s * kWave + bk[k]) * kBucketStep, 0);
 #ifdef FPS_PROBE
         if (probe_first) { FPS_STAMP(3) }
 #endif
-        float d2[4];
+        float d2[G];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < G; ++k) {
           const float d = sqdist3(q[k].x, q[k].y, q[k].z, x1, y1, z1);
-          d2[k] = fminf(d, q[k].w);
-          FPS_REC(s * kWave + bk[k])->w = d2[k];
+          const float told = q[k].w;
+          asm("v_min_f32 %0, %1, %2" : "=v"(d2[k]) : "v"(d), "v"(told));
+          fps_buffer_store_f32(d2[k], rec_rs, rec_off + 12, (s * kWave + bk[k]) * kBucketStep, 0);
         }
 #ifdef FPS_PROBE
         if (probe_first) { FPS_STAMP(4) }
 #endif
-        // four maxima from one tree: rows 0..3 of r end up holding the maximum of bucket 0, 2, 1, 3
+        // G maxima from one tree
         float r;
+        float mx[G];
         {
-          unsigned a0, a1, c0, c1;
+          unsigned a0, a1;
           swap_rows<true>(__builtin_bit_cast(unsigned, d2[0]), __builtin_bit_cast(unsigned, d2[1]), a0, a1);
-          swap_rows<true>(__builtin_bit_cast(unsigned, d2[2]), __builtin_bit_cast(unsigned, d2[3]), c0, c1);
-          float m01, m23;
+          float m01;
           {
             const float f0 = __builtin_bit_cast(float, a0), f1 = __builtin_bit_cast(float, a1);
             asm("v_max_f32 %0, %1, %2" : "=v"(m01) : "v"(f0), "v"(f1));
+          }
+          float m23 = m01;
+          if (G == 4) {
+            unsigned c0, c1;
+            swap_rows<true>(__builtin_bit_cast(unsigned, d2[G - 2]), __builtin_bit_cast(unsigned, d2[G - 1]), c0, c1);
             const float g0 = __builtin_bit_cast(float, c0), g1 = __builtin_bit_cast(float, c1);
             asm("v_max_f32 %0, %1, %2" : "=v"(m23) : "v"(g0), "v"(g1));
           }
@@ -404,33 +432,37 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
           FPS_DPP_OP("v_max_f32_dpp", r, "row_half_mirror");
           FPS_DPP_OP("v_max_f32_dpp", r, "row_mirror");
         }
-        float mx[4];
+        // rows 0..3 of r: G == 4: buckets 0, 2, 1, 3;  G == 2: buckets 0, 0, 1, 1
         mx[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 0));
-        mx[2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 16));
         mx[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 32));
-        mx[3] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 48));
-        unsigned long long tie[4];
-        int holders = 0;   // lanes holding a maximum: 4 unless some bucket has an exact tie
+        if (G == 4) {
+          mx[G - 2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 16));
+          mx[G - 1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 48));
+        }
+        unsigned long long tie[G];
+        int holders = 0;   // lanes holding a maximum: G unless some bucket has an exact tie
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < G; ++k) {
           tie[k] = __ballot(d2[k] == mx[k]);
           holders += __popcll(tie[k]);
         }
-        int win[4];
+        int win[G];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) win[k] = __builtin_ctzll(tie[k]);
-        if (__builtin_expect(holders > 4, 0)) {  // exact ties inside a bucket: the reference's order decides
+        for (int k = 0; k < G; ++k) win[k] = __builtin_ctzll(tie[k]);
+        if (__builtin_expect(holders > G, 0)) {  // exact ties inside a bucket: the reference's order decides
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (tie[k] & (tie[k] - 1ull)) win[k] = wave_tie_break(tie[k], qi[k], log2bs);
+          for (int k = 0; k < G; ++k)
+            if (tie[k] & (tie[k] - 1ull))
+              win[k] = wave_tie_break(tie[k], pidx[(w + W * (s * kWave + bk[k])) * kWave + lane], log2bs);
         }
 #ifdef FPS_PROBE
         if (probe_first) { FPS_STAMP(5) }
 #endif
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          far_pt[lane == win[k] ? w + W * (s * kWave + bk[k]) : far_nowhere] =
-              make_float4(q[k].x, q[k].y, q[k].z, __builtin_bit_cast(float, qi[k]));
+        for (int k = 0; k < G; ++k) {
+          const int gb = w + W * (s * kWave + bk[k]);
+          far_pt[lane == win[k] ? gb : far_nowhere] =
+              make_float4(q[k].x, q[k].y, q[k].z, __builtin_bit_cast(float, gb * kWave + lane));
           bval[s] = lane == bk[k] ? mx[k] : bval[s];
         }
 #ifdef FPS_PROBE
@@ -444,7 +476,7 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
     if (blockIdx.x == 0 && lane == 0 && j < 2048)
       fps_probe_v[j * 16 + w] = (unsigned char)(probe_visits > 255 ? 255 : probe_visits);
 #endif
-    // (3) the wave's farthest bucket, then the workgroup's
+    // (3) the wave's farthest bucket ...
     float cv = bval[0];
 #pragma unroll
     for (int s = 1; s < META; ++s) cv = fmaxf(cv, bval[s]);
@@ -461,14 +493,14 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
 #pragma unroll
     for (int s = META - 1; s >= 0; --s)
       if (eq[s]) best_jj = s * kWave + (int)__builtin_ctzll(eq[s]);
-    if (__builtin_expect(total > 1, 0)) {  // equal maxima in several buckets: smallest key wins
+    if (__builtin_expect(total > 1 && wm > -2.0f, 0)) {  // equal maxima in several buckets: smallest key wins
       unsigned key = 0xFFFFFFFFu;
       int kjj = 0;
 #pragma unroll
       for (int s = 0; s < META; ++s) {
         if (bval[s] == wm) {
           const int jj = s * kWave + lane;
-          const unsigned kk = fps_key(__builtin_bit_cast(int, far_pt[w + W * jj].w), log2bs);
+          const unsigned kk = fps_key(pidx[__builtin_bit_cast(int, far_pt[w + W * jj].w)], log2bs);
           if (kk < key) { key = kk; kjj = jj; }
         }
       }
@@ -476,31 +508,43 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
       best_jj = __builtin_amdgcn_readlane(kjj, __builtin_ctzll(__ballot(key == mk)));
     }
     FPS_STAMP(9)
-    {
-      const float4 c = far_pt[w + W * best_jj];   // one address: broadcast read
-      if (lane == 0) {
-        float *slot = slots[j & 1] + w * 8;
-        *reinterpret_cast<float4 *>(slot) = make_float4(wm, c.w, c.x, c.y);
-        slot[4] = c.z;
-      }
-    }
+    if (lane == 0) slots[j & 1][w] = make_int2(__builtin_bit_cast(int, wm), w + W * best_jj);
     __syncthreads();
     FPS_STAMP(10)
-    const FpsPick p = fps_pick_collect<W>(slots[j & 1], log2bs);
+    // ... and the workgroup's: lane i < W takes wave i's candidate, log2(W) DPP steps, one ballot
+    constexpr int CL = W <= 8 ? 8 : 16;
+    int2 cand = make_int2(__builtin_bit_cast(int, -2.0f), 0);
+    if (lane < W) cand = slots[j & 1][lane];
+    const float cvl = __builtin_bit_cast(float, cand.x);
+    const float best = wave_max_f32<CL>(cvl);
+    const unsigned long long ceq = __ballot(cvl == best) & ((1ull << W) - 1ull);
+    int pick_gb = __builtin_amdgcn_readlane(cand.y, (int)__builtin_ctzll(ceq));
+    if (__builtin_expect((ceq & (ceq - 1ull)) != 0ull, 0)) {  // equal maxima in several waves: smallest key wins
+      unsigned key = 0xFFFFFFFFu;
+      if ((ceq >> lane) & 1ull)
+        key = fps_key(pidx[__builtin_bit_cast(int, far_pt[cand.y].w)], log2bs);
+      const unsigned mk = wave_min_u32(key);
+      pick_gb = __builtin_amdgcn_readlane(cand.y, (int)__builtin_ctzll(__ballot(key == mk)));
+    }
     FPS_STAMP(11)
-    const bool first = p.idx == 0;   // (the reference re-reads point 0 itself, skipped or not)
-    x1 = first ? p0x : p.x; y1 = first ? p0y : p.y; z1 = first ? p0z : p.z;
-    if (tid == 0) out[j] = p.idx;
+    const float4 c = far_pt[pick_gb];   // one address: broadcast read
+    x1 = c.x; y1 = c.y; z1 = c.z;
+    if (tid == 0) out[j] = __builtin_bit_cast(int, c.w);   // position; translated below
+    __syncthreads();   // the owner of pick_gb rewrites far_pt[pick_gb] in the next round
     FPS_STAMP(12)
   }
-#undef FPS_REC
-#undef FPS_PIDX
+  // positions -> original indices (wave 0 wrote them: same-wave program order)
+  if (w == 0)
+    for (int j = 1 + lane; j < m; j += kWave) out[j] = pidx[out[j]];
 }
 
 }  // namespace
 
 #ifndef FPS_BUCKET_WAVES
 #define FPS_BUCKET_WAVES 8
+#endif
+#ifndef FPS_BUCKET_GROUP
+#define FPS_BUCKET_GROUP 2
 #endif
 
 // largest cloud the bucketed tier accepts: W waves x 3 metadata sets x 64 buckets x 64 points
@@ -549,7 +593,7 @@ int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, vo
   constexpr int WV = FPS_BUCKET_WAVES;
   const int per_wave = ((int)(stride / kWave) + WV - 1) / WV;   // buckets per wave
 #define FPS_ROUNDS(META)                                                                       \
-  hipLaunchKernelGGL((fps_bucket_rounds_kernel<WV, META>), dim3(b), dim3(WV * kWave), 0, \
+  hipLaunchKernelGGL((fps_bucket_rounds_kernel<WV, META, FPS_BUCKET_GROUP>), dim3(b), dim3(WV * kWave), 0, \
                      stream, n, m, log2bs, stride, dataset, rec, pidx, bbox, n_valid, idxs)
   if (per_wave <= kWave) FPS_ROUNDS(1);
   else if (per_wave <= 2 * kWave) FPS_ROUNDS(2);

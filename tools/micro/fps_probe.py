@@ -22,7 +22,7 @@ CSRC = os.path.join(ROOT, "3dioumatch_amd", "csrc")
 src = os.path.join(HERE, "fps_probe.hip")
 
 
-CONFIGS = ((8, 4), (4, 4), (16, 4))
+CONFIGS = ((8, 2), (4, 2), (4, 4))
 
 
 def load(waves, group=4):
@@ -56,7 +56,7 @@ scene = data_mod.make_batch(B, N, cfg, seed=100)["point_clouds"][:, :, :3].conti
 torch.manual_seed(0)
 uniform = (torch.rand(B, N, 3, device=dev) * 6.0).contiguous()
 res = {}
-for WV, GG, tag, xyz in [(wv, gg, "scene", scene) for wv, gg in CONFIGS] + [(8, 4, "uniform", uniform)]:
+for WV, GG, tag, xyz in [(wv, gg, "scene", scene) for wv, gg in CONFIGS] + [(8, 2, "uniform", uniform)]:
     lib = load(WV, GG)
     nbytes = lib.fps_probe_scratch(B, N)
     scratch = torch.empty(nbytes // 4 + 16, device=dev)
@@ -84,8 +84,8 @@ for WV, GG, tag, xyz in [(wv, gg, "scene", scene) for wv, gg in CONFIGS] + [(8, 
            "visits_per_wave_mean": round(float(vis.mean()), 3),
            "visits_max_over_waves_mean": round(float(vis.max(axis=1).mean()), 3)}
     seg = {"stamp_cost(0-1)": (0, 1), "box_tests(1-2)": (1, 2), "visits_all(2-7)": (2, 7),
-           "sets+wave_max(7-8)": (7, 8), "select_bucket(8-9)": (8, 9), "far_pt_read+slot+barrier(9-10)": (9, 10),
-           "collect(10-11)": (10, 11), "select+store(11-12)": (11, 12)}
+           "sets+wave_max(7-8)": (7, 8), "select_bucket(8-9)": (8, 9), "slot+barrier(9-10)": (9, 10),
+           "collect(10-11)": (10, 11), "far_pt_read+barrier(11-12)": (11, 12)}
     out["clk"] = {k: round(float((T[:, :, b] - T[:, :, a]).mean()), 1) for k, (a, b) in seg.items()}
     out["clk"]["loop_back(12-next0)"] = round(float((nxt - T[:, :, 12]).mean()), 1)
     out["clk"]["barrier_min_over_waves(9-10)"] = round(float((T[:, :, 10] - T[:, :, 9]).min(axis=1).mean()), 1)
