@@ -312,6 +312,7 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
                          const int *__restrict__ pidx_all, const float *__restrict__ bbox_all,
                          const int *__restrict__ n_valid_in, int *__restrict__ idxs) {
   static_assert(G == 2 || G == 4, "group of 2 or 4 buckets");
+  constexpr int NG = 3;   // groups whose loads are issued together
   __shared__ __attribute__((aligned(16))) int2 slots[2][W];   // (bits of the wave's maximum, bucket id)
   // by bucket id: (x, y, z, position) of its farthest point; then one scratch entry per lane, the
   // target of the lanes that have nothing to write (a select on the address instead of a branch)
@@ -375,100 +376,109 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
 #endif
     }
     FPS_STAMP(2)
-    // (2) update the selected buckets, G at a time
+    // (2) update the selected buckets: the loads of up to NG groups of G are issued together
+    //     (one L2 latency per round, not per group), then group after group is reduced
 #pragma unroll
     for (int s = 0; s < META; ++s) {
       unsigned long long vm = visit[s];
       while (vm) {
-        int bk[G];
-        bk[0] = __builtin_ctzll(vm);
-        vm &= vm - 1ull;
+        const int nv = __popcll(vm);
+        int bk[NG * G];
+        fps_f32x4 q[NG * G];
 #pragma unroll
-        for (int k = 1; k < G; ++k) {
-          bk[k] = vm ? (int)__builtin_ctzll(vm) : bk[k - 1];
-          vm = vm ? (vm & (vm - 1ull)) : 0ull;
+        for (int g = 0; g < NG; ++g) {
+          if (g == 0 || nv > g * G) {   // wave-uniform
+#pragma unroll
+            for (int k = g * G; k < (g + 1) * G; ++k) {
+              bk[k] = (k == 0 || vm) ? (int)__builtin_ctzll(vm) : bk[k - 1];
+              vm = vm ? (vm & (vm - 1ull)) : 0ull;
+              q[k] = fps_buffer_load_x4(rec_rs, rec_off, (s * kWave + bk[k]) * kBucketStep, 0);
+            }
+          }
         }
-        fps_f32x4 q[G];
-#pragma unroll
-        for (int k = 0; k < G; ++k)
-          q[k] = fps_buffer_load_x4(rec_rs, rec_off, (s * kWave + bk[k]) * kBucketStep, 0);
 #ifdef FPS_PROBE
         if (probe_first) { FPS_STAMP(3) }
 #endif
-        float d2[G];
 #pragma unroll
-        for (int k = 0; k < G; ++k) {
-          const float d = sqdist3(q[k].x, q[k].y, q[k].z, x1, y1, z1);
-          const float told = q[k].w;
-          asm("v_min_f32 %0, %1, %2" : "=v"(d2[k]) : "v"(d), "v"(told));
-          fps_buffer_store_f32(d2[k], rec_rs, rec_off + 12, (s * kWave + bk[k]) * kBucketStep, 0);
-        }
+        for (int g = 0; g < NG; ++g) {
+          if (g == 0 || nv > g * G) {   // wave-uniform
+            const int k0 = g * G;
+            float d2[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+              const float d = sqdist3(q[k0 + k].x, q[k0 + k].y, q[k0 + k].z, x1, y1, z1);
+              const float told = q[k0 + k].w;
+              asm("v_min_f32 %0, %1, %2" : "=v"(d2[k]) : "v"(d), "v"(told));
+              fps_buffer_store_f32(d2[k], rec_rs, rec_off + 12, (s * kWave + bk[k0 + k]) * kBucketStep, 0);
+            }
 #ifdef FPS_PROBE
-        if (probe_first) { FPS_STAMP(4) }
+            if (probe_first) { FPS_STAMP(4) }
 #endif
-        // G maxima from one tree
-        float r;
-        float mx[G];
-        {
-          unsigned a0, a1;
-          swap_rows<true>(__builtin_bit_cast(unsigned, d2[0]), __builtin_bit_cast(unsigned, d2[1]), a0, a1);
-          float m01;
-          {
-            const float f0 = __builtin_bit_cast(float, a0), f1 = __builtin_bit_cast(float, a1);
-            asm("v_max_f32 %0, %1, %2" : "=v"(m01) : "v"(f0), "v"(f1));
+            // G maxima from one tree
+            float r;
+            float mx[G];
+            {
+              unsigned a0, a1;
+              swap_rows<true>(__builtin_bit_cast(unsigned, d2[0]), __builtin_bit_cast(unsigned, d2[1]), a0, a1);
+              float m01;
+              {
+                const float f0 = __builtin_bit_cast(float, a0), f1 = __builtin_bit_cast(float, a1);
+                asm("v_max_f32 %0, %1, %2" : "=v"(m01) : "v"(f0), "v"(f1));
+              }
+              float m23 = m01;
+              if (G == 4) {
+                unsigned c0, c1;
+                swap_rows<true>(__builtin_bit_cast(unsigned, d2[G - 2]), __builtin_bit_cast(unsigned, d2[G - 1]), c0, c1);
+                const float g0 = __builtin_bit_cast(float, c0), g1 = __builtin_bit_cast(float, c1);
+                asm("v_max_f32 %0, %1, %2" : "=v"(m23) : "v"(g0), "v"(g1));
+              }
+              swap_rows<false>(__builtin_bit_cast(unsigned, m01), __builtin_bit_cast(unsigned, m23), a0, a1);
+              const float f0 = __builtin_bit_cast(float, a0), f1 = __builtin_bit_cast(float, a1);
+              asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(f0), "v"(f1));
+              FPS_DPP_OP("v_max_f32_dpp", r, "quad_perm:[1,0,3,2]");
+              FPS_DPP_OP("v_max_f32_dpp", r, "quad_perm:[2,3,0,1]");
+              FPS_DPP_OP("v_max_f32_dpp", r, "row_half_mirror");
+              FPS_DPP_OP("v_max_f32_dpp", r, "row_mirror");
+            }
+            // rows 0..3 of r: G == 4: buckets 0, 2, 1, 3;  G == 2: buckets 0, 0, 1, 1
+            mx[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 0));
+            mx[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 32));
+            if (G == 4) {
+              mx[G - 2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 16));
+              mx[G - 1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 48));
+            }
+            unsigned long long tie[G];
+            int holders = 0;   // lanes holding a maximum: G unless some bucket has an exact tie
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+              tie[k] = __ballot(d2[k] == mx[k]);
+              holders += __popcll(tie[k]);
+            }
+            int win[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) win[k] = __builtin_ctzll(tie[k]);
+            if (__builtin_expect(holders > G, 0)) {  // exact ties inside a bucket: the reference's order decides
+#pragma unroll
+              for (int k = 0; k < G; ++k)
+                if (tie[k] & (tie[k] - 1ull))
+                  win[k] = wave_tie_break(tie[k], pidx[(w + W * (s * kWave + bk[k0 + k])) * kWave + lane], log2bs);
+            }
+#ifdef FPS_PROBE
+            if (probe_first) { FPS_STAMP(5) }
+#endif
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+              const int gb = w + W * (s * kWave + bk[k0 + k]);
+              far_pt[lane == win[k] ? gb : far_nowhere] =
+                  make_float4(q[k0 + k].x, q[k0 + k].y, q[k0 + k].z, __builtin_bit_cast(float, gb * kWave + lane));
+              bval[s] = lane == bk[k0 + k] ? mx[k] : bval[s];
+            }
+#ifdef FPS_PROBE
+            if (probe_first) { FPS_STAMP(6) }
+            probe_first = false;
+#endif
           }
-          float m23 = m01;
-          if (G == 4) {
-            unsigned c0, c1;
-            swap_rows<true>(__builtin_bit_cast(unsigned, d2[G - 2]), __builtin_bit_cast(unsigned, d2[G - 1]), c0, c1);
-            const float g0 = __builtin_bit_cast(float, c0), g1 = __builtin_bit_cast(float, c1);
-            asm("v_max_f32 %0, %1, %2" : "=v"(m23) : "v"(g0), "v"(g1));
-          }
-          swap_rows<false>(__builtin_bit_cast(unsigned, m01), __builtin_bit_cast(unsigned, m23), a0, a1);
-          const float f0 = __builtin_bit_cast(float, a0), f1 = __builtin_bit_cast(float, a1);
-          asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(f0), "v"(f1));
-          FPS_DPP_OP("v_max_f32_dpp", r, "quad_perm:[1,0,3,2]");
-          FPS_DPP_OP("v_max_f32_dpp", r, "quad_perm:[2,3,0,1]");
-          FPS_DPP_OP("v_max_f32_dpp", r, "row_half_mirror");
-          FPS_DPP_OP("v_max_f32_dpp", r, "row_mirror");
         }
-        // rows 0..3 of r: G == 4: buckets 0, 2, 1, 3;  G == 2: buckets 0, 0, 1, 1
-        mx[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 0));
-        mx[1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 32));
-        if (G == 4) {
-          mx[G - 2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 16));
-          mx[G - 1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 48));
-        }
-        unsigned long long tie[G];
-        int holders = 0;   // lanes holding a maximum: G unless some bucket has an exact tie
-#pragma unroll
-        for (int k = 0; k < G; ++k) {
-          tie[k] = __ballot(d2[k] == mx[k]);
-          holders += __popcll(tie[k]);
-        }
-        int win[G];
-#pragma unroll
-        for (int k = 0; k < G; ++k) win[k] = __builtin_ctzll(tie[k]);
-        if (__builtin_expect(holders > G, 0)) {  // exact ties inside a bucket: the reference's order decides
-#pragma unroll
-          for (int k = 0; k < G; ++k)
-            if (tie[k] & (tie[k] - 1ull))
-              win[k] = wave_tie_break(tie[k], pidx[(w + W * (s * kWave + bk[k])) * kWave + lane], log2bs);
-        }
-#ifdef FPS_PROBE
-        if (probe_first) { FPS_STAMP(5) }
-#endif
-#pragma unroll
-        for (int k = 0; k < G; ++k) {
-          const int gb = w + W * (s * kWave + bk[k]);
-          far_pt[lane == win[k] ? gb : far_nowhere] =
-              make_float4(q[k].x, q[k].y, q[k].z, __builtin_bit_cast(float, gb * kWave + lane));
-          bval[s] = lane == bk[k] ? mx[k] : bval[s];
-        }
-#ifdef FPS_PROBE
-        if (probe_first) { FPS_STAMP(6) }
-        probe_first = false;
-#endif
       }
     }
     FPS_STAMP(7)
