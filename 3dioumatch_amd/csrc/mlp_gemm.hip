@@ -206,12 +206,25 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
                 float *__restrict__ ext = nullptr, size_t ext_plane = 0,
                 const float *__restrict__ pool_gamma = nullptr) {
   constexpr int MB = TM / WM / 32, NB = TN / WN / 32;
-  constexpr int LDA = TM + 4;       // [k][m] rows; 16-byte aligned rows, conflict-free fragments
+  // LDS layout "k-quads": the chunk's 16 k are four planes of [row][4 consecutive k], so that a
+  // lane fetches the fragments of FOUR MFMA steps with one 16-byte read (m or n = its row, the
+  // plane = 2 * (lane >> 5) + half of the chunk): 2 * (MB + NB) reads feed the chunk's
+  // 8 * MB * NB MFMAs and need no address arithmetic (one base register per operand, immediate
+  // offsets).  The previous [k][row] layout cost one 4-byte read per MFMA operand and step, with
+  // a VALU add per pair of reads, and kept the matrix pipes 50-70 % busy -- what a stream of
+  // MFMAs that waits for one LDS read per MFMA reaches in isolation (tools/micro/mfma_peak.py).
+  // The MFMA consumes k in the order (t, 8 + t), t = 0..7, instead of (2t, 2t + 1): a
+  // permutation of the summation order inside the chunk.
+  // B rows carry 16 bytes of padding after every 8 rows: the 16 lanes that stage one k row write
+  // rows 8 apart (SEG = 8) and would otherwise meet in the same banks.
+  constexpr int PLA = TM * 4 + 16;              // floats per A plane (+16: planes start 16 banks apart)
+  constexpr int PLB = TN * 4 + (TN / 8) * 4;    // floats per B plane
   constexpr int AV = TM * KC / 4 / 256;  // 16-byte A pieces per lane and chunk
   constexpr int SEG = TN / 16;      // B elements per lane: 16 lanes share one row
   static_assert(AV >= 1 && SEG % 4 == 0, "tile too small for the vector paths");
-  __shared__ __attribute__((aligned(16))) float As[2][KC * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][KC * TN];
+  static_assert(KC == 16, "four k-quads per chunk");
+  __shared__ __attribute__((aligned(16))) float As[2][4 * PLA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][4 * PLB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int r0 = blockIdx.x * TN, m0 = blockIdx.y * TM, b = blockIdx.z;
@@ -300,11 +313,12 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
 #pragma unroll
     for (int e = 0; e < AV; ++e) {
       const int t = tid + e * 256;
-      if (A_TRANS) {
-        *reinterpret_cast<float4 *>(&As[buf][(t / (TM / 4)) * LDA + (t % (TM / 4)) * 4]) = areg[e];
-      } else {
-        float *dst = &As[buf][((t % (KC / 4)) * 4) * LDA + t / (KC / 4)];
-        dst[0] = areg[e].x; dst[LDA] = areg[e].y; dst[2 * LDA] = areg[e].z; dst[3 * LDA] = areg[e].w;
+      if (A_TRANS) {  // one k row, four consecutive m
+        const int kk = t / (TM / 4), mm = (t % (TM / 4)) * 4;
+        float *dst = &As[buf][(kk >> 2) * PLA + mm * 4 + (kk & 3)];
+        dst[0] = areg[e].x; dst[4] = areg[e].y; dst[8] = areg[e].z; dst[12] = areg[e].w;
+      } else {        // one m row, four consecutive k: exactly one k-quad
+        *reinterpret_cast<float4 *>(&As[buf][(t % (KC / 4)) * PLA + (t / (KC / 4)) * 4]) = areg[e];
       }
     }
 #pragma unroll
@@ -323,24 +337,36 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
         v.z = transform<MODE>(bx[i + 2], bdz[i + 2], rc);
         v.w = transform<MODE>(bx[i + 3], bdz[i + 3], rc);
       }
-      *reinterpret_cast<float4 *>(&Bs[buf][bkk * TN + bnn + i]) = v;
+      {
+        const int n = bnn + i;
+        float *dst = &Bs[buf][(bkk >> 2) * PLB + n * 4 + (n >> 3) * 4 + (bkk & 3)];
+        dst[0] = v.x; dst[4] = v.y; dst[8] = v.z; dst[12] = v.w;
+      }
     }
   };
-  auto multiply = [&](int buf, int kk_lo, int kk_hi) {
+  // fragments of half a chunk (four MFMA steps): plane 2 * (lane >> 5) + hh, this lane's rows
+  const int a_frag = (2 * (lane >> 5)) * PLA + ((wm * MB) * 32 + (lane & 31)) * 4;
+  const int b_row = (wn * NB) * 32 + (lane & 31);
+  const int b_frag = (2 * (lane >> 5)) * PLB + b_row * 4 + (b_row >> 3) * 4;
+  auto fragments = [&](int buf, int hh, float4 (&af)[MB], float4 (&bf)[NB]) {
 #pragma unroll
-    for (int kk = kk_lo; kk < kk_hi; kk += 2) {
-      const int krow = kk + (lane >> 5);
-      float af[MB], bf[NB];
+    for (int i = 0; i < MB; ++i)
+      af[i] = *reinterpret_cast<const float4 *>(&As[buf][a_frag + hh * PLA + i * 128]);
 #pragma unroll
-      for (int i = 0; i < MB; ++i) af[i] = As[buf][krow * LDA + (wm * MB + i) * 32 + (lane & 31)];
+    for (int j = 0; j < NB; ++j)
+      bf[j] = *reinterpret_cast<const float4 *>(&Bs[buf][b_frag + hh * PLB + j * (128 + 16)]);
+  };
+  auto multiply = [&](const float4 (&af)[MB], const float4 (&bf)[NB]) {
 #pragma unroll
-      for (int j = 0; j < NB; ++j) bf[j] = Bs[buf][krow * TN + (wn * NB + j) * 32 + (lane & 31)];
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
+        for (int j = 0; j < NB; ++j) {
+          const float av = e == 0 ? af[i].x : e == 1 ? af[i].y : e == 2 ? af[i].z : af[i].w;
+          const float bv = e == 0 ? bf[j].x : e == 1 ? bf[j].y : e == 2 ? bf[j].z : bf[j].w;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+        }
   };
 
   const int chunks = (k_total + KC - 1) / KC;
@@ -350,10 +376,13 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
   __syncthreads();
   for (int i = 0; i < chunks; ++i) {
     const int cur = i & 1;
-    multiply(cur, 0, KC / 2);
+    float4 af0[MB], bf0[NB], af1[MB], bf1[NB];
+    fragments(cur, 0, af0, bf0);
+    fragments(cur, 1, af1, bf1);                   // in flight during the first 4 * MB * NB MFMAs
+    multiply(af0, bf0);
     if (i + 1 < chunks) stash(cur ^ 1);            // chunk i+1: registers -> the other buffer
     if (i + 2 < chunks) fetch((i + 2) * KC);       // chunk i+2: in flight during the MFMAs
-    multiply(cur, KC / 2, KC);
+    multiply(af1, bf1);
     __syncthreads();  // buffer cur is free again, buffer cur^1 is complete
   }
   // C/D layout of the 32x32 block: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
@@ -424,8 +453,8 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
     // chunks swizzled [row][chunk ^ (row & 15)] (conflict-free for the column-wise 4-byte writes
     // and for the row-wise 16-byte reads), then lane (row = lane & 31, half = lane >> 5) scans
     // 32 consecutive samples of its row for the largest value and its first position.
-    constexpr int AS_FLOATS = 2 * KC * LDA;
-    static_assert(AS_FLOATS >= 2 * 2048 && (AS_FLOATS >= 4 * 2048 || 2 * KC * TN >= 2 * 2048),
+    constexpr int AS_FLOATS = 2 * 4 * PLA;
+    static_assert(AS_FLOATS >= 2 * 2048 && (AS_FLOATS >= 4 * 2048 || 2 * 4 * PLB >= 2 * 2048),
                   "operand buffers too small to park the accumulators");
     float *park = AS_FLOATS >= 4 * 2048 ? &As[0][0] + wave * 2048
                                         : (wave < 2 ? &As[0][0] + wave * 2048 : &Bs[0][0] + (wave - 2) * 2048);
