@@ -26,6 +26,8 @@ python tools/pmc_table.py $O/${TAG}_pair_sq_counters.csv --filter grid_ $P/psq/p
 # -- VALU-bound operators
 run ops_valu rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d $P/ops -o ops -- python tools/op_bench.py 3
 python tools/valu_util.py $P/ops/ops_counter_collection.csv $O/${TAG}_ops_valu_util.json > $O/ops_valu.txt 2>&1
+# -- furthest point sampling: product timings, round clocks
+timeout 120 python tools/micro/fps_time.py > $O/${TAG}_fps_time.json 2> $O/fps_time.log; echo "fps_time rc=$?"
 # -- shared-MLP GEMMs
 run gemm_util rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $P/gemm -o g -- python tools/gemm_bench.py
 python tools/mfma_util.py $P/gemm/g_counter_collection.csv $O/${TAG}_gemm_mfma_util.csv > /dev/null 2>&1

@@ -16,7 +16,7 @@ import sys
 from collections import defaultdict
 
 WANT = ("pair_matrix_kernel", "three_nn_kernel", "ball_query_bf_kernel", "scene_max_kernel",
-        "nms_mask_kernel", "grid_query_kernel", "fps_bucket_kernel", "fps_reg_kernel")
+        "nms_mask_kernel", "grid_query_kernel", "fps_bucket_rounds_kernel", "fps_bucket_setup_kernel", "fps_reg_kernel")
 agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
