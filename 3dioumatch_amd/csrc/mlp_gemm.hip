@@ -217,7 +217,13 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
   // permutation of the summation order inside the chunk.
   // B rows carry 16 bytes of padding after every 8 rows: the 16 lanes that stage one k row write
   // rows 8 apart (SEG = 8) and would otherwise meet in the same banks.
+  // A_TRANS (dgrad: the weight as stored) stages 4-byte pieces of rows 4 apart, which would land
+  // in 4 of the 16 bank groups: there the rows are rotated inside their group of 16 by the group's
+  // number (a_slot).  Measured on one box, forward / dgrad shapes of tools/gemm_bench.py:
+  // [k][row] layout 1454-1463 / 1911-1916 us, k-quads 1416-1418 / 1963-1994, k-quads with the
+  // rotation 1448-1452 / 1887-1907 -- hence the rotation for the transposed operand only.
   constexpr int PLA = TM * 4 + 16;              // floats per A plane (+16: planes start 16 banks apart)
+  auto a_slot = [](int row) { return A_TRANS ? ((row & ~15) | ((row + (row >> 4)) & 15)) : row; };
   constexpr int PLB = TN * 4 + (TN / 8) * 4;    // floats per B plane
   constexpr int AV = TM * KC / 4 / 256;  // 16-byte A pieces per lane and chunk
   constexpr int SEG = TN / 16;      // B elements per lane: 16 lanes share one row
@@ -315,10 +321,11 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
       const int t = tid + e * 256;
       if (A_TRANS) {  // one k row, four consecutive m
         const int kk = t / (TM / 4), mm = (t % (TM / 4)) * 4;
-        float *dst = &As[buf][(kk >> 2) * PLA + mm * 4 + (kk & 3)];
-        dst[0] = areg[e].x; dst[4] = areg[e].y; dst[8] = areg[e].z; dst[12] = areg[e].w;
+        float *dst = &As[buf][(kk >> 2) * PLA + (kk & 3)];
+        dst[a_slot(mm) * 4] = areg[e].x; dst[a_slot(mm + 1) * 4] = areg[e].y;
+        dst[a_slot(mm + 2) * 4] = areg[e].z; dst[a_slot(mm + 3) * 4] = areg[e].w;
       } else {        // one m row, four consecutive k: exactly one k-quad
-        *reinterpret_cast<float4 *>(&As[buf][(t % (KC / 4)) * PLA + (t / (KC / 4)) * 4]) = areg[e];
+        *reinterpret_cast<float4 *>(&As[buf][(t % (KC / 4)) * PLA + a_slot(t / (KC / 4)) * 4]) = areg[e];
       }
     }
 #pragma unroll
@@ -345,13 +352,16 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
     }
   };
   // fragments of half a chunk (four MFMA steps): plane 2 * (lane >> 5) + hh, this lane's rows
-  const int a_frag = (2 * (lane >> 5)) * PLA + ((wm * MB) * 32 + (lane & 31)) * 4;
+  const int a_frag = (2 * (lane >> 5)) * PLA;
+  int a_row[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) a_row[i] = a_slot((wm * MB + i) * 32 + (lane & 31)) * 4;
   const int b_row = (wn * NB) * 32 + (lane & 31);
   const int b_frag = (2 * (lane >> 5)) * PLB + b_row * 4 + (b_row >> 3) * 4;
   auto fragments = [&](int buf, int hh, float4 (&af)[MB], float4 (&bf)[NB]) {
 #pragma unroll
     for (int i = 0; i < MB; ++i)
-      af[i] = *reinterpret_cast<const float4 *>(&As[buf][a_frag + hh * PLA + i * 128]);
+      af[i] = *reinterpret_cast<const float4 *>(&As[buf][a_frag + hh * PLA + a_row[i]]);
 #pragma unroll
     for (int j = 0; j < NB; ++j)
       bf[j] = *reinterpret_cast<const float4 *>(&Bs[buf][b_frag + hh * PLB + j * (128 + 16)]);
