@@ -46,6 +46,10 @@ _SIGNATURES = {
     "pn2_fps_grid_supported": [_c_int],
     "pn2_furthest_point_sampling_grid": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _sz, _c_float, _vp,
                                          _sz, _vp],
+    "pn2_fps_ties_supported": [_c_int],
+    "pn2_furthest_point_sampling_ties": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _sz, _c_float, _vp,
+                                         _sz, _vp, _vp],
+    "pn2_furthest_point_sampling_prefix": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _sz, _vp, _vp],
     "pn2_error_string": [_c_int],
     "mlp_bn_workspace_floats": [_c_int, _c_int, _c_int],
     "mlp_bn_train_stats": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _c_float, _c_float, _vp, _vp, _vp,

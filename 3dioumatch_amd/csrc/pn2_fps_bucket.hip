@@ -310,7 +310,8 @@ __global__ void __launch_bounds__(W * kWave)
 fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
                          const float *__restrict__ dataset, float4 *__restrict__ rec_all,
                          const int *__restrict__ pidx_all, const float *__restrict__ bbox_all,
-                         const int *__restrict__ n_valid_in, int *__restrict__ idxs) {
+                         const int *__restrict__ n_valid_in, int *__restrict__ idxs,
+                         int *__restrict__ first_tie_out, const int *__restrict__ prefix_first_tie) {
   static_assert(G == 2 || G == 4, "group of 2 or 4 buckets");
   constexpr int NG = 3;   // groups whose loads are issued together
   __shared__ __attribute__((aligned(16))) int2 slots[2][W];   // (bits of the wave's maximum, bucket id)
@@ -326,11 +327,24 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
   const int *pidx = pidx_all + (size_t)blockIdx.x * cloud_stride;
   const int n_valid = n_valid_in[blockIdx.x];
   const int n_buckets = (n_valid + kWave - 1) / kWave;
+  if (prefix_first_tie != nullptr && prefix_first_tie[blockIdx.x] >= m) {
+    // the cloud is the head of a sampling sequence without ties so far: see pn2_hip.h
+    for (int j = tid; j < m; j += W * kWave) out[j] = j;
+    if (tid == 0 && first_tie_out != nullptr) first_tie_out[blockIdx.x] = prefix_first_tie[blockIdx.x];
+    return;
+  }
   if (tid == 0) out[0] = 0;
   if (n_valid == 0) {  // every point skipped: the reference keeps returning index 0
     for (int j = 1 + tid; j < m; j += W * kWave) out[j] = 0;
+    if (tid == 0 && first_tie_out != nullptr) first_tie_out[blockIdx.x] = 0;
     return;
   }
+  // Exact ties of the GLOBAL maximum are tracked on the side (bit 30 of a bucket's far-point
+  // position: its maximum is held by two lanes; bit 30 of a wave's bucket id: two of its buckets
+  // hold its maximum; equal wave maxima): first_tie = the first round in which two points were
+  // equally far.  Up to that round the picks are strict maxima over ALL points.
+  constexpr int kTieBit = 1 << 30, kNoTie = kTieBit - 1;
+  int first_tie = m;
   // my point of the wave's jj-th bucket: descriptor + lane offset + jj * (W KiB)
   const fps_i32x4 rec_rs = buffer_rsrc(rec_all + (size_t)blockIdx.x * cloud_stride,
                                        (unsigned)(cloud_stride * sizeof(float4)));
@@ -469,8 +483,9 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
 #pragma unroll
             for (int k = 0; k < G; ++k) {
               const int gb = w + W * (s * kWave + bk[k0 + k]);
+              const int pos0 = gb * kWave + ((tie[k] & (tie[k] - 1ull)) ? kTieBit : 0);
               far_pt[lane == win[k] ? gb : far_nowhere] =
-                  make_float4(q[k0 + k].x, q[k0 + k].y, q[k0 + k].z, __builtin_bit_cast(float, gb * kWave + lane));
+                  make_float4(q[k0 + k].x, q[k0 + k].y, q[k0 + k].z, __builtin_bit_cast(float, pos0 + lane));
               bval[s] = lane == bk[k0 + k] ? mx[k] : bval[s];
             }
 #ifdef FPS_PROBE
@@ -510,7 +525,7 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
       for (int s = 0; s < META; ++s) {
         if (bval[s] == wm) {
           const int jj = s * kWave + lane;
-          const unsigned kk = fps_key(pidx[__builtin_bit_cast(int, far_pt[w + W * jj].w)], log2bs);
+          const unsigned kk = fps_key(pidx[__builtin_bit_cast(int, far_pt[w + W * jj].w) & kNoTie], log2bs);
           if (kk < key) { key = kk; kjj = jj; }
         }
       }
@@ -518,7 +533,9 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
       best_jj = __builtin_amdgcn_readlane(kjj, __builtin_ctzll(__ballot(key == mk)));
     }
     FPS_STAMP(9)
-    if (lane == 0) slots[j & 1][w] = make_int2(__builtin_bit_cast(int, wm), w + W * best_jj);
+    if (lane == 0)
+      slots[j & 1][w] = make_int2(__builtin_bit_cast(int, wm),
+                                  (w + W * best_jj) | ((total > 1 && wm > -2.0f) ? kTieBit : 0));
     __syncthreads();
     FPS_STAMP(10)
     // ... and the workgroup's: lane i < W takes wave i's candidate, log2(W) DPP steps, one ballot
@@ -529,23 +546,29 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
     const float best = wave_max_f32<CL>(cvl);
     const unsigned long long ceq = __ballot(cvl == best) & ((1ull << W) - 1ull);
     int pick_gb = __builtin_amdgcn_readlane(cand.y, (int)__builtin_ctzll(ceq));
-    if (__builtin_expect((ceq & (ceq - 1ull)) != 0ull, 0)) {  // equal maxima in several waves: smallest key wins
+    bool tied = (ceq & (ceq - 1ull)) != 0ull;
+    if (__builtin_expect(tied, 0)) {  // equal maxima in several waves: smallest key wins
       unsigned key = 0xFFFFFFFFu;
       if ((ceq >> lane) & 1ull)
-        key = fps_key(pidx[__builtin_bit_cast(int, far_pt[cand.y].w)], log2bs);
+        key = fps_key(pidx[__builtin_bit_cast(int, far_pt[cand.y & kNoTie].w) & kNoTie], log2bs);
       const unsigned mk = wave_min_u32(key);
       pick_gb = __builtin_amdgcn_readlane(cand.y, (int)__builtin_ctzll(__ballot(key == mk)));
     }
+    tied = tied || (pick_gb & kTieBit) != 0;
+    pick_gb &= kNoTie;
     FPS_STAMP(11)
     const float4 c = far_pt[pick_gb];   // one address: broadcast read
     x1 = c.x; y1 = c.y; z1 = c.z;
-    if (tid == 0) out[j] = __builtin_bit_cast(int, c.w);   // position; translated below
+    const int cpos = __builtin_bit_cast(int, c.w);
+    if (tid == 0) out[j] = cpos & kNoTie;   // position; translated below
+    if (tied || (cpos & kTieBit) != 0) first_tie = first_tie < j ? first_tie : j;
     __syncthreads();   // the owner of pick_gb rewrites far_pt[pick_gb] in the next round
     FPS_STAMP(12)
   }
   // positions -> original indices (wave 0 wrote them: same-wave program order)
   if (w == 0)
     for (int j = 1 + lane; j < m; j += kWave) out[j] = pidx[out[j]];
+  if (tid == 0 && first_tie_out != nullptr) first_tie_out[blockIdx.x] = first_tie;
 }
 
 }  // namespace
@@ -579,7 +602,7 @@ int pn2_fps_bucket_grid_max_points() { return 65535; }
 // returns 0 and sets *handled when the bucketed kernels were launched
 int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, void *scratch,
                        size_t scratch_bytes, int *idxs, hipStream_t stream, int *handled,
-                       float grid_radius, void *grid) {
+                       float grid_radius, void *grid, int *first_tie_out, const int *prefix_first_tie) {
   *handled = 0;
   if (n > kBucketMaxPoints || scratch == nullptr) return 0;
   if (scratch_bytes < pn2_fps_bucket_scratch_bytes(b, n)) return 0;
@@ -604,7 +627,7 @@ int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, vo
   const int per_wave = ((int)(stride / kWave) + WV - 1) / WV;   // buckets per wave
 #define FPS_ROUNDS(META)                                                                       \
   hipLaunchKernelGGL((fps_bucket_rounds_kernel<WV, META, FPS_BUCKET_GROUP>), dim3(b), dim3(WV * kWave), 0, \
-                     stream, n, m, log2bs, stride, dataset, rec, pidx, bbox, n_valid, idxs)
+                     stream, n, m, log2bs, stride, dataset, rec, pidx, bbox, n_valid, idxs, first_tie_out, prefix_first_tie)
   if (per_wave <= kWave) FPS_ROUNDS(1);
   else if (per_wave <= 2 * kWave) FPS_ROUNDS(2);
   else FPS_ROUNDS(3);

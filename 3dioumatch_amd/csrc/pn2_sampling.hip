@@ -33,12 +33,17 @@ using namespace fps;
 template <int THREADS, int PPT>
 __global__ void __launch_bounds__(THREADS)
 fps_reg_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
-               int *__restrict__ idxs) {
+               int *__restrict__ idxs, const int *__restrict__ prefix_first_tie) {
   constexpr int NW = THREADS / kWave;
   __shared__ __attribute__((aligned(16))) float slots[2][NW * 8];
   const int tid = threadIdx.x;
   const float *pts = dataset + (size_t)blockIdx.x * n * 3;
   int *out = idxs + (size_t)blockIdx.x * m;
+  if (prefix_first_tie != nullptr && prefix_first_tie[blockIdx.x] >= m) {
+    // the cloud is the head of a sampling sequence without ties so far (pn2_hip.h)
+    for (int j = tid; j < m; j += THREADS) out[j] = j;
+    return;
+  }
 
   float px[PPT], py[PPT], pz[PPT], td[PPT];
 #pragma unroll
@@ -79,13 +84,18 @@ fps_reg_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS)
 fps_stream_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
-                  float *__restrict__ temp, int *__restrict__ idxs) {
+                  float *__restrict__ temp, int *__restrict__ idxs,
+                  const int *__restrict__ prefix_first_tie) {
   constexpr int NW = THREADS / kWave;
   __shared__ __attribute__((aligned(16))) float slots[2][NW * 8];
   const int tid = threadIdx.x;
   const float *pts = dataset + (size_t)blockIdx.x * n * 3;
   float *tmp = temp + (size_t)blockIdx.x * n;
   int *out = idxs + (size_t)blockIdx.x * m;
+  if (prefix_first_tie != nullptr && prefix_first_tie[blockIdx.x] >= m) {
+    for (int j = tid; j < m; j += THREADS) out[j] = j;
+    return;
+  }
 
   for (int k = tid; k < n; k += THREADS)
     tmp[k] = fps_skipped(pts[k * 3 + 0], pts[k * 3 + 1], pts[k * 3 + 2]) ? -1.0f : 1e10f;
@@ -145,7 +155,7 @@ int pn2_fps_bucket_grid_max_points();
 size_t pn2_grid_layout_bytes(int b, int n);
 int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, void *scratch,
                        size_t scratch_bytes, int *idxs, hipStream_t stream, int *handled,
-                       float grid_radius, void *grid);
+                       float grid_radius, void *grid, int *first_tie_out, const int *prefix_first_tie);
 
 // clouds with at least this many points use the bucketed (spatially pruned) tier when a
 // workspace is supplied; overridable for experiments with PN2_FPS_BUCKET_MIN_N
@@ -168,22 +178,21 @@ PN2_API size_t pn2_fps_workspace_bytes(int b, int n, int m) {
   return n > 16384 ? sizeof(float) * (size_t)b * n : 0;  // streaming tier: (b,n) distances
 }
 
-PN2_API int pn2_furthest_point_sampling_ws(int b, int n, int m, const float *dataset,
-                                           int *idxs, void *workspace, size_t workspace_bytes,
-                                           void *stream_) {
+// every tier; prefix_first_tie (device, per cloud, or null): see pn2_furthest_point_sampling_prefix
+static int fps_dispatch(int b, int n, int m, const float *dataset, int *idxs, void *workspace,
+                        size_t workspace_bytes, const int *prefix_first_tie, hipStream_t stream) {
   if (b <= 0 || m <= 0) return 0;
   if (n <= 0 || n >= (1 << 22)) return (int)hipErrorInvalidValue;
-  hipStream_t stream = (hipStream_t)stream_;
   const int log2bs = ref_log2_block(n);
   if (n >= fps_bucket_min_n()) {
     int handled = 0;
     const int rc = pn2_fps_bucket_try(b, n, m, log2bs, dataset, workspace, workspace_bytes, idxs,
-                                      stream, &handled, 0.f, nullptr);
+                                      stream, &handled, 0.f, nullptr, nullptr, prefix_first_tie);
     if (rc != 0 || handled) return rc;
   }
 #define FPS_REG(T, P)                                                                     \
   hipLaunchKernelGGL((fps_reg_kernel<T, P>), dim3(b), dim3(T), 0, stream, n, m, log2bs,   \
-                     dataset, idxs)
+                     dataset, idxs, prefix_first_tie)
   if (n < 512) {            // bs <= 256 divides 256
     FPS_REG(256, 2);
   } else if (n <= 512) {
@@ -202,10 +211,50 @@ PN2_API int pn2_furthest_point_sampling_ws(int b, int n, int m, const float *dat
     if (!workspace || workspace_bytes < sizeof(float) * (size_t)b * n)
       return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(b), dim3(1024), 0, stream, n, m, log2bs,
-                       dataset, (float *)workspace, idxs);
+                       dataset, (float *)workspace, idxs, prefix_first_tie);
   }
 #undef FPS_REG
   return pn2_launch_status();
+}
+
+PN2_API int pn2_furthest_point_sampling_ws(int b, int n, int m, const float *dataset,
+                                           int *idxs, void *workspace, size_t workspace_bytes,
+                                           void *stream_) {
+  return fps_dispatch(b, n, m, dataset, idxs, workspace, workspace_bytes, nullptr,
+                      (hipStream_t)stream_);
+}
+
+PN2_API int pn2_furthest_point_sampling_prefix(int b, int n, int m, const float *dataset, int *idxs,
+                                               void *workspace, size_t workspace_bytes,
+                                               const int *first_tie, void *stream_) {
+  if (m > n) return (int)hipErrorInvalidValue;
+  return fps_dispatch(b, n, m, dataset, idxs, workspace, workspace_bytes, first_tie,
+                      (hipStream_t)stream_);
+}
+
+PN2_API int pn2_fps_grid_supported(int n);
+
+// Does pn2_furthest_point_sampling_ties accept clouds of n points?  (bucketed tier)
+PN2_API int pn2_fps_ties_supported(int n) {
+  return n >= fps_bucket_min_n() && pn2_fps_bucket_scratch_bytes(1, n) != 0;
+}
+
+PN2_API int pn2_furthest_point_sampling_ties(int b, int n, int m, const float *dataset, int *idxs,
+                                             void *workspace, size_t workspace_bytes,
+                                             float grid_radius, void *grid, size_t grid_bytes,
+                                             int *first_tie, void *stream_) {
+  if (b <= 0 || m <= 0) return 0;
+  if (!pn2_fps_ties_supported(n) || !first_tie) return (int)hipErrorInvalidValue;
+  if (grid != nullptr &&
+      (!pn2_fps_grid_supported(n) || grid_bytes < pn2_grid_layout_bytes(b, n) ||
+       !(grid_radius > 1e-6f) || !(grid_radius < 1e6f)))
+    return (int)hipErrorInvalidValue;
+  int handled = 0;
+  const int rc = pn2_fps_bucket_try(b, n, m, ref_log2_block(n), dataset, workspace,
+                                    workspace_bytes, idxs, (hipStream_t)stream_, &handled,
+                                    grid_radius, grid, first_tie, nullptr);
+  if (rc != 0) return rc;
+  return handled ? 0 : (int)hipErrorInvalidValue;  // (workspace too small for the bucketed tier)
 }
 
 // Can pn2_furthest_point_sampling_grid leave cell lists behind for a cloud of n points?
@@ -225,7 +274,7 @@ PN2_API int pn2_furthest_point_sampling_grid(int b, int n, int m, const float *d
   int handled = 0;
   const int rc = pn2_fps_bucket_try(b, n, m, ref_log2_block(n), dataset, workspace,
                                     workspace_bytes, idxs, (hipStream_t)stream_, &handled,
-                                    grid_radius, grid);
+                                    grid_radius, grid, nullptr, nullptr);
   if (rc != 0) return rc;
   return handled ? 0 : (int)hipErrorInvalidValue;  // (workspace too small for the bucketed tier)
 }

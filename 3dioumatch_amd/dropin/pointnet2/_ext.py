@@ -440,6 +440,64 @@ def furthest_point_sampling_with_grid(points, nsamples, radius):
     return out, CellLists(gbuf, b, n, radius)
 
 
+def furthest_point_sampling_ties(points, nsamples, radius=None):
+    """furthest_point_sampling that also reports, per cloud, the first round in which two points
+    were equally far (nsamples if none): up to that round every pick was a STRICT maximum.
+    Returns (inds (B,nsamples) i32, CellLists or None, first_tie (B,) i32 or None); first_tie is
+    None when the cloud size is outside the bucketed tier (then: a plain sampling).  radius: also
+    leave the cell lists behind, as furthest_point_sampling_with_grid."""
+    _chk_f32(points, "points")
+    if not points.is_cuda:
+        raise RuntimeError("CPU not supported")
+    b, n, _ = points.shape
+    nsamples = int(nsamples)
+    if not _lib.pn2_fps_ties_supported(n):
+        if radius is None:
+            return furthest_point_sampling(points, nsamples), None, None
+        inds, lists = furthest_point_sampling_with_grid(points, nsamples, radius)
+        return inds, lists, None
+    with_lists = radius is not None and bool(_lib.pn2_fps_grid_supported(n))
+    out = torch.empty((b, nsamples), dtype=torch.int32, device=points.device)
+    ties = torch.empty((b,), dtype=torch.int32, device=points.device)
+    with torch.cuda.device(points.device):
+        need = int(_lib.pn2_fps_workspace_bytes(b, n, nsamples))
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=points.device)
+        gbytes = int(_lib.pn2_grid_bytes(b, n)) if with_lists else 0
+        gbuf = torch.empty(gbytes, dtype=torch.uint8, device=points.device) if with_lists else None
+        _L.check(_lib.pn2_furthest_point_sampling_ties(
+            b, n, nsamples, points.data_ptr(), out.data_ptr(), ws.data_ptr(), need,
+            float(radius) if with_lists else 0.0, gbuf.data_ptr() if with_lists else None, gbytes,
+            ties.data_ptr(), _stream(points)), "furthest_point_sampling_ties")
+    return out, (CellLists(gbuf, b, n, radius) if with_lists else None), ties
+
+
+def furthest_point_sampling_prefix(points, nsamples, first_tie):
+    """furthest_point_sampling(points, nsamples) for a cloud that is the HEAD -- the first N picks,
+    in order -- of a sampling sequence whose ties were recorded by furthest_point_sampling_ties
+    (or the head of such a head): clouds with first_tie >= nsamples get 0..nsamples-1 without a
+    single round (include/pn2_hip.h explains why that is the reference's answer), the others are
+    sampled as usual.  first_tie None = furthest_point_sampling."""
+    if first_tie is None:
+        return furthest_point_sampling(points, nsamples)
+    _chk_f32(points, "points")
+    if not points.is_cuda:
+        raise RuntimeError("CPU not supported")
+    b, n, _ = points.shape
+    nsamples = int(nsamples)
+    if first_tie.dtype != torch.int32 or first_tie.numel() != b or first_tie.device != points.device:
+        raise ValueError("first_tie must be (B,) int32 on the device of points")
+    out = torch.empty((b, nsamples), dtype=torch.int32, device=points.device)
+    with torch.cuda.device(points.device):
+        need = int(_lib.pn2_fps_workspace_bytes(b, n, nsamples))
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=points.device)
+        _L.check(_lib.pn2_furthest_point_sampling_prefix(b, n, nsamples, points.data_ptr(),
+                                                         out.data_ptr(), ws.data_ptr(), need,
+                                                         first_tie.contiguous().data_ptr(),
+                                                         _stream(points)),
+                 "furthest_point_sampling_prefix")
+    return out
+
+
 def ball_query_prebuilt(new_xyz, xyz, radius, nsample, grid):
     """ball_query on CellLists built earlier for (xyz, radius)."""
     _chk_f32(new_xyz, "new_xyz"); _chk_f32(xyz, "xyz"); _chk_dev(new_xyz, (xyz, "xyz"))

@@ -166,6 +166,21 @@ def sample_with_cell_lists(xyz, npoint, radius):
     return inds, lists
 
 
+def sample_chain(xyz, npoint, radius, first_tie=None, head=False):
+    """One link of a set-abstraction stack's sampling chain.  head=False: xyz is a raw cloud --
+    sample_with_cell_lists that also records the run's first tie when the kernel can
+    (`_ext.furthest_point_sampling_ties`).  head=True: xyz is the previous link's centroids in
+    pick order -- `_ext.furthest_point_sampling_prefix`: 0..npoint-1 without a round for every
+    cloud whose chain has had no tie before round npoint.  Returns (inds, lists, first_tie)."""
+    ties = getattr(_ext, "furthest_point_sampling_ties", None)
+    if ties is None or not xyz.is_cuda:
+        inds, lists = sample_with_cell_lists(xyz, npoint, radius)
+        return inds, lists, None
+    if head:
+        return _ext.furthest_point_sampling_prefix(xyz.detach(), npoint, first_tie), None, first_tie
+    return ties(xyz.detach(), npoint, radius)
+
+
 class BallQuery(Function):
     @staticmethod
     def forward(ctx, radius, nsample, xyz, new_xyz):

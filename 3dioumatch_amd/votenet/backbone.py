@@ -53,11 +53,15 @@ class Pointnet2Backbone(nn.Module):
         from pointnet2 import pointnet2_utils
         xyz, in_features = self._break_up_pc(pointcloud)
         geometry = {}
+        first_tie = None
         for i in range(1, 5):
             sa = getattr(self, "sa%d" % i)
             # (large clouds: the sampling kernel leaves the cloud's cell lists behind and the
-            #  ball query runs on them -- no separate cell-list build in the chain)
-            inds, lists = pointnet2_utils.sample_with_cell_lists(xyz, sa.npoint, sa.radius)
+            #  ball query runs on them -- no separate cell-list build in the chain.  Layers 2..4
+            #  sample the centroids of the layer before, in pick order: the reference's kernel
+            #  finds 0, 1, 2, ... again unless the first run met an exact tie, which it records)
+            inds, lists, first_tie = pointnet2_utils.sample_chain(
+                xyz, sa.npoint, sa.radius, first_tie, head=i > 1 and first_tie is not None)
             new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(),
                                                        inds).transpose(1, 2).contiguous()
             geometry["sa%d_inds" % i] = inds

@@ -169,6 +169,33 @@ int pn2_furthest_point_sampling_grid(int b, int n, int m, const float *dataset, 
                                      void *workspace, size_t workspace_bytes, float grid_radius,
                                      void *grid, size_t grid_bytes, void *stream);
 
+/* ---- sampling a sampled cloud -------------------------------------------------------------
+ * A set-abstraction stack samples the cloud it has just sampled: SA2 runs
+ * furthest_point_sampling on the 2048 centroids SA1 picked, in the order SA1 picked them
+ * (pointnet2_modules.py:236-240 on the previous layer's new_xyz; backbone_module.py:97-112).  The
+ * reference's K1 (sampling_gpu.cu:75-178) starts from index 0 and then takes, round after round,
+ * the point farthest from everything taken so far.  On a cloud S = (s_0, s_1, ...) that IS such a
+ * sequence over a larger cloud, round j finds s_j again: s_j was the strict maximum over the
+ * whole cloud, hence over S, and the running distances of the points of S evolve exactly as they
+ * did (same picks, same fp32 operations in the same order).  So the answer is 0, 1, ..., m-1
+ * -- unless some round j < m of the run that produced S had TWO points equally far (the
+ * reference's reduction-tree key then decides by index, and the indices of S are new).
+ *
+ * pn2_furthest_point_sampling_ties = pn2_furthest_point_sampling_grid (grid may be null: no cell
+ * lists) that also reports, per cloud, first_tie[b] = the first round whose maximum was held by
+ * two or more points (m if none; 0 when no point takes part).
+ * pn2_furthest_point_sampling_prefix = pn2_furthest_point_sampling_ws for a cloud that is the
+ * head (first n picks, in order) of the sequence a _ties call produced, or of a head of it:
+ * clouds with first_tie[b] >= m get 0..m-1 without running a round; the others are sampled as
+ * usual.  first_tie is read on the device (graph-capturable); null = always sample. */
+int pn2_fps_ties_supported(int n);
+int pn2_furthest_point_sampling_ties(int b, int n, int m, const float *dataset, int *idxs,
+                                     void *workspace, size_t workspace_bytes, float grid_radius,
+                                     void *grid, size_t grid_bytes, int *first_tie, void *stream);
+int pn2_furthest_point_sampling_prefix(int b, int n, int m, const float *dataset, int *idxs,
+                                       void *workspace, size_t workspace_bytes,
+                                       const int *first_tie, void *stream);
+
 /* ---- scatter-add through an inverse index ---------------------------------------------------
  * group_points_grad (group_points.cpp:42-65, K6 group_points_gpu.cu:48-69) adds every element of
  * grad_out into grad_points[idx] with a same-address atomic.  idx is reused by every channel and

@@ -558,6 +558,101 @@ def test_streams_and_second_device_context(ext, oracle, synth):
     assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(xyz[:, :64], xyz, 0.3, 16))
 
 
+def _first_tie_reference(xyz, inds):
+    """Per cloud: the first round of the reference's FPS (picks = inds) whose maximum running
+    distance is held by two or more participating points; len(picks) if none.  fp32, every
+    operation rounded, the reference's order (sampling_gpu.cu:100-118)."""
+    out = []
+    m = inds.shape[1]
+    for b in range(xyz.shape[0]):
+        p = xyz[b].astype(np.float32)
+        mag = (p[:, 0] * p[:, 0] + p[:, 1] * p[:, 1]) + p[:, 2] * p[:, 2]
+        part = mag.astype(np.float64) > 1e-3
+        td = np.where(part, np.float32(1e10), np.float32(-1.0)).astype(np.float32)
+        first = m if part.any() else 0
+        for j in range(1, m):
+            if not part.any():
+                break
+            d = p - p[inds[b, j - 1]]
+            d = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            td = np.where(part, np.minimum(d, td), td)
+            best = td[part].max()
+            assert td[inds[b, j]] == best
+            if (td[part] == best).sum() > 1:
+                first = j
+                break
+        out.append(first)
+    return np.array(out, np.int32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["uniform", "room", "duplicates", "identical", "mixed"])
+def test_fps_ties_and_prefix(ext, oracle_omp, synth, case):
+    """Sampling a sampled cloud (SA2..SA4): the picks of a run, in order, sample to 0, 1, 2, ...
+    as long as the run met no exact tie (include/pn2_hip.h).  The kernel's first_tie against a
+    numpy restatement, and furthest_point_sampling_prefix against the oracle's FPS of the head --
+    both where the shortcut applies and where a tie forces the real sampling."""
+    n, m1, m2 = 9000, 700, 300
+    if case == "uniform":
+        xyz = synth.cloud_uniform(2, n, 3.0, seed=11)
+    elif case == "room":
+        xyz = synth.cloud_room(2, n, seed=12)
+    elif case == "duplicates":
+        xyz = synth.cloud_edge_cases(2, n, 2.0, seed=13, near_origin=8, duplicates=400)
+    elif case == "identical":
+        xyz = np.ones((2, n, 3), np.float32)
+        xyz[1, : n // 2] = 4.0
+    else:
+        xyz = synth.cloud_uniform(2, n, 3.0, seed=14)
+        xyz[1] = synth.cloud_edge_cases(1, n, 2.0, seed=15, near_origin=8, duplicates=400)[0]
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    t = torch.from_numpy(xyz).cuda()
+    inds, lists, ties = ext.furthest_point_sampling_ties(t, m1, 0.3)
+    assert ties is not None and lists is not None
+    want1 = oracle_omp.furthest_point_sampling(xyz, m1)
+    assert np.array_equal(inds.cpu().numpy(), want1)
+    plain, _, ties2 = ext.furthest_point_sampling_ties(t, m1)      # without the cell lists
+    assert torch.equal(plain, inds) and torch.equal(ties, ties2)
+    ref_tie = _first_tie_reference(xyz, want1)
+    assert np.array_equal(ties.cpu().numpy(), ref_tie), (ties.cpu().numpy(), ref_tie)
+    if case in ("uniform", "room"):
+        assert (ref_tie == m1).all()
+    if case in ("duplicates", "identical"):
+        assert (ref_tie < m1).all()
+    head = np.ascontiguousarray(np.take_along_axis(xyz, want1[:, :, None].astype(np.int64), axis=1))
+    for m, nh in ((m2, m1), (m2, m2 + 50), (100, 200)):      # heads of the sequence, and of heads
+        sub = np.ascontiguousarray(head[:, :nh])
+        got = ext.furthest_point_sampling_prefix(torch.from_numpy(sub).cuda(), m, ties).cpu().numpy()
+        want = oracle_omp.furthest_point_sampling(sub, m)
+        assert np.array_equal(got, want), (case, m, nh)
+        for b in range(2):
+            if ref_tie[b] >= m:
+                assert np.array_equal(got[b], np.arange(m))
+    # no record of ties: the plain sampling
+    got = ext.furthest_point_sampling_prefix(torch.from_numpy(head).cuda(), m2, None).cpu().numpy()
+    assert np.array_equal(got, oracle_omp.furthest_point_sampling(head, m2))
+
+
+@pytest.mark.gpu
+def test_backbone_sampling_chain_matches_reference_chain(oracle_omp, synth):
+    """compute_geometry's four samplings (the last three answered from the first run's tie
+    record) against four independent oracle samplings, on a cloud large enough for the bucketed
+    tier, with and without early ties."""
+    import importlib
+    backbone = importlib.import_module("3dioumatch_amd.votenet.backbone")
+    net = backbone.Pointnet2Backbone(input_feature_dim=1).cuda()
+    for seed, dup in ((21, 0), (22, 600)):
+        xyz = synth.cloud_edge_cases(2, 12000, 3.0, seed=seed, near_origin=4, duplicates=dup) if dup \
+            else synth.cloud_room(2, 12000, seed=seed)
+        pc = np.concatenate([xyz, np.zeros((2, 12000, 1), np.float32)], axis=2).astype(np.float32)
+        geo = net.compute_geometry(torch.from_numpy(pc).cuda())
+        cur = np.ascontiguousarray(xyz, np.float32)
+        for i, m in enumerate((2048, 1024, 512, 256), start=1):
+            want = oracle_omp.furthest_point_sampling(cur, m)
+            assert np.array_equal(geo["sa%d_inds" % i].cpu().numpy(), want), (seed, i)
+            cur = np.ascontiguousarray(np.take_along_axis(cur, want[:, :, None].astype(np.int64), axis=1))
+
+
 def test_fps_bucket_tier_small_clouds_subprocess(synth):
     """Force the bucketed (spatially pruned) FPS tier onto SMALL clouds, where the oracle is
     cheap, including heavy ties, skipped points, all-skipped and n not a multiple of 64.

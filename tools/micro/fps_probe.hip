@@ -10,7 +10,7 @@ extern "C" __attribute__((visibility("default"))) int fps_probe_run(int b, int n
                                                                       void *stream) {
   int handled = 0;
   const int rc = pn2_fps_bucket_try(b, n, m, log2bs, (const float *)xyz, scratch, bytes, (int *)idx,
-                                    (hipStream_t)stream, &handled, 0.f, nullptr);
+                                    (hipStream_t)stream, &handled, 0.f, nullptr, nullptr, nullptr);
   return rc ? rc : (handled ? 0 : -1);
 }
 extern "C" __attribute__((visibility("default"))) int fps_probe_read(void *t, void *v) {
