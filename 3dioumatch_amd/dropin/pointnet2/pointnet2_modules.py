@@ -32,13 +32,16 @@ def _sample_centroids(xyz, npoint, inds=None, radius=None):
     the sampling may also leave the cloud's cell lists for ball queries of that radius behind
     (third return value, None otherwise)."""
     lists = None
+    first_tie = None
     if inds is None:
-        if radius is not None:
-            inds, lists = pointnet2_utils.sample_with_cell_lists(xyz, npoint, radius)
-        else:
-            inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
+        # a cloud that is the previous module's centroids, in pick order, samples to 0, 1, 2, ...
+        # unless that run met an exact tie (pointnet2_utils.sample_chain, include/pn2_hip.h)
+        first_tie = pointnet2_utils.head_record(xyz)
+        inds, lists, first_tie = pointnet2_utils.sample_chain(xyz, npoint, radius, first_tie,
+                                                              head=first_tie is not None)
     flipped = xyz.transpose(1, 2).contiguous()
     new_xyz = pointnet2_utils.gather_operation(flipped, inds).transpose(1, 2).contiguous()
+    pointnet2_utils.remember_head(new_xyz, first_tie)
     return (new_xyz, inds, lists) if radius is not None else (new_xyz, inds)
 
 

@@ -166,6 +166,36 @@ def sample_with_cell_lists(xyz, npoint, radius):
     return inds, lists
 
 
+# Centroid tensors that are the picks of a sampling run, in pick order: id -> (weak reference,
+# in-place version, first_tie of the run).  A set-abstraction module hands its new_xyz to the next
+# module as that module's cloud (backbone_module.py:97-112): the next module's sampling looks its
+# cloud up here and, when it finds it, answers from the tie record (sample_chain).  A tensor that
+# was sliced, permuted, copied or modified in place is a different object / version: no record.
+_HEADS = {}
+
+
+def remember_head(new_xyz, first_tie):
+    import weakref
+    if first_tie is None:
+        return
+    if len(_HEADS) > 64:
+        for key in [k for k, (ref, _, _) in _HEADS.items() if ref() is None]:
+            del _HEADS[key]
+    _HEADS[id(new_xyz)] = (weakref.ref(new_xyz), new_xyz._version, first_tie)
+
+
+def head_record(xyz):
+    """first_tie of the sampling run whose picks `xyz` holds in order, or None."""
+    rec = _HEADS.get(id(xyz))
+    if rec is None:
+        return None
+    ref, version, first_tie = rec
+    if ref() is not xyz or xyz._version != version or first_tie.device != xyz.device or \
+            first_tie.numel() != xyz.shape[0]:
+        return None
+    return first_tie
+
+
 def sample_chain(xyz, npoint, radius, first_tie=None, head=False):
     """One link of a set-abstraction stack's sampling chain.  head=False: xyz is a raw cloud --
     sample_with_cell_lists that also records the run's first tie when the kernel can

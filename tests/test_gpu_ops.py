@@ -653,6 +653,36 @@ def test_backbone_sampling_chain_matches_reference_chain(oracle_omp, synth):
             cur = np.ascontiguousarray(np.take_along_axis(cur, want[:, :, None].astype(np.int64), axis=1))
 
 
+@pytest.mark.gpu
+def test_module_chain_recognises_its_own_centroids(oracle_omp, synth):
+    """The reference's call sequence -- every SA module samples the new_xyz the module before
+    returned (backbone_module.py:97-112) -- through the drop-in modules: the second to fourth
+    samplings are answered from the first run's tie record, found through the tensor's identity;
+    a copy of the same tensor is sampled the ordinary way.  Centroids against the oracle chain."""
+    import importlib
+    backbone = importlib.import_module("3dioumatch_amd.votenet.backbone")
+    utils = importlib.import_module("pointnet2.pointnet2_utils")
+    ext = importlib.import_module("pointnet2._ext")
+    net = backbone.Pointnet2Backbone(input_feature_dim=1).cuda().eval()
+    xyz = synth.cloud_room(2, 12000, seed=31)
+    pc = torch.from_numpy(np.concatenate([xyz, np.zeros((2, 12000, 1), np.float32)], axis=2)).cuda()
+    with torch.no_grad():
+        end_points = net(pc)
+    cur = np.ascontiguousarray(xyz, np.float32)
+    for i, m in enumerate((2048, 1024, 512, 256), start=1):
+        want = oracle_omp.furthest_point_sampling(cur, m)
+        cur = np.ascontiguousarray(np.take_along_axis(cur, want[:, :, None].astype(np.int64), axis=1))
+        assert np.array_equal(end_points["sa%d_xyz" % i].cpu().numpy(), cur), i
+        if i <= 2:
+            assert np.array_equal(end_points["sa%d_inds" % i].cpu().numpy(), want)
+    head = end_points["sa1_xyz"]
+    ties = utils.head_record(head)
+    assert ties is not None and int(ties.min()) == 2048
+    assert utils.head_record(head.clone()) is None            # another tensor: no record
+    got = ext.furthest_point_sampling(head.clone(), 1024)      # ... and the ordinary sampling agrees
+    assert torch.equal(got.cpu(), torch.arange(1024, dtype=torch.int32).expand(2, -1))
+
+
 def test_fps_bucket_tier_small_clouds_subprocess(synth):
     """Force the bucketed (spatially pruned) FPS tier onto SMALL clouds, where the oracle is
     cheap, including heavy ties, skipped points, all-skipped and n not a multiple of 64.
