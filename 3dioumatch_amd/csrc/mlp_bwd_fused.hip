@@ -326,7 +326,7 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
           float *dst = dq + ((size_t)b * k_total + xyz + 32 * kbd + 4 * lhi) * r + col0 + nb * 32 + l31;
 #pragma unroll
           for (int q = 0; q < 16; ++q)
-            dst[(size_t)((q & 3) + 8 * (q >> 2)) * r] = accD[e][n][q];
+            __builtin_nontemporal_store(accD[e][n][q], &dst[(size_t)((q & 3) + 8 * (q >> 2)) * r]);
         }
       }
     }

@@ -131,7 +131,7 @@ gemm_nn_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = m0 + (wm * MB + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        if (row < m_total && col < r) cb[(size_t)row * r + col] = acc[i][j][q];
+        if (row < m_total && col < r) __builtin_nontemporal_store(acc[i][j][q], &cb[(size_t)row * r + col]);
       }
     }
 }
@@ -405,7 +405,7 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = m0 + (wm * MB + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        if (row < m_total) cb[(size_t)row * r + col] = acc[i][j][q];
+        if (row < m_total) __builtin_nontemporal_store(acc[i][j][q], &cb[(size_t)row * r + col]);
       }
     }
   if (STATS) {
@@ -638,7 +638,7 @@ gemm_nn_small_kernel(int m_total, int k_total, int r, const float *__restrict__ 
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = m0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        if (row < m_total && col < r) cb[(size_t)row * r + col] = acc[i][j][q];
+        if (row < m_total && col < r) __builtin_nontemporal_store(acc[i][j][q], &cb[(size_t)row * r + col]);
       }
     }
 }
