@@ -453,7 +453,7 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
         const int s = h * kWave + lane;
         const int e = L.perm[s < have ? s : 0];  // tail: first hit
         rr[h] = L.list[e];
-        if (s < nsample) row[s] = __builtin_bit_cast(int, rr[h].w);
+        if (s < nsample) __builtin_nontemporal_store(__builtin_bit_cast(int, rr[h].w), &row[s]);
       }
     } else {  // no hit: the reference's zero-initialised row -> point 0 everywhere
 #pragma unroll
@@ -474,12 +474,12 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
           if (g.normalize) {
             rx = __fmul_rn(rx, g.inv_radius); ry = __fmul_rn(ry, g.inv_radius); rz = __fmul_rn(rz, g.inv_radius);
           }
-          ob[s] = rx;
-          ob[plane + s] = ry;
-          ob[2 * plane + s] = rz;
+          __builtin_nontemporal_store(rx, &ob[s]);
+          __builtin_nontemporal_store(ry, &ob[plane + s]);
+          __builtin_nontemporal_store(rz, &ob[2 * plane + s]);
           const unsigned v = __builtin_bit_cast(unsigned, rr[h].w);
           for (int l = 0; l < g.c; ++l)
-            ob[(size_t)(3 + l) * plane + s] = g.features[((size_t)b * g.c + l) * n + v];
+            __builtin_nontemporal_store(g.features[((size_t)b * g.c + l) * n + v], &ob[(size_t)(3 + l) * plane + s]);
         }
       }
     }

@@ -379,6 +379,9 @@ group_points_grad_sorted_kernel(int c, int n, int mns, int c_total, int channel0
 // Fused tail of QueryAndGroup (pointnet2_utils.py:348-358): given idx, write the
 // (b, 3+c, m, ns) tensor: channels 0..2 = xyz[idx] - centroid (optionally * 1/radius),
 // channels 3.. = features[idx].
+// (written once, read by the next kernel from HBM anyway: streaming stores)
+typedef float gc_f4 __attribute__((ext_vector_type(4)));
+
 template <bool VEC>
 __global__ void __launch_bounds__(256)
 group_concat_kernel(int c, int n, int m, int ns, float inv_radius, int normalize, int skip_xyz,
@@ -418,7 +421,7 @@ group_concat_kernel(int c, int n, int m, int ns, float inv_radius, int normalize
     for (int d = 0; d < 3; ++d) {
       float *dst = out + ((size_t)b * ctot + d) * mns + e;
       if (VEC) {
-        *reinterpret_cast<float4 *>(dst) = make_float4(r[d][0], r[d][1], r[d][2], r[d][3]);
+        __builtin_nontemporal_store(gc_f4{r[d][0], r[d][1], r[d][2], r[d][3]}, reinterpret_cast<gc_f4 *>(dst));
       } else {
         for (int t = 0; t < live; ++t) dst[t] = r[d][t];
       }
@@ -428,7 +431,7 @@ group_concat_kernel(int c, int n, int m, int ns, float inv_radius, int normalize
     const float *src = features + ((size_t)b * c + l) * n;
     float *dst = out + ((size_t)b * ctot + 3 + l) * mns + e;
     if (VEC) {
-      *reinterpret_cast<float4 *>(dst) = make_float4(src[ii[0]], src[ii[1]], src[ii[2]], src[ii[3]]);
+      __builtin_nontemporal_store(gc_f4{src[ii[0]], src[ii[1]], src[ii[2]], src[ii[3]]}, reinterpret_cast<gc_f4 *>(dst));
     } else {
       for (int t = 0; t < live; ++t) dst[t] = src[ii[t]];
     }
