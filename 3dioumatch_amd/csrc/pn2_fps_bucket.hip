@@ -8,33 +8,31 @@
 // distance, and those are spatially clustered.  So:
 //
 //   * SETUP kernel (1024 lanes per cloud): the cloud is counting-sorted by a coarse Morton cell
-//     (16^3 cells, LDS histogram + LDS atomic cursors) into a scratch array of (x, y, z,
-//     original index) and cut into BUCKETS of 64 consecutive sorted points.  A second workgroup
-//     per cloud builds, on request, the ball-query cell lists of the same cloud (grid_common.h);
-//   * ROUNDS kernel (W = 4 or 8 waves per cloud -- ONE or TWO waves per SIMD, see below).
-//     Bucket b belongs to wave b % W; lane l of that wave holds point l of the bucket and keeps
-//     ITS running distance in a register for the whole call: the wave's buckets are a register
-//     file of up to 160 entries per lane, addressed with a wave-uniform index (s_set_gpr_idx);
-//   * lane j of a wave also holds the metadata of the wave's buckets j, 64 + j, 128 + j: tight
-//     bounding box, current maximum running distance and the point that attains it;
+//     (16^3 cells, LDS histogram + LDS atomic cursors) into records (x, y, z, RUNNING DISTANCE)
+//     + an array of original indices, cut into BUCKETS of 64 consecutive sorted points, each
+//     with its tight bounding box.  A second workgroup per cloud builds, on request, the
+//     ball-query cell lists of the same cloud (grid_common.h);
+//   * ROUNDS kernel (8 waves per cloud -- two per SIMD).  Bucket b belongs to wave b % 8; lane j
+//     of a wave holds box + current maximum of the wave's buckets j, 64 + j, 128 + j;
 //   * a round = (1) every lane tests its buckets: if the squared distance from the new sample
 //     to the bounding box (shrunk by 1e-6 relative, to stay conservative under fp32 rounding)
 //     is not below the bucket's maximum, no point of the bucket can change -> skip;
-//     (2) the wave walks the set bits of the ballots: the 1 KiB loads of up to four visited
-//     buckets are issued together, then each gets the reference's exact fp32 update and a
-//     64-lane argmax (DPP / permlane, fps_common.h);
-//     (3) argmax over the per-bucket maxima of the wave, then across the W waves through LDS
-//     with one barrier (fps_block_pick).
+//     (2) the wave walks the set bits of the ballots, two buckets at a time: one 1 KiB load per
+//     bucket (up to three pairs in flight), the reference's exact fp32 update, a 4-byte store
+//     of the new distances, both 64-lane maxima from one reduction tree; the lane that owns a
+//     bucket's farthest point writes it to LDS;
+//     (3) the wave's maximum, an 8-byte exchange across the waves through LDS with one
+//     barrier, the winner's coordinates from LDS.
 //   After a few dozen rounds ~15 of the 625 buckets of a 40 000-point cloud are touched per round.
 //
-// Why few waves: a round is a latency chain, not a throughput problem.  Measured with per-round
-// clocks (tools/micro/fps_probe.py, profiles/r3_fps_round_clocks.json) the previous form --
-// 16 waves, the wave's 40 buckets as 40 unrolled wave-uniform branches -- spent 1400 of its
-// 5000 clocks per round walking the branch ladder (84 KB of code, 40 taken branches), 1900 in
-// the pick (every one of the 16 waves repeats the final argmax; four waves share a SIMD's
-// issue slot) and 750 per visited bucket with the loads serialised.  One wave per SIMD runs
-// the same dependent chain without contention, a visited-bit walk costs nothing for the
-// buckets that are skipped, and the loads overlap.
+// Why this shape: a round is a latency chain, not a throughput problem.  Measured with per-round
+// clocks (tools/micro/fps_probe.py, profiles/r3_fps_round_clocks.json) the round-2 form -- one
+// kernel, 16 waves, the wave's 40 buckets as 40 unrolled wave-uniform branches, the running
+// distances in 40 registers per lane -- spent 1400 of its 5000 clocks per round walking the
+// branch ladder (84 KB of code), 1900 in the pick (every one of the 16 waves repeats the final
+// argmax; four waves share a SIMD's issue slot) and 750 per visited bucket with the loads
+// serialised.  The rounds kernel below prices every construct on the chain
+// (profiles/r3_instruction_costs.json): 1.27 us per round instead of 2.15.
 //
 // Exactness: skipping is a no-op by construction (min(d, t) == t for every point of a skipped
 // bucket), the update arithmetic is the reference's, and ties are resolved by the reference's
