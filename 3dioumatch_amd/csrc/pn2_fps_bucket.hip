@@ -325,7 +325,7 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
   const int *pidx = pidx_all + (size_t)blockIdx.x * cloud_stride;
   const int n_valid = n_valid_in[blockIdx.x];
   const int n_buckets = (n_valid + kWave - 1) / kWave;
-  if (prefix_first_tie != nullptr && prefix_first_tie[blockIdx.x] >= m) {
+  if (prefix_first_tie != nullptr && prefix_first_tie[blockIdx.x] >= n) {
     // the cloud is the head of a sampling sequence without ties so far: see pn2_hip.h
     for (int j = tid; j < m; j += W * kWave) out[j] = j;
     if (tid == 0 && first_tie_out != nullptr) first_tie_out[blockIdx.x] = prefix_first_tie[blockIdx.x];
@@ -340,7 +340,8 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
   // Exact ties of the GLOBAL maximum are tracked on the side (bit 30 of a bucket's far-point
   // position: its maximum is held by two lanes; bit 30 of a wave's bucket id: two of its buckets
   // hold its maximum; equal wave maxima): first_tie = the first round in which two points were
-  // equally far.  Up to that round the picks are strict maxima over ALL points.
+  // equally far, or nothing was left to take.  Up to that round the picks are strict maxima over
+  // ALL points, and distinct.
   constexpr int kTieBit = 1 << 30, kNoTie = kTieBit - 1;
   int first_tie = m;
   // my point of the wave's jj-th bucket: descriptor + lane offset + jj * (W KiB)
@@ -552,7 +553,9 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
       const unsigned mk = wave_min_u32(key);
       pick_gb = __builtin_amdgcn_readlane(cand.y, (int)__builtin_ctzll(__ballot(key == mk)));
     }
-    tied = tied || (pick_gb & kTieBit) != 0;
+    // (a maximum of zero: every participating point has been taken -- from here on the picks
+    //  repeat earlier ones, which is a tie for whoever samples them as a cloud)
+    tied = tied || (pick_gb & kTieBit) != 0 || !(best > 0.f);
     pick_gb &= kNoTie;
     FPS_STAMP(11)
     const float4 c = far_pt[pick_gb];   // one address: broadcast read

@@ -39,7 +39,7 @@ fps_reg_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
   const int tid = threadIdx.x;
   const float *pts = dataset + (size_t)blockIdx.x * n * 3;
   int *out = idxs + (size_t)blockIdx.x * m;
-  if (prefix_first_tie != nullptr && prefix_first_tie[blockIdx.x] >= m) {
+  if (prefix_first_tie != nullptr && prefix_first_tie[blockIdx.x] >= n) {
     // the cloud is the head of a sampling sequence without ties so far (pn2_hip.h)
     for (int j = tid; j < m; j += THREADS) out[j] = j;
     return;
@@ -92,7 +92,7 @@ fps_stream_kernel(int n, int m, int log2bs, const float *__restrict__ dataset,
   const float *pts = dataset + (size_t)blockIdx.x * n * 3;
   float *tmp = temp + (size_t)blockIdx.x * n;
   int *out = idxs + (size_t)blockIdx.x * m;
-  if (prefix_first_tie != nullptr && prefix_first_tie[blockIdx.x] >= m) {
+  if (prefix_first_tie != nullptr && prefix_first_tie[blockIdx.x] >= n) {
     for (int j = tid; j < m; j += THREADS) out[j] = j;
     return;
   }

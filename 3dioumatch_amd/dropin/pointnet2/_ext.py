@@ -442,7 +442,8 @@ def furthest_point_sampling_with_grid(points, nsamples, radius):
 
 def furthest_point_sampling_ties(points, nsamples, radius=None):
     """furthest_point_sampling that also reports, per cloud, the first round in which two points
-    were equally far (nsamples if none): up to that round every pick was a STRICT maximum.
+    were equally far or nothing was left to take (nsamples if none): up to that round every pick
+    was a STRICT maximum, and a new point.
     Returns (inds (B,nsamples) i32, CellLists or None, first_tie (B,) i32 or None); first_tie is
     None when the cloud size is outside the bucketed tier (then: a plain sampling).  radius: also
     leave the cell lists behind, as furthest_point_sampling_with_grid."""
@@ -474,9 +475,9 @@ def furthest_point_sampling_ties(points, nsamples, radius=None):
 def furthest_point_sampling_prefix(points, nsamples, first_tie):
     """furthest_point_sampling(points, nsamples) for a cloud that is the HEAD -- the first N picks,
     in order -- of a sampling sequence whose ties were recorded by furthest_point_sampling_ties
-    (or the head of such a head): clouds with first_tie >= nsamples get 0..nsamples-1 without a
-    single round (include/pn2_hip.h explains why that is the reference's answer), the others are
-    sampled as usual.  first_tie None = furthest_point_sampling."""
+    (or the head of such a head): clouds with first_tie >= N get 0..nsamples-1 without a single
+    round (include/pn2_hip.h explains why that is the reference's answer), the others are sampled
+    as usual.  first_tie None = furthest_point_sampling."""
     if first_tie is None:
         return furthest_point_sampling(points, nsamples)
     _chk_f32(points, "points")

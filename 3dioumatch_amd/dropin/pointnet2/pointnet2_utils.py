@@ -201,7 +201,7 @@ def sample_chain(xyz, npoint, radius, first_tie=None, head=False):
     sample_with_cell_lists that also records the run's first tie when the kernel can
     (`_ext.furthest_point_sampling_ties`).  head=True: xyz is the previous link's centroids in
     pick order -- `_ext.furthest_point_sampling_prefix`: 0..npoint-1 without a round for every
-    cloud whose chain has had no tie before round npoint.  Returns (inds, lists, first_tie)."""
+    cloud whose chain had neither a tie nor a repeated pick among the picks it holds.  Returns (inds, lists, first_tie)."""
     ties = getattr(_ext, "furthest_point_sampling_ties", None)
     if ties is None or not xyz.is_cuda:
         inds, lists = sample_with_cell_lists(xyz, npoint, radius)

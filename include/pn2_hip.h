@@ -178,16 +178,19 @@ int pn2_furthest_point_sampling_grid(int b, int n, int m, const float *dataset, 
  * sequence over a larger cloud, round j finds s_j again: s_j was the strict maximum over the
  * whole cloud, hence over S, and the running distances of the points of S evolve exactly as they
  * did (same picks, same fp32 operations in the same order).  So the answer is 0, 1, ..., m-1
- * -- unless some round j < m of the run that produced S had TWO points equally far (the
- * reference's reduction-tree key then decides by index, and the indices of S are new).
+ * -- unless some round of the run that produced S had TWO points equally far (the reference's
+ * reduction-tree key then decides by index, and the indices of S are new), or had nothing left to
+ * take (a maximum of zero: the run then repeats earlier picks, and a cloud that holds the same
+ * point twice ties with itself from the first round on).
  *
  * pn2_furthest_point_sampling_ties = pn2_furthest_point_sampling_grid (grid may be null: no cell
  * lists) that also reports, per cloud, first_tie[b] = the first round whose maximum was held by
- * two or more points (m if none; 0 when no point takes part).
- * pn2_furthest_point_sampling_prefix = pn2_furthest_point_sampling_ws for a cloud that is the
- * head (first n picks, in order) of the sequence a _ties call produced, or of a head of it:
- * clouds with first_tie[b] >= m get 0..m-1 without running a round; the others are sampled as
- * usual.  first_tie is read on the device (graph-capturable); null = always sample. */
+ * two or more points or was zero (m if none; 0 when no point takes part): the first first_tie
+ * picks are strict maxima over the whole cloud, and distinct.
+ * pn2_furthest_point_sampling_prefix = pn2_furthest_point_sampling_ws for a cloud of n points that
+ * is the head (first n picks, in order) of the sequence a _ties call produced, or of a head of
+ * it: clouds with first_tie[b] >= n get 0..m-1 without running a round; the others are sampled
+ * as usual.  first_tie is read on the device (graph-capturable); null = always sample. */
 int pn2_fps_ties_supported(int n);
 int pn2_furthest_point_sampling_ties(int b, int n, int m, const float *dataset, int *idxs,
                                      void *workspace, size_t workspace_bytes, float grid_radius,

@@ -560,8 +560,9 @@ def test_streams_and_second_device_context(ext, oracle, synth):
 
 def _first_tie_reference(xyz, inds):
     """Per cloud: the first round of the reference's FPS (picks = inds) whose maximum running
-    distance is held by two or more participating points; len(picks) if none.  fp32, every
-    operation rounded, the reference's order (sampling_gpu.cu:100-118)."""
+    distance is held by two or more participating points, or is zero (nothing left to take);
+    len(picks) if none.  fp32, every operation rounded, the reference's order
+    (sampling_gpu.cu:100-118)."""
     out = []
     m = inds.shape[1]
     for b in range(xyz.shape[0]):
@@ -578,7 +579,7 @@ def _first_tie_reference(xyz, inds):
             td = np.where(part, np.minimum(d, td), td)
             best = td[part].max()
             assert td[inds[b, j]] == best
-            if (td[part] == best).sum() > 1:
+            if (td[part] == best).sum() > 1 or not best > 0:
                 first = j
                 break
         out.append(first)
@@ -586,7 +587,8 @@ def _first_tie_reference(xyz, inds):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["uniform", "room", "duplicates", "identical", "mixed"])
+@pytest.mark.parametrize("case", ["uniform", "room", "duplicates", "identical", "mixed", "two_points",
+                                  "few_points"])
 def test_fps_ties_and_prefix(ext, oracle_omp, synth, case):
     """Sampling a sampled cloud (SA2..SA4): the picks of a run, in order, sample to 0, 1, 2, ...
     as long as the run met no exact tie (include/pn2_hip.h).  The kernel's first_tie against a
@@ -602,9 +604,18 @@ def test_fps_ties_and_prefix(ext, oracle_omp, synth, case):
     elif case == "identical":
         xyz = np.ones((2, n, 3), np.float32)
         xyz[1, : n // 2] = 4.0
-    else:
+    elif case == "mixed":
         xyz = synth.cloud_uniform(2, n, 3.0, seed=14)
         xyz[1] = synth.cloud_edge_cases(1, n, 2.0, seed=15, near_origin=8, duplicates=400)[0]
+    else:
+        # almost every point inside the skip radius: the run exhausts its candidates after one
+        # (two_points) or 40 (few_points) rounds and repeats picks from then on -- the picked
+        # sequence holds the same point many times and ties with itself when sampled as a cloud
+        g = np.random.default_rng(16)
+        xyz = (g.random((2, n, 3), dtype=np.float32) - 0.5) * 0.02
+        keep = 1 if case == "two_points" else 40
+        xyz[:, 0] = 3.0
+        xyz[:, 100:100 + keep] = g.random((2, keep, 3), dtype=np.float32) * 2.0 + 1.0
     xyz = np.ascontiguousarray(xyz, np.float32)
     t = torch.from_numpy(xyz).cuda()
     inds, lists, ties = ext.furthest_point_sampling_ties(t, m1, 0.3)
@@ -626,7 +637,7 @@ def test_fps_ties_and_prefix(ext, oracle_omp, synth, case):
         want = oracle_omp.furthest_point_sampling(sub, m)
         assert np.array_equal(got, want), (case, m, nh)
         for b in range(2):
-            if ref_tie[b] >= m:
+            if ref_tie[b] >= nh:
                 assert np.array_equal(got[b], np.arange(m))
     # no record of ties: the plain sampling
     got = ext.furthest_point_sampling_prefix(torch.from_numpy(head).cuda(), m2, None).cpu().numpy()
