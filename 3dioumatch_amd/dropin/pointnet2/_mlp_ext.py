@@ -415,6 +415,8 @@ def lin4_supported(w0, w1, x):
     kernels of the second layer (w1 (64,64))?"""
     if os.environ.get("MLP_FIRST4_VIRTUAL", "1") == "0":
         return False
+    if os.environ.get("MLP_WGRAD_FIRST4", "1") == "0":
+        return False  # the virtual layer's weight gradient only exists as mlp_wgrad_first4
     if tuple(w0.shape) != (64, 4) or tuple(w1.shape) != (64, 64) or x.shape[1] != 4:
         return False
     b = x.shape[0]
