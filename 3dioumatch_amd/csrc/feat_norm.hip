@@ -25,8 +25,21 @@ channel_normalize_kernel(int c, int n, const float *__restrict__ x, const float 
   const int c_lo = (int)((long long)c * wave / 4), c_hi = (int)((long long)c * (wave + 1) / 4);
   float acc = 0.f;
   if (live) {
-    for (int ch = c_lo; ch < c_hi; ++ch) {
-      const float v = x[base + (size_t)ch * n];  // forward: x; backward: y
+    // eight rows in flight per lane (128 workgroups x 4 waves with one 256-byte load each in
+    // flight left the kernel at 0.6 TB/s); the sum keeps its channel order
+    int ch = c_lo;
+    for (; ch + 8 <= c_hi; ch += 8) {
+      float v[8], g[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v[u] = x[base + (size_t)(ch + u) * n];  // forward: x; backward: y
+        g[u] = GRAD ? dy[base + (size_t)(ch + u) * n] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += GRAD ? g[u] * v[u] : v[u] * v[u];
+    }
+    for (; ch < c_hi; ++ch) {
+      const float v = x[base + (size_t)ch * n];
       acc += GRAD ? dy[base + (size_t)ch * n] * v : v * v;
     }
   }
@@ -37,9 +50,11 @@ channel_normalize_kernel(int c, int n, const float *__restrict__ x, const float 
   if (!GRAD) {
     const float len = sqrtf(total);
     if (wave == 0) norm[(size_t)b * n + j] = len;
+#pragma unroll 8
     for (int ch = c_lo; ch < c_hi; ++ch) out[base + (size_t)ch * n] = x[base + (size_t)ch * n] / len;
   } else {
     const float len = norm[(size_t)b * n + j];
+#pragma unroll 8
     for (int ch = c_lo; ch < c_hi; ++ch) {
       const size_t o = base + (size_t)ch * n;
       out[o] = (dy[o] - x[o] * total) / len;

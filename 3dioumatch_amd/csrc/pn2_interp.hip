@@ -252,8 +252,10 @@ static int interpolate_grad_run(int b, int c, int n, int m, const float *grad_ou
                                 const int *idx, const float *weight, float *grad_points,
                                 hipStream_t stream) {
   if (b <= 0 || c <= 0 || m <= 0) return 0;
-  if (n > 0 && m <= 1024) {  // 16 destination rows fit 64 KB of LDS
-    constexpr int CPW = 16;
+  if (n > 0 && m <= 1024) {  // the destination rows of a workgroup fit its LDS
+    // 4 channels per workgroup: the FP layers' 256 channels x 8 clouds are 512 workgroups (16
+    // channels each left half the CUs idle with one 4-wave workgroup on the others: 50 us)
+    constexpr int CPW = 4;
     hipLaunchKernelGGL(three_interpolate_grad_lds_kernel<CPW>, dim3(pn2_ceil_div(c, CPW), b),
                        dim3(256), sizeof(float) * (size_t)CPW * m, stream, c, n, m, grad_out,
                        g_bstride, idx, weight, grad_points);
