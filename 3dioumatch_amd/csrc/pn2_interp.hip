@@ -141,8 +141,10 @@ three_interpolate_lds_kernel(int c, int m, int n, const float *__restrict__ poin
         r[t] = __fadd_rn(__fadd_rn(__fmul_rn(row[ii[3 * t]], ww[3 * t]),
                                    __fmul_rn(row[ii[3 * t + 1]], ww[3 * t + 1])),
                          __fmul_rn(row[ii[3 * t + 2]], ww[3 * t + 2]));
-      *reinterpret_cast<float4 *>(out + (size_t)b * out_bstride + (size_t)(l0 + cc) * n + j0) =
-          make_float4(r[0], r[1], r[2], r[3]);
+      // (n >= 2048 on this path: tens of MB read next by a GEMM from HBM anyway -> streaming store)
+      typedef float ti_f4 __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(ti_f4{r[0], r[1], r[2], r[3]},
+                                  reinterpret_cast<ti_f4 *>(out + (size_t)b * out_bstride + (size_t)(l0 + cc) * n + j0));
     }
   }
 }
