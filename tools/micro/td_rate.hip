@@ -42,6 +42,40 @@ td_rate_kernel(const char *__restrict__ base, unsigned cloud_bytes, int m, int r
   if (lane == 0) out[wg] = acc;
 }
 
+// the same nine 16-byte row loads as LDS-direct loads (global_load_lds_dwordx4: the data goes
+// from the memory pipeline into LDS without passing through VGPRs), read back from LDS
+template <int STORES>
+__global__ void __launch_bounds__(64)
+td_rate_lds_kernel(const char *__restrict__ base, unsigned cloud_bytes, int m, int rows,
+                   float *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float4 stage[9 * 64];
+  const int wg = blockIdx.x, b = wg / m, j = wg - b * m;
+  const int lane = threadIdx.x & 63;
+  const char *cloud = base + (size_t)b * cloud_bytes;
+  unsigned h = (unsigned)j * 2654435761u + 12345u;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    h = h * 1664525u + 1013904223u;
+    const unsigned off = ((h >> 8) % (cloud_bytes / 16 - 64)) * 16u;
+    const char *p = cloud + off + (unsigned)lane * 16;
+    if (r < rows)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                       (__attribute__((address_space(3))) void *)(stage + r * 64), 16, 0, 0);
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  float acc = 0.f;
+#pragma unroll
+  for (int r = 0; r < 9; ++r)
+    if (r < rows) { const float4 v = stage[r * 64 + lane]; acc += v.x + v.y + v.z + v.w; }
+  if (STORES == 5) {
+    const size_t plane = (size_t)gridDim.x * 64;
+    for (int p = 0; p < 5; ++p) out[p * plane + (size_t)wg * 64 + lane] = acc + p;
+    return;
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) out[wg] = acc;
+}
+
 extern "C" __attribute__((visibility("default")))
 int td_rate_launch(int bytes, const void *base, unsigned cloud_bytes, int b, int m, int rows,
                    float *out, void *stream) {
@@ -55,5 +89,7 @@ int td_rate_launch(int bytes, const void *base, unsigned cloud_bytes, int b, int
   else if (bytes == 162) hipLaunchKernelGGL((td_rate_kernel<16, 2>), dim3(b * m), dim3(64), 0, s, p, cloud_bytes, m, rows, out);
   else if (bytes == 1654) hipLaunchKernelGGL((td_rate_kernel<16, 5, 4>), dim3(b * m / 4), dim3(256), 0, s, p, cloud_bytes, m, rows, out);
   else if (bytes == 16516) hipLaunchKernelGGL((td_rate_kernel<16, 5, 16>), dim3(b * m / 16), dim3(1024), 0, s, p, cloud_bytes, m, rows, out);
+  else if (bytes == 1600) hipLaunchKernelGGL((td_rate_lds_kernel<0>), dim3(b * m), dim3(64), 0, s, p, cloud_bytes, m, rows, out);
+  else if (bytes == 1605) hipLaunchKernelGGL((td_rate_lds_kernel<5>), dim3(b * m), dim3(64), 0, s, p, cloud_bytes, m, rows, out);
   return (int)hipGetLastError();
 }

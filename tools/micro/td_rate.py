@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 so = os.path.join(HERE, "libtd_rate.so")
-if not os.path.exists(so):
+if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(HERE, "td_rate.hip")):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC",
                            os.path.join(HERE, "td_rate.hip"), "-o", so])
 lib = ctypes.CDLL(so)
@@ -51,6 +51,14 @@ for tag, code in (("five_dword_stores", 165), ("one_dwordx4_plus_one_dword_store
                                     torch.cuda.current_stream().cuda_stream)
             assert rc == 0
         res["rows0_%s_us" % tag] = round(bench.time_op(run0, iters=20, warm=3), 2)
+for tag, code in (("rows9_bytes16_lds_direct", 1600), ("rows9_bytes16_lds_direct_five_dword_stores", 1605)):
+    def run():
+        rc = lib.td_rate_launch(code, data.data_ptr(), cloud_bytes, B, M, 9, out.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+    res["%s_us" % tag] = round(bench.time_op(run, iters=20, warm=3), 2)
+
+
 def run00():
     rc = lib.td_rate_launch(165, data.data_ptr(), cloud_bytes, B, M, 0, out.data_ptr(),
                             torch.cuda.current_stream().cuda_stream)
