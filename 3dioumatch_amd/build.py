@@ -18,6 +18,7 @@ OBJ = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-munsafe-fp-atomics", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("PN2_EXTRA_HIPCC_FLAGS", "").split()  # A/B experiments (tools/micro/README.md)
 
 
 def sources():

@@ -30,8 +30,10 @@
 //             compacted into an LDS list of records by mask rank, then RANKED by index with a
 //             counting sort over 64 index buckets (LDS atomics + one wave scan + a count of
 //             smaller indices inside the bucket); the hit of rank s is slot s of the row.
-//             Balls with more hits than the list holds fall back to the brute-force scan of
-//             ball_common.h inside the same launch.
+//             Rows longer than a wave, seam centroids and balls with more hits than the list
+//             holds take the general path of the same kernel: pipelined sweeps over the rows'
+//             chunks and a histogram SELECT of the nsample smallest indices (no scan of the
+//             cloud at any density).
 //   group   : in the fused kernel the lane that owns slot s takes its point's coordinates from
 //             the LDS record, gathers its feature channels and writes the (b, 3+c, m, ns) tensor
 //             directly: 256-byte row segments per wave, the index array is never re-read and no
@@ -40,8 +42,11 @@
 // The order in which LDS atomics fill a cell is irrelevant: selection and ordering are by index.
 #include "common.h"
 #include <type_traits>
-#include "ball_common.h"
 #include "grid_common.h"
+
+#ifdef GRID_PROBE  // tools/micro/grid_probe.py: per-centroid clocks and path of the query kernel
+__device__ unsigned long long grid_probe_t[16384 * 8];
+#endif
 
 namespace {
 
@@ -241,6 +246,9 @@ struct alignas(16) WaveLds {
   typename std::conditional<(MAXH > 256), unsigned short, unsigned char>::type perm[MAXH];
   int cnt[kWave];             // hits per index bucket
   int off[kWave];             // exclusive prefix of cnt
+#ifdef GRID_LDS_PAD
+  int pad[GRID_LDS_PAD / 4];  // occupancy experiment (tools/micro/README.md)
+#endif
 };
 
 // inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS traffic)
@@ -258,7 +266,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
   return v;
 }
 
-// MAXH : capacity of the hit list (192 / 256 / 512; denser balls: in-launch brute force);
+// MAXH : capacity of the hit list (192 / 256 / 512; denser balls: histogram select, general path);
 //        nsample <= 64 (192), 128 (256), 256 (512)
 // WPB  : waves (= centroids in flight) per workgroup
 // GROUP: also write the grouped (b, ctot, m, ns) tensor
@@ -300,6 +308,11 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
   for (int cq = 0; cq < CPW; ++cq) {
     const int j = ((wg - b * wg_per_cloud) * WPB + wave) * CPW + cq;
     if (j >= m) return;  // whole wave
+#ifdef GRID_PROBE
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long probe_t1 = 0, probe_t2 = 0, probe_t3 = 0;  // starts known / list complete / ranked
+    int probe_sweeps = 0, probe_chunks = 0;
+#endif
     const float *ctr = new_xyz + ((size_t)b * m + j) * 3;
     int *row = idx + ((size_t)b * m + j) * nsample;
     const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
@@ -309,39 +322,59 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
 
     // ---- the nine x-rows: CSR ranges [s0, s0 + len) -------------------------------------------
     // (the row's cells gx-1 .. gx+1 are adjacent in memory; at the lattice seam the cell that
-    //  wraps around is handled as an extra range below)
+    //  wraps around is a second range [s1, s1 + len1) of the same row: the row's load takes its
+    //  first len lanes from one and the next len1 lanes from the other)
     const int xa = gx > 0 ? gx - 1 : 0, xb = gx < kG - 1 ? gx + 1 : kG - 1;
-    int s0[9], len[9];
-    bool fast = gx != 0 && gx != kG - 1;
-    {
-      // lanes 0..8 fetch the row starts, lanes 16..24 the row ends: ONE vector load and 18 lane
-      // reads instead of 18 scalar loads with their scalar address arithmetic (the scalar unit
-      // is shared by the CU's four SIMDs and was this kernel's busiest resource)
-      const int rr9 = lane & 15;
-      const int r = rr9 < 9 ? rr9 : 0;
-      const int rz = (r * 11) >> 5;              // r / 3 for r < 9
-      const int rowbase = (((gz + rz - 1) & (kG - 1)) * kG + ((gy + (r - 3 * rz) - 1) & (kG - 1))) * kG;
-      const int v = st[rowbase + ((lane & 16) ? xb + 1 : xa)];
-      // lane q < 9: row q's length (its end sits 16 lanes up: row_shl needs same-row lanes, so
-      // the end is fetched with one LDS-free permute through the upper half of the row pair)
-      const int vend = __shfl_down(v, 16, kWave);
-      const int lenv = vend - v;
-      fast = fast && __builtin_amdgcn_ballot_w64(rr9 < 9 && (lane & 48) == 0 && lenv > kWave) == 0ull;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        s0[q] = __builtin_amdgcn_readlane(v, q);
-        len[q] = __builtin_amdgcn_readlane(lenv, q);
-      }
-    }
+    const bool seam = gx == 0 || gx == kG - 1;
+    bool fast;
     int total = 0;
-    {
+    int vrow, lrow, vwrap = 0, lwrap = 0;  // lane q < 9: start / length of row q and of its wrapped cell
+    // two copies of the same code, so that the wave of an interior centroid (the usual one)
+    // executes nothing of the seam's second range
+    auto nine_rows = [&](auto seam_tag) {
+      constexpr bool SEAM = decltype(seam_tag)::value;
+      int s0[9], len[9], s1[9], len1[9];
+      {
+        // lanes 0..8 fetch the row starts, lanes 16..24 the row ends: ONE vector load and 18 lane
+        // reads instead of 18 scalar loads with their scalar address arithmetic (the scalar unit
+        // is shared by the CU's four SIMDs and was this kernel's busiest resource)
+        const int rr9 = lane & 15;
+        const int r = rr9 < 9 ? rr9 : 0;
+        const int rz = (r * 11) >> 5;              // r / 3 for r < 9
+        const int rowbase = (((gz + rz - 1) & (kG - 1)) * kG + ((gy + (r - 3 * rz) - 1) & (kG - 1))) * kG;
+        const int v = st[rowbase + ((lane & 16) ? xb + 1 : xa)];
+        int w = 0;
+        if (SEAM) w = st[rowbase + (gx == 0 ? kG - 1 : 0) + ((lane & 16) ? 1 : 0)];
+        // lane q < 9: row q's length (its end sits 16 lanes up: row_shl needs same-row lanes, so
+        // the end is fetched with one LDS-free permute through the upper half of the row pair)
+        const int lenv = __shfl_down(v, 16, kWave) - v;
+        int lenw = 0;
+        if (SEAM) lenw = __shfl_down(w, 16, kWave) - w;
+        fast = __builtin_amdgcn_ballot_w64(rr9 < 9 && (lane & 48) == 0 && lenv + lenw > kWave) == 0ull;
+        vrow = v; lrow = lenv;
+        if (SEAM) { vwrap = w; lwrap = lenw; }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          s0[q] = __builtin_amdgcn_readlane(v, q);
+          len[q] = __builtin_amdgcn_readlane(lenv, q);
+          if (SEAM) {
+            s1[q] = __builtin_amdgcn_readlane(w, q);
+            len1[q] = __builtin_amdgcn_readlane(lenw, q);
+          }
+        }
+      }
+      if (!fast) return;
       // all nine loads are in flight before the first test (one L2 round trip for ~400
       // candidates); lanes past the end of a row read the cloud's last record (always valid)
       // and are masked out of the hit test
       float4 q[9];
 #pragma unroll
       for (int r = 0; r < 9; ++r) {
-        const int p = s0[r] + lane;
+        int p = s0[r] + lane;
+        if (SEAM) {
+          p = lane < len[r] ? p : s1[r] + (lane - len[r]);
+          len[r] += len1[r];
+        }
         q[r] = cloud[(unsigned)(p < n ? p : n - 1)];
       }
       bool hit[9];
@@ -358,48 +391,185 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
 #pragma unroll
         for (int r = 0; r < 9; ++r)
           if (hit[r]) L.list[at[r]] = q[r];
+      } else {
+        fast = false;
       }
-    }
-    if (!fast) {  // rows longer than a wave, and the wrapped cell at the lattice seam (both rare)
-      auto scan_range = [&](int from, int to) {
-        for (int p0 = from; p0 < to; p0 += kWave) {
-          const int p = p0 + lane;
-          float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (p < to) q = cloud[p];
-          const bool h = p < to && sqdist3(cx, cy, cz, q.x, q.y, q.z) < radius2;
-          const unsigned long long hm = __ballot(h);
-          const int pos = total + mask_rank(hm);
-          if (h && pos < MAXH) L.list[pos] = q;
-          total += __popcll(hm);
-        }
+    };
+    if (!seam) nine_rows(std::false_type{});
+    else nine_rows(std::true_type{});
+#ifdef GRID_PROBE
+    probe_t1 = __builtin_amdgcn_s_memtime();
+#endif
+    if (!fast) {
+      // ---- general path: rows longer than a wave and balls with more hits than the list
+      // holds.  Any density, exact, no scan of the cloud:
+      //   ranges : lanes 0..8 own the nine rows, lanes 9..17 the nine wrapped cells of a seam
+      //            centroid; their 64-record chunks form ONE work list (a wave scan of the chunk
+      //            counts; chunk i -> range by a ballot), swept kSweep chunks at a time with all
+      //            kSweep loads in flight before the first test.
+      //   select : only the nsample SMALLEST indices matter (ball_query_gpu.cu:24-47 stops at
+      //            cnt == nsample).  A sweep appends the hits with index < cut to the list and
+      //            histograms them over 64 index buckets of width 2^shift starting at `lo`.
+      //            First sweep: cut = infinity.  If more than MAXH hits arrived, the bucket T
+      //            where the running count reaches nsample gives a new cut = end of bucket T:
+      //            at most nsample - 1 + count[T] hits survive.  If even that exceeds the list
+      //            (index-clustered clouds), bucket T is split into 64 narrower buckets and
+      //            counted again -- at width 1 a bucket holds one index, so this ends after at
+      //            most ceil(log64 n) levels.
+#ifndef GRID_SWEEP
+#define GRID_SWEEP 4
+#endif
+      constexpr int kSweep = GRID_SWEEP;
+      // lanes 0..8: the rows (start / length already fetched above); lanes 9..17: the wrapped cells
+      const int src = lane < 9 ? lane : lane - 9;
+      const int fa = __shfl(vrow, src, kWave), la = __shfl(lrow, src, kWave);
+      const int fb = __shfl(vwrap, src, kWave), lb = __shfl(lwrap, src, kWave);
+      const int from = lane < 9 ? fa : fb;
+      const int to = lane < 9 ? fa + la : (lane < 18 ? fb + lb : fb);
+      const int nch = (to - from + kWave - 1) >> 6;
+      const int ch_incl = wave_inclusive_scan(nch);
+      const int ch_excl = ch_incl - nch;
+      const int n_chunks = __builtin_amdgcn_readlane(ch_incl, kWave - 1);
+      unsigned cut = 0xffffffffu, lo = 0;
+      int below = 0;  // hits with index < lo (all of them are wanted)
+      int shift = 32 - __builtin_clz((unsigned)(n > 1 ? n - 1 : 1)) - 6;  // (n - 1) >> shift < 64
+      shift = shift > 0 ? shift : 0;
+      // chunk table: lane l holds [base, end) of chunk g0 + l (refilled every 64 chunks), so
+      // that a chunk's request is two lane reads instead of a ballot and three
+      int tbase = 0, tend = 0;
+      auto fill_table = [&](int g0) {
+        const int c = g0 + lane;
+        int r = 0;  // range of chunk c: ch_excl[r] <= c < ch_incl[r] (r = 18: empty, past the end)
+#pragma unroll
+        for (int k = 0; k < 18; ++k) r += __builtin_amdgcn_readlane(ch_incl, k) <= c ? 1 : 0;
+        tbase = __shfl(from, r, kWave) + (c - __shfl(ch_excl, r, kWave)) * kWave;
+        tend = __shfl(to, r, kWave);
       };
+      // The FIRST sweep tightens `cut` on the fly: when the next chunk's hits would not fit, at
+      // least nsample hits have been seen (MAXH - nsample >= 64), so the end of the bucket where
+      // their running count reaches nsample (a histogram of the list, taken then) bounds every
+      // index that can still matter; later hits at or above it are dropped at the test, and the
+      // list is compacted to the hits below it.  One sweep then serves a ball of any density
+      // unless ONE bucket overflows the list (index-clustered clouds): the list is marked
+      // incomplete and the counting re-sweeps below decide.
+      bool adaptive = true, counting = false;
+      auto sweep = [&]() -> int {
+        if (counting) {
+          L.cnt[lane] = 0;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+        int tot = 0;
+        // a rolling window of kSweep loads: chunk i is tested as soon as IT has arrived (loads
+        // return in order) and chunk i + kSweep is requested into its registers right away
+        float4 q[kSweep];
+        bool ok[kSweep];
+        static_assert(kWave % kSweep == 0, "a table refill falls on window slot 0 only");
+        auto request = [&](int i, float4 &qq, bool &okk, bool slot0) {
+          if (slot0 && (i & (kWave - 1)) == 0) fill_table(i);  // wave-uniform
+          const int p = __builtin_amdgcn_readlane(tbase, i & (kWave - 1)) + lane;
+          okk = p < __builtin_amdgcn_readlane(tend, i & (kWave - 1));
+          qq = cloud[(unsigned)(okk ? p : n - 1)];
+        };
+#pragma unroll
+        for (int u = 0; u < kSweep; ++u) request(u, q[u], ok[u], u == 0);
 #pragma unroll 1
-      for (int r = 0; r < 9; ++r) {
-        if (len[r] > kWave) scan_range(s0[r] + kWave, s0[r] + len[r]);
-        if (gx == 0 || gx == kG - 1) {
-          const int cell = (((gz + r / 3 - 1) & (kG - 1)) * kG + ((gy + r % 3 - 1) & (kG - 1))) * kG +
-                           (gx == 0 ? kG - 1 : 0);
-          scan_range(st[cell], st[cell + 1]);
+        for (int i0 = 0; i0 < n_chunks; i0 += kSweep) {
+#pragma unroll
+          for (int u = 0; u < kSweep; ++u) {
+            const unsigned v = __builtin_bit_cast(unsigned, q[u].w);
+            bool h = ok[u] && sqdist3(cx, cy, cz, q[u].x, q[u].y, q[u].z) < radius2 && v < cut;
+            unsigned long long hm = __builtin_amdgcn_ballot_w64(h);
+            if (hm) {  // wave-uniform
+              if (adaptive && tot + __popcll(hm) > MAXH) {  // wave-uniform, rare; tot <= MAXH here
+                // histogram of the list (first sweep: lo == 0, below == 0)
+                L.cnt[lane] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+                for (int e = lane; e < tot; e += kWave)
+                  atomicAdd(&L.cnt[__builtin_bit_cast(unsigned, L.list[e].w) >> shift], 1);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int incl = wave_inclusive_scan(L.cnt[lane]);
+                const int T = __builtin_ctzll(__builtin_amdgcn_ballot_w64(incl >= nsample));
+                const unsigned new_cut = (unsigned)(T + 1) << shift;
+                if (new_cut < cut) {
+                  cut = new_cut;
+                  int w = 0;
+#pragma unroll 1
+                  for (int e0 = 0; e0 < tot; e0 += kWave) {  // in-order compaction: writes trail the reads
+                    const int e = e0 + lane;
+                    float4 rec4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    bool kp = false;
+                    if (e < tot) {
+                      rec4 = L.list[e];
+                      kp = __builtin_bit_cast(unsigned, rec4.w) < cut;
+                    }
+                    const unsigned long long km = __builtin_amdgcn_ballot_w64(kp);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (kp) L.list[w + mask_rank(km)] = rec4;
+                    w += __popcll(km);
+                  }
+                  tot = w;
+                  h = h && v < cut;
+                  hm = __builtin_amdgcn_ballot_w64(h);
+                }
+                if (tot + __popcll(hm) > MAXH) adaptive = false;  // the list loses hits from here on
+              }
+              const int pos = tot + mask_rank(hm);
+              if (h) {
+                if (pos < MAXH) L.list[pos] = q[u];
+                if (counting && v >= lo) atomicAdd(&L.cnt[(v - lo) >> shift], 1);
+              }
+              tot += __popcll(hm);
+            }
+            request(i0 + kSweep + u, q[u], ok[u], u == 0);  // (past the end: an empty range, one cached record)
+          }
+        }
+        adaptive = false;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        return tot;
+      };
+#ifdef GRID_PROBE
+      probe_chunks = n_chunks;
+#endif
+      // a long sweep is the tail of the launch: let this wave issue ahead of its SIMD's others
+      if (n_chunks > 2 * kSweep) __builtin_amdgcn_s_setprio(3);
+#pragma unroll 1
+      for (;;) {  // ONE call site: the sweep is inlined once
+        total = sweep();
+#ifdef GRID_PROBE
+        ++probe_sweeps;
+#endif
+        if (total <= MAXH) break;  // wave-uniform
+        if (!counting) {           // the adaptive cut failed: count every hit below the cut reached
+          counting = true;
+          continue;
+        }
+        // total == below + sum(cnt) >= nsample
+        const int c = L.cnt[lane];
+        const int incl = wave_inclusive_scan(c);
+        const int T = __builtin_ctzll(__builtin_amdgcn_ballot_w64(below + incl >= nsample));
+        const int keep = below + __builtin_amdgcn_readlane(incl, T);
+        cut = lo + ((unsigned)(T + 1) << shift);
+        if (keep > MAXH) {  // bucket T alone overflows the list: split it
+          below += __builtin_amdgcn_readlane(incl - c, T);
+          lo += (unsigned)T << shift;
+          shift = shift > 6 ? shift - 6 : 0;
         }
       }
+      __builtin_amdgcn_s_setprio(0);
     }
 
+#ifdef GRID_PROBE
+    probe_t2 = __builtin_amdgcn_s_memtime();
+#endif
     // rr[h]: the record (x, y, z, index) of slot h * 64 + lane of the row
     float4 rr[NH];
-    bool have_rr = true;
-    if (total > MAXH) {  // very dense ball: exact brute-force scan for this centroid
-      ball_query_wave_scan<1>(pts, n, ctr, 1, radius2, nsample, row);
-      if (GROUP) {
-        // the gather below needs the row: make this wave's own stores visible to its loads
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          const int s = h * kWave + lane;
-          const int v = s < nsample ? row[s] : 0;
-          rr[h] = make_float4(pts[v * 3 + 0], pts[v * 3 + 1], pts[v * 3 + 2], __builtin_bit_cast(float, v));
-        }
-      }
-    } else if (total > 0) {
+    if (total > 0) {
       const int have = total < nsample ? total : nsample;
       {
         // ---- rank the hits by index ----------------------------------------------------------
@@ -462,7 +632,9 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
         if (GROUP) rr[h] = make_float4(pts[0], pts[1], pts[2], 0.f);
       }
     }
-    (void)have_rr;
+#ifdef GRID_PROBE
+    probe_t3 = __builtin_amdgcn_s_memtime();
+#endif
     if (GROUP) {
       // ---- fused gather: slot s of centroid j in every channel --------------------------------
       float *ob = g.out + (size_t)b * g.ctot * plane + (size_t)j * nsample;
@@ -483,6 +655,16 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
         }
       }
     }
+#ifdef GRID_PROBE
+    if ((size_t)b * m + j < 16384) {
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+      if (lane == 0) {
+        unsigned long long *o = grid_probe_t + ((size_t)b * m + j) * 8;
+        o[0] = probe_t0; o[1] = t1; o[2] = (unsigned long long)probe_sweeps << 32 | (unsigned)probe_chunks;
+        o[3] = (unsigned long long)total; o[4] = probe_t1; o[5] = probe_t2; o[6] = probe_t3;
+      }
+    }
+#endif
     if (CPW > 1) {  // the next centroid reuses this wave's LDS
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();

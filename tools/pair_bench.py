@@ -35,7 +35,10 @@ out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else N
 
 B, N, M, NS, R = 8, 40000, 2048, 64, 0.2
 dev = torch.device("cuda:0")
-xyz = torch.from_numpy(synth.cloud_uniform(B, N, synth.cube_side(N, R, NS), seed=1)).to(dev)
+# --cloud U (default; SURVEY 8(d) cloud U(L)) | R (cloud R, room shell) | step (the point clouds of
+# the batch bench.py's timed step runs on: votenet/data.py:make_batch, seed 100)
+cloud = sys.argv[sys.argv.index("--cloud") + 1] if "--cloud" in sys.argv else "U"
+xyz = bench.pair_cloud(cloud).to(dev)
 flipped = xyz.transpose(1, 2).contiguous()
 feat = torch.rand(B, 1, N, device=dev)
 inds = ext.furthest_point_sampling(xyz, M)
@@ -79,7 +82,7 @@ if plain:
     torch.cuda.synchronize()
     print("pair_bench done (plain)")
 else:
-    res = {"shape": {"B": B, "N": N, "m": M, "nsample": NS, "radius": R},
+    res = {"shape": {"B": B, "N": N, "m": M, "nsample": NS, "radius": R}, "cloud": cloud,
            "algorithmic_bytes": bench.PAIR_BYTES}
     for name, fn in (("api", api), ("fused", fused), ("layer", layer), ("build_only", build_only)):
         us = bench.time_op(fn, iters=iters, warm=3)
