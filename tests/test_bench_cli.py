@@ -37,10 +37,16 @@ def test_bench_default_line_has_roofline_and_cpu_baseline():
     assert roof["traffic"] is None or (roof["traffic_source"] and 0 < roof["traffic"] < 2 * roof["algorithmic_bytes"])
     forms = roof["forms"]
     assert set(forms) == {"layer", "self_contained", "reference_api_3_calls",
-                          "reference_api_3_calls_cached_lists", "layer_rotating_inputs"}
+                          "reference_api_3_calls_cached_lists", "layer_rotating_inputs",
+                          "layer_cloud_R", "layer_cloud_step"}
     # (replays on one input set find their reads in L2 / MALL; twelve rotating sets do not)
     assert 0.8 * forms["layer"]["us"] < forms["layer_rotating_inputs"]["us"] < 2.5 * forms["layer"]["us"]
-    assert abs(forms["layer"]["us"] - roof["duration_us"]) < 1e-6
+    # the headline duration is the SLOWEST of the three clouds the kernel is quoted on
+    per_cloud = [forms[k]["us"] for k in ("layer", "layer_cloud_R", "layer_cloud_step")]
+    assert abs(max(per_cloud) - roof["duration_us"]) < 1e-6
+    # density independence of the query kernel: the timed step's own batch (dense object
+    # clusters) within 1.6x of the uniform cloud (round 3: 86 us against 18 us)
+    assert forms["layer_cloud_step"]["us"] < 1.6 * forms["layer"]["us"]
     assert forms["layer"]["us"] < forms["self_contained"]["us"] < forms["reference_api_3_calls"]["us"]
     # with the cloud's cell lists found in _ext's cache the three reference calls skip the build
     assert forms["layer"]["us"] < forms["reference_api_3_calls_cached_lists"]["us"] < \

@@ -251,6 +251,60 @@ def test_north_star_pair_config2_properties(ext, synth):
     assert torch.equal(grouped, want)
 
 
+@pytest.mark.parametrize("kind", ["step", "R"])
+def test_north_star_pair_on_the_step_and_room_clouds(ext, oracle_omp, synth, kind):
+    """The fused query + gather at the north-star shape on the two other clouds the roofline is
+    quoted on (bench.pair_cloud): the xyz of the timed train step's batch (votenet/data.py, seed
+    100: half the points inside <= 12 object boxes -> rows of > 64 records, balls with > 192
+    hits: the general path with its adaptive cut) and cloud R (room shell; walls at x = 0 put
+    centroids on the lattice seam).  Two clouds at full size against the oracle, idx and grouped
+    tensor bit-exact, with and without the cell lists the sampling kernel leaves behind."""
+    import bench
+    b, n, m, r, ns = 2, 40000, 2048, 0.2, 64
+    xyz = bench.pair_cloud(kind)[:b].numpy().copy()
+    d_xyz = dev(xyz)
+    fps, lists = ext.furthest_point_sampling_with_grid(d_xyz, m, r)
+    assert np.array_equal(fps.cpu().numpy(), oracle_omp.furthest_point_sampling(xyz, m))
+    flipped = d_xyz.transpose(1, 2).contiguous()
+    new_xyz = ext.gather_points(flipped, fps).transpose(1, 2).contiguous()
+    cen = new_xyz.cpu().numpy()
+    want_idx = oracle_omp.ball_query(cen, xyz, r, ns)
+    feat = np.random.default_rng(5).standard_normal((b, 1, n)).astype(np.float32)
+    gx = oracle_omp.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), want_idx)
+    gx = (gx - cen.transpose(0, 2, 1)[..., None]) * (np.float32(1.0) / np.float32(r))
+    gf = oracle_omp.group_points(feat, want_idx)
+    for grid in (lists, None):
+        idx, out = ext.query_and_group(new_xyz, d_xyz, dev(feat), r, ns, True, None, grid)
+        assert np.array_equal(idx.cpu().numpy(), want_idx)
+        out = out.cpu().numpy()
+        assert np.array_equal(bits(out[:, :3]), bits(gx.astype(np.float32)))
+        assert np.array_equal(bits(out[:, 3:]), bits(gf))
+    # how dense this cloud is (the test is only worth its name if the dense paths ran)
+    if kind == "step":
+        d2 = ((cen[0, :, None, :] - xyz[0, None, ::8, :]) ** 2).sum(-1)
+        assert ((d2 < r * r).sum(1) * 8).max() > 192
+
+
+def test_ballquery_general_path_bucket_refinement(ext, oracle_omp, synth):
+    """n = 80 000 (index buckets of 2048) with 3000 CONSECUTIVE indices packed into one cell and
+    2000 more into its neighbour: one bucket alone overflows the hit list, so the adaptive cut
+    fails and the counting sweeps split the bucket (width 2048 -> 32) before the list is
+    collected.  nsample 64 and 128."""
+    g = np.random.default_rng(23)
+    b, n, m, r = 2, 80000, 256, 0.2
+    xyz = synth.cloud_uniform(b, n, 3.5, seed=41)
+    xyz[0, 1000:4000] = 1.05 + g.random((3000, 3), dtype=np.float32) * 0.08
+    xyz[0, 50000:52000] = np.array([1.25, 1.05, 1.05], np.float32) + g.random((2000, 3), dtype=np.float32) * 0.08
+    xyz[1, :2500] = 2.0 + g.random((2500, 3), dtype=np.float32) * 0.02
+    cen = xyz[:, g.permutation(n)[:m]].copy()
+    cen[0, :64] = xyz[0, 1000:4000:47][:64]     # centroids inside the blobs
+    cen[1, :32] = xyz[1, 0:2500:79][:32]
+    for ns in (64, 128):
+        want = oracle_omp.ball_query(cen, xyz, r, ns)
+        got = ext.ball_query(dev(cen), dev(xyz), r, ns).cpu().numpy()
+        assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+
+
 def test_stress_config5_sa1_front_end(ext, oracle_omp, synth):
     """BASELINE configs[4] (stress): B=32, N=80000, nsample=128, the SA1 front end end to end at
     full size -- FPS on the bucketed tier (two metadata sets per lane beyond 65 536 points),
@@ -737,7 +791,8 @@ print("BUCKET_TIER_OK", len(cases))
 def test_ballquery_cell_list_tier_edge_cases(ext, oracle_omp, synth, case):
     """The cell-list tier (n >= 4096, nsample <= 128) against the oracle where its special
     paths trigger: lattice aliasing (cloud wider than 32 cells), cell overflow (> 64 points
-    in one cell -> flagged cloud -> in-launch brute force), > 384 hits in a ball, negative
+    in one cell with CONSECUTIVE indices -> the general path's bucket refinement), > 384 hits in a
+    ball (histogram select of the nsample smallest indices), negative
     coordinates, small nsample, 64 < nsample <= 128 (second selection pass; balls with fewer /
     more than 128 hits), nsample > 128 (tier declines), radius so small that balls hold only
     their own centroid."""
@@ -788,7 +843,7 @@ def test_query_and_group_fused_cell_list(ext, oracle_omp, synth, case):
     features (bit-exact) and relative xyz against the reference composition
     (pointnet2_utils.py:335-358) done with the oracle -- with 0 / 1 / 12 feature channels (more
     than 8 go through the channel-parallel gather), 64 < nsample <= 256, balls with more hits than the list holds
-    (in-launch brute force, then the gather), the lattice seam (negative coordinates put
+    (general path: adaptive cut / histogram select, then the gather), the lattice seam (negative coordinates put
     centroids in cells 0 and 31), aliasing, clumps, and n / m that are not multiples of 4."""
     g = np.random.default_rng(17)
     b, n, m, c, r, ns = 2, 6000, 300, 1, 0.2, 64
@@ -801,7 +856,7 @@ def test_query_and_group_fused_cell_list(ext, oracle_omp, synth, case):
         ns, r = 100, 0.3
     elif case == "ns_200":      # 128 < nsample <= 256: the 512-entry hit list
         ns, r = 200, 0.4
-    elif case == "ns_256_dense":  # more than 512 hits in most balls: in-launch brute force
+    elif case == "ns_256_dense":  # more than 512 hits in most balls: the general path's select
         ns, r = 256, 0.65
     elif case == "dense_hits":
         r = 0.6

@@ -56,37 +56,39 @@ for kind in ("U", "R", "step"):
     t = np.zeros((16384, 8), np.uint64)
     assert lib.grid_probe_read(t.ctypes.data) == 0
     if '--raw' in sys.argv:
+        os.makedirs(os.path.join(ROOT, 'gpurun_out', 'r4a'), exist_ok=True)
         np.save(os.path.join(ROOT, 'gpurun_out', 'r4a', 'grid_probe_raw_%s.npy' % kind), t)
-    t0, t1 = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)
-    sweeps, chunks, hits = (t[:, 2] >> np.uint64(32)).astype(np.int64), (t[:, 2] & np.uint64(0xffffffff)).astype(np.int64), t[:, 3].astype(np.int64)
-    CLK = 2300.0  # s_memtime ticks per us as measured in profiles/r3_instruction_costs.json (per XCD, unsynchronised)
-    dur = (t1 - t0) / CLK
-    base = np.repeat(np.array([t0[c * M:(c + 1) * M].min() for c in range(B)]), M)  # one cloud = one XCD
-    start = (t0 - base) / CLK
-    end = (t1 - base) / CLK
-    gen = sweeps > 0
-    r = {"span_us_per_cloud": [round(float(end[c * M:(c + 1) * M].max()), 2) for c in range(B)],
-         "general_per_cloud": [int(gen[c * M:(c + 1) * M].sum()) for c in range(B)],
-         "last_start_us_per_cloud": [round(float(start[c * M:(c + 1) * M].max()), 2) for c in range(B)],
-         "mean_concurrency_per_cloud": [round(float(dur[c * M:(c + 1) * M].sum() / end[c * M:(c + 1) * M].max()), 1) for c in range(B)],
-         "fast": {"count": int((~gen).sum()), "dur_us_mean": round(float(dur[~gen].mean()), 2),
-                  "dur_us_p99": round(float(np.percentile(dur[~gen], 99)), 2)}}
-    if gen.any():
-        r["general"] = {"count": int(gen.sum()), "dur_us_mean": round(float(dur[gen].mean()), 2),
-                        "dur_us_p99": round(float(np.percentile(dur[gen], 99)), 2),
-                        "dur_us_max": round(float(dur[gen].max()), 2),
-                        "chunks_mean": round(float(chunks[gen].mean()), 1), "chunks_max": int(chunks.max()),
-                        "two_or_more_sweeps": int((sweeps > 1).sum()),
-                        "dur_us_multi_sweep_mean": round(float(dur[sweeps > 1].mean()), 2) if (sweeps > 1).any() else None}
-    worst = int(np.argmax(r["span_us_per_cloud"]))
-    sl = slice(worst * M, (worst + 1) * M)
-    order = np.argsort(end[sl])[-6:] + worst * M
-    r["last_finishers_of_slowest_cloud"] = [
-        {"start_us": round(float(start[i]), 2), "end_us": round(float(end[i]), 2), "general": bool(gen[i]),
-         "chunks": int(chunks[i]), "sweeps": int(sweeps[i]), "hits": int(hits[i])} for i in order]
-    # waves in flight over time for the slowest cloud (1 us bins)
-    tl = np.arange(0, end[sl].max() + 1, 1.0)
-    r["in_flight_slowest_cloud_per_us"] = [int(((start[sl] <= x) & (end[sl] > x)).sum()) for x in tl]
+    t = t.astype(np.int64)
+    CLK = 2300.0  # s_memtime ticks per us (profiles/r3_instruction_costs.json); the counter's base
+    #               differs from CU to CU, so only differences inside one wave / one CU are used
+    sweeps, chunks, hits = t[:, 2] >> 32, t[:, 2] & 0xffffffff, t[:, 3]
+    d = lambda x, y: (t[:, x] - t[:, y]) / CLK  # noqa: E731
+    total, s_start, s_sweep, s_rank, s_out = d(1, 0), d(4, 0), d(5, 4), d(6, 5), d(1, 6)
+    r = {"classes": {}}
+    for name, msk in (("fast", sweeps == 0), ("general_1_8_chunks", (sweeps > 0) & (chunks <= 8)),
+                      ("general_9_16_chunks", (sweeps > 0) & (chunks > 8) & (chunks <= 16)),
+                      ("general_17_24_chunks", (sweeps > 0) & (chunks > 16) & (chunks <= 24)),
+                      ("general_over_24_chunks", (sweeps > 0) & (chunks > 24))):
+        if msk.any():
+            r["classes"][name] = {
+                "centroids": int(msk.sum()), "wave_us_mean": round(float(total[msk].mean()), 2),
+                "wave_us_max": round(float(total[msk].max()), 2),
+                "centre_and_row_starts_us": round(float(s_start[msk].mean()), 2),
+                "sweeps_us": round(float(s_sweep[msk].mean()), 2),
+                "ranking_us": round(float(s_rank[msk].mean()), 2),
+                "gather_and_stores_us": round(float(s_out[msk].mean()), 2),
+                "hits_mean": round(float(hits[msk].mean()), 1),
+                "more_than_one_sweep": int((sweeps[msk] > 1).sum())}
+    r["stage_note"] = ("centre_and_row_starts_us of the fast class also holds its nine row loads and "
+                       "tests; sweeps_us is the general path's loads + tests + list")
+    # activity span per time base (one CU, sometimes a few with the same base): first wave start
+    # to last wave end
+    order = np.argsort(t[:, 0])
+    gaps = np.nonzero(np.diff(t[order, 0]) > 3 * CLK)[0]
+    spans = [(t[g, 1].max() - t[g, 0].min()) / CLK for g in np.split(order, gaps + 1) if 32 <= len(g) <= 135]  # one or two CUs
+    r["activity_span_us_per_cu_burst"] = {"bursts": len(spans), "median": round(float(np.median(spans)), 2),
+                                          "p90": round(float(np.percentile(spans, 90)), 2),
+                                          "max": round(float(np.max(spans)), 2)}
     res[kind] = r
 print(json.dumps(res))
 if len(sys.argv) > 1 and not sys.argv[1].startswith("--"):

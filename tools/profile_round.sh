@@ -1,9 +1,9 @@
 #!/bin/bash
 # Every rocprofv3 summary of a round, at HEAD (run on the GPU box from the repo root):
-#     bash tools/profile_round.sh r3
+#     bash tools/profile_round.sh r4
 # writes gpurun_out/<tag>_profiles/*, to be copied into profiles/.  Counter passes are separate
 # runs (MI355X_MICROARCH.md); every pass is bounded by `timeout`.
-TAG=${1:-r3}
+TAG=${1:-r4}
 export TMPDIR=/tmp
 ROOT=$(pwd)
 O=$ROOT/gpurun_out/${TAG}_profiles; mkdir -p $O
@@ -17,6 +17,13 @@ python tools/step_breakdown.py $P/semi/step_kernel_trace.csv 20 400 $O/${TAG}_se
 # -- the north-star pair
 run pair_stats rocprofv3 --kernel-trace --stats --output-format csv -d $P/pair -o pair -- python tools/pair_bench.py 10 --plain
 cp $P/pair/pair_kernel_stats.csv $O/${TAG}_pair_kernel_stats.csv
+cp $P/pair/pair_kernel_stats.csv $O/${TAG}_pair_kernel_stats_U.csv
+# -- the same on cloud R and on the timed step's own batch (bench.pair_cloud)
+for c in R step; do
+  run pair_stats_$c rocprofv3 --kernel-trace --stats --output-format csv -d $P/pair_$c -o pair -- python tools/pair_bench.py 10 --plain --cloud $c
+  cp $P/pair_$c/pair_kernel_stats.csv $O/${TAG}_pair_kernel_stats_$c.csv
+done
+timeout 120 python tools/micro/grid_probe.py $O/${TAG}_pair_centroid_clocks.json > /dev/null 2> $O/grid_probe.log; echo "grid_probe rc=$?"
 run pair_fetch rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pf -o pair -- python tools/pair_bench.py 5 --plain
 run pair_write rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pw -o pair -- python tools/pair_bench.py 5 --plain
 python tools/pair_pmc.py $P/pf/pair_counter_collection.csv $P/pw/pair_counter_collection.csv $P/pair/pair_kernel_stats.csv $O/${TAG}_pair_pmc.json > $O/pair_pmc.txt 2>&1
