@@ -186,6 +186,49 @@ __device__ __forceinline__ float half_wave_extreme(float v) {
   return v;
 }
 
+// ---- fp32 products on the bf16 matrix pipe -----------------------------------------------------
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate.  An fp32 value is the EXACT sum of three
+// bf16 values (truncation split: hi = the top 8 significand bits, mid = the next 8, lo = the
+// last 8; each difference is exact), a bf16 x bf16 product is exact in fp32, and the matrix pipe
+// accumulates in fp32.  Of the nine partial products of a * b the three below 2^-24 |a b|
+// (mid*lo, lo*mid, lo*lo) are dropped -- the same order as one fp32 rounding -- and the other six
+// are issued as v_mfma_f32_32x32x16_bf16: 6 x 32 cycles per 16 k instead of 8 x 64 (2.7x less
+// matrix time) for fp32-grade results (max error over the layer shapes 1e-7 of the output
+// range, profiles/r4_split_bf16.json).  A lane's MFMA operand (row / column lane & 31, k half
+// lane >> 5, eight consecutive k) is exactly what the k-quad LDS layout hands it in two 16-byte
+// reads, so the split happens on the fragments, in registers.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+struct Split3 { bf16x8 hi, mid, lo; };
+
+__device__ __forceinline__ unsigned pack_hi16(float a, float b) {  // (b.hi16 << 16) | a.hi16
+  return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
+}
+
+__device__ __forceinline__ Split3 split3(const float4 &u, const float4 &v) {
+  const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+  float h[8], m[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    h[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x[e]) & 0xffff0000u);
+    const float r1 = x[e] - h[e];                       // exact
+    m[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1) & 0xffff0000u);
+    l[e] = r1 - m[e];                                   // exact, at most 8 significant bits
+  }
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+  u32x4v ph, pm, pl;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    ph[e] = pack_hi16(h[2 * e], h[2 * e + 1]);
+    pm[e] = pack_hi16(m[2 * e], m[2 * e + 1]);
+    pl[e] = pack_hi16(l[2 * e], l[2 * e + 1]);
+  }
+  Split3 o;
+  o.hi = __builtin_bit_cast(bf16x8, ph);
+  o.mid = __builtin_bit_cast(bf16x8, pm);
+  o.lo = __builtin_bit_cast(bf16x8, pl);
+  return o;
+}
+
 // A_VEC: the rows of A are 16-byte aligned (lda % 4 == 0 and an aligned base)
 // STATS: the epilogue also reduces every output row over the tile's columns to a
 //        (mean, M2) pair for the BatchNorm that follows (one per row, cloud and column tile, all
@@ -198,8 +241,8 @@ __device__ __forceinline__ float half_wave_extreme(float v) {
 //        pass no longer re-reads y either.  ext: 2 planes (value, first index) of
 //        (b, m_total, r / POOL).
 template <int TM, int TN, int WM, int WN, int MODE, bool A_TRANS, bool A_VEC, bool STATS = false,
-          int POOL = 0>
-__global__ void __launch_bounds__(256, ((MODE <= OP_BNRELU || MODE == OP_LIN4) && TM <= 128) ? 4 : 2)
+          int POOL = 0, bool X6 = false>
+__global__ void __launch_bounds__(256, X6 ? 2 : (((MODE <= OP_BNRELU || MODE == OP_LIN4) && TM <= 128) ? 4 : 2))
 gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int lda,
                 unsigned a_bytes, OperandB opb, float *__restrict__ c, size_t b_stride_in,
                 size_t b_stride_out, float *__restrict__ stats = nullptr, int stat_channels = 0,
@@ -389,10 +432,38 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
     float4 af0[MB], bf0[NB], af1[MB], bf1[NB];
     fragments(cur, 0, af0, bf0);
     fragments(cur, 1, af1, bf1);                   // in flight during the first 4 * MB * NB MFMAs
-    multiply(af0, bf0);
-    if (i + 1 < chunks) stash(cur ^ 1);            // chunk i+1: registers -> the other buffer
-    if (i + 2 < chunks) fetch((i + 2) * KC);       // chunk i+2: in flight during the MFMAs
-    multiply(af1, bf1);
+    if constexpr (X6) {
+      // the lane's eight k of the chunk (af0 | af1), as three bf16 terms each; six products per
+      // block, the small ones first
+      Split3 sa[MB], sb[NB];
+#pragma unroll
+      for (int ii = 0; ii < MB; ++ii) sa[ii] = split3(af0[ii], af1[ii]);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) sb[j] = split3(bf0[j], bf1[j]);
+#pragma unroll
+      for (int ii = 0; ii < MB; ++ii)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ii].lo, sb[j].hi, acc[ii][j], 0, 0, 0);
+          acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ii].hi, sb[j].lo, acc[ii][j], 0, 0, 0);
+          acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ii].mid, sb[j].mid, acc[ii][j], 0, 0, 0);
+        }
+      if (i + 1 < chunks) stash(cur ^ 1);
+      if (i + 2 < chunks) fetch((i + 2) * KC);
+#pragma unroll
+      for (int ii = 0; ii < MB; ++ii)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ii].mid, sb[j].hi, acc[ii][j], 0, 0, 0);
+          acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ii].hi, sb[j].mid, acc[ii][j], 0, 0, 0);
+          acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ii].hi, sb[j].hi, acc[ii][j], 0, 0, 0);
+        }
+    } else {
+      multiply(af0, bf0);
+      if (i + 1 < chunks) stash(cur ^ 1);            // chunk i+1: registers -> the other buffer
+      if (i + 2 < chunks) fetch((i + 2) * KC);       // chunk i+2: in flight during the MFMAs
+      multiply(af1, bf1);
+    }
     __syncthreads();  // buffer cur is free again, buffer cur^1 is complete
   }
   // C/D layout of the 32x32 block: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
@@ -811,6 +882,12 @@ reduce_partials_kernel(int count, int parts, const float *__restrict__ part,
   }
 }
 
+// fp32 products as six bf16 MFMAs (see split3): on unless MLP_GEMM_SPLIT_BF16=0 (read once)
+bool gemm_x6() {
+  static const bool on = !(getenv("MLP_GEMM_SPLIT_BF16") && atoi(getenv("MLP_GEMM_SPLIT_BF16")) == 0);
+  return on;
+}
+
 // forward GEMM whose epilogue also leaves BatchNorm partials (see gemm_nn2_kernel STATS); only
 // instantiated for the operand modes of the forward pass
 template <int TM, int TN, int WM, int WN, int MODE, bool A_TRANS>
@@ -820,14 +897,13 @@ void launch_stats(bool a_vec, int r, int b, hipStream_t stream, int rows, int k,
   if constexpr (!A_TRANS && MODE <= OP_BNRELU) {
     // partial (part, channel) pairs: part = cloud * tiles + tile, channel = done + row
     float *st = stats + (size_t)done * 2;
-    if (a_vec)
-      hipLaunchKernelGGL((gemm_nn2_kernel<TM, TN, WM, WN, MODE, false, true, true>),
-                         dim3(pn2_ceil_div(r, TN), 1, b), dim3(256), 0, stream, rows, k, r, a_t, lda,
-                         a_bytes, op, c_t, in_stride, out_stride, st, channels);
-    else
-      hipLaunchKernelGGL((gemm_nn2_kernel<TM, TN, WM, WN, MODE, false, false, true>),
-                         dim3(pn2_ceil_div(r, TN), 1, b), dim3(256), 0, stream, rows, k, r, a_t, lda,
-                         a_bytes, op, c_t, in_stride, out_stride, st, channels);
+#define ST_LAUNCH(AV, X6)                                                                         \
+  hipLaunchKernelGGL((gemm_nn2_kernel<TM, TN, WM, WN, MODE, false, AV, true, 0, X6>),               \
+                     dim3(pn2_ceil_div(r, TN), 1, b), dim3(256), 0, stream, rows, k, r, a_t, lda,   \
+                     a_bytes, op, c_t, in_stride, out_stride, st, channels)
+    if (gemm_x6()) { if (a_vec) ST_LAUNCH(true, true); else ST_LAUNCH(false, true); }
+    else { if (a_vec) ST_LAUNCH(true, false); else ST_LAUNCH(false, false); }
+#undef ST_LAUNCH
   }
 }
 
@@ -859,6 +935,14 @@ int launch_nn(int b, int m, int k, int r, const float *a, int lda, const Operand
     if (stats)                                                                                  \
       launch_stats<TM, TN, WM, WN, MODE, A_TRANS>(a_vec, r, b, stream, rows, k, a_t, lda, a_bytes, \
                                                   op, c_t, in_stride, out_stride, stats, m, done); \
+    else if (pipelined && a_vec && gemm_x6())                                                   \
+      hipLaunchKernelGGL((gemm_nn2_kernel<TM, TN, WM, WN, MODE, A_TRANS, true, false, 0, true>), \
+                         dim3(pn2_ceil_div(r, TN), 1, b), dim3(256), 0, stream, rows, k, r, a_t,  \
+                         lda, a_bytes, op, c_t, in_stride, out_stride);                         \
+    else if (pipelined && gemm_x6())                                                            \
+      hipLaunchKernelGGL((gemm_nn2_kernel<TM, TN, WM, WN, MODE, A_TRANS, false, false, 0, true>), \
+                         dim3(pn2_ceil_div(r, TN), 1, b), dim3(256), 0, stream, rows, k, r, a_t,  \
+                         lda, a_bytes, op, c_t, in_stride, out_stride);                         \
     else if (pipelined && a_vec)                                                                \
       hipLaunchKernelGGL((gemm_nn2_kernel<TM, TN, WM, WN, MODE, A_TRANS, true>),                \
                          dim3(pn2_ceil_div(r, TN), 1, b), dim3(256), 0, stream, rows, k, r, a_t,  \
@@ -968,10 +1052,12 @@ MLP_API int mlp_gemm_forward_stats_pool(int b, int m, int k, int r, const float 
   const size_t in_stride = (size_t)k * r, out_stride = (size_t)m * r;
   const size_t plane = (size_t)b * m * (r / ns);
   const unsigned a_bytes = (unsigned)(4 * (size_t)m * k);
-#define POOLED(TM, TN, WM, WN, NS)                                                                 \
-  hipLaunchKernelGGL((gemm_nn2_kernel<TM, TN, WM, WN, OP_BNRELU, false, true, true, NS>),          \
+#define POOLED_X(TM, TN, WM, WN, NS, X6)                                                           \
+  hipLaunchKernelGGL((gemm_nn2_kernel<TM, TN, WM, WN, OP_BNRELU, false, true, true, NS, X6>),      \
                      dim3(r / TN, 1, b), dim3(256), 0, stream, m, k, r, w, k, a_bytes, op, y,     \
                      in_stride, out_stride, pairs, m, ext, plane, gamma)
+#define POOLED(TM, TN, WM, WN, NS)                                                                 \
+  do { if (gemm_x6()) POOLED_X(TM, TN, WM, WN, NS, true); else POOLED_X(TM, TN, WM, WN, NS, false); } while (0)
   if (m == 256 && ns == 16) POOLED(256, 64, 4, 1, 16);
   else if (m == 256 && ns == 32) POOLED(256, 64, 4, 1, 32);
   else if (m == 256) POOLED(256, 64, 4, 1, 64);
@@ -979,6 +1065,7 @@ MLP_API int mlp_gemm_forward_stats_pool(int b, int m, int k, int r, const float 
   else if (ns == 32) POOLED(128, 128, 2, 2, 32);
   else POOLED(128, 128, 2, 2, 64);
 #undef POOLED
+#undef POOLED_X
   return pn2_launch_status();
 }
 
@@ -994,9 +1081,14 @@ MLP_API int mlp_gemm_forward_stats_lin4(int b, int r, const float *w, const floa
       (reinterpret_cast<size_t>(w) & 15) != 0 || (reinterpret_cast<size_t>(w1) & 15) != 0)
     return (int)hipErrorInvalidValue;
   OperandB op = {x4, nullptr, scale, shift, nullptr, nullptr, nullptr, nullptr, 0, 0, w1};
-  hipLaunchKernelGGL((gemm_nn2_kernel<64, 128, 2, 2, OP_LIN4, false, true, true>),
-                     dim3(r / 128, 1, b), dim3(256), 0, (hipStream_t)stream_, m, k, r, w, k,
-                     (unsigned)(4 * (size_t)m * k), op, y, (size_t)4 * r, (size_t)m * r, pairs, m);
+  if (gemm_x6())
+    hipLaunchKernelGGL((gemm_nn2_kernel<64, 128, 2, 2, OP_LIN4, false, true, true, 0, true>),
+                       dim3(r / 128, 1, b), dim3(256), 0, (hipStream_t)stream_, m, k, r, w, k,
+                       (unsigned)(4 * (size_t)m * k), op, y, (size_t)4 * r, (size_t)m * r, pairs, m);
+  else
+    hipLaunchKernelGGL((gemm_nn2_kernel<64, 128, 2, 2, OP_LIN4, false, true, true>),
+                       dim3(r / 128, 1, b), dim3(256), 0, (hipStream_t)stream_, m, k, r, w, k,
+                       (unsigned)(4 * (size_t)m * k), op, y, (size_t)4 * r, (size_t)m * r, pairs, m);
   return pn2_launch_status();
 }
 
