@@ -31,11 +31,17 @@
 //     rows are 3*TN dot products per chunk on the vector ALU.
 #include "common.h"
 #include "mlp_operand.h"
+#include "mlp_bwd_x6.h"
 #include <stdlib.h>
 
 namespace {
 
-template <int MB, int KB, int KBD, int NB, int PMODE, int QMODE, int OCC, bool STATS, bool DGRAD = true>
+// X6: the products run as six bf16 MFMAs on an exact three-term split of the fp32 fragments
+// (mlp_operand.h: split3 / mfma_x6): a fragment is then a lane's EIGHT consecutive reduction
+// indices -- eight 4-byte LDS reads from the same conflict-free tiles -- and an MFMA step covers
+// 16 of them, so a chunk is M/16 dgrad steps and TN/16 wgrad steps.
+template <int MB, int KB, int KBD, int NB, int PMODE, int QMODE, int OCC, bool STATS, bool DGRAD = true,
+          bool X6 = false>
 __global__ void __launch_bounds__(256, OCC)
 gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, int xyz,
                       OperandB opp, OperandB opq, const float *__restrict__ w,
@@ -55,8 +61,8 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
   constexpr int DN = KBD >= 4 ? NB : 1;
   static_assert(KBD >= 4 ? KBD % 4 == 0 : (KBD == 2 && NB == 2), "dQ blocks must split over 4 waves");
   // MFMA groups of one chunk: DG of dgrad (DU reduction steps each), WG of wgrad (WU steps each)
-  constexpr int DU = 4, DG = DGRAD ? (M / 2) / DU : 0;  // DGRAD false: the weight gradient only
-  constexpr int WU = WMB * WKB >= 4 ? 1 : 2, WG = (TN / 2) / WU;
+  constexpr int DU = 4, DG = DGRAD ? (X6 ? M / 16 : (M / 2) / DU) : 0;  // DGRAD false: the weight gradient only
+  constexpr int WU = WMB * WKB >= 4 ? 1 : 2, WG = X6 ? TN / 16 : (TN / 2) / WU;
   // staging slices of one chunk per lane: a float4 (pair) of a P row, then of a Q row
   constexpr int NS = 4 * (PP + QP), NG = DG + WG;
 
@@ -135,7 +141,8 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
     const int kbd = KBD >= 4 ? wave * DK + e : (wave >> 1);
     const float *wc = w + xyz + 32 * kbd + l31;
 #pragma unroll
-    for (int s = 0; s < M / 2; ++s) wreg[e][s] = wc[(size_t)(2 * s + lhi) * k_total];
+    for (int s = 0; s < M / 2; ++s)  // X6: step S = s / 8 holds m = 16 S + 8 lhi + (s % 8)
+      wreg[e][s] = wc[(size_t)(X6 ? 16 * (s >> 3) + 8 * lhi + (s & 7) : 2 * s + lhi) * k_total];
   }
   for (int t = tid; t < 3 * M; t += 256) Wx[t] = DGRAD && xyz ? w[(size_t)(t % M) * k_total + t / M] : 0.f;
 
@@ -290,6 +297,37 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
         for (int n = 0; n < DN; ++n)
 #pragma unroll
           for (int q = 0; q < 16; ++q) accD[e][n][q] = 0.f;
+      if constexpr (X6) {
+        // step g: m = 16 g + 8 lhi + (0..7).  The raw fragments of step g+1 are requested as soon as
+        // those of step g have been split (single raw buffer: the registers are free by then)
+        float bp8[DN][8];
+        auto frag8 = [&](int g) {
+#pragma unroll
+          for (int n = 0; n < DN; ++n) {
+            const int nb = KBD >= 4 ? n : (wave & 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bp8[n][j] = Pc[(nb * 32 + l31) * LDP + 16 * g + 8 * lhi + j];
+          }
+        };
+        frag8(0);
+#pragma unroll
+        for (int g = 0; g < DG; ++g) {
+          Split3 sb[DN];
+#pragma unroll
+          for (int n = 0; n < DN; ++n) sb[n] = split3(bp8[n]);
+          if (g + 1 < DG) frag8(g + 1);
+#pragma unroll
+          for (int e = 0; e < DK; ++e) {
+            float w8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w8[j] = wreg[e][g * 8 + j];
+            const Split3 sa = split3(w8);
+#pragma unroll
+            for (int n = 0; n < DN; ++n) mfma_x6(accD[e][n], sa, sb[n]);
+          }
+          between(g);
+        }
+      } else {
       // the P fragments of group g+1 are requested before the MFMAs of group g are issued
       float bp[2][DU][DN];
       auto frag = [&](int g, float (&dst)[DU][DN]) {
@@ -316,6 +354,7 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
                                                                 accD[e][n], 0, 0, 0);
         between(g);
         __builtin_amdgcn_sched_barrier(0);
+      }
       }
 #pragma unroll
       for (int e = 0; e < DK; ++e) {
@@ -351,7 +390,45 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
       }
     };
     // ---- wgrad: dW blocks += P chunk * Q chunk^T (both LDS)
-    {
+    if constexpr (X6) {
+      // step g: n = 16 g + 8 lhi + (0..7).  The P fragments of the wave's row blocks are split
+      // first; the Q column blocks follow one at a time, the next block's raw values on their way
+      // while the current block's MFMAs are issued
+      float qraw[8];
+      auto qfrag = [&](int g, int j) {
+        const int kb = MB >= 4 ? j : (wave / MB) + (4 / MB) * j;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const float raw = Qc[(16 * g + 8 * lhi + jj) * LDQ + kb * 32 + l31];
+          qraw[jj] = RAWQ ? fmaxf(__fmaf_rn(raw, fsc[j], fsh[j]), 0.f) : raw;
+        }
+      };
+#pragma unroll
+      for (int g = 0; g < WG; ++g) {
+        Split3 sp[WMB];
+#pragma unroll
+        for (int i = 0; i < WMB; ++i) {
+          const int mb = MB >= 4 ? wave + 4 * i : wave % MB;
+          float praw[8];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) praw[jj] = Pc[(16 * g + 8 * lhi + jj) * LDP + mb * 32 + l31];
+          sp[i] = split3(praw);
+        }
+        qfrag(g, 0);
+#pragma unroll
+        for (int j = 0; j < WKB; ++j) {
+          const Split3 sq = split3(qraw);
+          if (j + 1 < WKB) qfrag(g, j + 1);
+#pragma unroll
+          for (int i = 0; i < WMB; ++i) mfma_x6(accW[i][j], sp[i], sq);
+        }
+        between(DG + g);
+        if (STATS) {
+#pragma unroll
+          for (int q = g * 16 / WG; q < (g + 1) * 16 / WG; ++q) stats_row(q);
+        }
+      }
+    } else {
       float ap[2][WU][WMB], bq[2][WU][WKB];
       auto frag = [&](int g, float (&a)[WU][WMB], float (&bb)[WU][WKB]) {
 #pragma unroll
@@ -562,22 +639,38 @@ MLP_API int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, 
   if (qmode == OP_LIN4 && !xlin_w) return (int)hipErrorInvalidValue;
   if (k != 64) stats_part = nullptr;
   OperandB Q = {x, nullptr, xscale, xshift, xmean, xinvstd, nullptr, nullptr, 0, 0, xlin_w};
-#define FUSED(MB, KB, KBD, NB, PM, QM, OCC, ST)                                                 \
-  hipLaunchKernelGGL((gemm_bwd_fused_kernel<MB, KB, KBD, NB, PM, QM, OCC, ST>), dim3(g),        \
+  {  // the bf16-split kernel with its operands split at staging, where it covers the shape
+    int gx = 0;
+    const int rcx = mlp_bwd_x6_try(m, k, r, b * (r / 32), r / 32, pmode, qmode, P, Q, w, dq, workspace,
+                                   fused_cus() < g ? fused_cus() : g, &gx, stream);
+    if (rcx > 0) return rcx;
+    if (rcx == 0) return mlp_reduce_partials(m * k, gx, workspace, dw, stream);
+  }
+  static const bool x6 = !(getenv("MLP_GEMM_SPLIT_BF16") && atoi(getenv("MLP_GEMM_SPLIT_BF16")) == 0) &&
+                         !(getenv("MLP_BWD_SPLIT_BF16") && atoi(getenv("MLP_BWD_SPLIT_BF16")) == 0);
+#define FUSED_X(MB, KB, KBD, NB, PM, QM, OCC, ST, X6)                                           \
+  hipLaunchKernelGGL((gemm_bwd_fused_kernel<MB, KB, KBD, NB, PM, QM, OCC, ST, true, X6>), dim3(g), \
                      dim3(256), 0, stream, k, r, total, cpc, s.xyz, P, Q, w, dq, workspace,     \
                      stats_part)
+#define FUSED(MB, KB, KBD, NB, PM, QM, OCC, ST)                                                 \
+  do { if (x6) FUSED_X(MB, KB, KBD, NB, PM, QM, OCC, ST, true);                                 \
+       else FUSED_X(MB, KB, KBD, NB, PM, QM, OCC, ST, false); } while (0)
+  // (the bf16 form wins where the registers hold it; measured per shape, profiles/r4_split_bf16.json)
+#define FUSED_F32(MB, KB, KBD, NB, PM, QM, OCC, ST) FUSED_X(MB, KB, KBD, NB, PM, QM, OCC, ST, false)
   if (m == 64 && k == 64 && qmode == OP_LIN4) FUSED(2, 2, 2, 2, OP_DY, OP_LIN4, 2, true);
   else if (m == 64 && k == 64) FUSED(2, 2, 2, 2, OP_DY, OP_BNRELU, 2, true);
   else if (m == 128 && k == 64) FUSED(4, 2, 2, 2, OP_POOLDY, OP_BNRELU, 1, true);
-  else if (m == 128 && k == 128 && pmode == OP_DY) FUSED(4, 4, 4, 1, OP_DY, OP_BNRELU, 2, false);
-  else if (m == 128 && k == 128) FUSED(4, 4, 4, 1, OP_POOLDY, OP_BNRELU, 2, false);
+  else if (m == 128 && k == 128 && pmode == OP_DY) FUSED_F32(4, 4, 4, 1, OP_DY, OP_BNRELU, 2, false);
+  else if (m == 128 && k == 128) FUSED_F32(4, 4, 4, 1, OP_POOLDY, OP_BNRELU, 2, false);
   else if (m == 256 && k == 128) FUSED(8, 4, 4, 1, OP_POOLDY, OP_BNRELU, 1, false);
   else if (m == 128 && k == 131) FUSED(4, 5, 4, 1, OP_DY, OP_DIRECT, 1, false);
-  else if (dq != nullptr) FUSED(4, 9, 8, 1, OP_DY, OP_DIRECT, 1, false);
+  else if (dq != nullptr) FUSED_F32(4, 9, 8, 1, OP_DY, OP_DIRECT, 1, false);
   else  // the layer's input needs no gradient: the persistent weight-gradient half alone
     hipLaunchKernelGGL((gemm_bwd_fused_kernel<4, 9, 8, 1, OP_DY, OP_DIRECT, 1, false, false>), dim3(g),
                        dim3(256), 0, stream, k, r, total, cpc, s.xyz, P, Q, w, dq, workspace, stats_part);
+#undef FUSED_F32
 #undef FUSED
+#undef FUSED_X
   int rc = pn2_launch_status();
   if (rc) return rc;
   return mlp_reduce_partials(m * k, g, workspace, dw, stream);

@@ -121,6 +121,66 @@ __device__ __forceinline__ void load_raw_segment(const OperandB &op, size_t off,
   }
 }
 
+// ---- fp32 products on the bf16 matrix pipe -----------------------------------------------------
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate.  An fp32 value is the EXACT sum of three
+// bf16 values (truncation split: hi = the top 8 significand bits, mid = the next 8, lo = the
+// last 8; each difference is exact), a bf16 x bf16 product is exact in fp32, and the matrix pipe
+// accumulates in fp32.  Of the nine partial products of a * b the three below 2^-24 |a b|
+// (mid*lo, lo*mid, lo*lo) are dropped -- the same order as one fp32 rounding -- and the other six
+// are issued as v_mfma_f32_32x32x16_bf16: 6 x 32 cycles per 16 k instead of 8 x 64 (2.7x less
+// matrix time) for fp32-grade results (max error over the layer shapes 1e-7 of the output
+// range, profiles/r4_split_bf16.json).  A lane's MFMA operand (row / column lane & 31, k half
+// lane >> 5, eight consecutive k) is exactly what the k-quad LDS layout hands it in two 16-byte
+// reads, so the split happens on the fragments, in registers.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+struct Split3 { bf16x8 hi, mid, lo; };
+
+__device__ __forceinline__ unsigned pack_hi16(float a, float b) {  // (b.hi16 << 16) | a.hi16
+  return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
+}
+
+__device__ __forceinline__ Split3 split3(const float4 &u, const float4 &v) {
+  const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+  float h[8], m[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    h[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x[e]) & 0xffff0000u);
+    const float r1 = x[e] - h[e];                       // exact
+    m[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1) & 0xffff0000u);
+    l[e] = r1 - m[e];                                   // exact, at most 8 significant bits
+  }
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+  u32x4v ph, pm, pl;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    ph[e] = pack_hi16(h[2 * e], h[2 * e + 1]);
+    pm[e] = pack_hi16(m[2 * e], m[2 * e + 1]);
+    pl[e] = pack_hi16(l[2 * e], l[2 * e + 1]);
+  }
+  Split3 o;
+  o.hi = __builtin_bit_cast(bf16x8, ph);
+  o.mid = __builtin_bit_cast(bf16x8, pm);
+  o.lo = __builtin_bit_cast(bf16x8, pl);
+  return o;
+}
+
+
+// the same split of eight values given one by one (fragments gathered with 4-byte LDS reads)
+__device__ __forceinline__ Split3 split3(const float (&x)[8]) {
+  return split3(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]));
+}
+
+// acc += a * b over the lane group's 16 k, fp32-grade: the six significant partial products,
+// small ones first
+__device__ __forceinline__ void mfma_x6(f32x16 &acc, const Split3 &a, const Split3 &b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.mid, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.hi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.mid, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
+}
+
 }  // namespace
 
 // dw[i] = sum_p part[p][i], i < count (mlp_gemm.hip): the deterministic reduction of the
