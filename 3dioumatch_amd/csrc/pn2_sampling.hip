@@ -227,8 +227,9 @@ PN2_API int pn2_furthest_point_sampling_ws(int b, int n, int m, const float *dat
 PN2_API int pn2_furthest_point_sampling_prefix(int b, int n, int m, const float *dataset, int *idxs,
                                                void *workspace, size_t workspace_bytes,
                                                const int *first_tie, void *stream_) {
-  if (m > n) return (int)hipErrorInvalidValue;
-  return fps_dispatch(b, n, m, dataset, idxs, workspace, workspace_bytes, first_tie,
+  // more samples than points: the reference's sampling repeats picks (sampling_gpu.cu:94-177) and
+  // the prefix shortcut does not describe that -- the plain sampling answers
+  return fps_dispatch(b, n, m, dataset, idxs, workspace, workspace_bytes, m > n ? nullptr : first_tie,
                       (hipStream_t)stream_);
 }
 

@@ -127,15 +127,34 @@ def _capturing(t):
     return t.is_cuda and torch.cuda.is_current_stream_capturing()
 
 
+def _tensor_version(t):
+    """In-place version of a tensor, or None where PyTorch keeps none (tensors created under
+    torch.inference_mode(): such clouds simply bypass the caches -- no hit, no insert)."""
+    if t.is_inference():
+        return None
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
 def _cached_lists(xyz, radius):
     if _capturing(xyz) and not _CACHE_IN_CAPTURE[0]:
         return None
     ent = _LISTS.get(id(xyz))
     if ent is None:
         return None
-    ref, version, rad, lists = ent
-    if ref() is not xyz or version != xyz._version or rad != float(radius):
+    ref, version, rad, lists, stream = ent
+    if ref() is not xyz or version is None or version != _tensor_version(xyz) or rad != float(radius):
         return None
+    cur = torch.cuda.current_stream(xyz.device)
+    if stream != cur.cuda_stream:
+        # built on another stream: order this stream after the build and keep the buffer alive
+        # for it (the allocator would otherwise hand it back to the building stream's pool)
+        if lists.event is None or _capturing(xyz):
+            return None
+        cur.wait_event(lists.event)
+        lists.buf.record_stream(cur)
     return lists
 
 
@@ -149,7 +168,13 @@ def _remember_lists(xyz, radius, lists):
         if ent is not None and ent[0] is _ref:
             del _LISTS[key]
 
-    _LISTS[key] = (weakref.ref(xyz, _drop), xyz._version, float(radius), lists)
+    version = _tensor_version(xyz)
+    if version is None:
+        return
+    cur = torch.cuda.current_stream(xyz.device)
+    lists.event = torch.cuda.Event()
+    lists.event.record(cur)
+    _LISTS[key] = (weakref.ref(xyz, _drop), version, float(radius), lists, cur.cuda_stream)
 
 
 def _lists_for(xyz, radius):
@@ -387,6 +412,7 @@ class CellLists(object):
 
     def __init__(self, buf, b, n, radius):
         self.buf, self.b, self.n, self.radius = buf, b, n, float(radius)
+        self.event = None  # recorded on the building stream when the lists enter _ext's cache
 
     def check(self, xyz, radius):
         if tuple(xyz.shape[:2]) != (self.b, self.n) or float(radius) != self.radius:
@@ -459,7 +485,7 @@ def furthest_point_sampling_ties(points, nsamples, radius=None):
         return inds, lists, None
     with_lists = radius is not None and bool(_lib.pn2_fps_grid_supported(n))
     out = torch.empty((b, nsamples), dtype=torch.int32, device=points.device)
-    ties = torch.empty((b,), dtype=torch.int32, device=points.device)
+    ties = torch.zeros((b,), dtype=torch.int32, device=points.device)  # (defined for nsamples == 0 too)
     with torch.cuda.device(points.device):
         need = int(_lib.pn2_fps_workspace_bytes(b, n, nsamples))
         ws = torch.empty(max(need, 1), dtype=torch.uint8, device=points.device)

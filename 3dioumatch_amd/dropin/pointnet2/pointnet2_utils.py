@@ -181,7 +181,10 @@ def remember_head(new_xyz, first_tie):
     if len(_HEADS) > 64:
         for key in [k for k, (ref, _, _) in _HEADS.items() if ref() is None]:
             del _HEADS[key]
-    _HEADS[id(new_xyz)] = (weakref.ref(new_xyz), new_xyz._version, first_tie)
+    version = _ext._tensor_version(new_xyz)
+    if version is None:  # inference-mode tensors keep no version counter: not remembered
+        return
+    _HEADS[id(new_xyz)] = (weakref.ref(new_xyz), version, first_tie)
 
 
 def head_record(xyz):
@@ -190,7 +193,7 @@ def head_record(xyz):
     if rec is None:
         return None
     ref, version, first_tie = rec
-    if ref() is not xyz or xyz._version != version or first_tie.device != xyz.device or \
+    if ref() is not xyz or _ext._tensor_version(xyz) != version or first_tie.device != xyz.device or \
             first_tie.numel() != xyz.shape[0]:
         return None
     return first_tie

@@ -12,6 +12,10 @@ import torch
 
 
 class DatasetConfig(object):
+    # the fused box decode + jitter kernel (votenet_bbox_jitter, detector._bbox_jitter_fused)
+    # hard-codes THIS class's class2angle_gpu; a subclass that overrides the decoding must set it False
+    fused_heading_decode = True
+
     def __init__(self, num_class, num_heading_bin, num_size_cluster, seed=0):
         self.num_class = num_class
         self.num_heading_bin = num_heading_bin

@@ -175,6 +175,11 @@ class VoteNet(nn.Module):
         center = end_points['center']
         if not center.is_cuda:
             return None
+        cfg = self.dataset_config
+        from .config import DatasetConfig
+        if not getattr(cfg, 'fused_heading_decode', False) or \
+                type(cfg).class2angle_gpu is not DatasetConfig.class2angle_gpu:
+            return None  # a custom heading decoding: the tensor-op path calls it
         from .heads import _fused_front_end
         _L = _fused_front_end()
         if _L is None or not hasattr(_L.lib, "votenet_bbox_jitter"):

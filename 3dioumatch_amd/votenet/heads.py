@@ -169,9 +169,15 @@ class GridConv(nn.Module):
         key = str(device)
         cache = self.__dict__.setdefault("_unit_cache", {})
         if key not in cache:
-            step = torch.linspace(-1, 1, self.GRID, device=device)
-            cache[key] = torch.stack(torch.meshgrid(step, step, step, indexing='ij'),
-                                     dim=-1).view(self.GRID ** 3, 3).contiguous()
+            # built outside inference mode (the tensor is reused by autograd passes later) and
+            # never cached from inside a graph capture (it would live in the graph's private pool)
+            with torch.inference_mode(False), torch.no_grad():
+                step = torch.linspace(-1, 1, self.GRID, device=device)
+                unit = torch.stack(torch.meshgrid(step, step, step, indexing='ij'),
+                                   dim=-1).view(self.GRID ** 3, 3).contiguous()
+            if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+                return unit
+            cache[key] = unit
         return cache[key]
 
     def _origin(self, end_points):

@@ -261,11 +261,50 @@ class SupervisedStep(object):
     # run the gradient collective even when world_size == 1 (a one-rank process group): lets a
     # single-GPU box exercise RCCL's init, the all-reduce and its ordering between the graphs
     exchange_always = False
+    # record device time of every eager gradient all-reduce (events on the current stream) in
+    # self.exchange_events: bench.py's N > 1 line reports their median
+    time_exchange = False
+    # capture the all-reduce at the head of the update graph G2 instead of launching it eagerly
+    # between the two replays.  Opt-in (STEP_GRAPH_ALLREDUCE=1 or this attribute): a collective
+    # inside a HIP graph can only be validated here with a ONE-rank nccl group (the box has one
+    # GPU), so the default stays the eager launch that torch.distributed documents.
+    capture_exchange = os.environ.get("STEP_GRAPH_ALLREDUCE") == "1"
+    _exchange_in_graph = False
+
+    def _exchanges(self):
+        return self.world > 1 or self.exchange_always
 
     def _exchange_gradients(self):
         """Data parallelism: the mean of the per-rank gradients, one collective per step."""
-        if self.world > 1 or self.exchange_always:
+        if not self._exchanges():
+            return
+        if self.time_exchange and self.device.type == "cuda" and \
+                not torch.cuda.is_current_stream_capturing():
+            if not hasattr(self, "exchange_events"):
+                self.exchange_events = []
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             torch.distributed.all_reduce(self.flat_grad)
+            e1.record()
+            self.exchange_events.append((e0, e1))
+            return
+        torch.distributed.all_reduce(self.flat_grad)
+
+    def exchange_report(self):
+        """{"backend", "world_size", "allreduce_us" (median device time, None if untimed),
+        "bytes", "in_graph"} of the gradient collective."""
+        us = None
+        if getattr(self, "exchange_events", None):
+            torch.cuda.synchronize(self.device)
+            t = sorted(a.elapsed_time(b_) * 1e3 for a, b_ in self.exchange_events)
+            us = round(t[len(t) // 2], 2)
+        dist = torch.distributed
+        on = dist.is_available() and dist.is_initialized()
+        return {"backend": dist.get_backend() if on else None,
+                "world_size": dist.get_world_size() if on else 1,
+                "allreduce_us": us, "samples": len(getattr(self, "exchange_events", [])),
+                "bytes": int(self.flat_grad.numel() * self.flat_grad.element_size()),
+                "in_graph": bool(self._exchange_in_graph)}
 
     def _apply(self, teacher=None, ema_weight=None):
         """Adam on the flat buffer (and, for the semi-supervised subclass, the teacher's EMA
@@ -489,9 +528,22 @@ class SupervisedStep(object):
         self._g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g1, **mode):
             self._loss, self._end_points = body_step()
-        self._g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g2, **mode):
-            self._apply()
+        self._exchange_in_graph = False
+        if self.capture_exchange and self._exchanges() and torch.distributed.get_backend() == "nccl":
+            try:  # the collective as the first node of G2 (the zero gradient makes it harmless here)
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, **mode):
+                    torch.distributed.all_reduce(self.flat_grad)
+                    self._apply()
+                self._g2, self._exchange_in_graph = g2, True
+            except Exception as err:  # noqa: BLE001
+                sys.stderr.write("SupervisedStep: all-reduce not capturable (%s: %s); it stays an "
+                                 "eager launch between the graphs\n" % (type(err).__name__, err))
+                torch.cuda.synchronize(dev)
+        if not self._exchange_in_graph:
+            self._g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g2, **mode):
+                self._apply()
         torch.cuda.synchronize(dev)
 
         # undo every side effect of warm-up and capture
@@ -551,7 +603,8 @@ class SupervisedStep(object):
         slot["token"] = -1
         self._stage_copies(slot)
         self._g1.replay()
-        self._exchange_gradients()
+        if not self._exchange_in_graph:
+            self._exchange_gradients()
         self._before_apply()
         self._g2.replay()
         batch.pop("geometry", None)

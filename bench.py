@@ -328,6 +328,10 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=device)
         else:
             torch.distributed.init_process_group("gloo")
+        # the driver computes scaling from --gpus: the process group must be exactly that wide
+        assert torch.distributed.get_world_size() == args.gpus == world, \
+            "process group of %d ranks, --gpus %d, WORLD_SIZE %d" % (
+                torch.distributed.get_world_size(), args.gpus, world)
     importlib.import_module("3dioumatch_amd")
     V = importlib.import_module("3dioumatch_amd.votenet")
     data = importlib.import_module("3dioumatch_amd.votenet.data")
@@ -335,6 +339,7 @@ def main():
     npts = 20000 if args.workload == "sunrgbd" else NPTS
 
     step = build_step(V, cfg, device, world, local_rank, args.workload)
+    step.runner.time_exchange = world > 1  # events around every eager gradient all-reduce
     if args.workload == "semi":
         scenes = SEMI_LABELED + SEMI_UNLABELED
         batch = data.make_semi_batch(SEMI_LABELED, SEMI_UNLABELED, NPTS, cfg, seed=100 + rank,
@@ -381,10 +386,21 @@ def main():
         return elapsed, views
 
     elapsed, views = timed_loop(step, batch, args.steps, args.warmup)
+    rccl = None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+        # what the N > 1 line needs to be checked from outside: the collective's backend, the
+        # width of the process group, which device every rank drove, the gradient all-reduce's
+        # device time (median over the warm-up + timed steps of rank 0)
+        mine = torch.tensor([torch.cuda.current_device()], dtype=torch.int64,
+                            device=device if args.backend == "nccl" else "cpu")
+        ids = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(ids, mine)
+        rccl = step.runner.exchange_report()
+        rccl["ranks_device_ids"] = [int(i.item()) for i in ids]
+        rccl["ranks_share_one_gpu"] = os.environ.get("BENCH_SHARE_GPU") == "1"
 
     # the same step with the index chain inline (not part of `value`): what the one-step-ahead
     # prefetch of the coordinate-only chain hides
@@ -416,6 +432,8 @@ def main():
                        "fps_prefetch_one_step_ahead": pipelined,
                        "hip_graphs": bool(step.runner.graphs)},
         }
+        if rccl is not None:
+            out["rccl"] = rccl
         if not args.no_kernels:
             table, forms = kernel_table(device)
             # headline = the SLOWEST of the three clouds the kernel is quoted on (cloud U(L), cloud R,

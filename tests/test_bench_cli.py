@@ -77,6 +77,36 @@ def test_bench_other_workloads(workload, scenes):
     assert d["config"]["hip_graphs"] is True and d["value"] > 0
 
 
+@pytest.mark.gpu
+def test_bench_two_ranks_line_is_self_verifying():
+    """The N > 1 line carries what is needed to check it from outside: the
+    backend and width of the process group, the device every rank drove, and the device time of
+    the gradient all-reduce.  Two ranks on the one GPU of this box, gloo between them."""
+    port = 36500 + (os.getpid() % 2000)
+    env = dict(os.environ, BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--backend", "gloo", "--no-kernels", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    d = json.loads(lines[0])
+    assert REQUIRED <= set(d) and d["n_gpus"] == 2 and d["config"]["global_batch"] == 16
+    rc = d["rccl"]
+    assert rc["backend"] == "gloo" and rc["world_size"] == 2 and rc["ranks_device_ids"] == [0, 0]
+    assert rc["ranks_share_one_gpu"] is True and rc["bytes"] > 4_000_000 and rc["in_graph"] is False
+    assert rc["samples"] == 4 and rc["allreduce_us"] > 0
+    # a process group narrower than --gpus is refused
+    bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port + 1),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0",
+                          "--backend", "gloo", "--no-kernels", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert bad.returncode != 0 and "process group of 2 ranks" in bad.stderr
+
+
 def test_bench_fails_loudly_without_a_gpu():
     """No CPU fallback in the measured path: on a machine without a GPU bench.py stops with a
     clear message instead of timing something else."""

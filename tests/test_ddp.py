@@ -310,11 +310,13 @@ def _rccl_worker(rank, world, port, out_dir):
     cfg = V.scannet_config()
     batch = lambda s: data.make_batch(2, 4096, cfg, seed=400 + s, num_objects=5, device=dev)  # noqa: E731
     out = {}
-    for name, with_group in (("plain", False), ("rccl", True)):
-        if with_group:
+    for name, with_group in (("plain", False), ("rccl", True), ("rccl_in_graph", True)):
+        if with_group and not dist.is_initialized():
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         runner = V.SupervisedStep(cfg, dev, world_size=1, num_proposal=K, graphs=True)
         runner.exchange_always = with_group
+        runner.time_exchange = name == "rccl"
+        runner.capture_exchange = name == "rccl_in_graph"  # the all-reduce as the first node of G2
         torch.manual_seed(7)
         losses = []
         for s in range(5):
@@ -324,6 +326,11 @@ def _rccl_worker(rank, world, port, out_dir):
         torch.cuda.synchronize(dev)
         out[name + "_params"] = runner.flat_params.detach().cpu().numpy().copy()
         out[name + "_losses"] = np.array(losses)
+        if with_group:
+            rep = runner.exchange_report()
+            assert rep["backend"] == "nccl" and rep["world_size"] == 1
+            out[name + "_in_graph"] = np.array([int(rep["in_graph"])])
+            out[name + "_us"] = np.array([-1.0 if rep["allreduce_us"] is None else rep["allreduce_us"]])
     out["backend"] = np.array([ord(c) for c in dist.get_backend()])
     np.savez(os.path.join(out_dir, "rccl.npz"), **out)
     dist.barrier()
@@ -345,3 +352,11 @@ def test_graph_step_with_a_one_rank_rccl_group(tmp_path):
     assert np.abs(r["rccl_params"] - r["plain_params"]).max() <= 5 * 3 * 1e-3
     rel = np.linalg.norm(r["rccl_params"] - r["plain_params"]) / np.linalg.norm(r["plain_params"])
     assert rel < 1e-2, rel
+    # the eager all-reduce was timed (events on the launching stream) ...
+    assert int(r["rccl_in_graph"][0]) == 0 and float(r["rccl_us"][0]) > 0
+    # ... and the opt-in form with the collective captured at the head of G2 runs the same step
+    # (when RCCL refuses the capture the runner falls back to the eager launch and says so)
+    assert np.all(np.isfinite(r["rccl_in_graph_losses"]))
+    assert np.abs(r["rccl_in_graph_params"] - r["plain_params"]).max() <= 5 * 3 * 1e-3
+    print("all-reduce captured in the update graph:", bool(int(r["rccl_in_graph_in_graph"][0])),
+          "| eager all-reduce of one rank: %.1f us" % float(r["rccl_us"][0]))

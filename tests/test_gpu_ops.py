@@ -895,6 +895,32 @@ def test_query_and_group_fused_cell_list(ext, oracle_omp, synth, case):
     assert torch.equal(idx2, idx)
 
 
+def test_reference_surface_under_inference_mode(ext, oracle_omp, synth):
+    """Tensors created under torch.inference_mode() keep no version counter: the per-cloud caches
+    behind furthest_point_sampling / ball_query (cell lists, tie records) must step aside instead
+    of raising, and the answers stay the oracle's.  Also an SA-style chain whose second sampling
+    asks for MORE points than the cloud holds (the reference repeats picks)."""
+    import pointnet2.pointnet2_utils as pu
+    b, n, m, r, ns = 2, 6000, 300, 0.2, 32
+    xyz_np = synth.cloud_uniform(b, n, 2.0, seed=51)
+    with torch.inference_mode():
+        xyz = dev(xyz_np)
+        inds = ext.furthest_point_sampling(xyz, m)
+        new_xyz = pu._sample_centroids(xyz, m)[0] if hasattr(pu, "_sample_centroids") and False else \
+            ext.gather_points(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+        idx = ext.ball_query(new_xyz, xyz, r, ns)
+        idx2 = ext.ball_query(new_xyz, xyz, r, ns)          # (would be a cache hit outside inference mode)
+    want_inds = oracle_omp.furthest_point_sampling(xyz_np, m)
+    assert np.array_equal(inds.cpu().numpy(), want_inds)
+    cen = np.take_along_axis(xyz_np, want_inds[..., None].astype(np.int64), axis=1)
+    want = oracle_omp.ball_query(cen, xyz_np, r, ns)
+    assert np.array_equal(idx.cpu().numpy(), want) and torch.equal(idx, idx2)
+    # more samples than points through the prefix entry point: plain sampling semantics
+    small = dev(xyz_np[:, :100].copy())
+    got = ext.furthest_point_sampling(small, 130).cpu().numpy()
+    assert np.array_equal(got, oracle_omp.furthest_point_sampling(xyz_np[:, :100].copy(), 130))
+
+
 def test_cell_list_cache_behind_the_reference_surface(ext, oracle_omp, synth):
     """The reference's layer calls furthest_point_sampling(xyz, npoint) and then
     ball_query(new_xyz, xyz, r, ns) on the same cloud (pointnet2_modules.py:236-250); the pybind
