@@ -42,10 +42,115 @@ __device__ __forceinline__ void block_sum2(float &a, float &b, float *scratch) {
   }
 }
 
+// ---- "the last workgroup finalizes" -------------------------------------------------------------
+// Every reduction here is partial sums per workgroup + a small finalize.  As two launches the
+// finalize is a 4-5 us kernel of its own, ~90 of them per train step.  Instead every partial
+// workgroup takes a ticket for its channel (an agent-scope release fence, then an atomic add) and
+// the one that draws the last ticket reads all partials of the channel back -- in the same fixed
+// order as the separate kernel, so the result does not depend on who is last -- and finalizes.
+// The counters return to zero (the last workgroup resets its own), so launches on one stream
+// need no memset; the families use separate counters.
+constexpr int kMaxTicketChannels = 4096;
+__device__ int bn_tickets[4][kMaxTicketChannels];
+
+// Partials travel between workgroups (possibly on different XCDs, whose L2s are not coherent with
+// one another) as agent-scope RELAXED atomics: write-through stores (sc1) and cache-bypassing
+// loads.  An agent-scope fence instead would write back and invalidate the whole L2 of the XCD
+// per workgroup (buffer_wbl2 / buffer_inv): measured, that made the train step 1.8 ms SLOWER.
+template <typename T>
+__device__ __forceinline__ void coherent_store(T *p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ T coherent_load(const T *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// true in every thread of the workgroup that arrived last among `expected` for counter `t`
+// (the partial of this workgroup was written by its thread 0 with coherent_store)
+__device__ __forceinline__ bool last_arrival(int *t, int expected) {
+  __shared__ int is_last;
+  if (threadIdx.x == 0) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0);  // the write-through stores of the partial have been acknowledged
+    asm volatile("" ::: "memory");
+    const int seen = __hip_atomic_fetch_add(t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = seen == expected - 1;
+    if (is_last) coherent_store(t, 0);
+  }
+  __syncthreads();
+  return is_last != 0;
+}
+
 // ---- forward statistics: one (n, mean, M2) triple per (channel, batch, slice) ---------------
+// ---- finalize: Chan combination, running statistics, affine coefficients ------------------
+// One wave per channel: lanes combine every 64th partial, then a butterfly merges the lanes.
+struct Moments { double n, mean, m2; };
+
+__device__ __forceinline__ Moments chan_merge(const Moments &a, const Moments &b) {
+  if (b.n <= 0.0) return a;
+  if (a.n <= 0.0) return b;
+  Moments o;
+  const double delta = b.mean - a.mean;
+  o.n = a.n + b.n;
+  o.mean = a.mean + delta * b.n / o.n;
+  o.m2 = a.m2 + b.m2 + delta * delta * a.n * b.n / o.n;
+  return o;
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, mask, kWave);
+  hi = __shfl_xor(hi, mask, kWave);
+  return __hiloint2double(hi, lo);
+}
+
+struct FwdFinalize {
+  const float *gamma, *beta;
+  float eps, momentum;
+  float *running_mean, *running_var, *mean_out, *invstd_out, *scale_out, *shift_out;
+};
+
+// one wave: Chan-merge the `parts` triples of channel ch, write its statistics and coefficients
+__device__ __forceinline__ void fwd_finalize_channel(int ch, int parts, const float *__restrict__ partial,
+                                                     const FwdFinalize &f) {
+  const int lane = lane_id();
+  Moments acc = {0.0, 0.0, 0.0};
+  const float *p = partial + (size_t)ch * parts * 3;
+  for (int q = lane; q < parts; q += kWave) {
+    const Moments part = {(double)coherent_load(p + q * 3), (double)coherent_load(p + q * 3 + 1),
+                          (double)coherent_load(p + q * 3 + 2)};
+    acc = chan_merge(acc, part);
+  }
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    Moments other = {shfl_xor_f64(acc.n, off), shfl_xor_f64(acc.mean, off),
+                     shfl_xor_f64(acc.m2, off)};
+    // merge in a lane-independent order so that every lane ends with the same bits
+    acc = (lane & off) ? chan_merge(other, acc) : chan_merge(acc, other);
+  }
+  if (lane != 0) return;
+  const double n = acc.n, mean = acc.mean, m2 = acc.m2;
+  const double var = n > 0.0 ? m2 / n : 0.0;  // biased, used for normalisation
+  const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+  const float fmean = (float)mean;
+  f.mean_out[ch] = fmean;
+  f.invstd_out[ch] = invstd;
+  const float sc = f.gamma[ch] * invstd;
+  f.scale_out[ch] = sc;
+  f.shift_out[ch] = f.beta[ch] - fmean * sc;
+  if (f.running_mean != nullptr) {  // nn.BatchNorm: unbiased variance in the running estimate
+    const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
+    f.running_mean[ch] = (1.f - f.momentum) * f.running_mean[ch] + f.momentum * fmean;
+    f.running_var[ch] = (1.f - f.momentum) * f.running_var[ch] + f.momentum * (float)unbiased;
+  }
+}
+
+// ---- forward statistics (continued): the partial sums; the last workgroup of a channel also
+// finalizes it (see last_arrival) ----------------------------------------------------------------
 __global__ void __launch_bounds__(kBnThreads)
 bn_partial_stats_kernel(int c, int r, int slices, const float *__restrict__ y,
-                        float *__restrict__ partial) {
+                        float *__restrict__ partial, FwdFinalize fin) {
   __shared__ float scratch[2 * kBnThreads / kWave];
   const int s = blockIdx.x, ch = blockIdx.y, b = blockIdx.z;
   const int per = (r + slices - 1) / slices;
@@ -88,72 +193,12 @@ bn_partial_stats_kernel(int c, int r, int slices, const float *__restrict__ y,
   if (threadIdx.x == 0) {
     float *out = partial + ((size_t)ch * gridDim.z * slices + (size_t)b * slices + s) * 3;
     const float fn = (float)n;
-    out[0] = fn;
-    out[1] = n > 0 ? shift + a1 / fn : 0.f;
-    out[2] = n > 0 ? a2 - a1 * a1 / fn : 0.f;
+    coherent_store(out, fn);
+    coherent_store(out + 1, n > 0 ? shift + a1 / fn : 0.f);
+    coherent_store(out + 2, n > 0 ? a2 - a1 * a1 / fn : 0.f);
   }
-}
-
-// ---- finalize: Chan combination, running statistics, affine coefficients ------------------
-// One wave per channel: lanes combine every 64th partial, then a butterfly merges the lanes.
-struct Moments { double n, mean, m2; };
-
-__device__ __forceinline__ Moments chan_merge(const Moments &a, const Moments &b) {
-  if (b.n <= 0.0) return a;
-  if (a.n <= 0.0) return b;
-  Moments o;
-  const double delta = b.mean - a.mean;
-  o.n = a.n + b.n;
-  o.mean = a.mean + delta * b.n / o.n;
-  o.m2 = a.m2 + b.m2 + delta * delta * a.n * b.n / o.n;
-  return o;
-}
-
-__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __shfl_xor(lo, mask, kWave);
-  hi = __shfl_xor(hi, mask, kWave);
-  return __hiloint2double(hi, lo);
-}
-
-__global__ void __launch_bounds__(256)
-bn_finalize_kernel(int c, int parts, const float *__restrict__ partial,
-                   const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                   float momentum, float *__restrict__ running_mean,
-                   float *__restrict__ running_var, float *__restrict__ mean_out,
-                   float *__restrict__ invstd_out, float *__restrict__ scale_out,
-                   float *__restrict__ shift_out) {
-  const int ch = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
-  if (ch >= c) return;
-  const int lane = lane_id();
-  Moments acc = {0.0, 0.0, 0.0};
-  const float *p = partial + (size_t)ch * parts * 3;
-  for (int q = lane; q < parts; q += kWave) {
-    const Moments part = {(double)p[q * 3], (double)p[q * 3 + 1], (double)p[q * 3 + 2]};
-    acc = chan_merge(acc, part);
-  }
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    Moments other = {shfl_xor_f64(acc.n, off), shfl_xor_f64(acc.mean, off),
-                     shfl_xor_f64(acc.m2, off)};
-    // merge in a lane-independent order so that every lane ends with the same bits
-    acc = (lane & off) ? chan_merge(other, acc) : chan_merge(acc, other);
-  }
-  if (lane != 0) return;
-  const double n = acc.n, mean = acc.mean, m2 = acc.m2;
-  const double var = n > 0.0 ? m2 / n : 0.0;  // biased, used for normalisation
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float fmean = (float)mean;
-  mean_out[ch] = fmean;
-  invstd_out[ch] = invstd;
-  const float sc = gamma[ch] * invstd;
-  scale_out[ch] = sc;
-  shift_out[ch] = beta[ch] - fmean * sc;
-  if (running_mean != nullptr) {  // nn.BatchNorm: unbiased variance in the running estimate
-    const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
-    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * fmean;
-    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
-  }
+  if (last_arrival(&bn_tickets[0][ch], (int)gridDim.z * slices) && threadIdx.x < kWave)
+    fwd_finalize_channel(ch, (int)gridDim.z * slices, partial, fin);
 }
 
 // The same from equal-count (mean, M2) pairs laid out [part][channel][2] (the epilogue of the
@@ -164,6 +209,45 @@ bn_finalize_kernel(int c, int parts, const float *__restrict__ partial,
 // stage 2 combines the slices.  (A single workgroup per channel block walked thousands of parts
 // with one dependent load per step: 0.3 ms for SA1.)
 constexpr int kPairSlices = 32;
+
+// channel ch from the kPairSlices slice sums (one lane per channel)
+__device__ __forceinline__ void pairs_finalize_channel(int ch, int c, int parts, int n_part,
+                                                       const float *__restrict__ pairs,
+                                                       const double *__restrict__ sums,
+                                                       const FwdFinalize &f) {
+  double s1 = 0.0, s2 = 0.0, sm2 = 0.0;
+  for (int q = 0; q < kPairSlices; ++q) {
+    const double *o = sums + ((size_t)q * c + ch) * 3;
+    s1 += o[0]; s2 += o[1]; sm2 += o[2];
+  }
+  const double ref = (double)pairs[(size_t)ch * 2];
+  const double P = (double)parts, n = P * (double)n_part;
+  const double mean = ref + s1 / P;
+  double m2 = sm2 + (double)n_part * (s2 - s1 * s1 / P);
+  if (m2 < 0.0) m2 = 0.0;
+  const double var = m2 / n;  // biased, used for normalisation
+  const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+  const float fmean = (float)mean;
+  f.mean_out[ch] = fmean;
+  f.invstd_out[ch] = invstd;
+  const float sc = f.gamma[ch] * invstd;
+  f.scale_out[ch] = sc;
+  f.shift_out[ch] = f.beta[ch] - fmean * sc;
+  if (f.running_mean != nullptr) {  // nn.BatchNorm: unbiased variance in the running estimate
+    const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
+    f.running_mean[ch] = (1.f - f.momentum) * f.running_mean[ch] + f.momentum * fmean;
+    f.running_var[ch] = (1.f - f.momentum) * f.running_var[ch] + f.momentum * (float)unbiased;
+  }
+}
+
+// (the ticket form was tried here too: the last slice's serial walk over 32 x 3 doubles per channel
+//  cost more than the second launch it saved, 193 against 170 us per step -- two kernels stay)
+__global__ void __launch_bounds__(256)
+bn_pairs_stage2_kernel(int c, int parts, int n_part, const float *__restrict__ pairs,
+                       const double *__restrict__ sums, FwdFinalize fin) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch < c) pairs_finalize_channel(ch, c, parts, n_part, pairs, sums, fin);
+}
 
 __global__ void __launch_bounds__(1024)
 bn_pairs_stage1_kernel(int c, int parts, const float *__restrict__ pairs,
@@ -196,43 +280,10 @@ bn_pairs_stage1_kernel(int c, int parts, const float *__restrict__ pairs,
   }
   red[w][0][lane] = s1; red[w][1][lane] = s2; red[w][2][lane] = sm2;
   __syncthreads();
-  if (w != 0 || ch >= c) return;
-  for (int q = 1; q < 16; ++q) { s1 += red[q][0][lane]; s2 += red[q][1][lane]; sm2 += red[q][2][lane]; }
-  double *o = sums + ((size_t)blockIdx.y * c + ch) * 3;
-  o[0] = s1; o[1] = s2; o[2] = sm2;
-}
-
-__global__ void __launch_bounds__(256)
-bn_pairs_stage2_kernel(int c, int parts, int n_part, const float *__restrict__ pairs,
-                       const double *__restrict__ sums, const float *__restrict__ gamma,
-                       const float *__restrict__ beta, float eps, float momentum,
-                       float *__restrict__ running_mean, float *__restrict__ running_var,
-                       float *__restrict__ mean_out, float *__restrict__ invstd_out,
-                       float *__restrict__ scale_out, float *__restrict__ shift_out) {
-  const int ch = blockIdx.x * 256 + threadIdx.x;
-  if (ch >= c) return;
-  double s1 = 0.0, s2 = 0.0, sm2 = 0.0;
-  for (int q = 0; q < kPairSlices; ++q) {
-    const double *o = sums + ((size_t)q * c + ch) * 3;
-    s1 += o[0]; s2 += o[1]; sm2 += o[2];
-  }
-  const double ref = (double)pairs[(size_t)ch * 2];
-  const double P = (double)parts, n = P * (double)n_part;
-  const double mean = ref + s1 / P;
-  double m2 = sm2 + (double)n_part * (s2 - s1 * s1 / P);
-  if (m2 < 0.0) m2 = 0.0;
-  const double var = m2 / n;  // biased, used for normalisation
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float fmean = (float)mean;
-  mean_out[ch] = fmean;
-  invstd_out[ch] = invstd;
-  const float sc = gamma[ch] * invstd;
-  scale_out[ch] = sc;
-  shift_out[ch] = beta[ch] - fmean * sc;
-  if (running_mean != nullptr) {  // nn.BatchNorm: unbiased variance in the running estimate
-    const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
-    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * fmean;
-    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+  if (w == 0 && ch < c) {
+    for (int q = 1; q < 16; ++q) { s1 += red[q][0][lane]; s2 += red[q][1][lane]; sm2 += red[q][2][lane]; }
+    double *o = sums + ((size_t)blockIdx.y * c + ch) * 3;
+    o[0] = s1; o[1] = s2; o[2] = sm2;
   }
 }
 
@@ -350,12 +401,49 @@ pool_from_extrema_kernel(int c, int groups, long long total, const float *__rest
   ymax[i] = yw;
 }
 
+// dgamma = s2, dbeta = s1, and the per-channel coefficients of dy (training mode); one wave
+// per channel
+struct BwdFinalize {
+  double count;
+  int training;
+  const float *gamma, *invstd;
+  float *dgamma, *dbeta, *coef;
+};
+
+__device__ __forceinline__ void bwd_finalize_channel(int ch, int parts, const float *__restrict__ partial,
+                                                     const BwdFinalize &f) {
+  const int lane = lane_id();
+  double s1 = 0.0, s2 = 0.0;
+  const float *p = partial + (size_t)ch * parts * 2;
+  for (int q = lane; q < parts; q += kWave) { s1 += coherent_load(p + q * 2); s2 += coherent_load(p + q * 2 + 1); }
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    s1 += shfl_xor_f64(s1, off);
+    s2 += shfl_xor_f64(s2, off);
+  }
+  if (lane != 0) return;
+  f.dbeta[ch] = (float)s1;
+  f.dgamma[ch] = (float)s2;
+  f.coef[ch * 3 + 0] = f.gamma[ch] * f.invstd[ch];
+  // eval mode: statistics are constants, dy = gamma*invstd*dzh
+  f.coef[ch * 3 + 1] = f.training ? (float)(s1 / f.count) : 0.f;
+  f.coef[ch * 3 + 2] = f.training ? (float)(s2 / f.count) : 0.f;
+}
+
+__global__ void __launch_bounds__(256)
+bn_bwd_finalize_kernel(int c, int parts, const float *__restrict__ partial, BwdFinalize f) {
+  const int ch = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+  if (ch >= c) return;
+  bwd_finalize_channel(ch, parts, partial, f);
+}
+
 // ---- backward sums: s1 = sum dzh, s2 = sum dzh * xhat, dzh = dz * [y*scale+shift > 0] --------
 __global__ void __launch_bounds__(kBnThreads)
 bn_relu_bwd_partial_kernel(int c, int r, int slices, const float *__restrict__ y,
                            const float *__restrict__ dz, const float *__restrict__ scale,
                            const float *__restrict__ shift, const float *__restrict__ mean,
-                           const float *__restrict__ invstd, float *__restrict__ partial) {
+                           const float *__restrict__ invstd, float *__restrict__ partial,
+                           BwdFinalize fin) {
   __shared__ float scratch[2 * kBnThreads / kWave];
   const int s = blockIdx.x, ch = blockIdx.y, b = blockIdx.z;
   const int per = (r + slices - 1) / slices;
@@ -396,9 +484,11 @@ bn_relu_bwd_partial_kernel(int c, int r, int slices, const float *__restrict__ y
   block_sum2(s1, s2, scratch);
   if (threadIdx.x == 0) {
     float *out = partial + ((size_t)ch * gridDim.z * slices + (size_t)b * slices + s) * 2;
-    out[0] = s1;
-    out[1] = s2;
+    coherent_store(out, s1);
+    coherent_store(out + 1, s2);
   }
+  if (last_arrival(&bn_tickets[2][ch], (int)gridDim.z * slices) && threadIdx.x < kWave)
+    bwd_finalize_channel(ch, (int)gridDim.z * slices, partial, fin);
 }
 
 // pooled layer: the same sums from the (B,C,m) tensors (dz is non-zero only at the arg-max)
@@ -406,7 +496,8 @@ __global__ void __launch_bounds__(kBnThreads)
 pool_bwd_partial_kernel(int c, int m, const float *__restrict__ dpooled,
                         const float *__restrict__ ymax, const float *__restrict__ scale,
                         const float *__restrict__ shift, const float *__restrict__ mean,
-                        const float *__restrict__ invstd, float *__restrict__ partial) {
+                        const float *__restrict__ invstd, float *__restrict__ partial,
+                        BwdFinalize fin) {
   __shared__ float scratch[2 * kBnThreads / kWave];
   const int ch = blockIdx.y, b = blockIdx.z;
   const size_t base = ((size_t)b * c + ch) * m;
@@ -421,36 +512,11 @@ pool_bwd_partial_kernel(int c, int m, const float *__restrict__ dpooled,
   block_sum2(s1, s2, scratch);
   if (threadIdx.x == 0) {
     float *out = partial + ((size_t)ch * gridDim.z + b) * 2;
-    out[0] = s1;
-    out[1] = s2;
+    coherent_store(out, s1);
+    coherent_store(out + 1, s2);
   }
-}
-
-// dgamma = s2, dbeta = s1, and the per-channel coefficients of dy (training mode); one wave
-// per channel
-__global__ void __launch_bounds__(256)
-bn_bwd_finalize_kernel(int c, int parts, double count, int training,
-                       const float *__restrict__ partial, const float *__restrict__ gamma,
-                       const float *__restrict__ invstd, float *__restrict__ dgamma,
-                       float *__restrict__ dbeta, float *__restrict__ coef) {
-  const int ch = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
-  if (ch >= c) return;
-  const int lane = lane_id();
-  double s1 = 0.0, s2 = 0.0;
-  const float *p = partial + (size_t)ch * parts * 2;
-  for (int q = lane; q < parts; q += kWave) { s1 += p[q * 2]; s2 += p[q * 2 + 1]; }
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    s1 += shfl_xor_f64(s1, off);
-    s2 += shfl_xor_f64(s2, off);
-  }
-  if (lane != 0) return;
-  dbeta[ch] = (float)s1;
-  dgamma[ch] = (float)s2;
-  coef[ch * 3 + 0] = gamma[ch] * invstd[ch];
-  // eval mode: statistics are constants, dy = gamma*invstd*dzh
-  coef[ch * 3 + 1] = training ? (float)(s1 / count) : 0.f;
-  coef[ch * 3 + 2] = training ? (float)(s2 / count) : 0.f;
+  if (last_arrival(&bn_tickets[3][ch], (int)gridDim.z) && threadIdx.x < kWave)
+    bwd_finalize_channel(ch, (int)gridDim.z, partial, fin);
 }
 
 // dy = a * (dzh - c1 - xhat*c2)
@@ -538,11 +604,10 @@ MLP_API int mlp_bn_train_stats(int b, int c, int r, const float *y, const float 
   if (b <= 0 || c <= 0 || r <= 0) return 0;
   hipStream_t stream = (hipStream_t)stream_;
   const int slices = slices_for(r);
+  if (c > kMaxTicketChannels) return (int)hipErrorInvalidValue;
+  const FwdFinalize fin = {gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
   hipLaunchKernelGGL(bn_partial_stats_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream, c,
-                     r, slices, y, workspace);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(pn2_ceil_div(c, 256 / kWave)), dim3(256), 0, stream, c,
-                     b * slices, workspace, gamma, beta, eps, momentum, running_mean,
-                     running_var, mean, invstd, scale, shift);
+                     r, slices, y, workspace, fin);
   return pn2_launch_status();
 }
 
@@ -559,14 +624,14 @@ MLP_API int mlp_bn_finalize_pairs(int c, int parts, int n_part, const float *pai
                                   float *invstd, float *scale, float *shift, void *scratch,
                                   void *stream_) {
   if (c <= 0 || parts <= 0 || n_part <= 0) return 0;
-  if (!scratch) return (int)hipErrorInvalidValue;
+  if (!scratch || c > kMaxTicketChannels * kWave) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
   double *sums = reinterpret_cast<double *>(scratch);
+  const FwdFinalize fin = {gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
   hipLaunchKernelGGL(bn_pairs_stage1_kernel, dim3(pn2_ceil_div(c, kWave), kPairSlices), dim3(1024),
                      0, stream, c, parts, pairs, sums);
   hipLaunchKernelGGL(bn_pairs_stage2_kernel, dim3(pn2_ceil_div(c, 256)), dim3(256), 0, stream, c,
-                     parts, n_part, pairs, sums, gamma, beta, eps, momentum, running_mean,
-                     running_var, mean, invstd, scale, shift);
+                     parts, n_part, pairs, sums, fin);
   return pn2_launch_status();
 }
 
@@ -622,13 +687,12 @@ MLP_API int mlp_bn_relu_backward(int b, int c, int r, int training, const float 
                                  float *dy, float *dgamma, float *dbeta, float *coef,
                                  float *workspace, void *stream_) {
   if (b <= 0 || c <= 0 || r <= 0) return 0;
+  if (c > kMaxTicketChannels) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
   const int slices = slices_for(r);
   hipLaunchKernelGGL(bn_relu_bwd_partial_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream,
-                     c, r, slices, y, dz, scale, shift, mean, invstd, workspace);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn2_ceil_div(c, 256 / kWave)), dim3(256), 0, stream, c,
-                     b * slices, (double)b * (double)r, training, workspace, gamma, invstd, dgamma,
-                     dbeta, coef);
+                     c, r, slices, y, dz, scale, shift, mean, invstd, workspace,
+                     BwdFinalize{(double)b * (double)r, training, gamma, invstd, dgamma, dbeta, coef});
   if (r % 4 == 0)
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<true>, dim3(pn2_ceil_div(r, 1024), c, b), dim3(256),
                        0, stream, c, r, y, dz, scale, shift, mean, invstd, coef, dy);
@@ -645,13 +709,12 @@ MLP_API int mlp_bn_relu_backward_stats(int b, int c, int r, int training, const 
                                        float *dgamma, float *dbeta, float *coef, float *workspace,
                                        void *stream_) {
   if (b <= 0 || c <= 0 || r <= 0) return 0;
+  if (c > kMaxTicketChannels) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
   const int slices = slices_for(r);
   hipLaunchKernelGGL(bn_relu_bwd_partial_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream,
-                     c, r, slices, y, dz, scale, shift, mean, invstd, workspace);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn2_ceil_div(c, 256 / kWave)), dim3(256), 0, stream, c,
-                     b * slices, (double)b * (double)r, training, workspace, gamma, invstd, dgamma,
-                     dbeta, coef);
+                     c, r, slices, y, dz, scale, shift, mean, invstd, workspace,
+                     BwdFinalize{(double)b * (double)r, training, gamma, invstd, dgamma, dbeta, coef});
   return pn2_launch_status();
 }
 
@@ -663,8 +726,8 @@ MLP_API int mlp_bn_backward_finalize(int c, int parts, double count, int trainin
                                      void *stream_) {
   if (c <= 0 || parts <= 0) return 0;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn2_ceil_div(c, 256 / kWave)), dim3(256), 0,
-                     (hipStream_t)stream_, c, parts, count, training, partial, gamma, invstd, dgamma,
-                     dbeta, coef);
+                     (hipStream_t)stream_, c, parts, partial,
+                     BwdFinalize{count, training, gamma, invstd, dgamma, dbeta, coef});
   return pn2_launch_status();
 }
 
@@ -687,12 +750,12 @@ MLP_API int mlp_bn_relu_pool_backward(int b, int c, int m, int ns, int training,
                                       float *dgamma, float *dbeta, float *coef, float *workspace,
                                       void *stream_) {
   if (b <= 0 || c <= 0 || m <= 0 || ns <= 0) return 0;
+  if (c > kMaxTicketChannels) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
   hipLaunchKernelGGL(pool_bwd_partial_kernel, dim3(1, c, b), dim3(kBnThreads), 0, stream, c, m,
-                     dpooled, ymax, scale, shift, mean, invstd, workspace);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn2_ceil_div(c, 256 / kWave)), dim3(256), 0, stream, c,
-                     b, (double)b * (double)m * (double)ns, training, workspace, gamma, invstd,
-                     dgamma, dbeta, coef);
+                     dpooled, ymax, scale, shift, mean, invstd, workspace,
+                     BwdFinalize{(double)b * (double)m * (double)ns, training, gamma, invstd, dgamma,
+                                 dbeta, coef});
   if (dy == nullptr) return pn2_launch_status();  // statistics only (mlp_gemm_*_pooled form dy)
   const long long r = (long long)m * ns;
   if (r % 4 == 0)

@@ -561,7 +561,9 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
 // their accumulators through LDS at the end.
 constexpr int KS = 64;  // K chunk of the small variant
 
-template <int MODE, bool A_TRANS>
+// X6: the chunk's 16 k-rows of a wave are ONE bf16 MFMA step; fragments gathered as eight 4-byte
+// reads per row block and split in registers (mlp_operand.h)
+template <int MODE, bool A_TRANS, bool X6 = false>
 __global__ void __launch_bounds__(256)
 gemm_nn_small_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int lda,
                      OperandB opb, float *__restrict__ c, size_t b_stride_in,
@@ -621,6 +623,29 @@ gemm_nn_small_kernel(int m_total, int k_total, int r, const float *__restrict__ 
     }
     __syncthreads();
     if (k0 + KS < k_total) fetch(k0 + KS);
+    if constexpr (X6) {
+      static_assert(KS / 4 == 16, "a wave's share of the chunk is one 16-deep MFMA step");
+      const int k0w = wave * (KS / 4) + 8 * (lane >> 5);
+      Split3 sa[2], sb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = As[(k0w + e) * LDA + i * 32 + (lane & 31)];
+        sa[i] = split3(v);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = Bs[(k0w + e) * TN + j * 32 + (lane & 31)];
+        sb[j] = split3(v);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mfma_x6(acc[i][j], sa[i], sb[j]);
+    } else {
 #pragma unroll
     for (int kk = 0; kk < KS / 4; kk += 2) {
       const int krow = wave * (KS / 4) + kk + (lane >> 5);
@@ -634,6 +659,7 @@ gemm_nn_small_kernel(int m_total, int k_total, int r, const float *__restrict__ 
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
     }
   }
   for (int s = 1; s < 4; ++s) {  // waves 1..3 hand their accumulators to wave 0
@@ -681,7 +707,7 @@ gemm_nn_small_kernel(int m_total, int k_total, int r, const float *__restrict__ 
 // r-steps; shares are summed through LDS at the end.  The R axis is staged [r][m] / [r][k].
 constexpr int RC = 32;  // r chunk (128-byte row segments per load)
 
-template <int PMODE, int QMODE, int KBW, int WK, int RS>
+template <int PMODE, int QMODE, int KBW, int WK, int RS, bool X6 = false>
 __global__ void __launch_bounds__(256)
 gemm_wgrad_kernel(int m_total, int k_begin, int k_end, int k_total, int r, int r_per_slice,
                   OperandB opp, OperandB opq, float *__restrict__ part, size_t p_stride,
@@ -756,6 +782,30 @@ gemm_wgrad_kernel(int m_total, int k_begin, int k_end, int k_total, int r, int r
             (q_ok[s] && rr + seg_r + i < r_hi) ? transform<QMODE>(qx[s][i], qdz[s][i], qc[s]) : 0.f;
     __syncthreads();
     if (rr + RC < r_hi) fetch(rr + RC);
+    if constexpr (X6 && (RC / RS) % 16 == 0) {
+      // a wave's share of the r-chunk in 16-deep bf16 MFMA steps (mlp_operand.h split3 / mfma_x6)
+#pragma unroll
+      for (int st = 0; st < RC / RS / 16; ++st) {
+        const int row0 = wr * (RC / RS) + 16 * st + 8 * (lane >> 5);
+        Split3 sp[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = Ps[(row0 + e) * LDP + i * 32 + (lane & 31)];
+          sp[i] = split3(v);
+        }
+#pragma unroll
+        for (int j = 0; j < KBW; ++j) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = Qs[(row0 + e) * LDQ + (wk * KBW + j) * 32 + (lane & 31)];
+          const Split3 sq = split3(v);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) mfma_x6(acc[i][j], sp[i], sq);
+        }
+      }
+    } else {
 #pragma unroll
     for (int st = 0; st < RC / 2 / RS; ++st) {
       const int row = wr * (RC / RS) + 2 * st + (lane >> 5);
@@ -769,6 +819,7 @@ gemm_wgrad_kernel(int m_total, int k_begin, int k_end, int k_total, int r, int r
 #pragma unroll
         for (int j = 0; j < KBW; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i], bq[j], acc[i][j], 0, 0, 0);
+    }
     }
   }
   if (RS > 1) {  // sum the r-shares of each column group: share s -> LDS -> share 0
@@ -845,6 +896,14 @@ bool gemm_x6() {
   return on;
 }
 
+// the stand-alone weight-gradient kernel split the same way: slower over the layer shapes (2436
+// against 2346 us, profiles/r4_split_bf16.json) -- its fragments are split by every wave again;
+// kept behind MLP_WGRAD_SPLIT_BF16=1
+bool wgrad_x6() {
+  static const bool on = gemm_x6() && getenv("MLP_WGRAD_SPLIT_BF16") && atoi(getenv("MLP_WGRAD_SPLIT_BF16")) == 1;
+  return on;
+}
+
 // forward GEMM whose epilogue also leaves BatchNorm partials (see gemm_nn2_kernel STATS); only
 // instantiated for the operand modes of the forward pass
 template <int TM, int TN, int WM, int WN, int MODE, bool A_TRANS>
@@ -871,9 +930,14 @@ int launch_nn(int b, int m, int k, int r, const float *a, int lda, const Operand
   const char *env = getenv("MLP_SMALL_GEMM_COLS");
   const long long small_cols = env ? atoll(env) : 16384;
   if ((long long)b * r <= small_cols) {  // a few hundred columns per cloud: latency-bound regime
-    hipLaunchKernelGGL((gemm_nn_small_kernel<MODE, A_TRANS>),
-                       dim3(pn2_ceil_div(r, 64), pn2_ceil_div(m, 64), b), dim3(256), 0, stream, m,
-                       k, r, a, lda, op, c, in_stride, out_stride);
+    if (gemm_x6() && !A_TRANS)  // (measured: the transposed / on-the-fly-dY forms are slower split)
+      hipLaunchKernelGGL((gemm_nn_small_kernel<MODE, A_TRANS, true>),
+                         dim3(pn2_ceil_div(r, 64), pn2_ceil_div(m, 64), b), dim3(256), 0, stream, m,
+                         k, r, a, lda, op, c, in_stride, out_stride);
+    else
+      hipLaunchKernelGGL((gemm_nn_small_kernel<MODE, A_TRANS>),
+                         dim3(pn2_ceil_div(r, 64), pn2_ceil_div(m, 64), b), dim3(256), 0, stream, m,
+                         k, r, a, lda, op, c, in_stride, out_stride);
     return pn2_launch_status();
   }
   // rows are covered by 256-row tiles, then one smaller tile for the remainder
@@ -1154,11 +1218,20 @@ static int wgrad_run(int b, int m, int k, int r, int pmode, const OperandB &P, i
       const int tk = wgrad_next_tile(k - kb);                                                   \
       const int ke = kb + tk < k ? kb + tk : k;                                                 \
       dim3 grid(1, pn2_ceil_div(m, 64), b * slices);                                            \
-      if (tk == 256)                                                                            \
+      if (tk == 256 && wgrad_x6())                                                              \
+        hipLaunchKernelGGL((gemm_wgrad_kernel<PM, QM, 2, 4, 1, true>), grid, dim3(256), 0, stream, m, \
+                           kb, ke, k, r, per, P, Q, workspace, ps, qs);                         \
+      else if (tk == 256)                                                                       \
         hipLaunchKernelGGL((gemm_wgrad_kernel<PM, QM, 2, 4, 1>), grid, dim3(256), 0, stream, m, \
+                           kb, ke, k, r, per, P, Q, workspace, ps, qs);                         \
+      else if (tk == 192 && wgrad_x6())                                                          \
+        hipLaunchKernelGGL((gemm_wgrad_kernel<PM, QM, 3, 2, 2, true>), grid, dim3(256), 0, stream, m, \
                            kb, ke, k, r, per, P, Q, workspace, ps, qs);                         \
       else if (tk == 192)                                                                       \
         hipLaunchKernelGGL((gemm_wgrad_kernel<PM, QM, 3, 2, 2>), grid, dim3(256), 0, stream, m, \
+                           kb, ke, k, r, per, P, Q, workspace, ps, qs);                         \
+      else if (tk == 128 && wgrad_x6())                                                          \
+        hipLaunchKernelGGL((gemm_wgrad_kernel<PM, QM, 2, 2, 2, true>), grid, dim3(256), 0, stream, m, \
                            kb, ke, k, r, per, P, Q, workspace, ps, qs);                         \
       else if (tk == 128)                                                                       \
         hipLaunchKernelGGL((gemm_wgrad_kernel<PM, QM, 2, 2, 2>), grid, dim3(256), 0, stream, m, \

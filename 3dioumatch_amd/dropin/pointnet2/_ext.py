@@ -150,11 +150,19 @@ def _cached_lists(xyz, radius):
     cur = torch.cuda.current_stream(xyz.device)
     if stream != cur.cuda_stream:
         # built on another stream: order this stream after the build and keep the buffer alive
-        # for it (the allocator would otherwise hand it back to the building stream's pool)
-        if lists.event is None or _capturing(xyz):
+        # for it (the allocator would otherwise hand it back to the building stream's pool).
+        # A build that has already completed needs no ordering; a capturing stream cannot wait
+        # on an outside event, so an unfinished build is a miss there.
+        if lists.event is None:
             return None
-        cur.wait_event(lists.event)
-        lists.buf.record_stream(cur)
+        done = lists.event.query()
+        if _capturing(xyz):
+            if not done:
+                return None
+        else:
+            if not done:
+                cur.wait_event(lists.event)
+            lists.buf.record_stream(cur)
     return lists
 
 
