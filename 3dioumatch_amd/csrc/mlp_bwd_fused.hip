@@ -603,8 +603,11 @@ MLP_API int mlp_gemm_backward_fused_supported(int b, int m, int k, int r, int pm
 // (k, parts, 2) for the layer below (qmode 1 only; 0 otherwise)
 MLP_API int mlp_gemm_backward_fused_stats_parts(int b, int m, int k, int r) {
   FusedShape s;
-  // the first set-abstraction level only: there the absorbed pass over (x, dq) costs ~95 us a
-  // layer; on the narrower levels the extra registers cost the GEMM more than the pass
+  // the (128,128) layers on the bf16-split kernel: one partial per workgroup
+  const int gx = mlp_bwd_x6_workgroups(b, m, k, r, fused_cus());
+  if (gx > 0) return gx;
+  // otherwise the first set-abstraction level only: there the absorbed pass over (x, dq) costs
+  // ~95 us a layer; on the narrower levels the extra registers cost the fp32 GEMM more than the pass
   if (!fused_shape(m, k, &s) || k != 64 || r % s.tn != 0) return 0;
   return fused_workgroups(s, (long long)b * (r / s.tn)) * 2;
 }
@@ -637,15 +640,15 @@ MLP_API int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, 
   OperandB P = {y, dz, scale, shift, mean, invstd, coef, argmax, ns, ns > 0 ? r / ns : 0};
   if ((qmode == OP_BNRELU || qmode == OP_LIN4) && (!xmean || !xinvstd)) return (int)hipErrorInvalidValue;
   if (qmode == OP_LIN4 && !xlin_w) return (int)hipErrorInvalidValue;
-  if (k != 64) stats_part = nullptr;
   OperandB Q = {x, nullptr, xscale, xshift, xmean, xinvstd, nullptr, nullptr, 0, 0, xlin_w};
   {  // the bf16-split kernel with its operands split at staging, where it covers the shape
     int gx = 0;
-    const int rcx = mlp_bwd_x6_try(m, k, r, b * (r / 32), r / 32, pmode, qmode, P, Q, w, dq, workspace,
-                                   fused_cus() < g ? fused_cus() : g, &gx, stream);
+    const int rcx = mlp_bwd_x6_try(b, m, k, r, pmode, qmode, P, Q, w, dq, workspace,
+                                   qmode == OP_BNRELU ? stats_part : nullptr, fused_cus(), &gx, stream);
     if (rcx > 0) return rcx;
     if (rcx == 0) return mlp_reduce_partials(m * k, gx, workspace, dw, stream);
   }
+  if (k != 64) stats_part = nullptr;
   static const bool x6 = !(getenv("MLP_GEMM_SPLIT_BF16") && atoi(getenv("MLP_GEMM_SPLIT_BF16")) == 0) &&
                          !(getenv("MLP_BWD_SPLIT_BF16") && atoi(getenv("MLP_BWD_SPLIT_BF16")) == 0);
 #define FUSED_X(MB, KB, KBD, NB, PM, QM, OCC, ST, X6)                                           \

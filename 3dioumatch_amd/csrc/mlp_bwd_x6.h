@@ -41,18 +41,40 @@ __device__ __forceinline__ bf16x4 lds_read_tr(const char *p) {
       (__attribute__((address_space(3))) bf16x4 *)(__attribute__((address_space(3))) char *)p);
 }
 
+// sum over the 32 lanes of each half-wave (DPP, no LDS); the total lands in lanes 16..31 / 48..63
+__device__ __forceinline__ float x6_half_wave_sum(float v) {
+#define HW_STEP(CTRL, RM) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RM, 0xf, false))
+  HW_STEP(0xB1, 0xf);   // quad_perm [1,0,3,2]
+  HW_STEP(0x4E, 0xf);   // quad_perm [2,3,0,1]
+  HW_STEP(0x141, 0xf);  // row_half_mirror
+  HW_STEP(0x140, 0xf);  // row_mirror        -> every lane: the total of its row of 16
+  HW_STEP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3 -> the total of the half-wave
+#undef HW_STEP
+  return v;
+}
+
 // MB = M / 32 (4 or 8: a wave owns MB / 4 row blocks of dW), KB = 32-column blocks of dW / rows
 // blocks of Q (K padded), KBD = 32-row blocks of dQ through the matrix cores (rows xyz ..)
-template <int MB, int KB, int KBD, int PMODE, int QMODE>
+// STATS: also the BatchNorm-backward sums of the layer BELOW (the one whose relu(bn(.)) output is Q),
+// s1 = sum g, s2 = sum g * xhat with g = dQ * [y*sc + sh > 0], xhat = (y - mu) * is, from the dQ
+// blocks in the accumulators and a raw fp32 copy of the Q rows kept next to the images (the same
+// arithmetic as the separate pass bn_relu_bwd_partial over (y, dQ), which it replaces):
+// stats_part (k, workgroups, 2).
+template <int MB, int KB, int KBD, int PMODE, int QMODE, bool STATS>
 __global__ void __launch_bounds__(256, 1)
 gemm_bwd_x6_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, int xyz,
                    OperandB opp, OperandB opq, const float *__restrict__ w,
-                   float *__restrict__ dq, float *__restrict__ part) {
+                   float *__restrict__ dq, float *__restrict__ part,
+                   float *__restrict__ stats_part) {
   constexpr int M = 32 * MB, KP = 32 * KB, TN = 32;
   constexpr int RP = TN * 2 + 16;              // row pitch of an image in bytes
   constexpr int PIMG = M * RP, QIMG = KP * RP;  // bytes per term
-  constexpr int BUF = 3 * (PIMG + QIMG);
-  static_assert(2 * BUF <= 160 * 1024, "two buffers of images must fit the LDS");
+  constexpr int RAWP = (TN + 4) * 4;           // row pitch of the raw Q copy (STATS), bytes
+  constexpr int QRAW = STATS ? KP * RAWP : 0;
+  constexpr int BUF = 3 * (PIMG + QIMG) + QRAW;
+  constexpr int RCOFF = 2 * BUF;               // float4 (sc, sh, mu, is) per Q row (STATS)
+  static_assert(2 * BUF + (STATS ? KP * 16 : 0) <= 160 * 1024, "two buffers of images must fit the LDS");
+  static_assert(!STATS || QMODE == OP_BNRELU, "the sums are those of a BatchNorm+ReLU layer below");
   static_assert(MB % 4 == 0 && KBD % 4 == 0, "blocks split over four waves");
   constexpr int WMB = MB / 4, WKB = KB;        // dW blocks per wave: rows wave + 4 i, all columns
   constexpr int DK = KBD / 4;                  // dQ row blocks per wave (one column block: TN = 32)
@@ -89,6 +111,19 @@ gemm_bwd_x6_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, i
   const int lane_g = PMODE == OP_POOLDY ? seg_c / P.ns : 0;
   const int lane_s = PMODE == OP_POOLDY ? seg_c % P.ns : 0;
 
+  if (STATS) {
+    float4 *rc = reinterpret_cast<float4 *>(lds + RCOFF);
+    for (int t = tid; t < KP; t += 256)
+      rc[t] = t < k_total ? make_float4(Q.scale[t], Q.shift[t], Q.mean[t], Q.invstd[t])
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // per lane: column l31 of the 16 accumulator rows of every dQ block, over all chunks
+  float st1[DK][STATS ? 16 : 1], st2[DK][STATS ? 16 : 1];
+#pragma unroll
+  for (int e = 0; e < DK; ++e)
+#pragma unroll
+    for (int q = 0; q < (STATS ? 16 : 1); ++q) { st1[e][q] = 0.f; st2[e][q] = 0.f; }
+
   // W^T fragments of this wave's dQ row blocks, split once: step s holds m = 16 s + 8 lhi + (0..7)
   Split3 wsp[DK][DG];
 #pragma unroll
@@ -115,13 +150,16 @@ gemm_bwd_x6_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, i
   const int c_lo = (int)blockIdx.x * per;
   const int c_hi = c_lo + per < total_chunks ? c_lo + per : total_chunks;
 
-  // raw operands of two chunks in flight (register sets 0 / 1 by chunk parity): the loads of chunk
-  // c+2 are ALL issued at the top of chunk c, into the set chunk c was staged from
-  float4 px[2][PS], pd[2][PS], qx[2][QS];
-  int pwin[2][PS];
-  float pdp[2][PS];
+  // raw operands of one chunk in registers: a slice of chunk c+1 is staged from them between two
+  // MFMA groups of chunk c and reloaded with chunk c+2 right away.  (Two register sets with all
+  // loads of chunk c+2 issued at the top of chunk c were measured: no faster -- the kernel runs at
+  // the rate its 128-byte-per-row access pattern gets from HBM -- and 48 registers dearer.)
+  constexpr int NSET = 1;
+  float4 px[NSET][PS], pd[NSET][PS], qx[NSET][QS];
+  int pwin[NSET][PS];
+  float pdp[NSET][PS];
 #pragma unroll
-  for (int z = 0; z < 2; ++z) {
+  for (int z = 0; z < NSET; ++z) {
 #pragma unroll
     for (int p = 0; p < PS; ++p) {
       pwin[z][p] = -1; pdp[z][p] = 0.f;
@@ -199,6 +237,9 @@ gemm_bwd_x6_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, i
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = q_ok[q] ? transform<QMODE>(xv[e], 0.f, qc[q]) : 0.f;
       store4(base + 3 * PIMG, QIMG, seg_row + q * 32, seg_c, v);
+      if (STATS)
+        *reinterpret_cast<float4 *>(base + 3 * (PIMG + QIMG) + (size_t)(seg_row + q * 32) * RAWP + seg_c * 4) =
+            qx[z][q];
     }
   };
 
@@ -210,9 +251,10 @@ gemm_bwd_x6_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, i
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl) fetch_slice(Z0{}, sl, first);
 #pragma unroll
-    for (int sl = 0; sl < NS; ++sl) fetch_slice(Z1{}, sl, second);
-#pragma unroll
-    for (int sl = 0; sl < NS; ++sl) stage_slice(Z0{}, sl, 0);
+    for (int sl = 0; sl < NS; ++sl) {
+      stage_slice(Z0{}, sl, 0);
+      fetch_slice(Z0{}, sl, second);
+    }
   }
   __syncthreads();
 
@@ -224,21 +266,16 @@ gemm_bwd_x6_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, i
 
   // one chunk: MFMAs on buffer `cur`; zt = the parity of chunk c (register set of chunks c, c+2)
   auto chunk = [&](auto zt, int c, int cur) {
-    constexpr int z = decltype(zt)::value;
-    using ZC = std::integral_constant<int, z>;        // set of chunk c (free) -> receives chunk c+2
-    using ZN = std::integral_constant<int, 1 - z>;    // set of chunk c+1 -> staged during this chunk
+    (void)zt;
     const char *Pc = lds + (size_t)cur * BUF, *Qc = Pc + 3 * PIMG;
-    {
-      const ChunkAt ahead = chunk_at(clampc(c + 2));
-#if !defined(BWDX6_ABL) || BWDX6_ABL != 1
-#pragma unroll
-      for (int sl = 0; sl < NS; ++sl) fetch_slice(ZC{}, sl, ahead);
-#endif
-    }
+    const ChunkAt ahead = chunk_at(clampc(c + 2));
     auto between = [&](int g) {
 #if !defined(BWDX6_ABL) || BWDX6_ABL != 1   // (timing ablation 1: no staging / loads in the loop)
 #pragma unroll
-      for (int sl = g * NS / NG; sl < (g + 1) * NS / NG; ++sl) stage_slice(ZN{}, sl, cur ^ 1);
+      for (int sl = g * NS / NG; sl < (g + 1) * NS / NG; ++sl) {
+        stage_slice(Z0{}, sl, cur ^ 1);
+        fetch_slice(Z0{}, sl, ahead);
+      }
 #endif
     };
     const int b = c / chunks_per_cloud;
@@ -251,7 +288,7 @@ gemm_bwd_x6_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, i
     for (int e = 0; e < DK; ++e)
 #pragma unroll
       for (int q = 0; q < 16; ++q) accD[e][q] = 0.f;
-    bf16x4 pf[3][3][2];  // [ring][term][half of the eight m]
+    bf16x4 pf[2][3][2];  // [ring][term][half of the eight m]
     auto frag = [&](int s, bf16x4 (&dst)[3][2]) {
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
@@ -261,9 +298,8 @@ gemm_bwd_x6_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, i
       }
     };
     frag(0, pf[0]);
-    if (DG > 1) frag(1, pf[1]);
     // wgrad fragments: P rows of this wave (per step), Q column blocks two ahead
-    Split3 sp[WMB], sq[3];
+    Split3 sp[WMB], sq[2];
     auto pfrag = [&](int s) {
 #pragma unroll
       for (int i = 0; i < WMB; ++i) {
@@ -281,22 +317,21 @@ gemm_bwd_x6_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, i
       dst.lo = *reinterpret_cast<const bf16x8 *>(q0 + 2 * QIMG);
     };
 #if defined(BWDX6_ABL) && BWDX6_ABL == 3   // (timing ablation 3: no dgrad)
-    pfrag(0); qfrag(0, sq[0]); qfrag(1, sq[1]);
+    pfrag(0); qfrag(0, sq[0]);
 #pragma unroll
     for (int s = 0; s < DG; ++s) between(s);
 #else
 #pragma unroll
     for (int s = 0; s < DG; ++s) {
-      if (s + 2 < DG) frag(s + 2, pf[(s + 2) % 3]);
+      if (s + 1 < DG) frag(s + 1, pf[(s + 1) & 1]);
       if (s == DG - 1) {  // the first wgrad fragments, under the last dgrad MFMAs
         pfrag(0);
         qfrag(0, sq[0]);
-        if (WG * WKB > 1) qfrag(1, sq[1]);
       }
       Split3 sb;
-      sb.hi = __builtin_shufflevector(pf[s % 3][0][0], pf[s % 3][0][1], 0, 1, 2, 3, 4, 5, 6, 7);
-      sb.mid = __builtin_shufflevector(pf[s % 3][1][0], pf[s % 3][1][1], 0, 1, 2, 3, 4, 5, 6, 7);
-      sb.lo = __builtin_shufflevector(pf[s % 3][2][0], pf[s % 3][2][1], 0, 1, 2, 3, 4, 5, 6, 7);
+      sb.hi = __builtin_shufflevector(pf[s & 1][0][0], pf[s & 1][0][1], 0, 1, 2, 3, 4, 5, 6, 7);
+      sb.mid = __builtin_shufflevector(pf[s & 1][1][0], pf[s & 1][1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+      sb.lo = __builtin_shufflevector(pf[s & 1][2][0], pf[s & 1][2][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
       for (int e = 0; e < DK; ++e) mfma_x6(accD[e], wsp[e][s], sb);
       between(s);
@@ -308,9 +343,9 @@ gemm_bwd_x6_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, i
     for (int u = 0; u < WG * WKB; ++u) {
       const int s = u / WKB, j = u % WKB;
 #if !defined(BWDX6_ABL) || BWDX6_ABL != 4   // (timing ablation 4: no wgrad)
-      if (u + 2 < WG * WKB) qfrag(u + 2, sq[(u + 2) % 3]);
+      if (u + 1 < WG * WKB) qfrag(u + 1, sq[(u + 1) & 1]);
 #pragma unroll
-      for (int i = 0; i < WMB; ++i) mfma_x6(accW[i][j], sp[i], sq[u % 3]);
+      for (int i = 0; i < WMB; ++i) mfma_x6(accW[i][j], sp[i], sq[u & 1]);
       if (j == WKB - 1 && s + 1 < WG) pfrag(s + 1);  // (the MFMAs above hold their operands already)
 #endif
 #if defined(BWDX6_ABL) && (BWDX6_ABL == 5 || BWDX6_ABL == 3)   // (timing ablation 5: no dQ stores)
@@ -332,6 +367,25 @@ gemm_bwd_x6_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, i
           }
         }
       }
+      if (STATS && u == 0) {
+        // every accumulator row of the dQ blocks: this lane holds column l31 and rows
+        // 32*kbd + 4*lhi + (q&3) + 8*(q>>2)
+        const float4 *rc = reinterpret_cast<const float4 *>(lds + RCOFF);
+        const char *raw = Pc + 3 * (PIMG + QIMG);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int ro = (q & 3) + 8 * (q >> 2);
+#pragma unroll
+          for (int e = 0; e < DK; ++e) {
+            const int row = 32 * (wave * DK + e) + 4 * lhi + ro;
+            const float4 c4 = rc[row];
+            const float yv = *reinterpret_cast<const float *>(raw + (size_t)row * RAWP + l31 * 4);
+            const float g = __fmaf_rn(yv, c4.x, c4.y) > 0.f ? accD[e][q] : 0.f;
+            st1[e][q] += g;
+            st2[e][q] = __fmaf_rn(g, (yv - c4.z) * c4.w, st2[e][q]);
+          }
+        }
+      }
       between(DG + u);
     }
     __syncthreads();  // chunk c read by everyone, chunk c+1 staged by everyone
@@ -341,6 +395,26 @@ gemm_bwd_x6_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, i
     if (c + 1 < c_hi) chunk(Z1{}, c + 1, 1);
   }
 
+  if (STATS && stats_part != nullptr) {
+    // the lanes' column sums -> row sums through LDS (the image buffers are free: the K loop's last
+    // barrier is behind every wave, and each wave parks and reads only its own rows)
+    const int parts = (int)gridDim.x;
+    float2 *park = reinterpret_cast<float2 *>(lds) + (size_t)wave * (32 * DK) * 33;
+#pragma unroll
+    for (int e = 0; e < DK; ++e)
+#pragma unroll
+      for (int q = 0; q < (STATS ? 16 : 1); ++q) {
+        const int lrow = 32 * e + 4 * lhi + (q & 3) + 8 * (q >> 2);
+        park[lrow * 33 + l31] = make_float2(st1[e][q], st2[e][q]);
+      }
+    for (int t = lane; t < 32 * DK; t += kWave) {  // (same wave wrote: LDS operations complete in order)
+      float a1 = 0.f, a2 = 0.f;
+      for (int c2 = 0; c2 < 32; ++c2) { const float2 v = park[t * 33 + c2]; a1 += v.x; a2 += v.y; }
+      const int row = 32 * wave * DK + t;
+      stats_part[((size_t)row * parts + blockIdx.x) * 2] = a1;
+      stats_part[((size_t)row * parts + blockIdx.x) * 2 + 1] = a2;
+    }
+  }
   float *out = part + (size_t)blockIdx.x * M * k_total;
 #pragma unroll
   for (int i = 0; i < WMB; ++i) {
@@ -360,36 +434,48 @@ gemm_bwd_x6_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, i
 
 }  // namespace
 
-// Launch the bf16-split backward for the shapes it covers (xyz == 0 forms); returns -1 when the
-// shape is not covered (the caller then runs the fp32 kernel), else the launch status.
-// g = workgroups (<= the partial-dW workspace the caller sized), one per CU at most.
-static int mlp_bwd_x6_try(int m, int k, int r, int total_chunks, int chunks_per_cloud, int pmode, int qmode,
-                   const OperandB &P, const OperandB &Q, const float *w, float *dq, float *part,
-                   int cus, int *workgroups, hipStream_t stream) {
+// workgroups of the bf16-split backward for a (128,128) layer of b clouds x r columns (one per CU,
+// at least 8 chunks each), or 0 when that kernel does not run (switched off / not this shape)
+static int mlp_bwd_x6_workgroups(int b, int m, int k, int r, int cus) {
   static const bool off = (getenv("MLP_GEMM_SPLIT_BF16") && atoi(getenv("MLP_GEMM_SPLIT_BF16")) == 0) ||
                           (getenv("MLP_BWD_SPLIT_BF16") && atoi(getenv("MLP_BWD_SPLIT_BF16")) == 0);
-  if (off || qmode != OP_BNRELU || dq == nullptr || r % 32 != 0) return -1;
-  if (!(m == 128 && k == 128)) return -1;
-  int g = cus;
-  if (g > total_chunks / 8) g = total_chunks / 8;
-  if (g < 1) g = 1;
+  if (off || !(m == 128 && k == 128) || r % 32 != 0 || b <= 0) return 0;
+  const long long total = (long long)b * (r / 32);
+  long long g = cus;
+  if (g > total / 8) g = total / 8;
+  return (int)(g < 1 ? 1 : g);
+}
+
+// Launch the bf16-split backward for the shapes it covers (xyz == 0 forms); returns -1 when the
+// shape is not covered (the caller then runs the fp32 kernel), else the launch status.
+// stats_part (k, workgroups, 2) or null: the BatchNorm-backward sums of the layer below.
+static int mlp_bwd_x6_try(int b, int m, int k, int r, int pmode, int qmode, const OperandB &P,
+                          const OperandB &Q, const float *w, float *dq, float *part,
+                          float *stats_part, int cus, int *workgroups, hipStream_t stream) {
+  const int g = mlp_bwd_x6_workgroups(b, m, k, r, cus);
+  if (g == 0 || qmode != OP_BNRELU || dq == nullptr) return -1;
+  const int total_chunks = b * (r / 32), chunks_per_cloud = r / 32;
   *workgroups = g;
   constexpr int RP = 80;
-  const size_t lds_bytes = 2 * 3 * (size_t)(m + k) * RP;
-#define BWDX6(MB, KB, KBD, PM, QM)                                                                  \
+#define BWDX6(MB, KB, KBD, PM, QM, ST)                                                              \
   do {                                                                                              \
-    auto kern = gemm_bwd_x6_kernel<MB, KB, KBD, PM, QM>;                                            \
+    const size_t lds_bytes = 2 * (3 * (size_t)(m + k) * RP + (ST ? (size_t)k * 144 : 0)) +         \
+                             (ST ? (size_t)k * 16 : 0);                                             \
+    auto kern = gemm_bwd_x6_kernel<MB, KB, KBD, PM, QM, ST>;                                        \
     static bool attr_set = false;                                                                   \
     if (!attr_set) {                                                                                \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                     \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);              \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);        \
       attr_set = true;                                                                              \
     }                                                                                               \
     hipLaunchKernelGGL(kern, dim3(g), dim3(256), lds_bytes, stream, k, r, total_chunks,             \
-                       chunks_per_cloud, 0, P, Q, w, dq, part);                                     \
+                       chunks_per_cloud, 0, P, Q, w, dq, part, stats_part);                         \
   } while (0)
-  if (pmode == OP_DY) BWDX6(4, 4, 4, OP_DY, OP_BNRELU);
-  else if (pmode == OP_POOLDY) BWDX6(4, 4, 4, OP_POOLDY, OP_BNRELU);
+  const bool st = stats_part != nullptr;
+  if (pmode == OP_DY && st) BWDX6(4, 4, 4, OP_DY, OP_BNRELU, true);
+  else if (pmode == OP_DY) BWDX6(4, 4, 4, OP_DY, OP_BNRELU, false);
+  else if (pmode == OP_POOLDY && st) BWDX6(4, 4, 4, OP_POOLDY, OP_BNRELU, true);
+  else if (pmode == OP_POOLDY) BWDX6(4, 4, 4, OP_POOLDY, OP_BNRELU, false);
   else return -1;
 #undef BWDX6
   return pn2_launch_status();

@@ -453,7 +453,7 @@ def main():
                 source = "profiles/r4_pair_pmc.json (separate rocprofv3 --pmc passes)"
             # VALU utilisation of the VALU-bound operators, from the committed
             # counter pass of tools/op_bench.py (tools/valu_util.py), not from this run
-            vu = os.path.join(ROOT, "profiles", "r3_ops_valu_util.json")
+            vu = os.path.join(ROOT, "profiles", "r4_ops_valu_util.json")
             if os.path.exists(vu):
                 busy = {k: v["valu_busy"] for k, v in json.load(open(vu))["kernels"].items()}
                 for op_name, kern in (("iou3d_2048x512", "pair_matrix_kernel<2>"),
@@ -461,7 +461,28 @@ def main():
                                       ("ball_query_sa2", "ball_query_bf_kernel<2>")):
                     if op_name in table and kern in busy:
                         table[op_name]["valu_busy"] = busy[kern]
-                        table[op_name]["valu_busy_source"] = "profiles/r3_ops_valu_util.json (%s)" % kern
+                        table[op_name]["valu_busy_source"] = "profiles/r4_ops_valu_util.json (%s)" % kern
+            # in-step duration of the kernels behind the table's entries, next to their standalone
+            # `us` (committed rocprofv3 summary of the timed steps, tools/step_breakdown.py): a
+            # kernel that behaves differently on the step's own data or beside the side stream
+            # shows up here (round 3: the query kernel, 18 us standalone / 86 us in the step)
+            ss = os.path.join(ROOT, "profiles", "r4_train_step_timed_summary.csv")
+            if os.path.exists(ss):
+                import csv
+                rows = {r["kernel"]: r for r in csv.DictReader(open(ss))}
+                for op_name, kern in (
+                        ("fps_40000_2048_with_cell_lists", "fps_bucket_rounds_kernel<8, 2, 2>"),
+                        ("query_and_group_sa1_fused_kernel", "grid_query_kernel<192, 1, true>"),
+                        ("group_grad_sa2_c128", "group_points_grad_sorted_kernel<32>"),
+                        ("group_inverse_sa2", "group_inverse_kernel"),
+                        ("three_interpolate_gridconv", "three_interpolate_lds_kernel<8>"),
+                        ("mlp_fwd_sa1_128x64", "gemm_nn2_kernel<128, 128, 2, 2, 1, false, true, true, 64, true>")):
+                    r_ = rows.get(kern)
+                    if op_name in table and r_ is not None and float(r_["launches_per_step"]) > 0:
+                        n_l = max(1.0, round(float(r_["launches_per_step"])))
+                        table[op_name]["in_step_us_per_launch"] = round(float(r_["us_per_step"]) / n_l, 2)
+                        table[op_name]["in_step_kernel"] = "%s (%s launches per step; profiles/%s)" % (
+                            kern, r_["launches_per_step"], os.path.basename(ss))
             out["roofline"] = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -255,7 +255,8 @@ def test_fused_backward_vs_two_gemms(b, m, k, groups, ns, pooled):
         none, dw_only, _ = K.gemm_backward_fused(w, x, xcoeff, xstats=xstats, need_dx=False, **kw)
         assert none is None
         close(dw_only, want_dw, 2e-5)
-    assert (below is not None) == (k == 64)  # the first set-abstraction level's layers
+    # the first set-abstraction level's layers, and the (128,128) layers on the bf16-split kernel
+    assert (below is not None) == (k == 64 or (m, k) == (128, 128))
     if below is not None:  # the layer below's BatchNorm-backward sums == its stats pass over (x, dx)
         dgamma, dbeta, coef = K.bn_relu_backward_stats(x, want_dx.contiguous(), xgamma, xscale, xshift,
                                                        xmean, xinv, True)
