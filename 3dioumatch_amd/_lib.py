@@ -134,6 +134,11 @@ def _load():
         raise ImportError(
             "3dioumatch_amd: %s is missing -- build it with `python 3dioumatch_amd/build.py` "
             "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime; load it FIRST so that this library binds to the
+    # runtime that owns the process's device context (dlopen-ing the library before `import torch`
+    # pulled in /opt/rocm's copy: two runtimes in one process, "no ROCm-capable device" at the
+    # first launch -- seen with __graft_entry__.build() followed by smoke() in one interpreter)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here == ABI mismatch, fail loudly
