@@ -668,7 +668,12 @@ MLP_API int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, 
   else if (m == 256 && k == 128) FUSED(8, 4, 4, 1, OP_POOLDY, OP_BNRELU, 1, false);
   else if (m == 128 && k == 131) FUSED(4, 5, 4, 1, OP_DY, OP_DIRECT, 1, false);
   else if (dq != nullptr) FUSED_F32(4, 9, 8, 1, OP_DY, OP_DIRECT, 1, false);
-  else  // the layer's input needs no gradient: the persistent weight-gradient half alone
+  else if (x6 && !(getenv("MLP_WGRAD_ONLY_SPLIT") && atoi(getenv("MLP_WGRAD_ONLY_SPLIT")) == 0))
+    // the layer's input needs no gradient: the persistent weight-gradient half alone (its bf16 form
+    // fits the registers: no W^T fragments, no dQ blocks)
+    hipLaunchKernelGGL((gemm_bwd_fused_kernel<4, 9, 8, 1, OP_DY, OP_DIRECT, 1, false, false, true>), dim3(g),
+                       dim3(256), 0, stream, k, r, total, cpc, s.xyz, P, Q, w, dq, workspace, stats_part);
+  else
     hipLaunchKernelGGL((gemm_bwd_fused_kernel<4, 9, 8, 1, OP_DY, OP_DIRECT, 1, false, false>), dim3(g),
                        dim3(256), 0, stream, k, r, total, cpc, s.xyz, P, Q, w, dq, workspace, stats_part);
 #undef FUSED_F32

@@ -1,13 +1,16 @@
-"""Which Python lines launch the tensor (aten) kernels of one supervised train step?  Runs the
-step eagerly under torch.profiler with stacks and prints, per (kernel family, innermost repo
-frame), the number of launches and their device time.    python tools/aten_sources.py"""
+"""Which Python lines issue the tensor (aten) operators of one supervised train step?  A
+TorchDispatchMode records every aten call on CUDA tensors with the innermost frame inside this
+repository (forward, loss and the Python bodies of the custom autograd functions; the mode is
+re-entered in the autograd worker thread through a hook on the engine's first function).
+    python tools/aten_sources.py"""
 import collections
 import importlib
 import os
 import sys
+import traceback
 
 import torch
-from torch.profiler import ProfilerActivity, profile
+from torch.utils._python_dispatch import TorchDispatchMode
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,34 +19,40 @@ V = importlib.import_module("3dioumatch_amd.votenet")
 data = importlib.import_module("3dioumatch_amd.votenet.data")
 dev = torch.device("cuda:0")
 cfg = V.scannet_config()
-# the graph-mode runner: its first call runs the step's Python eagerly twice on a warm-up stream
-# (then captures it); those two eager passes are what is profiled -- the same code paths the
-# captured graphs hold (fused loss, host-side mask facts baked in), with stacks
-runner = V.SupervisedStep(cfg, dev, world_size=1, num_proposal=256, graphs=True)
+runner = V.SupervisedStep(cfg, dev, world_size=1, num_proposal=256, graphs=False)
 batch = data.make_batch(8, 40000, cfg, seed=100, device=dev)
+SKIP = ("aten::view", "aten::_unsafe_view", "aten::reshape", "aten::transpose", "aten::permute", "aten::slice",
+        "aten::select", "aten::expand", "aten::unsqueeze", "aten::squeeze", "aten::detach", "aten::alias",
+        "aten::as_strided", "aten::t", "aten::empty", "aten::empty_like", "aten::empty_strided", "aten::size",
+        "aten::stride", "aten::is_contiguous", "aten::unbind", "aten::split", "aten::_local_scalar_dense",
+        "aten::lift_fresh", "aten::narrow", "aten::view_as", "aten::numel", "aten::contiguous", "aten::to",
+        "aten::_to_copy", "aten::item", "aten::sym_size", "aten::unflatten", "aten::flatten", "aten::chunk")
+agg = collections.Counter()
+
+
+class Tracer(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = func._schema.name
+        cuda = any(isinstance(a, torch.Tensor) and a.is_cuda for a in list(args) + list((kwargs or {}).values()))
+        if cuda and name not in SKIP:
+            frame = "?"
+            for fs in reversed(traceback.extract_stack()[:-1]):
+                fn = fs.filename
+                if ("3dioumatch_amd" in fn) and "tools/" not in fn:
+                    frame = "%s:%d %s" % (fn.split("3dioumatch_amd/")[-1], fs.lineno, fs.name)
+                    break
+            agg[(name, frame)] += 1
+        return func(*args, **(kwargs or {}))
+
+
+inputs = dict(batch)
+inputs.update(runner._host_info(batch))
+for _ in range(2):
+    runner._forward_backward(dict(inputs))
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    runner(dict(batch))
-    torch.cuda.synchronize()
-PASSES = 2.0
-agg = collections.defaultdict(lambda: [0, 0.0])
-for ev in prof.events():
-    if ev.device_type != torch.autograd.DeviceType.CPU:
-        continue
-    kt = sum(k.duration for k in ev.kernels) if ev.kernels else 0.0
-    if not ev.kernels or not ev.name.startswith("aten::"):
-        continue
-    frame = "?"
-    for fr in (ev.stack or []):
-        if ("3dioumatch_amd/" in fr or "bench.py" in fr) and "site-packages" not in fr and "dist-packages" not in fr:
-            frame = fr.split("3dioumatch_amd/")[-1]
-            break
-    names = ",".join(sorted({k.name.split("<")[0].split("(")[0][-40:] for k in ev.kernels}))
-    key = (ev.name, frame)
-    agg[key][0] += len(ev.kernels)
-    agg[key][1] += kt
-rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-tot_n = sum(v[0] for _, v in rows); tot_t = sum(v[1] for _, v in rows)
-print("aten kernels per step (two eager warm-up passes / 2): %.0f launches, %.0f us" % (tot_n / PASSES, tot_t / PASSES))
-for (name, frame), (n, t) in rows[:80]:
-    print("%5.1f  %7.1f us  %-24s %s" % (n / PASSES, t / PASSES, name, frame[:110]))
+with Tracer():
+    runner._forward_backward(dict(inputs))
+torch.cuda.synchronize()
+print("aten calls on GPU tensors in one forward + loss + backward (views / allocations skipped): %d" % sum(agg.values()))
+for (name, frame), n in agg.most_common(90):
+    print("%4d  %-26s %s" % (n, name, frame))
