@@ -199,7 +199,10 @@ __device__ __forceinline__ float half_wave_extreme(float v) {
 //        (b, m_total, r / POOL).
 template <int TM, int TN, int WM, int WN, int MODE, bool A_TRANS, bool A_VEC, bool STATS = false,
           int POOL = 0, bool X6 = false>
-__global__ void __launch_bounds__(256, X6 ? 2 : (((MODE <= OP_BNRELU || MODE == OP_LIN4) && TM <= 128) ? 4 : 2))
+#ifndef MLP_X6_OCC
+#define MLP_X6_OCC 3
+#endif
+__global__ void __launch_bounds__(256, X6 ? (TM <= 128 ? MLP_X6_OCC : 2) : (((MODE <= OP_BNRELU || MODE == OP_LIN4) && TM <= 128) ? 4 : 2))
 gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int lda,
                 unsigned a_bytes, OperandB opb, float *__restrict__ c, size_t b_stride_in,
                 size_t b_stride_out, float *__restrict__ stats = nullptr, int stat_channels = 0,
@@ -392,29 +395,21 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
     if constexpr (X6) {
       // the lane's eight k of the chunk (af0 | af1), as three bf16 terms each; six products per
       // block, the small ones first
-      Split3 sa[MB], sb[NB];
+      Split3 sa[MB];
 #pragma unroll
       for (int ii = 0; ii < MB; ++ii) sa[ii] = split3(af0[ii], af1[ii]);
+      // one column block at a time (its split lives for MB x 6 MFMAs); the next chunk is staged and
+      // the one after it requested after the first block's MFMAs are issued
 #pragma unroll
-      for (int j = 0; j < NB; ++j) sb[j] = split3(bf0[j], bf1[j]);
+      for (int j = 0; j < NB; ++j) {
+        const Split3 sb = split3(bf0[j], bf1[j]);
 #pragma unroll
-      for (int ii = 0; ii < MB; ++ii)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ii].lo, sb[j].hi, acc[ii][j], 0, 0, 0);
-          acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ii].hi, sb[j].lo, acc[ii][j], 0, 0, 0);
-          acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ii].mid, sb[j].mid, acc[ii][j], 0, 0, 0);
+        for (int ii = 0; ii < MB; ++ii) mfma_x6(acc[ii][j], sa[ii], sb);
+        if (j == 0) {
+          if (i + 1 < chunks) stash(cur ^ 1);
+          if (i + 2 < chunks) fetch((i + 2) * KC);
         }
-      if (i + 1 < chunks) stash(cur ^ 1);
-      if (i + 2 < chunks) fetch((i + 2) * KC);
-#pragma unroll
-      for (int ii = 0; ii < MB; ++ii)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ii].mid, sb[j].hi, acc[ii][j], 0, 0, 0);
-          acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ii].hi, sb[j].mid, acc[ii][j], 0, 0, 0);
-          acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ii].hi, sb[j].hi, acc[ii][j], 0, 0, 0);
-        }
+      }
     } else {
       multiply(af0, bf0);
       if (i + 1 < chunks) stash(cur ^ 1);            // chunk i+1: registers -> the other buffer
