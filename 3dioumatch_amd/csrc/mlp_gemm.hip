@@ -205,7 +205,7 @@ template <int TM, int TN, int WM, int WN, int MODE, bool A_TRANS, bool A_VEC, bo
 #ifndef MLP_X6_OCC_256
 #define MLP_X6_OCC_256 3
 #endif
-__global__ void __launch_bounds__(256, X6 ? (TM <= 128 ? MLP_X6_OCC : MLP_X6_OCC_256) : (((MODE <= OP_BNRELU || MODE == OP_LIN4) && TM <= 128) ? 4 : 2))
+__global__ void __launch_bounds__(256, X6 ? (((MODE <= OP_BNRELU || MODE == OP_LIN4) && !A_TRANS) ? (TM <= 128 ? MLP_X6_OCC : MLP_X6_OCC_256) : 2) : (((MODE <= OP_BNRELU || MODE == OP_LIN4) && TM <= 128) ? 4 : 2))
 gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int lda,
                 unsigned a_bytes, OperandB opb, float *__restrict__ c, size_t b_stride_in,
                 size_t b_stride_out, float *__restrict__ stats = nullptr, int stat_channels = 0,
