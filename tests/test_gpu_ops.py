@@ -136,7 +136,10 @@ def test_ballquery_vs_oracle(ext, oracle, synth, b, n, m, r, ns):
                                       # LDS-staged tier: 64 KB and 160 KB rows, ragged n / m*ns,
                                       # the largest row that fits and the first that does not
                                       (3, 40000, 128, 64), (2, 40960, 100, 41), (1, 30001, 99, 43),
-                                      (5, 16385, 64, 64), (2, 40961, 128, 32), (200, 1024, 128, 32)])
+                                      (5, 16385, 64, 64), (2, 40961, 128, 32), (200, 1024, 128, 32),
+                                      # many rows of a large cloud: one whole row per workgroup (b*c >= 128);
+                                      # the few-row cases above run the range-partitioned kernel
+                                      (70, 20000, 64, 32)])
 def test_group_vs_oracle(ext, oracle, c, n, m, ns):
     g = np.random.default_rng(c + n)
     pts = g.standard_normal((2, c, n)).astype(np.float32)
