@@ -51,7 +51,7 @@ __device__ __forceinline__ void block_sum2(float &a, float &b, float *scratch) {
 // The counters return to zero (the last workgroup resets its own), so launches on one stream
 // need no memset; the families use separate counters.
 constexpr int kMaxTicketChannels = 4096;
-__device__ int bn_tickets[4][kMaxTicketChannels];
+__device__ int bn_tickets[kMaxTicketChannels];  // default counters (see tickets_for)
 
 // Partials travel between workgroups (possibly on different XCDs, whose L2s are not coherent with
 // one another) as agent-scope RELAXED atomics: write-through stores (sc1) and cache-bypassing
@@ -106,6 +106,7 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 }
 
 struct FwdFinalize {
+  int *tickets;  // one counter per channel, zero between launches (tickets_for(stream))
   const float *gamma, *beta;
   float eps, momentum;
   float *running_mean, *running_var, *mean_out, *invstd_out, *scale_out, *shift_out;
@@ -197,7 +198,7 @@ bn_partial_stats_kernel(int c, int r, int slices, const float *__restrict__ y,
     coherent_store(out + 1, n > 0 ? shift + a1 / fn : 0.f);
     coherent_store(out + 2, n > 0 ? a2 - a1 * a1 / fn : 0.f);
   }
-  if (last_arrival(&bn_tickets[0][ch], (int)gridDim.z * slices) && threadIdx.x < kWave)
+  if (last_arrival(&fin.tickets[ch], (int)gridDim.z * slices) && threadIdx.x < kWave)
     fwd_finalize_channel(ch, (int)gridDim.z * slices, partial, fin);
 }
 
@@ -404,6 +405,7 @@ pool_from_extrema_kernel(int c, int groups, long long total, const float *__rest
 // dgamma = s2, dbeta = s1, and the per-channel coefficients of dy (training mode); one wave
 // per channel
 struct BwdFinalize {
+  int *tickets;  // one counter per channel, zero between launches (tickets_for(stream))
   double count;
   int training;
   const float *gamma, *invstd;
@@ -487,7 +489,7 @@ bn_relu_bwd_partial_kernel(int c, int r, int slices, const float *__restrict__ y
     coherent_store(out, s1);
     coherent_store(out + 1, s2);
   }
-  if (last_arrival(&bn_tickets[2][ch], (int)gridDim.z * slices) && threadIdx.x < kWave)
+  if (last_arrival(&fin.tickets[ch], (int)gridDim.z * slices) && threadIdx.x < kWave)
     bwd_finalize_channel(ch, (int)gridDim.z * slices, partial, fin);
 }
 
@@ -515,7 +517,7 @@ pool_bwd_partial_kernel(int c, int m, const float *__restrict__ dpooled,
     coherent_store(out, s1);
     coherent_store(out + 1, s2);
   }
-  if (last_arrival(&bn_tickets[3][ch], (int)gridDim.z) && threadIdx.x < kWave)
+  if (last_arrival(&fin.tickets[ch], (int)gridDim.z) && threadIdx.x < kWave)
     bwd_finalize_channel(ch, (int)gridDim.z, partial, fin);
 }
 
@@ -589,6 +591,36 @@ int slices_for(int r) {
 
 }  // namespace
 
+#include <mutex>
+#include <unordered_map>
+
+// Ticket counters of a launch.  Launches on ONE stream run one after the other and may share an
+// array (every launch leaves it zeroed); launches on different streams may overlap, so every stream
+// gets its own array on first use (a stream first seen while it is being captured into a graph
+// cannot allocate: it shares the default array, which is safe as long as that graph is not
+// replayed beside another user of the default array -- the train step runs these kernels on its
+// main stream only).
+static int *tickets_for(hipStream_t stream) {
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, int *> table;
+  static int *fallback = nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (fallback == nullptr && hipGetSymbolAddress(reinterpret_cast<void **>(&fallback), HIP_SYMBOL(bn_tickets)) != hipSuccess)
+    return nullptr;
+  if (stream == nullptr) return fallback;
+  auto it = table.find(stream);
+  if (it != table.end()) return it->second;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone || table.size() >= 64)
+    return fallback;
+  int *buf = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&buf), sizeof(int) * kMaxTicketChannels) != hipSuccess ||
+      hipMemset(buf, 0, sizeof(int) * kMaxTicketChannels) != hipSuccess)
+    return fallback;
+  table.emplace(stream, buf);
+  return buf;
+}
+
 #define MLP_API extern "C" __attribute__((visibility("default")))
 
 // number of floats of scratch the statistics kernels need
@@ -605,7 +637,8 @@ MLP_API int mlp_bn_train_stats(int b, int c, int r, const float *y, const float 
   hipStream_t stream = (hipStream_t)stream_;
   const int slices = slices_for(r);
   if (c > kMaxTicketChannels) return (int)hipErrorInvalidValue;
-  const FwdFinalize fin = {gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
+  const FwdFinalize fin = {tickets_for(stream), gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
+  if (fin.tickets == nullptr) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(bn_partial_stats_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream, c,
                      r, slices, y, workspace, fin);
   return pn2_launch_status();
@@ -627,7 +660,7 @@ MLP_API int mlp_bn_finalize_pairs(int c, int parts, int n_part, const float *pai
   if (!scratch || c > kMaxTicketChannels * kWave) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
   double *sums = reinterpret_cast<double *>(scratch);
-  const FwdFinalize fin = {gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
+  const FwdFinalize fin = {nullptr, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
   hipLaunchKernelGGL(bn_pairs_stage1_kernel, dim3(pn2_ceil_div(c, kWave), kPairSlices), dim3(1024),
                      0, stream, c, parts, pairs, sums);
   hipLaunchKernelGGL(bn_pairs_stage2_kernel, dim3(pn2_ceil_div(c, 256)), dim3(256), 0, stream, c,
@@ -692,7 +725,7 @@ MLP_API int mlp_bn_relu_backward(int b, int c, int r, int training, const float 
   const int slices = slices_for(r);
   hipLaunchKernelGGL(bn_relu_bwd_partial_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream,
                      c, r, slices, y, dz, scale, shift, mean, invstd, workspace,
-                     BwdFinalize{(double)b * (double)r, training, gamma, invstd, dgamma, dbeta, coef});
+                     BwdFinalize{tickets_for(stream), (double)b * (double)r, training, gamma, invstd, dgamma, dbeta, coef});
   if (r % 4 == 0)
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<true>, dim3(pn2_ceil_div(r, 1024), c, b), dim3(256),
                        0, stream, c, r, y, dz, scale, shift, mean, invstd, coef, dy);
@@ -714,7 +747,7 @@ MLP_API int mlp_bn_relu_backward_stats(int b, int c, int r, int training, const 
   const int slices = slices_for(r);
   hipLaunchKernelGGL(bn_relu_bwd_partial_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream,
                      c, r, slices, y, dz, scale, shift, mean, invstd, workspace,
-                     BwdFinalize{(double)b * (double)r, training, gamma, invstd, dgamma, dbeta, coef});
+                     BwdFinalize{tickets_for(stream), (double)b * (double)r, training, gamma, invstd, dgamma, dbeta, coef});
   return pn2_launch_status();
 }
 
@@ -727,7 +760,7 @@ MLP_API int mlp_bn_backward_finalize(int c, int parts, double count, int trainin
   if (c <= 0 || parts <= 0) return 0;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pn2_ceil_div(c, 256 / kWave)), dim3(256), 0,
                      (hipStream_t)stream_, c, parts, partial,
-                     BwdFinalize{count, training, gamma, invstd, dgamma, dbeta, coef});
+                     BwdFinalize{nullptr, count, training, gamma, invstd, dgamma, dbeta, coef});
   return pn2_launch_status();
 }
 
@@ -754,8 +787,8 @@ MLP_API int mlp_bn_relu_pool_backward(int b, int c, int m, int ns, int training,
   hipStream_t stream = (hipStream_t)stream_;
   hipLaunchKernelGGL(pool_bwd_partial_kernel, dim3(1, c, b), dim3(kBnThreads), 0, stream, c, m,
                      dpooled, ymax, scale, shift, mean, invstd, workspace,
-                     BwdFinalize{(double)b * (double)m * (double)ns, training, gamma, invstd, dgamma,
-                                 dbeta, coef});
+                     BwdFinalize{tickets_for(stream), (double)b * (double)m * (double)ns, training, gamma, invstd,
+                                 dgamma, dbeta, coef});
   if (dy == nullptr) return pn2_launch_status();  // statistics only (mlp_gemm_*_pooled form dy)
   const long long r = (long long)m * ns;
   if (r % 4 == 0)

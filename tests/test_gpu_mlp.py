@@ -525,3 +525,41 @@ def test_virtual_first_layer_chain_vs_sequential(pool, monkeypatch):
         assert rel < 3e-2, (n1, rel)   # vs torch (mask flips at rounding level, as in the chain test)
     for (n1, b1), (n2, b2) in zip(mlp.named_buffers(), ref.named_buffers()):
         close(b1.float(), b2.float(), 2e-4)
+
+
+def test_reductions_on_two_streams_at_once():
+    """The BatchNorm reductions finalize in their last workgroup through per-channel ticket
+    counters; launches on different streams may overlap and must not share counters (one array
+    per stream).  Two streams run statistics + backward sums of different tensors back to back,
+    forty times each; every result equals the one computed alone."""
+    load_pkg()
+    K = importlib.import_module("pointnet2._mlp_ext")
+    g = torch.Generator().manual_seed(5)
+    cases = []
+    for c, r in ((64, 40000), (128, 9000)):
+        y = (torch.randn(4, c, r, generator=g) * 1.5 + 0.3).to(DEV)
+        dz = torch.randn(4, c, r, generator=g).to(DEV)
+        gamma = (torch.rand(c, generator=g) + 0.5).to(DEV)
+        beta = (torch.randn(c, generator=g) * 0.3).to(DEV)
+        cases.append((y, dz, gamma, beta))
+
+    def work(case):
+        y, dz, gamma, beta = case
+        rm, rv = torch.zeros_like(gamma), torch.ones_like(gamma)
+        mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, 0.1, 1e-5, True)
+        dgamma, dbeta, coef = K.bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, True)
+        return [mean, invstd, dgamma, dbeta, coef]
+
+    alone = [[t.clone() for t in work(cs)] for cs in cases]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = [[], []]
+    for _ in range(40):
+        for si, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                got[si].append(work(cases[si]))
+    torch.cuda.synchronize()
+    for si in range(2):
+        for res in got[si]:
+            for a, b in zip(res, alone[si]):
+                assert torch.equal(a, b)
