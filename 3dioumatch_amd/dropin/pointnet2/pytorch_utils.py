@@ -282,20 +282,56 @@ class _FusedMLPChain(Function):
 
 
 _deferred_counters = None
+_deferred_axpy = None   # (tensor, other, alpha): tensor += alpha * other, applied at context exit
+# inside deferred_bn_counters() a gradient that is identically zero (the bias of a convolution that
+# feeds a training-mode BatchNorm) may be returned as None instead of a freshly zeroed tensor:
+# the train step's gradient packing substitutes zeros (votenet/step.py:_pack_gradients)
+zero_grads_as_none = False
 
 
 @contextlib.contextmanager
 def deferred_bn_counters():
-    """Inside this context the fused layers collect their `num_batches_tracked += 1` updates and
-    apply them with ONE multi-tensor add at exit (37 one-element kernels per forward otherwise)."""
-    global _deferred_counters
+    """Inside this context the fused layers collect their `num_batches_tracked += 1` updates (and
+    the running-mean corrections `rm += momentum * bias` of the head chains) and apply them with
+    ONE multi-tensor add each at exit (37 + 6 one-element / one-row kernels per forward otherwise)."""
+    global _deferred_counters, _deferred_axpy
     previous, _deferred_counters = _deferred_counters, []
+    previous_axpy, _deferred_axpy = _deferred_axpy, []
     try:
         yield
     finally:
         pending, _deferred_counters = _deferred_counters, previous
+        axpy, _deferred_axpy = _deferred_axpy, previous_axpy
         if pending:
             torch._foreach_add_(pending, 1)
+        by_alpha = {}
+        for t, other, alpha in axpy:
+            by_alpha.setdefault(float(alpha), ([], []))
+            by_alpha[float(alpha)][0].append(t)
+            by_alpha[float(alpha)][1].append(other)
+        for alpha, (ts, others) in by_alpha.items():
+            torch._foreach_add_(ts, others, alpha=alpha)
+
+
+@contextlib.contextmanager
+def zero_grads_none():
+    """Run a backward pass with `zero_grads_as_none` set (the caller packs the gradients itself
+    and treats a missing one as zeros)."""
+    global zero_grads_as_none
+    previous, zero_grads_as_none = zero_grads_as_none, True
+    try:
+        yield
+    finally:
+        zero_grads_as_none = previous
+
+
+def deferred_axpy(tensor, other, alpha):
+    """tensor += alpha * other, now or -- inside deferred_bn_counters() -- batched at its exit
+    (nothing reads `tensor`, a BatchNorm running mean, before then)."""
+    if _deferred_axpy is not None:
+        _deferred_axpy.append((tensor, other.detach(), alpha))
+    else:
+        tensor.add_(other.detach(), alpha=alpha)
 
 
 def bump_batches_tracked(counter):

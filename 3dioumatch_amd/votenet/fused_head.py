@@ -41,7 +41,8 @@ class _HeadChain(Function):
                                                            training)
             if bias is not None:
                 if training:
-                    rm.add_(bias.detach(), alpha=momentum)  # running mean of (W x + b)
+                    from pointnet2.pytorch_utils import deferred_axpy
+                    deferred_axpy(rm, bias, momentum)  # running mean of (W x + b)
                 else:
                     shift = shift + scale * bias.detach()    # scale*(y + b - rm) + beta
                     mean = mean - bias.detach()              # x-hat of the biased pre-activation
@@ -85,7 +86,10 @@ class _HeadChain(Function):
             if not present:
                 return None
             # training: sum(dy) vanishes identically; eval: dy = gamma*invstd*dz_masked
-            return torch.zeros_like(dbeta) if training else coef.reshape(-1)[0::3] * dbeta  # coef is [C][3]
+            if training:
+                from pointnet2 import pytorch_utils
+                return None if pytorch_utils.zero_grads_as_none else torch.zeros_like(dbeta)
+            return coef.reshape(-1)[0::3] * dbeta  # coef is [C][3]
 
         db2 = dbias(ctx.has_bias[1], coef2, dbe2)
         db1 = dbias(ctx.has_bias[0], coef1, dbe1)

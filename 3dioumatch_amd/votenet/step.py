@@ -24,7 +24,7 @@ import sys
 import numpy as np
 import torch
 
-from pointnet2.pytorch_utils import deferred_bn_counters
+from pointnet2.pytorch_utils import deferred_bn_counters, zero_grads_none
 
 from .detector import VoteNet
 from .losses import get_labeled_loss
@@ -242,21 +242,27 @@ class SupervisedStep(object):
         end_points.update({k: v for k, v in batch.items()
                            if torch.is_tensor(v) or k in ("all_supervised", "labeled_num")})
         loss, end_points = get_labeled_loss(end_points, self.cfg, {"dataset_config": self.cfg})
-        loss.backward()
+        with zero_grads_none():
+            loss.backward()
         self._pack_gradients()
         return loss, end_points
 
     def _pack_gradients(self):
         """p.grad (fresh tensors from autograd) -> flat_grad, one concatenation kernel."""
-        if all(p.grad is not None for p in self._params):
-            torch.cat([p.grad.reshape(-1) for p in self._params], out=self.flat_grad)
-            return
-        self.flat_grad.zero_()
-        off = 0
-        for p in self._params:
-            if p.grad is not None:
-                self.flat_grad[off:off + p.numel()].copy_(p.grad.reshape(-1))
-            off += p.numel()
+        missing = [p for p in self._params if p.grad is None]
+        if missing:
+            # identically-zero gradients arrive as None (zero_grads_none): one cached zero buffer
+            # stands in for all of them inside the same concatenation
+            need = max(p.numel() for p in missing)
+            zeros = getattr(self, "_grad_zeros", None)
+            if zeros is None or zeros.numel() < need:
+                zeros = self._grad_zeros = torch.zeros(need, dtype=self.flat_grad.dtype,
+                                                       device=self.flat_grad.device)
+            pieces = [p.grad.reshape(-1) if p.grad is not None else zeros[:p.numel()]
+                      for p in self._params]
+        else:
+            pieces = [p.grad.reshape(-1) for p in self._params]
+        torch.cat(pieces, out=self.flat_grad)
 
     # run the gradient collective even when world_size == 1 (a one-rank process group): lets a
     # single-GPU box exercise RCCL's init, the all-reduce and its ordering between the graphs
@@ -704,7 +710,8 @@ class SemiSupervisedStep(SupervisedStep):
                                                         self.config_dict)
         loss = detection_loss + unlabeled_loss * self.unlabeled_loss_weight
         end_points["loss"] = loss
-        loss.backward()
+        with zero_grads_none():
+            loss.backward()
         self._pack_gradients()
         return loss, end_points
 
