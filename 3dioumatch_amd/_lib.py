@@ -101,6 +101,8 @@ _SIGNATURES = {
     "mlp_gemm_backward_fused_stats_parts": [_c_int, _c_int, _c_int, _c_int],
     "mlp_bn_backward_finalize": [_c_int, _c_int, ctypes.c_double, _c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _vp],
+    "mlp_defer_weight_reductions": [_c_int],
+    "mlp_flush_weight_reductions": [],
     "lhs_nms3d_aabb": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _c_int, _c_int, _vp,
                        _vp],
     "lhs_nms_samecls": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _c_int, _vp, _vp],

@@ -646,7 +646,7 @@ MLP_API int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, 
     const int rcx = mlp_bwd_x6_try(b, m, k, r, pmode, qmode, P, Q, w, dq, workspace,
                                    qmode == OP_BNRELU ? stats_part : nullptr, fused_cus(), &gx, stream);
     if (rcx > 0) return rcx;
-    if (rcx == 0) return mlp_reduce_partials(m * k, gx, workspace, dw, stream);
+    if (rcx == 0) return mlp_reduce_weight_partials(m * k, gx, workspace, dw, stream);
   }
   if (k != 64) stats_part = nullptr;
   static const bool x6 = !(getenv("MLP_GEMM_SPLIT_BF16") && atoi(getenv("MLP_GEMM_SPLIT_BF16")) == 0) &&
@@ -681,5 +681,5 @@ MLP_API int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, 
 #undef FUSED_X
   int rc = pn2_launch_status();
   if (rc) return rc;
-  return mlp_reduce_partials(m * k, g, workspace, dw, stream);
+  return mlp_reduce_weight_partials(m * k, g, workspace, dw, stream);
 }

@@ -25,6 +25,7 @@
 // fragment reads); each wave accumulates (TM/WM) x (TN/WN) in 32x32 MFMA blocks.
 #include "common.h"
 #include "mlp_operand.h"
+#include <mutex>
 #include <stdlib.h>
 
 namespace {
@@ -861,12 +862,12 @@ gemm_wgrad_kernel(int m_total, int k_begin, int k_end, int k_total, int r, int r
 // dw[i] = sum_p part[p][i]: a workgroup owns 32 consecutive elements, its 8 lane groups each sum
 // every 8th partial (128-byte rows, four loads in flight per lane), LDS adds the groups in a
 // fixed order -- deterministic, and a few hundred partials finish in a few microseconds
-__global__ void __launch_bounds__(256)
-reduce_partials_kernel(int count, int parts, const float *__restrict__ part,
-                       float *__restrict__ out) {
+__device__ __forceinline__ void reduce_partials_block(int block, int count, int parts,
+                                                      const float *__restrict__ part,
+                                                      float *__restrict__ out) {
   __shared__ float sums[8][32];
   const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + e;
+  const int i = block * 32 + e;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < count) {
     int p = grp;
@@ -886,6 +887,32 @@ reduce_partials_kernel(int count, int parts, const float *__restrict__ part,
     for (int q = 1; q < 8; ++q) t += sums[q][e];
     out[i] = t;
   }
+}
+
+__global__ void __launch_bounds__(256)
+reduce_partials_kernel(int count, int parts, const float *__restrict__ part,
+                       float *__restrict__ out) {
+  reduce_partials_block((int)blockIdx.x, count, parts, part, out);
+}
+
+// Many reductions in one launch (the queued weight gradients of a backward pass): the table
+// travels as the kernel argument, a workgroup finds its entry by a scalar scan of the block
+// prefix.  Same arithmetic and order per element as the single form.
+constexpr int kReduceBatch = 40;
+struct ReduceBatch {
+  int n;
+  int first_block[kReduceBatch + 1];
+  int count[kReduceBatch];
+  int parts[kReduceBatch];
+  const float *part[kReduceBatch];
+  float *out[kReduceBatch];
+};
+
+__global__ void __launch_bounds__(256) reduce_partials_batch_kernel(const ReduceBatch t) {
+  const int blk = (int)blockIdx.x;
+  int e = 0;
+  while (e + 1 < t.n && blk >= t.first_block[e + 1]) ++e;
+  reduce_partials_block(blk - t.first_block[e], t.count[e], t.parts[e], t.part[e], t.out[e]);
 }
 
 // fp32 products as six bf16 MFMAs (see split3): on unless MLP_GEMM_SPLIT_BF16=0 (read once)
@@ -1000,6 +1027,59 @@ int mlp_reduce_partials(int count, int parts, const float *part, float *out, hip
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(pn2_ceil_div((long long)count, 32)), dim3(256), 0,
                      stream, count, parts, part, out);
   return pn2_launch_status();
+}
+
+// ---- queued weight-gradient reductions (mlp_operand.h) ------------------------------------------
+// One process-wide queue: the backward pass runs on autograd's worker thread, the flush on the
+// caller's.  Entries of one flush share a stream (a launch on another stream flushes first).
+namespace {
+std::mutex reduce_queue_mutex;
+bool reduce_deferred = false;
+ReduceBatch reduce_queue = {};
+hipStream_t reduce_queue_stream = nullptr;
+
+int reduce_queue_launch() {  // caller holds the mutex
+  if (reduce_queue.n == 0) return 0;
+  const int blocks = reduce_queue.first_block[reduce_queue.n];
+  hipLaunchKernelGGL(reduce_partials_batch_kernel, dim3(blocks), dim3(256), 0, reduce_queue_stream,
+                     reduce_queue);
+  reduce_queue.n = 0;
+  return pn2_launch_status();
+}
+}  // namespace
+
+int mlp_reduce_weight_partials(int count, int parts, const float *part, float *out, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(reduce_queue_mutex);
+  if (!reduce_deferred) return mlp_reduce_partials(count, parts, part, out, stream);
+  if (reduce_queue.n > 0 && (reduce_queue_stream != stream || reduce_queue.n == kReduceBatch)) {
+    const int rc = reduce_queue_launch();
+    if (rc) return rc;
+  }
+  const int e = reduce_queue.n++;
+  if (e == 0) reduce_queue.first_block[0] = 0;
+  reduce_queue_stream = stream;
+  reduce_queue.count[e] = count;
+  reduce_queue.parts[e] = parts;
+  reduce_queue.part[e] = part;
+  reduce_queue.out[e] = out;
+  reduce_queue.first_block[e + 1] = reduce_queue.first_block[e] + (int)pn2_ceil_div((long long)count, 32);
+  return 0;
+}
+
+// on != 0: queue the weight-gradient reductions issued from now on; on == 0: back to immediate
+// launches (anything still queued is launched first).  Returns 0 or a HIP error.
+MLP_API int mlp_defer_weight_reductions(int on) {
+  std::lock_guard<std::mutex> lock(reduce_queue_mutex);
+  int rc = 0;
+  if (!on) rc = reduce_queue_launch();
+  reduce_deferred = on != 0;
+  return rc;
+}
+
+// launch what is queued (one kernel, on the stream the entries were issued on)
+MLP_API int mlp_flush_weight_reductions(void) {
+  std::lock_guard<std::mutex> lock(reduce_queue_mutex);
+  return reduce_queue_launch();
 }
 
 MLP_API int mlp_gemm_forward(int b, int m, int k, int r, const float *w, const float *x, int mode,
@@ -1247,9 +1327,7 @@ static int wgrad_run(int b, int m, int k, int r, int pmode, const OperandB &P, i
   else if (qmode == OP_DIRECT) WG(OP_POOLDY, OP_DIRECT);
   else WG(OP_POOLDY, OP_BNRELU);
 #undef WG
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(pn2_ceil_div((long long)m * k, 32)), dim3(256),
-                     0, stream, m * k, b * slices, workspace, dw);
-  return pn2_launch_status();
+  return mlp_reduce_weight_partials(m * k, b * slices, workspace, dw, stream);
 }
 
 // dW (m x k) = sum_b dY[b] * X[b]^T; dY given (pmode 0) or on the fly (pmode 2, from y/dz);

@@ -186,3 +186,8 @@ __device__ __forceinline__ void mfma_x6(f32x16 &acc, const Split3 &a, const Spli
 // dw[i] = sum_p part[p][i], i < count (mlp_gemm.hip): the deterministic reduction of the
 // per-workgroup partial weight gradients
 int mlp_reduce_partials(int count, int parts, const float *part, float *out, hipStream_t stream);
+// The same for a WEIGHT gradient, whose only reader is the optimizer's gradient packing: while
+// mlp_defer_weight_reductions(1) is in force the reduction is queued instead of launched, and
+// mlp_flush_weight_reductions() runs every queued one in ONE launch (a backward pass has ~30 of
+// them at 3-6 us each).  `part` must stay allocated until the flush.
+int mlp_reduce_weight_partials(int count, int parts, const float *part, float *out, hipStream_t stream);

@@ -4,6 +4,7 @@
 No reference counterpart: the reference runs nn.BatchNorm2d / nn.ReLU / F.max_pool2d here
 (pointnet2/pytorch_utils.py:14-124, pointnet2/pointnet2_modules.py:256-262).
 """
+import contextlib
 import os
 
 import torch
@@ -264,6 +265,43 @@ def gemm_dgrad(w, dy=None, fly=None, pooled=None):
     return dx
 
 
+_queued_workspaces = None  # not None: weight-gradient reductions are queued (see below)
+
+
+def _keep_until_flush(ws):
+    if _queued_workspaces is not None:
+        _queued_workspaces.append(ws)
+
+
+@contextlib.contextmanager
+def deferred_weight_reductions(enabled=True):
+    """Inside this context the reductions that finish gemm_wgrad / gemm_backward_fused are queued
+    and run as ONE launch at exit (include/mlp_hip.h: mlp_defer_weight_reductions).  The returned
+    dw tensors are undefined until then -- for a backward pass whose weight gradients nobody reads
+    before the context ends (the train step: loss.backward(), then the gradient packing)."""
+    global _queued_workspaces
+    if not enabled or _queued_workspaces is not None:
+        yield
+        return
+    _queued_workspaces = []
+    _L.check(_lib.mlp_defer_weight_reductions(1), "mlp_defer_weight_reductions")
+    try:
+        yield
+    finally:
+        held, device = _queued_workspaces, None
+        if held:
+            device = held[0].device
+        try:
+            if device is not None:
+                with torch.cuda.device(device):
+                    rc = _lib.mlp_defer_weight_reductions(0)
+            else:
+                rc = _lib.mlp_defer_weight_reductions(0)
+        finally:
+            _queued_workspaces = None
+        _L.check(rc, "mlp_defer_weight_reductions")
+
+
 def gemm_wgrad(m, k, x, xcoeff=None, dy=None, fly=None, pooled=None):
     """dw (M,K) = sum_b dy[b] @ x[b]^T; x direct or relu(bn(.)) via xcoeff=(scale, shift);
     dy direct or on the fly (fly as in gemm_dgrad)."""
@@ -274,6 +312,7 @@ def gemm_wgrad(m, k, x, xcoeff=None, dy=None, fly=None, pooled=None):
     with torch.cuda.device(x.device):
         ws = torch.empty(max(int(_lib.mlp_gemm_wgrad_workspace_floats(b, m, k, r)), 1),
                          dtype=torch.float32, device=x.device)
+        _keep_until_flush(ws)
         if dy is not None:
             rc = _lib.mlp_gemm_wgrad(b, m, k, r, 0, dy.data_ptr(), None, None, None, None, None,
                                      None, None, 0 if xcoeff is None else 1, x.data_ptr(),
@@ -340,6 +379,7 @@ def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None, n
     with torch.cuda.device(x.device):
         ws = torch.empty(max(int(_lib.mlp_gemm_backward_fused_workspace_floats(b, m, k, r)), 1),
                          dtype=torch.float32, device=x.device)
+        _keep_until_flush(ws)
         sp = torch.empty((k, parts, 2), dtype=torch.float32, device=x.device) if parts else None
         _L.check(_lib.mlp_gemm_backward_fused(b, m, k, r, w.data_ptr(), pmode, y.data_ptr(),
                                               dz.data_ptr(), _ptr(argmax), ns, scale.data_ptr(),

@@ -24,6 +24,7 @@ import sys
 import numpy as np
 import torch
 
+from pointnet2._mlp_ext import deferred_weight_reductions
 from pointnet2.pytorch_utils import deferred_bn_counters, zero_grads_none
 
 from .detector import VoteNet
@@ -242,10 +243,14 @@ class SupervisedStep(object):
         end_points.update({k: v for k, v in batch.items()
                            if torch.is_tensor(v) or k in ("all_supervised", "labeled_num")})
         loss, end_points = get_labeled_loss(end_points, self.cfg, {"dataset_config": self.cfg})
-        with zero_grads_none():
+        with zero_grads_none(), deferred_weight_reductions(self.defer_weight_reductions):
             loss.backward()
         self._pack_gradients()
         return loss, end_points
+
+    # the ~30 partial-sum reductions that finish the weight gradients of a backward pass run as one
+    # launch after it (nothing reads a weight gradient before _pack_gradients)
+    defer_weight_reductions = os.environ.get("STEP_DEFER_WGRAD_REDUCE", "1") != "0"
 
     def _pack_gradients(self):
         """p.grad (fresh tensors from autograd) -> flat_grad, one concatenation kernel."""
@@ -710,7 +715,7 @@ class SemiSupervisedStep(SupervisedStep):
                                                         self.config_dict)
         loss = detection_loss + unlabeled_loss * self.unlabeled_loss_weight
         end_points["loss"] = loss
-        with zero_grads_none():
+        with zero_grads_none(), deferred_weight_reductions(self.defer_weight_reductions):
             loss.backward()
         self._pack_gradients()
         return loss, end_points

@@ -222,6 +222,16 @@ int mlp_gemm_backward_fused_stats_parts(int b, int m, int k, int r);
 int mlp_bn_backward_finalize(int c, int parts, double count, int training, const float *partial,
                              const float *gamma, const float *invstd, float *dgamma, float *dbeta,
                              float *coef, void *stream);
+/* The weight gradients above (mlp_gemm_wgrad*, mlp_gemm_backward_fused) end with a deterministic
+ * reduction of per-workgroup partials in `workspace`.  A weight gradient's only reader is the
+ * optimizer (conv2d backward-weight, pytorch_utils.py:70-124, then train.py's optimizer.step()), so
+ * a training step may queue those ~30 small reductions of a backward pass and run them as ONE
+ * launch: mlp_defer_weight_reductions(1) starts queueing (process-wide), mlp_flush_weight_reductions()
+ * launches what is queued on the stream it was issued on, mlp_defer_weight_reductions(0) flushes and
+ * returns to immediate launches.  While queued, dw is undefined and the call's workspace must stay
+ * allocated. */
+int mlp_defer_weight_reductions(int on);
+int mlp_flush_weight_reductions(void);
 
 /* ---- weight gradient of a 4 -> 64 first layer without its output ------------------------------
  * SA1's first layer (mlp [1+3, 64, ...], pointnet2_modules.py:230-262 / pytorch_utils.py:70-124):

@@ -563,3 +563,55 @@ def test_reductions_on_two_streams_at_once():
         for res in got[si]:
             for a, b in zip(res, alone[si]):
                 assert torch.equal(a, b)
+
+
+def test_queued_weight_gradient_reductions_equal_immediate_ones():
+    """Inside deferred_weight_reductions() the partial-sum reductions of gemm_wgrad /
+    gemm_backward_fused are queued and run as one launch at exit (more than one when the queue of
+    40 fills): every dw is bit-identical to the one reduced at once, data gradients are untouched,
+    and outside the context the launches are immediate again."""
+    load_pkg()
+    K = importlib.import_module("pointnet2._mlp_ext")
+    g = torch.Generator().manual_seed(11)
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=g).to(DEV)
+
+    plain = []  # (m, k, x, dy): stand-alone weight gradients of assorted shapes
+    for m, k, r in ((64, 4, 4096), (128, 64, 3000), (256, 259, 1000), (128, 131, 2048), (2, 3, 64),
+                    (256, 256, 512), (79, 128, 1024)):
+        plain.append((m, k, rnd(2, k, r), rnd(2, m, r)))
+
+    def fused_case(b, m, k, groups, ns):  # both gradients of one layer from one pass over (y, dz)
+        w = rnd(m, k) / k ** 0.5
+        x, y, dz = rnd(b, k, groups, ns), rnd(b, m, groups, ns), rnd(b, m, groups, ns)
+        gamma = (torch.rand(m, generator=g) + 0.5).to(DEV)
+        beta = rnd(m) * 0.3
+        rm, rv = torch.zeros(m, device=DEV), torch.ones(m, device=DEV)
+        mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, 0.1, 1e-5, True)
+        _, _, coef = K.bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, True)
+        return w, x, (y, dz, scale, shift, mean, invstd, coef)
+
+    fused = [fused_case(2, 128, 131, 40, 32), fused_case(5, 128, 259, 26, 16)]
+
+    def run():
+        out = []
+        for rep in range(7):  # 7 x (7 + 2) = 63 queued reductions: the queue of 40 overflows once
+            for m, k, x, dy in plain:
+                out.append(K.gemm_wgrad(m, k, x, None, dy=dy))
+            for w, x, fly in fused:
+                both = K.gemm_backward_fused(w, x, None, fly=fly)
+                assert both is not None
+                out.extend([both[0], both[1]])
+        return out
+
+    ref = [t.clone() for t in run()]
+    with K.deferred_weight_reductions():
+        got = run()
+    torch.cuda.synchronize()
+    assert len(got) == len(ref) and len(ref) >= 49
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    again = run()  # immediate launches after the context
+    for a, b in zip(again, ref):
+        assert torch.equal(a, b)

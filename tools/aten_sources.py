@@ -28,6 +28,7 @@ SKIP = ("aten::view", "aten::_unsafe_view", "aten::reshape", "aten::transpose", 
         "aten::lift_fresh", "aten::narrow", "aten::view_as", "aten::numel", "aten::contiguous", "aten::to",
         "aten::_to_copy", "aten::item", "aten::sym_size", "aten::unflatten", "aten::flatten", "aten::chunk")
 agg = collections.Counter()
+size = collections.Counter()  # elements of the largest tensor argument, summed per (op, line)
 
 
 class Tracer(TorchDispatchMode):
@@ -42,6 +43,8 @@ class Tracer(TorchDispatchMode):
                     frame = "%s:%d %s" % (fn.split("3dioumatch_amd/")[-1], fs.lineno, fs.name)
                     break
             agg[(name, frame)] += 1
+            size[(name, frame)] += max([a.numel() for a in list(args) + list((kwargs or {}).values())
+                                        if isinstance(a, torch.Tensor)] or [0])
         return func(*args, **(kwargs or {}))
 
 
@@ -54,5 +57,5 @@ with Tracer():
     runner._forward_backward(dict(inputs))
 torch.cuda.synchronize()
 print("aten calls on GPU tensors in one forward + loss + backward (views / allocations skipped): %d" % sum(agg.values()))
-for (name, frame), n in agg.most_common(90):
-    print("%4d  %-26s %s" % (n, name, frame))
+for (name, frame), n in agg.most_common(200):
+    print("%4d  %-26s %10d  %s" % (n, name, size[(name, frame)], frame))
