@@ -860,7 +860,7 @@ gemm_wgrad_kernel(int m_total, int k_begin, int k_end, int k_total, int r, int r
 }
 
 // dw[i] = sum_p part[p][i]: a workgroup owns 32 consecutive elements, its 8 lane groups each sum
-// every 8th partial (128-byte rows, four loads in flight per lane), LDS adds the groups in a
+// every 8th partial (128-byte rows, eight loads in flight per lane), LDS adds the groups in a
 // fixed order -- deterministic, and a few hundred partials finish in a few microseconds
 __device__ __forceinline__ void reduce_partials_block(int block, int count, int parts,
                                                       const float *__restrict__ part,
@@ -868,18 +868,25 @@ __device__ __forceinline__ void reduce_partials_block(int block, int count, int 
   __shared__ float sums[8][32];
   const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int i = block * 32 + e;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
   if (i < count) {
     int p = grp;
-    for (; p + 24 < parts; p += 32) {
-      s0 += part[(size_t)p * count + i];
-      s1 += part[(size_t)(p + 8) * count + i];
-      s2 += part[(size_t)(p + 16) * count + i];
-      s3 += part[(size_t)(p + 24) * count + i];
+    const float *col = part + i;
+    for (; p + 56 < parts; p += 64) {  // eight rows in flight per lane
+      const float v0 = col[(size_t)p * count], v1 = col[(size_t)(p + 8) * count];
+      const float v2 = col[(size_t)(p + 16) * count], v3 = col[(size_t)(p + 24) * count];
+      const float v4 = col[(size_t)(p + 32) * count], v5 = col[(size_t)(p + 40) * count];
+      const float v6 = col[(size_t)(p + 48) * count], v7 = col[(size_t)(p + 56) * count];
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
     }
-    for (; p < parts; p += 8) s0 += part[(size_t)p * count + i];
+    for (; p + 24 < parts; p += 32) {
+      const float v0 = col[(size_t)p * count], v1 = col[(size_t)(p + 8) * count];
+      const float v2 = col[(size_t)(p + 16) * count], v3 = col[(size_t)(p + 24) * count];
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; p < parts; p += 8) s0 += col[(size_t)p * count];
   }
-  sums[grp][e] = (s0 + s1) + (s2 + s3);
+  sums[grp][e] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
   __syncthreads();
   if (grp == 0 && i < count) {
     float t = sums[0][e];
