@@ -485,7 +485,7 @@ def main():
                         ("mlp_fwd_sa1_128x64", "gemm_nn2_kernel<128, 128, 2, 2, 1, false, true, true, 64, true>")):
                     r_ = rows.get(kern)
                     if op_name in table and r_ is not None and float(r_["launches_per_step"]) > 0:
-                        n_l = max(1.0, round(float(r_["launches_per_step"])))
+                        n_l = float(r_["launches_per_step"])  # 0.9: 18 prefetches in 20 timed steps
                         table[op_name]["in_step_us_per_launch"] = round(float(r_["us_per_step"]) / n_l, 2)
                         table[op_name]["in_step_kernel"] = "%s (%s launches per step; profiles/%s)" % (
                             kern, r_["launches_per_step"], os.path.basename(ss))
