@@ -492,3 +492,78 @@ def gemm_forward_bn_lin4(w, x4, w1, coeff1, gamma, beta, running_mean, running_v
                                             out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
                                             scratch.data_ptr(), _stream(x4)), "mlp_bn_finalize_pairs")
     return y, out[0], out[1], out[2], out[3]
+
+
+# ---- first layer of a set-abstraction module applied before the gather (csrc/mlp_pregather.hip) ----
+def pregather_supported(b, c, n, m, ns):
+    return bool(_lib.mlp_pregather_supported(int(b), int(c), int(n), int(m), int(ns)))
+
+
+def pregather_pack(xyz, new_xyz, features, s):
+    """src_ext (B, 3+C, N+m) = [xyz*s | new_xyz*s ; features | 0] from xyz (B,N,3), new_xyz (B,m,3),
+    features (B,C,N)."""
+    _f32c(xyz, "xyz"); _f32c(new_xyz, "new_xyz"); _f32c(features, "features")
+    b, n, _ = xyz.shape
+    m, c = new_xyz.shape[1], features.shape[1]
+    out = torch.empty((b, 3 + c, n + m), dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _L.check(_lib.mlp_pregather_pack(b, n, m, c, float(s), xyz.data_ptr(), new_xyz.data_ptr(),
+                                         features.data_ptr(), out.data_ptr(), _stream(xyz)),
+                 "mlp_pregather_pack")
+    return out
+
+
+def pregather_unpack_grad(dsrc_ext, n, m):
+    """d features (B, C, n) out of d src_ext (B, 3+C, n+m)."""
+    _f32c(dsrc_ext, "dsrc_ext")
+    b, c = dsrc_ext.shape[0], dsrc_ext.shape[1] - 3
+    out = torch.empty((b, c, n), dtype=torch.float32, device=dsrc_ext.device)
+    with torch.cuda.device(dsrc_ext.device):
+        _L.check(_lib.mlp_pregather_unpack_grad(b, n, m, c, dsrc_ext.data_ptr(), out.data_ptr(),
+                                                _stream(dsrc_ext)), "mlp_pregather_unpack_grad")
+    return out
+
+
+def pregather_forward(z_ext, idx, n, stats=None):
+    """y (B, c, m, ns) = z_ext[:, :, idx] - z_ext[:, :, n + j].  stats = (gamma, beta, running_mean,
+    running_var, momentum, eps): also the training-mode BatchNorm coefficients of y
+    (mean, invstd, scale, shift), from the per-row moments the kernel leaves behind."""
+    _f32c(z_ext, "z_ext")
+    b, c, w = z_ext.shape
+    m, ns = idx.shape[1], idx.shape[2]
+    if idx.dtype != torch.int32 or not idx.is_contiguous() or w != n + m:
+        raise RuntimeError("idx must be a contiguous int32 (B, m, ns) and z_ext (B, c, n + m)")
+    y = torch.empty((b, c, m, ns), dtype=torch.float32, device=z_ext.device)
+    pairs = torch.empty((b, c, 2), dtype=torch.float32, device=z_ext.device) if stats else None
+    with torch.cuda.device(z_ext.device):
+        _L.check(_lib.mlp_pregather_forward(b, c, n, m, ns, z_ext.data_ptr(), idx.data_ptr(),
+                                            y.data_ptr(), _ptr(pairs), _stream(z_ext)),
+                 "mlp_pregather_forward")
+        if not stats:
+            return y
+        gamma, beta, running_mean, running_var, momentum, eps = stats
+        out = torch.empty((4, c), dtype=torch.float32, device=z_ext.device)
+        scratch = torch.empty(int(_lib.mlp_bn_finalize_pairs_scratch_bytes(c)), dtype=torch.uint8,
+                              device=z_ext.device)
+        _L.check(_lib.mlp_bn_finalize_pairs(c, b, m * ns, pairs.data_ptr(), gamma.data_ptr(),
+                                            beta.data_ptr(), float(eps), float(momentum),
+                                            _ptr(running_mean), _ptr(running_var),
+                                            out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                            out[3].data_ptr(), scratch.data_ptr(), _stream(z_ext)),
+                 "mlp_bn_finalize_pairs")
+    return y, out[0], out[1], out[2], out[3]
+
+
+def pregather_backward(fly, inverse, n):
+    """dz_ext (B, c, n + m) from fly = (y, dz, scale, shift, mean, invstd, coef) as gemm_dgrad
+    takes it and the inverse index of the layer's idx (_ext.group_inverse)."""
+    y, dz, scale, shift, mean, invstd, coef = fly
+    _f32c(y, "y"); _f32c(dz, "dz")
+    b, c, m, ns = y.shape
+    out = torch.empty((b, c, n + m), dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        _L.check(_lib.mlp_pregather_backward(b, c, n, m, ns, y.data_ptr(), dz.data_ptr(),
+                                             scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                             invstd.data_ptr(), coef.data_ptr(), inverse.data_ptr(),
+                                             out.data_ptr(), _stream(y)), "mlp_pregather_backward")
+    return out

@@ -173,6 +173,24 @@ class PointnetSAModuleVotes(nn.Module):
                 raise RuntimeError("a precomputed grouped tensor needs inds, new_xyz, max pooling "
                                    "and input features without gradient")
             return new_xyz, self.mlp_module.forward_pooled(grouped), inds
+        if (self.pooling == 'max' and not self.ret_unique_cnt and self.use_xyz
+                and isinstance(self.grouper, pointnet2_utils.QueryAndGroup)
+                and not self.grouper.sample_uniformly and new_xyz is not None
+                and self.mlp_module.pregather_ok(xyz, new_xyz, features, self.npoint, self.nsample)):
+            # the first layer commutes with the gather: run it over the N points and gather its
+            # output; the (3+C)-row grouped tensor and its gradient are never formed
+            if ball_idx is None:
+                if lists is not None and self.nsample <= 256:
+                    ball_idx = pointnet2_utils._ext.ball_query_prebuilt(new_xyz, xyz, self.radius,
+                                                                        self.nsample, lists)
+                else:
+                    ball_idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+            if ball_inv is None:
+                ball_inv = pointnet2_utils._ext.group_inverse(ball_idx, xyz.shape[1])
+            if ball_inv is not None:
+                scale = 1.0 / self.radius if self.normalize_xyz else 1.0
+                return new_xyz, self.mlp_module.forward_pregathered(xyz, new_xyz, features, ball_idx,
+                                                                    ball_inv, scale), inds
         if ball_idx is not None and isinstance(self.grouper, pointnet2_utils.QueryAndGroup):
             grouped = self.grouper(xyz, new_xyz, features, ball_idx, None, ball_inv)
         elif lists is not None:

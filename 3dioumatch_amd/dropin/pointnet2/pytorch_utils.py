@@ -142,10 +142,15 @@ class _FusedMLPChain(Function):
     gradient (backward) on the fly.  Per layer only the raw GEMM output y_i is kept; no
     normalised / rectified activation and no mask is ever written to memory.
 
-    apply(x, pool, training, momenta, epss, w_0, g_0, b_0, rm_0, rv_0, w_1, ...)"""
+    apply(x, pool, training, momenta, epss, pre, w_0, g_0, b_0, rm_0, rv_0, w_1, ...)
+
+    pre = None, or (idx (B,m,ns) int32, inverse (B,entries) int32, n): the first layer is applied
+    BEFORE the gather (csrc/mlp_pregather.hip) -- x is then the packed point-major operand
+    src_ext (B, 3+C, n+m) of _mlp_ext.pregather_pack instead of the grouped tensor (B, 3+C, m, ns),
+    which is never formed: y_0 = (W_0 . src_ext)[.., idx] - (W_0 . src_ext)[.., n + j]."""
 
     @staticmethod
-    def forward(ctx, x, pool, training, momenta, epss, *params):
+    def forward(ctx, x, pool, training, momenta, epss, pre, *params):
         from pointnet2 import _mlp_ext as K
         n_layers = len(params) // 5
         x = x.contiguous()
@@ -156,6 +161,8 @@ class _FusedMLPChain(Function):
         # and every kernel that needs a row of it recomputes that row (four FMAs per element)
         # instead of a 268 MB tensor being written once and read three times.
         moments = None
+        if pre is not None and (n_layers < 2 or x.dim() != 3):
+            raise RuntimeError("the pre-gather form needs src_ext (B, 3+C, n+m) and two layers or more")
         virtual0 = (training and n_layers >= 3 and x.dim() == 4 and not ctx.needs_input_grad[0]
                     and K.lin4_supported(params[0].reshape(params[0].shape[0], -1),
                                          params[5].reshape(params[5].shape[0], -1), x))
@@ -163,6 +170,20 @@ class _FusedMLPChain(Function):
             w, gamma, beta, rm, rv = params[5 * i:5 * i + 5]
             w2 = w.reshape(w.shape[0], -1)
             ext = None
+            if pre is not None and i == 0:
+                idx, _, npts = pre
+                z = K.gemm_forward(w2, x)  # over the n + m points, not the m * ns gathered columns
+                if training:  # the gather kernel leaves the rows' moments behind
+                    y, mean, invstd, scale, shift = K.pregather_forward(
+                        z, idx, npts, (gamma, beta, rm, rv, momenta[0], epss[0]))
+                else:
+                    y = K.pregather_forward(z, idx, npts)
+                    mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, momenta[0],
+                                                                   epss[0], False)
+                ys.append(y)
+                coefs.append((mean, invstd, scale, shift))
+                cur, cur_coeff = y, (scale, shift)
+                continue
             if virtual0 and i == 0:
                 moments = K.first4_moments(x)
                 mean, invstd, scale, shift = K.first4_bn(moments, x.numel() // 4, w2, gamma, beta, rm, rv,
@@ -206,6 +227,7 @@ class _FusedMLPChain(Function):
         ctx.save_for_backward(x, *ys, *flat, *extra, *params)
         ctx.n_layers, ctx.pool, ctx.training = n_layers, pool, training
         ctx.moments = moments  # not None: the first layer is virtual (ys[0] is a placeholder)
+        ctx.pre = pre
         return out
 
     @staticmethod
@@ -248,6 +270,14 @@ class _FusedMLPChain(Function):
                 dy_tensor, fly = None, (ys[i], dz, scale, shift, mean, invstd, coef)
             grads[5 * i + 1], grads[5 * i + 2] = dgamma, dbeta
             m, k = w2.shape
+            if ctx.pre is not None and i == 0:
+                # gradient of z_ext = W_0 . src_ext: the BatchNorm / ReLU backward of (y_0, dz) formed
+                # on the fly, scatter-added over idx and summed per group; then two GEMMs over
+                # the n + m points
+                dzx = K.pregather_backward(fly, ctx.pre[1], ctx.pre[2])
+                grads[0] = K.gemm_wgrad(m, k, x, None, dy=dzx).view_as(w)
+                dx = K.gemm_dgrad(w2, dy=dzx).view_as(x) if need_dx else None
+                continue
             virtual0 = ctx.moments is not None
             src = x if (i == 0 or (i == 1 and virtual0)) else ys[i - 1]
             src_coeff = None if i == 0 else (coefs[i - 1][2], coefs[i - 1][3])
@@ -278,7 +308,7 @@ class _FusedMLPChain(Function):
             else:
                 grads[5 * i] = K.gemm_wgrad(m, k, src, src_coeff, dy_tensor, fly, pooled).view_as(w)
                 dz = K.gemm_dgrad(w2, dy_tensor, fly, pooled)  # gradient w.r.t. relu(bn(y_{i-1}))
-        return (dx if need_dx else None, None, None, None, None, *grads)
+        return (dx if need_dx else None, None, None, None, None, None, *grads)
 
 
 _deferred_counters = None
@@ -386,7 +416,7 @@ class SharedMLP(nn.Sequential):
         return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and len(self) > 0
                 and _fused_enabled() and all(self._fusable(layer) for layer in self))
 
-    def _run(self, x, pool):
+    def _run(self, x, pool, pre=None):
         layers = list(self)
         if _mfma_enabled():
             bns = [next(layer.bn.children()) for layer in layers]
@@ -399,7 +429,7 @@ class SharedMLP(nn.Sequential):
                     params += [layer.conv.weight, bn.weight, bn.bias, bn.running_mean,
                                bn.running_var]
                 return _FusedMLPChain.apply(x, pool, training, [bn.momentum for bn in bns],
-                                            [bn.eps for bn in bns], *params)
+                                            [bn.eps for bn in bns], pre, *params)
         for i, layer in enumerate(layers):
             bn = next(layer.bn.children())
             y = layer.conv(x)
@@ -416,11 +446,60 @@ class SharedMLP(nn.Sequential):
             return self._run(x, pool=False)
         return super().forward(x)
 
+    def pregather_ok(self, xyz, new_xyz, features, m, ns):
+        """Can forward_pregathered replace forward_pooled(grouped) for these inputs (m groups of
+        ns members)?"""
+        if features is None or len(self) < 2 or not _pregather_enabled():
+            return False
+        if not (features.is_cuda and features.dtype == torch.float32 and _fused_enabled()
+                and _mfma_enabled() and all(self._fusable(layer) for layer in self)):
+            return False
+        if xyz.requires_grad or new_xyz.requires_grad:
+            return False
+        bns = [next(layer.bn.children()) for layer in self]
+        if any(bn.training != bns[0].training for bn in bns):
+            return False
+        from pointnet2 import _mlp_ext as K
+        conv = self[0].conv
+        return (conv.in_channels == features.shape[1] + 3 and
+                K.pregather_supported(features.shape[0], conv.out_channels, xyz.shape[1], m, ns))
+
+    def forward_pregathered(self, xyz, new_xyz, features, idx, inverse, scale):
+        """forward_pooled of the grouped tensor [(xyz[idx] - new_xyz) * scale ; features[idx]]
+        WITHOUT forming it: the first layer runs before the gather (csrc/mlp_pregather.hip).
+        xyz (B,N,3), new_xyz (B,m,3), features (B,C,N), idx (B,m,ns) int32, inverse = its
+        _ext.group_inverse; -> (B, C', m)."""
+        src = _PackPoints.apply(xyz, new_xyz, features, float(scale))
+        return self._run(src, pool=True, pre=(idx, inverse, xyz.shape[1]))
+
     def forward_pooled(self, x):
         """max over the last axis of forward(x): (B, C, npoint, nsample) -> (B, C', npoint)."""
         if self._use_fused(x):
             return self._run(x, pool=True)
         return torch.max(super().forward(x), dim=3)[0]
+
+
+class _PackPoints(Function):
+    """(xyz (B,N,3), new_xyz (B,m,3), features (B,C,N), s) -> src_ext (B, 3+C, N+m), the operand of
+    the pre-gather first layer (_mlp_ext.pregather_pack).  Only the features carry a gradient here
+    (callers use this form when the coordinates need none)."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, features, s):
+        from pointnet2 import _mlp_ext as K
+        ctx.dims = (xyz.shape[1], new_xyz.shape[1])
+        return K.pregather_pack(xyz.contiguous(), new_xyz.contiguous(), features.contiguous(), s)
+
+    @staticmethod
+    def backward(ctx, dsrc):
+        from pointnet2 import _mlp_ext as K
+        n, m = ctx.dims
+        dfeat = K.pregather_unpack_grad(dsrc.contiguous(), n, m) if ctx.needs_input_grad[2] else None
+        return None, None, dfeat, None
+
+
+def _pregather_enabled():
+    return os.environ.get("PN2_PREGATHER", "1") != "0"
 
 
 class FC(nn.Sequential):

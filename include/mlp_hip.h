@@ -233,6 +233,38 @@ int mlp_bn_backward_finalize(int c, int parts, double count, int training, const
 int mlp_defer_weight_reductions(int on);
 int mlp_flush_weight_reductions(void);
 
+/* ---- first layer of a set-abstraction module applied BEFORE the gather ---------------------------
+ * QueryAndGroup (pointnet2_utils.py:335-358) writes grouped = [(xyz[idx] - new_xyz)*s ; feat[idx]]
+ * (b, 3+c, m, ns) and the module's first Conv2d (pytorch_utils.py:70-124, called from
+ * pointnet2_modules.py:230-262) reads it again.  A 1x1 convolution commutes with the gather:
+ *   y1[:, j, t] = (W1 . src)[:, idx[j, t]] - (W1[:, :3] . new_xyz*s)[:, j],  src = [xyz*s ; feat],
+ * so the GEMM (mlp_gemm_forward) runs over the n points, not the m*ns gathered columns, on the packed
+ * operand src_ext (b, 3+c, n+m) = [xyz*s | new_xyz*s ; feat | 0]; z_ext = W1 . src_ext (b, M, n+m). */
+/* 1 when the shape is covered (n, m <= 4096, m*ns <= 32768, ns a power of two >= 4, c % 4 == 0;
+ * sizing helper for the grouping of pointnet2_utils.py:335-358) */
+int mlp_pregather_supported(int b, int c, int n, int m, int ns);
+/* src_ext from xyz (b,n,3), new_xyz (b,m,3), features (b,c,n) (the operand of the reference's
+ * grouping, pointnet2_utils.py:348-358, before it is gathered) */
+int mlp_pregather_pack(int b, int n, int m, int c, float s, const float *xyz, const float *new_xyz,
+                       const float *features, float *src_ext, void *stream);
+/* d features (b,c,n) out of d src_ext (b, 3+c, n+m) (the backward of the grouping's feature
+ * gather, group_points_gpu.cu:48-80, collapses to this copy) */
+int mlp_pregather_unpack_grad(int b, int n, int m, int c, const float *dsrc_ext, float *dfeatures,
+                              void *stream);
+/* y (b,c,m,ns) = z_ext[.., idx] - z_ext[.., n + j]: the first layer's raw output, as the Conv2d of
+ * pytorch_utils.py:70-124 on the grouped tensor would give it; pairs (b, c, 2) or NULL: (mean, M2)
+ * of every (cloud, channel) row for mlp_bn_finalize_pairs (parts = b, n_part = m*ns) */
+int mlp_pregather_forward(int b, int c, int n, int m, int ns, const float *z_ext, const int *idx,
+                          float *y, float *pairs, void *stream);
+/* dz_ext (b, c, n+m): the gradient of z_ext.  dy = BatchNorm/ReLU backward of (y, dz) on the fly
+ * (operands as mlp_gemm_dgrad_nt's pmode 2), scatter-added over idx through `inverse`
+ * (pn2_group_inverse_build) into columns < n, minus its per-group sums into columns n + j
+ * (replaces conv2d backward-input + group_points_grad, group_points_gpu.cu:48-80) */
+int mlp_pregather_backward(int b, int c, int n, int m, int ns, const float *y, const float *dz,
+                           const float *scale, const float *shift, const float *mean,
+                           const float *invstd, const float *coef, const unsigned *inverse,
+                           float *dz_ext, void *stream);
+
 /* ---- weight gradient of a 4 -> 64 first layer without its output ------------------------------
  * SA1's first layer (mlp [1+3, 64, ...], pointnet2_modules.py:230-262 / pytorch_utils.py:70-124):
  * y = w x is a rank-4 function of x, so only the ReLU-gated part of the BatchNorm backward needs

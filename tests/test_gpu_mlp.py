@@ -615,3 +615,62 @@ def test_queued_weight_gradient_reductions_equal_immediate_ones():
     again = run()  # immediate launches after the context
     for a, b in zip(again, ref):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("b,n,c,m,ns,widths,scale,training", [
+    (2, 2048, 128, 1024, 32, (128, 128, 256), 1.0, True),
+    (3, 1024, 256, 512, 16, (128, 128, 256), 1.0 / 0.8, True),
+    (2, 512, 256, 256, 16, (128, 128, 256), 1.0, True),
+    (2, 1000, 64, 300, 8, (64, 128), 2.5, True),
+    (2, 2048, 128, 1024, 32, (128, 128, 256), 1.0, False)])
+def test_pregathered_first_layer_vs_grouped(b, n, c, m, ns, widths, scale, training):
+    """SharedMLP.forward_pregathered (first layer applied over the N points, its output gathered:
+    csrc/mlp_pregather.hip) == forward_pooled of the grouped tensor the reference forms
+    (pointnet2_utils.py:335-358 + pytorch_utils.py:14-39): pooled output, gradients of the features
+    and of every parameter, running statistics."""
+    import copy
+    pt = _mods()
+    ext = importlib.import_module("pointnet2._ext")
+    g = torch.Generator().manual_seed(b * 1000 + n + c + m + ns)
+    xyz = (torch.rand(b, n, 3, generator=g) * 4 - 2).to(DEV)
+    new_xyz = xyz[:, torch.randperm(n, generator=g)[:m].to(DEV)].contiguous()
+    idx = torch.randint(0, n, (b, m, ns), generator=g, dtype=torch.int32).to(DEV)
+    idx[:, :, 1] = idx[:, :, 0]  # repeated members, as ball_query pads
+    inverse = ext.group_inverse(idx, n)
+    assert inverse is not None
+    feats = [torch.randn(b, c, n, generator=g).to(DEV).requires_grad_(True) for _ in range(2)]
+    feats[1].data.copy_(feats[0].data)
+    torch.manual_seed(5)
+    mlp_a = pt.SharedMLP([c + 3] + list(widths), bn=True).to(DEV)
+    for mod in mlp_a.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.3)
+    mlp_b = copy.deepcopy(mlp_a)
+    mlp_a.train(training); mlp_b.train(training)
+    assert mlp_b.pregather_ok(xyz, new_xyz, feats[1], m, ns)
+    # the reference's grouped tensor
+    li = idx.long()
+    gx = torch.gather(xyz.transpose(1, 2).unsqueeze(2).expand(b, 3, m, n), 3,
+                      li.unsqueeze(1).expand(b, 3, m, ns))
+    gx = (gx - new_xyz.transpose(1, 2).unsqueeze(-1)) * scale
+    gf = torch.gather(feats[0].unsqueeze(2).expand(b, c, m, n), 3, li.unsqueeze(1).expand(b, c, m, ns))
+    out_a = mlp_a.forward_pooled(torch.cat([gx, gf], dim=1).contiguous())
+    out_b = mlp_b.forward_pregathered(xyz, new_xyz, feats[1], idx, inverse, scale)
+    close(out_b, out_a, 2e-5)
+    if training:
+        dout = torch.randn(out_a.shape, generator=g).to(DEV)
+        out_a.backward(dout)
+        out_b.backward(dout)
+        # the two forwards differ in the last ulp, so a pre-activation within rounding of 0 can flip
+        # its ReLU mask and a max over nsample pick another near-tied sample (as in
+        # test_fused_chain_vs_sequential): almost every element agrees tightly, the sums in L2
+        d = (feats[1].grad - feats[0].grad).abs()
+        assert float((d > 5e-4 * max(1.0, float(feats[0].grad.abs().max()))).float().mean()) < 2e-3
+        rel = float((feats[1].grad - feats[0].grad).norm() / feats[0].grad.norm())
+        assert rel < 3e-2, rel
+        for (na, pa), (nb, pb) in zip(mlp_a.named_parameters(), mlp_b.named_parameters()):
+            rel = float((pb.grad - pa.grad).norm() / (pa.grad.norm() + 1e-12))
+            assert rel < 3e-2, (na, rel)
+    for (na, ba), (nb, bb) in zip(mlp_a.named_buffers(), mlp_b.named_buffers()):
+        close(bb.float(), ba.float(), 2e-5)
