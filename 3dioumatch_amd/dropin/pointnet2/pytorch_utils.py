@@ -454,8 +454,6 @@ class SharedMLP(nn.Sequential):
         if not (features.is_cuda and features.dtype == torch.float32 and _fused_enabled()
                 and _mfma_enabled() and all(self._fusable(layer) for layer in self)):
             return False
-        if xyz.requires_grad or new_xyz.requires_grad:
-            return False
         bns = [next(layer.bn.children()) for layer in self]
         if any(bn.training != bns[0].training for bn in bns):
             return False
@@ -481,21 +479,31 @@ class SharedMLP(nn.Sequential):
 
 class _PackPoints(Function):
     """(xyz (B,N,3), new_xyz (B,m,3), features (B,C,N), s) -> src_ext (B, 3+C, N+m), the operand of
-    the pre-gather first layer (_mlp_ext.pregather_pack).  Only the features carry a gradient here
-    (callers use this form when the coordinates need none)."""
+    the pre-gather first layer (_mlp_ext.pregather_pack).  Its gradient splits back into the three
+    inputs: rows 0..2 are the coordinates' (columns < N: xyz, the others: new_xyz -- what
+    QueryAndGroup's backward scatters / sums, pointnet2_utils.py:348-358), the other rows the
+    features'."""
 
     @staticmethod
     def forward(ctx, xyz, new_xyz, features, s):
         from pointnet2 import _mlp_ext as K
-        ctx.dims = (xyz.shape[1], new_xyz.shape[1])
+        ctx.dims = (xyz.shape[1], new_xyz.shape[1], float(s))
         return K.pregather_pack(xyz.contiguous(), new_xyz.contiguous(), features.contiguous(), s)
 
     @staticmethod
     def backward(ctx, dsrc):
         from pointnet2 import _mlp_ext as K
-        n, m = ctx.dims
-        dfeat = K.pregather_unpack_grad(dsrc.contiguous(), n, m) if ctx.needs_input_grad[2] else None
-        return None, None, dfeat, None
+        n, m, s = ctx.dims
+        dsrc = dsrc.contiguous()
+        dfeat = K.pregather_unpack_grad(dsrc, n, m) if ctx.needs_input_grad[2] else None
+        dxyz = dnew = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dc = dsrc[:, :3].transpose(1, 2)  # (B, N+m, 3)
+            if s != 1.0:
+                dc = dc * s
+            dxyz = dc[:, :n].contiguous() if ctx.needs_input_grad[0] else None
+            dnew = dc[:, n:].contiguous() if ctx.needs_input_grad[1] else None
+        return dxyz, dnew, dfeat, None
 
 
 def _pregather_enabled():

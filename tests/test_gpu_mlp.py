@@ -632,8 +632,11 @@ def test_pregathered_first_layer_vs_grouped(b, n, c, m, ns, widths, scale, train
     pt = _mods()
     ext = importlib.import_module("pointnet2._ext")
     g = torch.Generator().manual_seed(b * 1000 + n + c + m + ns)
-    xyz = (torch.rand(b, n, 3, generator=g) * 4 - 2).to(DEV)
-    new_xyz = xyz[:, torch.randperm(n, generator=g)[:m].to(DEV)].contiguous()
+    xyzs = [(torch.rand(b, n, 3, generator=torch.Generator().manual_seed(3)) * 4 - 2).to(DEV)
+            .requires_grad_(True) for _ in range(2)]
+    pick = torch.randperm(n, generator=g)[:m].to(DEV)
+    news = [x[:, pick] for x in xyzs]  # centroids are points of the cloud: their gradient flows on
+    xyz, new_xyz = xyzs[1], news[1]
     idx = torch.randint(0, n, (b, m, ns), generator=g, dtype=torch.int32).to(DEV)
     idx[:, :, 1] = idx[:, :, 0]  # repeated members, as ball_query pads
     inverse = ext.group_inverse(idx, n)
@@ -651,9 +654,9 @@ def test_pregathered_first_layer_vs_grouped(b, n, c, m, ns, widths, scale, train
     assert mlp_b.pregather_ok(xyz, new_xyz, feats[1], m, ns)
     # the reference's grouped tensor
     li = idx.long()
-    gx = torch.gather(xyz.transpose(1, 2).unsqueeze(2).expand(b, 3, m, n), 3,
+    gx = torch.gather(xyzs[0].transpose(1, 2).unsqueeze(2).expand(b, 3, m, n), 3,
                       li.unsqueeze(1).expand(b, 3, m, ns))
-    gx = (gx - new_xyz.transpose(1, 2).unsqueeze(-1)) * scale
+    gx = (gx - news[0].transpose(1, 2).unsqueeze(-1)) * scale
     gf = torch.gather(feats[0].unsqueeze(2).expand(b, c, m, n), 3, li.unsqueeze(1).expand(b, c, m, ns))
     out_a = mlp_a.forward_pooled(torch.cat([gx, gf], dim=1).contiguous())
     out_b = mlp_b.forward_pregathered(xyz, new_xyz, feats[1], idx, inverse, scale)
@@ -669,6 +672,8 @@ def test_pregathered_first_layer_vs_grouped(b, n, c, m, ns, widths, scale, train
         assert float((d > 5e-4 * max(1.0, float(feats[0].grad.abs().max()))).float().mean()) < 2e-3
         rel = float((feats[1].grad - feats[0].grad).norm() / feats[0].grad.norm())
         assert rel < 3e-2, rel
+        rel = float((xyzs[1].grad - xyzs[0].grad).norm() / xyzs[0].grad.norm())
+        assert rel < 3e-2, rel  # scatter over idx + (through the centroids) minus the group sums
         for (na, pa), (nb, pb) in zip(mlp_a.named_parameters(), mlp_b.named_parameters()):
             rel = float((pb.grad - pa.grad).norm() / (pa.grad.norm() + 1e-12))
             assert rel < 3e-2, (na, rel)
