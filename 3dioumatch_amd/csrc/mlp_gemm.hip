@@ -563,7 +563,7 @@ constexpr int KS = 64;  // K chunk of the small variant
 // X6: the chunk's 16 k-rows of a wave are ONE bf16 MFMA step; fragments gathered as eight 4-byte
 // reads per row block and split in registers (mlp_operand.h)
 template <int MODE, bool A_TRANS, bool X6 = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (X6 && A_TRANS) ? 2 : 1)
 gemm_nn_small_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int lda,
                      OperandB opb, float *__restrict__ c, size_t b_stride_in,
                      size_t b_stride_out) {
@@ -859,6 +859,119 @@ gemm_wgrad_kernel(int m_total, int k_begin, int k_end, int k_total, int r, int r
     }
 }
 
+// ---- weight gradient with the MFMA fragments read STRAIGHT from memory ---------------------------
+// dW[m][k] = sum_r P[m][r] Q[k][r]: the reduction runs over the columns r, which are contiguous in
+// BOTH operands -- exactly the eight consecutive reduction elements per lane a 32x32x16 bf16
+// MFMA fragment holds (row / column = lane & 31).  So no LDS staging and no transposition: a lane
+// loads 16 consecutive columns of its P and Q rows (64 bytes; the two lane halves of a row make a
+// 128-byte run), applies the operand transform, splits into bf16 terms and issues two k-steps
+// (the first over its columns 0..7, the second over 8..15 -- any 16 columns form a k-step as long
+// as both operands agree).  A wave owns a 64 x 64 block of dW over its share of the workgroup's
+// column range (32-column chunks dealt round-robin to the four waves, the next chunk's loads in
+// flight during the MFMAs), the shares are added through LDS, one partial block per workgroup.
+// For the small layers (FP modules, heads, the pre-gather first layers: a few thousand columns per
+// cloud, operands resident in L2) this replaces the LDS-staged kernel above at 0.4-0.6 of its time.
+template <int PMODE, int QMODE>
+__global__ void __launch_bounds__(256, 2)
+gemm_wgrad_direct_kernel(int m_total, int k_total, int r, int r_per_slice, int slices, OperandB opp,
+                         OperandB opq, float *__restrict__ part, size_t p_stride, size_t q_stride) {
+  __shared__ float red[4 * 16 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const BlockId blk = xcd_block_id();
+  const int k0 = blk.x * 64, m0 = blk.y * 64;
+  const int b = blk.z / slices, slice = blk.z % slices;
+  const int r_lo = slice * r_per_slice;
+  const int r_hi = r_lo + r_per_slice < r ? r_lo + r_per_slice : r;
+  OperandB P = opp, Q = opq;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  bool p_ok[2], q_ok[2];
+  RowCoef pc[2], qc[2];
+  size_t p_row[2], q_row[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int gm = m0 + i * 32 + l31, gk = k0 + i * 32 + l31;
+    p_ok[i] = gm < m_total;
+    q_ok[i] = gk < k_total;
+    pc[i] = load_row_coef<PMODE>(P, gm, p_ok[i]);
+    qc[i] = load_row_coef<QMODE>(Q, gk, q_ok[i]);
+    p_row[i] = (size_t)b * p_stride + (size_t)gm * r;
+    q_row[i] = (size_t)b * q_stride + (size_t)gk * r;
+  }
+  const bool vec_ok = (r & 3) == 0;
+  float px[2][16], pdz[2][16], qx[2][16], qdz[2][16];
+  auto fetch = [&](int c0) {  // the lane's 16 columns of chunk c0: c0 + 16 * half ..
+    const int col = c0 + 16 * half;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      load_raw_segment<PMODE, 16>(P, p_row[i] + col, col, r_hi, vec_ok, p_ok[i], px[i], pdz[i]);
+      load_raw_segment<QMODE, 16>(Q, q_row[i] + col, col, r_hi, vec_ok, q_ok[i], qx[i], qdz[i]);
+    }
+  };
+  int c0 = r_lo + 32 * wave;
+  if (c0 < r_hi) fetch(c0);
+  for (; c0 < r_hi; c0 += 128) {
+    const int col = c0 + 16 * half;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {  // one k-step's fragments live at a time (registers)
+      Split3 sp[2], sq[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float vp[8], vq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool in = col + 8 * st + e < r_hi;
+          vp[e] = (p_ok[i] && in) ? transform<PMODE>(px[i][8 * st + e], pdz[i][8 * st + e], pc[i]) : 0.f;
+          vq[e] = (q_ok[i] && in) ? transform<QMODE>(qx[i][8 * st + e], qdz[i][8 * st + e], qc[i]) : 0.f;
+        }
+        sp[i] = split3(vp);
+        sq[i] = split3(vq);
+      }
+      if (st == 1 && c0 + 128 < r_hi) fetch(c0 + 128);  // the raw registers are free again
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mfma_x6(acc[i][j], sp[i], sq[j]);
+    }
+  }
+  // add the four waves' blocks: waves 1..3 -> LDS -> wave 0, one 32 x 32 tile at a time
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __syncthreads();
+      if (wave != 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red[((wave * 16) + q) * 64 + lane] = acc[i][j][q];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          acc[i][j][q] += (red[(16 + q) * 64 + lane] + red[(32 + q) * 64 + lane]) + red[(48 + q) * 64 + lane];
+      }
+    }
+  if (wave != 0) return;
+  float *out = part + (size_t)blk.z * m_total * k_total;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = k0 + j * 32 + l31;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = m0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+        if (row < m_total && col < k_total) out[(size_t)row * k_total + col] = acc[i][j][q];
+      }
+    }
+}
+
 // dw[i] = sum_p part[p][i]: a workgroup owns 32 consecutive elements, its 8 lane groups each sum
 // every 8th partial (128-byte rows, eight loads in flight per lane), LDS adds the groups in a
 // fixed order -- deterministic, and a few hundred partials finish in a few microseconds
@@ -962,7 +1075,9 @@ int launch_nn(int b, int m, int k, int r, const float *a, int lda, const Operand
   const char *env = getenv("MLP_SMALL_GEMM_COLS");
   const long long small_cols = env ? atoll(env) : 16384;
   if ((long long)b * r <= small_cols) {  // a few hundred columns per cloud: latency-bound regime
-    if (gemm_x6() && !A_TRANS)  // (measured: the transposed / on-the-fly-dY forms are slower split)
+    // (measured, tools/small_gemm_bench.py: the transposed form with a plain operand gains from the
+    //  split at two workgroups per CU, 20 -> 15.6 us; with the on-the-fly dY operand it spills and does not)
+    if (gemm_x6() && (!A_TRANS || MODE == OP_DIRECT))
       hipLaunchKernelGGL((gemm_nn_small_kernel<MODE, A_TRANS, true>),
                          dim3(pn2_ceil_div(r, 64), pn2_ceil_div(m, 64), b), dim3(256), 0, stream, m,
                          k, r, a, lda, op, c, in_stride, out_stride);
@@ -1284,15 +1399,55 @@ static int wgrad_r_per_slice(int b, int m, int k, int r) {
   return (int)per;
 }
 
+static int wgrad_direct_r_per_slice(int b, int m, int k, int r);
+
 MLP_API size_t mlp_gemm_wgrad_workspace_floats(int b, int m, int k, int r) {
   const int per = wgrad_r_per_slice(b, m, k, r);
   const int slices = (r + per - 1) / per;
-  return (size_t)b * slices * m * k;
+  const int per_d = wgrad_direct_r_per_slice(b, m, k, r);
+  const int slices_d = (r + per_d - 1) / per_d;  // (either kernel may run: size for both)
+  return (size_t)b * (slices > slices_d ? slices : slices_d) * m * k;
+}
+
+// the direct-fragment kernel: small layers only (its operands must stay in L2: every 64 x 64 block
+// of dW re-reads its rows), operand modes without the pooled gradient; MLP_WGRAD_DIRECT=0 disables
+static bool wgrad_direct_ok(int b, int m, int k, int r, int pmode, int qmode) {
+  static const bool off = getenv("MLP_WGRAD_DIRECT") && atoi(getenv("MLP_WGRAD_DIRECT")) == 0;
+  static const long long cols = getenv("MLP_WGRAD_DIRECT_COLS") ? atoll(getenv("MLP_WGRAD_DIRECT_COLS")) : 32768;
+  return !off && gemm_x6() && (pmode == OP_DIRECT || pmode == OP_DY) &&
+         (qmode == OP_DIRECT || qmode == OP_BNRELU) && (long long)b * r <= cols && r >= 32;
+}
+
+static int wgrad_direct_r_per_slice(int b, int m, int k, int r) {
+  // about 640 workgroups in flight (two per CU and some slack), at least 128 columns each
+  const long long tiles = (long long)pn2_ceil_div(m, 64) * pn2_ceil_div(k, 64) * b;
+  long long slices = (640 + tiles / 2) / tiles;
+  if (slices < 1) slices = 1;
+  long long per = (r + slices - 1) / slices;
+  per = (per + 127) / 128 * 128;
+  return (int)per;
 }
 
 static int wgrad_run(int b, int m, int k, int r, int pmode, const OperandB &P, int qmode,
                      const float *x, const float *xscale, const float *xshift, float *dw,
                      float *workspace, hipStream_t stream) {
+  if (wgrad_direct_ok(b, m, k, r, pmode, qmode)) {
+    const int per = wgrad_direct_r_per_slice(b, m, k, r);
+    const int slices = (r + per - 1) / per;
+    OperandB Q = {x, nullptr, xscale, xshift, nullptr, nullptr, nullptr};
+    const dim3 grid(pn2_ceil_div(k, 64), pn2_ceil_div(m, 64), b * slices);
+#define WGD(PM, QM)                                                                              \
+  hipLaunchKernelGGL((gemm_wgrad_direct_kernel<PM, QM>), grid, dim3(256), 0, stream, m, k, r, per, \
+                     slices, P, Q, workspace, (size_t)m * r, (size_t)k * r)
+    if (pmode == OP_DIRECT && qmode == OP_DIRECT) WGD(OP_DIRECT, OP_DIRECT);
+    else if (pmode == OP_DIRECT) WGD(OP_DIRECT, OP_BNRELU);
+    else if (qmode == OP_DIRECT) WGD(OP_DY, OP_DIRECT);
+    else WGD(OP_DY, OP_BNRELU);
+#undef WGD
+    const int rc = pn2_launch_status();
+    if (rc) return rc;
+    return mlp_reduce_weight_partials(m * k, b * slices, workspace, dw, stream);
+  }
   const int per = wgrad_r_per_slice(b, m, k, r);
   const int slices = (r + per - 1) / per;
   OperandB Q = {x, nullptr, xscale, xshift, nullptr, nullptr, nullptr};
