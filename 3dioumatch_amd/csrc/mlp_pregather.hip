@@ -93,19 +93,31 @@ pregather_forward_kernel(int c, int n, int m, int ns, const float *__restrict__ 
     a1[q] = 0.f; a2[q] = 0.f;
     sh[q] = zrow[q][idx[(size_t)b * mns]] - vrow[q][0];  // shifted sums: y[b, ch, 0, 0]
   }
-  for (int e4 = tid; e4 < mns / 4; e4 += kPgThreads) {  // ns % 4 == 0: the four share a group
-    const int4 ii = i4[e4];
-    const int j = (e4 * 4) / ns;
+  // m * ns <= 32768: at most eight 16-byte index loads per lane, all in flight before the first use
+  const int n4 = mns / 4;
+  int4 iv[8];
 #pragma unroll
-    for (int q = 0; q < kPgCB; ++q) {
-      const float vv = vrow[q][j];
-      float4 o;
-      o.x = zrow[q][ii.x] - vv; o.y = zrow[q][ii.y] - vv;
-      o.z = zrow[q][ii.z] - vv; o.w = zrow[q][ii.w] - vv;
-      reinterpret_cast<float4 *>(y + ((size_t)b * c + ch0 + q) * mns)[e4] = o;
-      const float d0 = o.x - sh[q], d1 = o.y - sh[q], d2 = o.z - sh[q], d3 = o.w - sh[q];
-      a1[q] += (d0 + d1) + (d2 + d3);
-      a2[q] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  for (int u = 0; u < 8; ++u) {
+    const int e4 = tid + u * kPgThreads;
+    iv[u] = e4 < n4 ? i4[e4] : make_int4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e4 = tid + u * kPgThreads;
+    if (e4 < n4) {  // ns % 4 == 0: the four share a group
+      const int4 ii = iv[u];
+      const int j = (e4 * 4) / ns;
+#pragma unroll
+      for (int q = 0; q < kPgCB; ++q) {
+        const float vv = vrow[q][j];
+        float4 o;
+        o.x = zrow[q][ii.x] - vv; o.y = zrow[q][ii.y] - vv;
+        o.z = zrow[q][ii.z] - vv; o.w = zrow[q][ii.w] - vv;
+        reinterpret_cast<float4 *>(y + ((size_t)b * c + ch0 + q) * mns)[e4] = o;
+        const float d0 = o.x - sh[q], d1 = o.y - sh[q], d2 = o.z - sh[q], d3 = o.w - sh[q];
+        a1[q] += (d0 + d1) + (d2 + d3);
+        a2[q] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
     }
   }
   if (pairs == nullptr) return;
@@ -145,12 +157,23 @@ pregather_backward_kernel(int c, int n, int m, int ns, OperandB op,
     const float4 *y4 = reinterpret_cast<const float4 *>(op.x + off);
     const float4 *d4 = reinterpret_cast<const float4 *>(op.dz + off);
     float4 *r4 = reinterpret_cast<float4 *>(row);
-    for (int t = tid; t < mns / 4; t += kPgThreads) {
-      const float4 yv = y4[t], dv = d4[t];
-      float4 o;
-      o.x = transform<OP_DY>(yv.x, dv.x, rc); o.y = transform<OP_DY>(yv.y, dv.y, rc);
-      o.z = transform<OP_DY>(yv.z, dv.z, rc); o.w = transform<OP_DY>(yv.w, dv.w, rc);
-      r4[t] = o;
+    for (int t0 = tid; t0 < mns / 4; t0 += 4 * kPgThreads) {  // eight 16-byte loads in flight
+      float4 yv[4], dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u * kPgThreads;
+        if (t < mns / 4) { yv[u] = y4[t]; dv[u] = d4[t]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u * kPgThreads;
+        if (t < mns / 4) {
+          float4 o;
+          o.x = transform<OP_DY>(yv[u].x, dv[u].x, rc); o.y = transform<OP_DY>(yv[u].y, dv[u].y, rc);
+          o.z = transform<OP_DY>(yv[u].z, dv[u].z, rc); o.w = transform<OP_DY>(yv[u].w, dv[u].w, rc);
+          r4[t] = o;
+        }
+      }
     }
   }
   for (int t = tid; t < n; t += kPgThreads) acc[t] = 0.f;
