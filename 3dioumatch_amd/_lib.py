@@ -101,6 +101,9 @@ _SIGNATURES = {
     "mlp_gemm_backward_fused_stats_parts": [_c_int, _c_int, _c_int, _c_int],
     "mlp_bn_backward_finalize": [_c_int, _c_int, ctypes.c_double, _c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _vp],
+    "mlp_gemm_backward_small_supported": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int],
+    "mlp_gemm_backward_small": [_c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_pregather_supported": [_c_int, _c_int, _c_int, _c_int, _c_int],
     "mlp_pregather_pack": [_c_int, _c_int, _c_int, _c_int, ctypes.c_float, _vp, _vp, _vp, _vp, _vp],
     "mlp_pregather_unpack_grad": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp],

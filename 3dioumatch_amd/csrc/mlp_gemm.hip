@@ -562,17 +562,17 @@ constexpr int KS = 64;  // K chunk of the small variant
 
 // X6: the chunk's 16 k-rows of a wave are ONE bf16 MFMA step; fragments gathered as eight 4-byte
 // reads per row block and split in registers (mlp_operand.h)
-template <int MODE, bool A_TRANS, bool X6 = false>
-__global__ void __launch_bounds__(256, (X6 && A_TRANS) ? 2 : 1)
-gemm_nn_small_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int lda,
-                     OperandB opb, float *__restrict__ c, size_t b_stride_in,
-                     size_t b_stride_out) {
+template <int MODE, bool A_TRANS, bool X6>
+__device__ __forceinline__ void gemm_nn_small_body(int blk_x, int blk_y, int blk_z, int m_total, int k_total,
+                                                   int r, const float *__restrict__ a, int lda,
+                                                   OperandB opb, float *__restrict__ c,
+                                                   size_t b_stride_in, size_t b_stride_out) {
   constexpr int TM = 64, TN = 64, LDA = TM + 1;
   constexpr int STAGE = KS * LDA + KS * TN, REDUCE = 4 * 16 * 64;
   __shared__ __attribute__((aligned(16))) float lds[STAGE > REDUCE ? STAGE : REDUCE];
   float *As = lds + KS * TN, *Bs = lds;  // Bs first: 16-byte aligned for the float4 stores
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r0 = blockIdx.x * TN, m0 = blockIdx.y * TM, b = blockIdx.z;
+  const int r0 = blk_x * TN, m0 = blk_y * TM, b = blk_z;
   OperandB op = opb;
   const size_t in_off = (size_t)b * b_stride_in;
   f32x16 acc[2][2];
@@ -694,6 +694,15 @@ gemm_nn_small_kernel(int m_total, int k_total, int r, const float *__restrict__ 
         if (row < m_total && col < r) __builtin_nontemporal_store(acc[i][j][q], &cb[(size_t)row * r + col]);
       }
     }
+}
+
+template <int MODE, bool A_TRANS, bool X6 = false>
+__global__ void __launch_bounds__(256, (X6 && A_TRANS) ? 2 : 1)
+gemm_nn_small_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int lda,
+                     OperandB opb, float *__restrict__ c, size_t b_stride_in,
+                     size_t b_stride_out) {
+  gemm_nn_small_body<MODE, A_TRANS, X6>((int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, m_total,
+                                        k_total, r, a, lda, opb, c, b_stride_in, b_stride_out);
 }
 
 // Partial wgrad: for one cloud b and one slice of R,
@@ -872,13 +881,13 @@ gemm_wgrad_kernel(int m_total, int k_begin, int k_end, int k_total, int r, int r
 // For the small layers (FP modules, heads, the pre-gather first layers: a few thousand columns per
 // cloud, operands resident in L2) this replaces the LDS-staged kernel above at 0.4-0.6 of its time.
 template <int PMODE, int QMODE>
-__global__ void __launch_bounds__(256, 2)
-gemm_wgrad_direct_kernel(int m_total, int k_total, int r, int r_per_slice, int slices, OperandB opp,
-                         OperandB opq, float *__restrict__ part, size_t p_stride, size_t q_stride) {
+__device__ __forceinline__ void wgrad_direct_body(const BlockId blk, int m_total, int k_total, int r,
+                                                  int r_per_slice, int slices, OperandB opp,
+                                                  OperandB opq, float *__restrict__ part,
+                                                  size_t p_stride, size_t q_stride) {
   __shared__ float red[4 * 16 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
-  const BlockId blk = xcd_block_id();
   const int k0 = blk.x * 64, m0 = blk.y * 64;
   const int b = blk.z / slices, slice = blk.z % slices;
   const int r_lo = slice * r_per_slice;
@@ -970,6 +979,47 @@ gemm_wgrad_direct_kernel(int m_total, int k_total, int r, int r_per_slice, int s
         if (row < m_total && col < k_total) out[(size_t)row * k_total + col] = acc[i][j][q];
       }
     }
+}
+
+template <int PMODE, int QMODE>
+__global__ void __launch_bounds__(256, 2)
+gemm_wgrad_direct_kernel(int m_total, int k_total, int r, int r_per_slice, int slices, OperandB opp,
+                         OperandB opq, float *__restrict__ part, size_t p_stride, size_t q_stride) {
+  wgrad_direct_body<PMODE, QMODE>(xcd_block_id(), m_total, k_total, r, r_per_slice, slices, opp, opq,
+                                  part, p_stride, q_stride);
+}
+
+// Both backward GEMMs of a SMALL layer in one launch: the data gradient dQ = W^T . P (the
+// 64 x 64-tile kernel above, blocks [0, nd)) and the weight gradient (the direct-fragment kernel,
+// blocks [nd, nd + nw)) are independent and neither fills the chip -- launched one after the other
+// they cost their sum (2 x 10-28 us per layer, 13 layers per step), together about the larger.
+struct SmallPairArgs {
+  int nd, dgx, dgy;             // data-gradient blocks and their (x, y) extents (z = cloud)
+  int m, k, r;                  // the layer: W (m, k), r columns per cloud
+  int wkx, wmy, per, slices;    // weight-gradient grid (x over k, y over m) and slicing
+  const float *w;               // (m, k)
+  float *dq, *part;
+};
+
+template <int PMODE, int QMODE, bool X6D>
+__global__ void __launch_bounds__(256, 2)
+gemm_small_backward_pair_kernel(SmallPairArgs t, OperandB opp, OperandB opq) {
+  const int id = (int)blockIdx.x;
+  if (id < t.nd) {
+    const int bx = id % t.dgx, by = (id / t.dgx) % t.dgy, bz = id / (t.dgx * t.dgy);
+    // dQ (k rows) = W^T (k x m, read transposed) . P (m rows): the small kernel's (m_total, k_total)
+    // are (k, m) here
+    gemm_nn_small_body<PMODE, true, X6D>(bx, by, bz, t.k, t.m, t.r, t.w, t.k, opp, t.dq,
+                                         (size_t)t.m * t.r, (size_t)t.k * t.r);
+  } else {
+    const int wid = id - t.nd;
+    BlockId blk;
+    blk.x = wid % t.wkx;
+    blk.y = (wid / t.wkx) % t.wmy;
+    blk.z = wid / (t.wkx * t.wmy);
+    wgrad_direct_body<PMODE, QMODE>(blk, t.m, t.k, t.r, t.per, t.slices, opp, opq, t.part,
+                                    (size_t)t.m * t.r, (size_t)t.k * t.r);
+  }
 }
 
 // dw[i] = sum_p part[p][i]: a workgroup owns 32 consecutive elements, its 8 lane groups each sum
@@ -1346,6 +1396,56 @@ MLP_API int mlp_gemm_dgrad_nt(int b, int m, int k, int r, const float *w, int mo
                                 (hipStream_t)stream_);
 }
 
+static bool wgrad_direct_ok(int b, int m, int k, int r, int pmode, int qmode);
+static int wgrad_direct_r_per_slice(int b, int m, int k, int r);
+
+// Both backward GEMMs of a small layer in ONE launch (gemm_small_backward_pair_kernel): 1 when
+// the layer is in the small regime of both kernels.
+MLP_API int mlp_gemm_backward_small_supported(int b, int m, int k, int r, int pmode, int qmode) {
+  static const bool off = getenv("MLP_SMALL_BWD_PAIR") && atoi(getenv("MLP_SMALL_BWD_PAIR")) == 0;
+  const char *env = getenv("MLP_SMALL_GEMM_COLS");
+  const long long small_cols = env ? atoll(env) : 16384;
+  return !off && b > 0 && m > 0 && k > 0 && (long long)b * r <= small_cols &&
+         wgrad_direct_ok(b, m, k, r, pmode, qmode);
+}
+
+// dq (b,k,r) = w^T P[b] and dw (m,k) = sum_b P[b] Q[b]^T; P = dy (pmode 0) or formed on the fly
+// from (y, dz) and the BatchNorm / ReLU backward constants (pmode 2); Q = x (qmode 0) or
+// relu(x*xscale + xshift) (qmode 1).  dq == NULL: the weight gradient alone.
+// workspace: mlp_gemm_wgrad_workspace_floats(b, m, k, r) floats.
+MLP_API int mlp_gemm_backward_small(int b, int m, int k, int r, const float *w, int pmode,
+                                    const float *dy_or_y, const float *dz, const float *scale,
+                                    const float *shift, const float *mean, const float *invstd,
+                                    const float *coef, int qmode, const float *x,
+                                    const float *xscale, const float *xshift, float *dq, float *dw,
+                                    float *workspace, void *stream_) {
+  if (!mlp_gemm_backward_small_supported(b, m, k, r, pmode, qmode)) return (int)hipErrorInvalidValue;
+  hipStream_t stream = (hipStream_t)stream_;
+  OperandB P = {dy_or_y, dz, scale, shift, mean, invstd, coef};
+  if (pmode == OP_DIRECT) P = OperandB{dy_or_y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  OperandB Q = {x, nullptr, xscale, xshift, nullptr, nullptr, nullptr};
+  SmallPairArgs t;
+  t.m = m; t.k = k; t.r = r;
+  t.dgx = pn2_ceil_div(r, 64); t.dgy = pn2_ceil_div(k, 64);
+  t.nd = dq ? t.dgx * t.dgy * b : 0;
+  t.per = wgrad_direct_r_per_slice(b, m, k, r);
+  t.slices = (r + t.per - 1) / t.per;
+  t.wkx = pn2_ceil_div(k, 64); t.wmy = pn2_ceil_div(m, 64);
+  t.w = w; t.dq = dq; t.part = workspace;
+  const int nw = t.wkx * t.wmy * b * t.slices;
+  const dim3 grid((unsigned)(t.nd + nw));
+#define PAIR(PM, QM, X6D)                                                                        \
+  hipLaunchKernelGGL((gemm_small_backward_pair_kernel<PM, QM, X6D>), grid, dim3(256), 0, stream, t, P, Q)
+  if (pmode == OP_DIRECT && qmode == OP_DIRECT) PAIR(OP_DIRECT, OP_DIRECT, true);
+  else if (pmode == OP_DIRECT) PAIR(OP_DIRECT, OP_BNRELU, true);
+  else if (qmode == OP_DIRECT) PAIR(OP_DY, OP_DIRECT, false);
+  else PAIR(OP_DY, OP_BNRELU, false);
+#undef PAIR
+  const int rc = pn2_launch_status();
+  if (rc) return rc;
+  return mlp_reduce_weight_partials(m * k, b * t.slices, workspace, dw, stream);
+}
+
 MLP_API int mlp_gemm_dgrad_pooled_nt(int b, int m, int k, int groups, int ns, const float *w,
                                      const float *y, const float *dpooled, const int *argmax,
                                      const float *scale, const float *shift, const float *mean,
@@ -1398,8 +1498,6 @@ static int wgrad_r_per_slice(int b, int m, int k, int r) {
   if (per < 64) per = 64;
   return (int)per;
 }
-
-static int wgrad_direct_r_per_slice(int b, int m, int k, int r);
 
 MLP_API size_t mlp_gemm_wgrad_workspace_floats(int b, int m, int k, int r) {
   const int per = wgrad_r_per_slice(b, m, k, r);

@@ -400,6 +400,41 @@ def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None, n
     return dx, dw, below
 
 
+def gemm_backward_small(w, x, xcoeff=None, dy=None, fly=None, need_dx=True):
+    """Both backward GEMMs of a SMALL layer (FP modules, heads, pre-gather first layers) in one
+    launch: -> (dx (B,K,...) or None, dw (M,K)), or None when the layer is outside the small
+    regime (callers then use gemm_dgrad + gemm_wgrad).  The gradient operand is dy (B,M,...) or
+    formed on the fly from fly = (y, dz, scale, shift, mean, invstd, coef); x direct or
+    relu(bn(.)) via xcoeff = (scale, shift)."""
+    m, k = w.shape
+    b = x.shape[0]
+    r = x.numel() // (b * k)
+    pmode = 0 if dy is not None else 2
+    qmode = 0 if xcoeff is None else 1
+    if not _lib.mlp_gemm_backward_small_supported(b, m, k, r, pmode, qmode):
+        return None
+    _f32c(w, "w"); _f32c(x, "x")
+    if dy is not None:
+        _f32c(dy, "dy")
+        p0, pdz, sc, sh, mean, invstd, coef = dy, None, None, None, None, None, None
+    else:
+        p0, pdz, sc, sh, mean, invstd, coef = fly
+        _f32c(p0, "y"); _f32c(pdz, "dz")
+    xs, xh = xcoeff if xcoeff is not None else (None, None)
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty((m, k), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        ws = torch.empty(max(int(_lib.mlp_gemm_wgrad_workspace_floats(b, m, k, r)), 1),
+                         dtype=torch.float32, device=x.device)
+        _keep_until_flush(ws)
+        _L.check(_lib.mlp_gemm_backward_small(b, m, k, r, w.data_ptr(), pmode, p0.data_ptr(),
+                                              _ptr(pdz), _ptr(sc), _ptr(sh), _ptr(mean),
+                                              _ptr(invstd), _ptr(coef), qmode, x.data_ptr(),
+                                              _ptr(xs), _ptr(xh), _ptr(dx), dw.data_ptr(),
+                                              ws.data_ptr(), _stream(x)), "mlp_gemm_backward_small")
+    return dx, dw
+
+
 def wgrad_first4(w, x, fly, moments=None):
     """dw (64,4) of a first layer y = w x with a 4-channel input x (B,4,...) behind BatchNorm +
     ReLU, from fly = (y, dz, scale, shift, mean, invstd, coef) as gemm_wgrad takes it -- y is

@@ -275,6 +275,10 @@ class _FusedMLPChain(Function):
                 # on the fly, scatter-added over idx and summed per group; then two GEMMs over
                 # the n + m points
                 dzx = K.pregather_backward(fly, ctx.pre[1], ctx.pre[2])
+                pair = K.gemm_backward_small(w2, x, None, dy=dzx, need_dx=need_dx)
+                if pair is not None:
+                    dx, grads[0] = pair[0], pair[1].view_as(w)
+                    continue
                 grads[0] = K.gemm_wgrad(m, k, x, None, dy=dzx).view_as(w)
                 dx = K.gemm_dgrad(w2, dy=dzx).view_as(x) if need_dx else None
                 continue
@@ -290,6 +294,11 @@ class _FusedMLPChain(Function):
             if lin_w is not None and both is None:
                 raise RuntimeError("the virtual first layer needs the fused backward kernel of the second")
             below = None
+            if both is None and pooled is None and lin_w is None and (i > 0 or need_dx):
+                # the small layers: both GEMMs in one launch (no BatchNorm sums for the layer below)
+                pair = K.gemm_backward_small(w2, src, src_coeff, fly=fly)
+                if pair is not None:
+                    both = (pair[0], pair[1], None)
             if both is not None:
                 below = both[2]  # BatchNorm-backward sums of layer i-1 (None for the first layer)
                 grads[5 * i] = both[1].view_as(w)

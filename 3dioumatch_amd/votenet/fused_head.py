@@ -69,18 +69,28 @@ class _HeadChain(Function):
         dy3 = dy3.contiguous()
         w1m, w2m, w3m = (w.reshape(w.shape[0], -1) for w in (w1, w2, w3))
         db3 = dy3.sum(dim=(0, 2)) if ctx.has_bias[2] else None
-        dw3 = K.gemm_wgrad(w3m.shape[0], w3m.shape[1], y2, (scale2, shift2), dy=dy3).view_as(w3)
-        dz2 = K.gemm_dgrad(w3m, dy=dy3)
+
+        def both(wm, src, src_coeff, need_dx=True, **grad):
+            """(dw, d src) of one layer: one launch for the two GEMMs where the layer is small"""
+            pair = K.gemm_backward_small(wm, src, src_coeff, need_dx=need_dx, **grad)
+            if pair is not None:
+                return pair[1], pair[0]
+            dwm = K.gemm_wgrad(wm.shape[0], wm.shape[1], src, src_coeff, **grad)
+            return dwm, (K.gemm_dgrad(wm, **grad) if need_dx else None)
+
+        dw3, dz2 = both(w3m, y2, (scale2, shift2), dy=dy3)
+        dw3 = dw3.view_as(w3)
         dg2, dbe2, coef2 = K.bn_relu_backward_stats(y2, dz2, g2, scale2, shift2, mean2, invstd2,
                                                     training)
         fly2 = (y2, dz2, scale2, shift2, mean2, invstd2, coef2)
-        dw2 = K.gemm_wgrad(w2m.shape[0], w2m.shape[1], y1, (scale1, shift1), fly=fly2).view_as(w2)
-        dz1 = K.gemm_dgrad(w2m, fly=fly2)
+        dw2, dz1 = both(w2m, y1, (scale1, shift1), fly=fly2)
+        dw2 = dw2.view_as(w2)
         dg1, dbe1, coef1 = K.bn_relu_backward_stats(y1, dz1, g1, scale1, shift1, mean1, invstd1,
                                                     training)
         fly1 = (y1, dz1, scale1, shift1, mean1, invstd1, coef1)
-        dw1 = K.gemm_wgrad(w1m.shape[0], w1m.shape[1], x, None, fly=fly1).view_as(w1)
-        dx = K.gemm_dgrad(w1m, fly=fly1).view_as(x) if ctx.needs_input_grad[0] else None
+        dw1, dx = both(w1m, x, None, need_dx=ctx.needs_input_grad[0], fly=fly1)
+        dw1 = dw1.view_as(w1)
+        dx = dx.view_as(x) if dx is not None else None
 
         def dbias(present, coef, dbeta):
             if not present:

@@ -213,6 +213,20 @@ int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, int pmod
                             const float *xshift, const float *xmean, const float *xinvstd,
                             const float *xlin_w, float *dq, float *dw, float *workspace,
                             float *stats_part, void *stream);
+/* The same two GEMMs for the SMALL layers (FP modules, vote / proposal / IoU heads, the pre-gather
+ * first layers: b*r <= 16384 columns): conv backward-input and backward-weight of
+ * pytorch_utils.py:70-124 are independent and neither fills the chip, so one launch runs both
+ * (about the larger of the two instead of their sum).  pmode 0: P = dy (b,m,r) given; pmode 2: P
+ * formed on the fly from y, dz and the BatchNorm / ReLU backward constants as in
+ * mlp_gemm_dgrad_nt; qmode 0 / 1 as in mlp_gemm_wgrad.  dq == NULL: the weight gradient alone.
+ * workspace: mlp_gemm_wgrad_workspace_floats(b, m, k, r) floats. */
+int mlp_gemm_backward_small_supported(int b, int m, int k, int r, int pmode, int qmode);
+int mlp_gemm_backward_small(int b, int m, int k, int r, const float *w, int pmode,
+                            const float *dy_or_y, const float *dz, const float *scale,
+                            const float *shift, const float *mean, const float *invstd,
+                            const float *coef, int qmode, const float *x, const float *xscale,
+                            const float *xshift, float *dq, float *dw, float *workspace,
+                            void *stream);
 /* partials per channel in stats_part; 0 when the layer leaves none (sizing helper for the
  * BatchNorm backward of pytorch_utils.py:42-50) */
 int mlp_gemm_backward_fused_stats_parts(int b, int m, int k, int r);

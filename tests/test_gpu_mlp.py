@@ -679,3 +679,39 @@ def test_pregathered_first_layer_vs_grouped(b, n, c, m, ns, widths, scale, train
             assert rel < 3e-2, (na, rel)
     for (na, ba), (nb, bb) in zip(mlp_a.named_buffers(), mlp_b.named_buffers()):
         close(bb.float(), ba.float(), 2e-5)
+
+
+@pytest.mark.parametrize("b,m,k,r", [(8, 256, 256, 1024), (8, 256, 512, 512), (3, 128, 128, 256),
+                                     (2, 79, 128, 256), (8, 128, 259, 768), (2, 259, 256, 1000),
+                                     (1, 64, 20, 36)])
+def test_small_backward_pair_vs_two_gemms(b, m, k, r):
+    """One launch for the data gradient and the weight gradient of a small layer
+    (mlp_gemm_backward_small) == gemm_dgrad + gemm_wgrad: the same two kernel bodies, so the same
+    bits for dq; dw within the tolerance of its (differently sliced) partial sums.  Gradient
+    operand given or formed on the fly, input direct or relu(bn(.)), with and without dq."""
+    load_pkg()
+    K = importlib.import_module("pointnet2._mlp_ext")
+    g = torch.Generator().manual_seed(m + k + r)
+    w = (torch.randn(m, k, generator=g) / k ** 0.5).to(DEV)
+    x = torch.randn(b, k, r, generator=g).to(DEV)
+    y = torch.randn(b, m, r, generator=g).to(DEV)
+    dz = torch.randn(b, m, r, generator=g).to(DEV)
+    gamma = (torch.rand(m, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(m, generator=g) * 0.3).to(DEV)
+    mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, torch.zeros(m, device=DEV),
+                                                   torch.ones(m, device=DEV), 0.1, 1e-5, True)
+    _, _, coef = K.bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, True)
+    fly = (y, dz, scale, shift, mean, invstd, coef)
+    xc = ((torch.rand(k, generator=g) + 0.5).to(DEV), (torch.randn(k, generator=g) * 0.2).to(DEV))
+    for grad in (dict(fly=fly), dict(dy=dz)):
+        for xcoeff in (None, xc):
+            pair = K.gemm_backward_small(w, x, xcoeff, **grad)
+            assert pair is not None, "shape not in the small regime"
+            dx, dw = pair
+            want_dx = K.gemm_dgrad(w, **grad).view_as(x)
+            want_dw = K.gemm_wgrad(m, k, x, xcoeff, **grad)
+            assert torch.equal(dx, want_dx)
+            close(dw, want_dw, 1e-5)
+            none, dw_only = K.gemm_backward_small(w, x, xcoeff, need_dx=False, **grad)
+            assert none is None
+            assert torch.equal(dw_only, dw)

@@ -208,20 +208,27 @@ def test_graph_replay_matches_eager(oracle_omp):
         runner.prefetch_geometry(second)
         loss0, ep0 = runner(first)
         loss0, inds0 = float(loss0), ep0["aggregated_vote_inds"].cpu().clone()
+        grads0 = step_mod.flat_grads(runner.net).cpu().clone()
         loss1, ep1 = runner(second)
         assert runner.graphs == graphs  # the capture did not fall back
         results.append((loss0, float(loss1), inds0, ep1["aggregated_vote_inds"].cpu().clone(),
                         step_mod.flat_params(runner.net).cpu(), step_mod.flat_grads(runner.net).cpu(),
                         runner.net.backbone_net.sa1.mlp_module.layer0.bn.bn.running_mean.cpu().clone(),
-                        int(runner.net.pnet.bn1.num_batches_tracked)))
+                        int(runner.net.pnet.bn1.num_batches_tracked), grads0))
     eager, graph = results
     assert torch.equal(eager[2], graph[2]) and torch.equal(eager[3], graph[3])
     assert abs(eager[0] - graph[0]) <= 1e-5 * max(1.0, abs(eager[0]))
     assert abs(eager[1] - graph[1]) <= 1e-3 * max(1.0, abs(eager[1]))
-    assert float((eager[5] - graph[5]).norm() / eager[5].norm()) < 5e-2  # grads after an Adam step
-    # Adam turns the sign of a near-zero gradient into a full +-lr step: bounded, not tiny
+    # same weights, same batch: the replayed graph's gradient IS the eager one up to the order of
+    # the fp32 atomics (measured 6e-7)
+    assert float((eager[8] - graph[8]).norm() / eager[8].norm()) < 1e-5
+    # After an Adam step the comparison is chaotic: Adam turns the sign of a near-zero gradient
+    # into a full +-lr step, and a label assignment / arg-max downstream can flip -- two EAGER runs
+    # differ by 1e-3 in the second step's gradient, and by a few 1e-2 when such a flip happens
+    # (the same discrete values recur run after run).  Bounded, not tiny:
+    assert float((eager[5] - graph[5]).norm() / eager[5].norm()) < 0.2
     assert float((eager[4] - graph[4]).abs().max()) <= 6e-3  # two Adam steps of lr 1e-3
-    assert float((eager[4] - graph[4]).norm() / eager[4].norm()) < 1e-3
+    assert float((eager[4] - graph[4]).norm() / eager[4].norm()) < 3e-3
     assert torch.allclose(eager[6], graph[6], rtol=1e-4, atol=1e-6)
     assert eager[7] == graph[7] == 2
 
