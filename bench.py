@@ -285,6 +285,24 @@ def kernel_table(device):
                    "frac_of_fp32_mfma_peak": round(flops / (us * 1e-6) / 1e12 / F32_PEAK_TFLOPS, 4),
                    "hbm_GBps": round(nbytes / us / 1e3, 1),
                    "frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    # SA2's first layer applied before the gather (csrc/mlp_pregather.hip): gather of the small
+    # GEMM's output with the BatchNorm moments / its backward (BN+ReLU backward on the fly, scatter
+    # through the inverse index), at N = 2048 -> m = 1024 x ns = 32, 128 channels
+    n2, m2_, ns2_, c2 = 2048, 1024, 32, 128
+    z_ext = torch.randn(B, c2, n2 + m2_, device=device)
+    pidx = torch.randint(0, n2, (B, m2_, ns2_), dtype=torch.int32, device=device)
+    pinv = ext.group_inverse(pidx, n2)
+    gamma = torch.rand(c2, device=device) + 0.5
+    beta, rmean, rvar = torch.zeros(c2, device=device), torch.zeros(c2, device=device), torch.ones(c2, device=device)
+    us = time_op(lambda: K.pregather_forward(z_ext, pidx, n2, (gamma, beta, rmean, rvar, 0.1, 1e-5)))
+    hbm("pregather_fwd_sa2", us, 4 * B * (c2 * m2_ * ns2_ + c2 * (n2 + m2_) + m2_ * ns2_))
+    y1 = torch.randn(B, c2, m2_, ns2_, device=device)
+    dz1 = torch.randn(B, c2, m2_, ns2_, device=device)
+    mean, invstd, scale, shift = K.bn_coefficients(y1, gamma, beta, rmean, rvar, 0.1, 1e-5, True)
+    _, _, coef = K.bn_relu_backward_stats(y1, dz1, gamma, scale, shift, mean, invstd, True)
+    fly = (y1, dz1, scale, shift, mean, invstd, coef)
+    us = time_op(lambda: K.pregather_backward(fly, pinv, n2))
+    hbm("pregather_bwd_sa2", us, 4 * B * (2 * c2 * m2_ * ns2_ + c2 * (n2 + m2_)) + 4 * pinv.numel())
     return t, forms
 
 
@@ -482,7 +500,8 @@ def main():
                         ("group_grad_sa2_c128", "group_points_grad_sorted_kernel<32>"),
                         ("group_inverse_sa2", "group_inverse_kernel"),
                         ("three_interpolate_gridconv", "three_interpolate_lds_kernel<8>"),
-                        ("mlp_fwd_sa1_128x64", "gemm_nn2_kernel<128, 128, 2, 2, 1, false, true, true, 64, true>")):
+                        ("mlp_fwd_sa1_128x64", "gemm_nn2_kernel<128, 128, 2, 2, 1, false, true, true, 64, true>"),
+                        ("pregather_bwd_sa2", "pregather_backward_kernel<32>")):
                     r_ = rows.get(kern)
                     if op_name in table and r_ is not None and float(r_["launches_per_step"]) > 0:
                         n_l = float(r_["launches_per_step"])  # 0.9: 18 prefetches in 20 timed steps

@@ -125,3 +125,30 @@ def test_boxes_bev_iou_cpu_matches_reference_golden():
         got = ut.boxes_bev_iou_cpu(g["a_" + tag], g["b_" + tag])  # numpy in -> numpy out
         assert isinstance(got, np.ndarray)
         assert np.array_equal(got.view(np.uint32), g["iou_bev_" + tag].view(np.uint32)), tag
+
+
+def test_host_side_shape_gates_of_the_round4_entry_points():
+    """The sizing / gating helpers of the pre-gather first layer and of the paired small backward
+    are host functions (no device needed): their answers at the network's shapes and just outside."""
+    pkg = load_pkg()
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(pkg.__file__), "lib3dioumatch_hip.so"))
+    ok = lib.mlp_pregather_supported
+    assert ok(8, 128, 2048, 1024, 32) == 1      # SA2
+    assert ok(8, 128, 1024, 512, 16) == 1       # SA3
+    assert ok(8, 128, 1024, 256, 16) == 1       # vote aggregation
+    assert ok(8, 128, 4097, 1024, 16) == 0      # source row beyond the LDS stage
+    assert ok(8, 128, 2048, 2048, 32) == 0      # m * ns beyond the inverse index
+    assert ok(8, 128, 2048, 1024, 3) == 0       # nsample not a power of two
+    assert ok(8, 130, 2048, 1024, 32) == 0      # channels not a multiple of 4
+    assert ok(0, 128, 2048, 1024, 32) == 0
+    small = lib.mlp_gemm_backward_small_supported
+    assert small(8, 256, 256, 1024, 2, 1) == 1  # a vote-head layer, gradient operand on the fly
+    assert small(8, 128, 259, 768, 0, 0) == 1   # SA4's pre-gather layer, plain operands
+    assert small(8, 256, 256, 4096, 2, 1) == 0  # 32768 columns: not the small regime
+    assert small(8, 256, 256, 1024, 3, 1) == 0  # pooled gradient operand: other kernels
+    assert small(8, 256, 256, 16, 2, 1) == 0    # fewer columns than one chunk
+    ws = lib.mlp_gemm_wgrad_workspace_floats
+    ws.restype = ctypes.c_size_t
+    for b, m, k, r in ((8, 256, 256, 1024), (8, 128, 259, 768), (2, 79, 128, 256), (8, 128, 131, 3072)):
+        need = ws(b, m, k, r)
+        assert need >= b * m * k and need % (m * k) == 0  # whole partial blocks, one per cloud at least
