@@ -614,9 +614,15 @@ static int *tickets_for(hipStream_t stream) {
   if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone || table.size() >= 64)
     return fallback;
   int *buf = nullptr;
-  if (hipMalloc(reinterpret_cast<void **>(&buf), sizeof(int) * kMaxTicketChannels) != hipSuccess ||
-      hipMemset(buf, 0, sizeof(int) * kMaxTicketChannels) != hipSuccess)
+  // cleared ON the stream that will use it: a hipMemset on the null stream is not ordered before a
+  // kernel on a non-blocking stream (the first launch on a fresh stream met counters that were
+  // still being cleared: tests/test_gpu_mlp.py::test_reductions_on_two_streams_at_once, 1 run in 4)
+  if (hipMalloc(reinterpret_cast<void **>(&buf), sizeof(int) * kMaxTicketChannels) != hipSuccess)
     return fallback;
+  if (hipMemsetAsync(buf, 0, sizeof(int) * kMaxTicketChannels, stream) != hipSuccess) {
+    (void)hipFree(buf);
+    return fallback;
+  }
   table.emplace(stream, buf);
   return buf;
 }

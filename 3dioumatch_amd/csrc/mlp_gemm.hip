@@ -435,11 +435,33 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
         if (row < m_total) __builtin_nontemporal_store(acc[i][j][q], &cb[(size_t)row * r + col]);
       }
     }
-  if (STATS) {
-    // per output row: shifted sums over this wave's NB*32 columns (shift = the row's first
-    // column in the wave: no cancellation) -> (mean, M2); the WN wave columns of a row are merged
-    // by one lane per row (equal counts), and the workgroup writes TM contiguous pairs
-    __shared__ float2 wave_stat[WN][TM];
+  // per output row (mean, M2) of this wave's NB*32 columns; the WN wave columns of a row are
+  // merged by one lane per row (equal counts), and the workgroup writes TM contiguous pairs.
+  // Where a wave owns 64 x 64 of the tile the sums come out of the row scan below (the
+  // accumulators transposed through LDS: 96 plain adds per lane instead of 64 cross-lane
+  // reductions of five DPP steps each -- the epilogue was ~640 vector instructions per wave
+  // and tile, more issue time than the tile's MFMAs at K = 64); the DPP form serves the rest.
+  constexpr bool SCAN_STATS = STATS && MB == 2 && NB == 2;
+  __shared__ float2 wave_stat[STATS ? WN : 1][STATS ? TM : 1];
+  auto merge_wave_stats = [&]() {
+    __syncthreads();
+    if (tid < TM && m0 + tid < m_total) {
+      float mean = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < WN; ++w2) { mean += wave_stat[w2][tid].x; m2 += wave_stat[w2][tid].y; }
+      mean *= 1.0f / (float)WN;
+#pragma unroll
+      for (int w2 = 0; w2 < WN; ++w2) {
+        const float d = wave_stat[w2][tid].x - mean;
+        m2 = __fmaf_rn((float)(NB * 32) * d, d, m2);
+      }
+      float *dst = stats + (((size_t)b * gridDim.x + blockIdx.x) * stat_channels + m0 + tid) * 2;
+      dst[0] = mean;
+      dst[1] = m2;
+    }
+  };
+  if constexpr (STATS && !SCAN_STATS) {
+    // shifted sums (shift = the row's first column in the wave: no cancellation)
     const int half = lane >> 5;
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -464,24 +486,10 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
           wave_stat[wn][lrow] = make_float2(shf + s1 * kInvN, fmaxf(s2 - s1 * s1 * kInvN, 0.f));
         }
       }
-    __syncthreads();
-    if (tid < TM && m0 + tid < m_total) {
-      float mean = 0.f, m2 = 0.f;
-#pragma unroll
-      for (int w2 = 0; w2 < WN; ++w2) { mean += wave_stat[w2][tid].x; m2 += wave_stat[w2][tid].y; }
-      mean *= 1.0f / (float)WN;
-#pragma unroll
-      for (int w2 = 0; w2 < WN; ++w2) {
-        const float d = wave_stat[w2][tid].x - mean;
-        m2 = __fmaf_rn((float)(NB * 32) * d, d, m2);
-      }
-      float *dst = stats + (((size_t)b * gridDim.x + blockIdx.x) * stat_channels + m0 + tid) * 2;
-      dst[0] = mean;
-      dst[1] = m2;
-    }
+    merge_wave_stats();
   }
-  if constexpr (POOL != 0) {
-    static_assert(NB == 2 && MB == 2 && (POOL == 16 || POOL == 32 || POOL == 64),
+  if constexpr (POOL != 0 || SCAN_STATS) {
+    static_assert(NB == 2 && MB == 2 && (POOL == 0 || POOL == 16 || POOL == 32 || POOL == 64),
                   "a wave owns 64 x 64 of the tile");
     // Which extreme wins is known before the statistics are: sign(scale) = sign(gamma).  Rows
     // with a negative gamma are parked negated, so one scan for the maximum serves all.
@@ -496,8 +504,9 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
     float *park = AS_FLOATS >= 4 * 2048 ? &As[0][0] + wave * 2048
                                         : (wave < 2 ? &As[0][0] + wave * 2048 : &Bs[0][0] + (wave - 2) * 2048);
     const int half = lane >> 5, l31 = lane & 31;
-    const int groups = r / POOL;
-    constexpr int GPL = 32 / (POOL < 32 ? POOL : 32);  // groups per lane: 2 for POOL == 16
+    constexpr int PL = POOL != 0 ? POOL : 64;  // (no pooling: the scan serves the statistics alone)
+    const int groups = r / PL;
+    constexpr int GPL = 32 / (PL < 32 ? PL : 32);  // groups per lane: 2 for POOL == 16
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
       const int rbase = m0 + (wm * MB + i) * 32;
@@ -505,7 +514,7 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
       for (int q = 0; q < 16; ++q) {
         const int cq = (q & 3) + 8 * (q >> 2);  // row of the block = cq + 4 * half
         const int rowq = rbase + cq + 4 * half;
-        const bool neg = rowq < m_total && pool_gamma[rowq] < 0.f;
+        const bool neg = POOL != 0 && rowq < m_total && pool_gamma[rowq] < 0.f;
         const int rsw = (cq & 15) ^ (half << 2);  // (row & 15) for cq + 4*half (bit 2 of cq is clear)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -520,15 +529,37 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
 #pragma unroll
       for (int gq = 0; gq < GPL; ++gq) { best[gq] = -__builtin_inff(); at[gq] = 0; }
       const float4 *prow = reinterpret_cast<const float4 *>(park + l31 * 64);
+      float t1 = 0.f, t2 = 0.f, tsh = 0.f;  // shifted sums of the lane's 32 samples (shift: the first)
 #pragma unroll
       for (int c4 = 0; c4 < 8; ++c4) {
         const float4 v4 = prow[(half * 8 + c4) ^ (l31 & 15)];
         const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        if (SCAN_STATS && c4 == 0) tsh = vv[0];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int s2 = c4 * 4 + e;             // sample within the lane's 32
-          const int gq = GPL == 2 ? s2 / 16 : 0;  // its group within the lane
-          if (vv[e] > best[gq]) { best[gq] = vv[e]; at[gq] = GPL == 2 ? s2 % 16 : s2; }
+          if constexpr (POOL != 0) {
+            const int s2 = c4 * 4 + e;             // sample within the lane's 32
+            const int gq = GPL == 2 ? s2 / 16 : 0;  // its group within the lane
+            if (vv[e] > best[gq]) { best[gq] = vv[e]; at[gq] = GPL == 2 ? s2 % 16 : s2; }
+          }
+          if constexpr (SCAN_STATS) {
+            const float d = vv[e] - tsh;
+            t1 += d;
+            t2 = __fmaf_rn(d, d, t2);
+          }
+        }
+      }
+      if constexpr (SCAN_STATS) {
+        // (mean, M2) of the lane's 32 samples, then of the row's 64 in this wave (equal counts)
+        const float mh = tsh + t1 * (1.0f / 32.0f), qh = fmaxf(t2 - t1 * t1 * (1.0f / 32.0f), 0.f);
+        const float mo = __shfl_xor(mh, 32, kWave), qo = __shfl_xor(qh, 32, kWave);
+        if (half == 0) {
+          const float dlt = mo - mh;
+          float mean = 0.5f * (mh + mo);
+          const float m2w = (qh + qo) + 16.0f * dlt * dlt;  // n_a n_b / (n_a + n_b) = 16
+          // rows parked negated (negative gamma, pooling): the mean changes sign, M2 does not
+          if (POOL != 0 && rbase + l31 < m_total && pool_gamma[rbase + l31] < 0.f) mean = -mean;
+          wave_stat[wn][(wm * MB + i) * 32 + l31] = make_float2(mean, m2w);
         }
       }
       if (POOL == 64) {  // the two halves of a row form one group: the lower half wins ties
@@ -537,7 +568,7 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
         if (half == 0 && ob > best[0]) { best[0] = ob; at[0] = 32 + oa; }
       }
       const int row = rbase + l31;
-      if (row < m_total && (POOL != 64 || half == 0)) {
+      if (POOL != 0 && row < m_total && (POOL != 64 || half == 0)) {
         const bool negr = pool_gamma[row] < 0.f;
         const int g0 = (r0 + wn * 64) / POOL + (POOL == 64 ? 0 : half * GPL);
         int *ei = reinterpret_cast<int *>(ext);
@@ -549,6 +580,7 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
         }
       }
     }
+    if constexpr (SCAN_STATS) merge_wave_stats();
   }
 }
 
