@@ -222,13 +222,19 @@ def test_graph_replay_matches_eager(oracle_omp):
     # same weights, same batch: the replayed graph's gradient IS the eager one up to the order of
     # the fp32 atomics (measured 6e-7)
     assert float((eager[8] - graph[8]).norm() / eager[8].norm()) < 1e-5
-    # After an Adam step the comparison is chaotic: Adam turns the sign of a near-zero gradient
-    # into a full +-lr step, and a label assignment / arg-max downstream can flip -- two EAGER runs
-    # differ by 1e-3 in the second step's gradient, and by a few 1e-2 when such a flip happens
-    # (the same discrete values recur run after run).  Bounded, not tiny:
-    assert float((eager[5] - graph[5]).norm() / eager[5].norm()) < 0.2
+    # After an Adam step the comparison is no longer a kernel check.  Some parameters have a
+    # mathematically ZERO gradient -- e.g. the bias of SA4's last BatchNorm on channels whose pooled
+    # maxima are positive: a constant shift of such a channel passes the interpolation and is
+    # removed by the next BatchNorm -- so what is computed for them is round-off, and Adam's first
+    # step turns round-off of either sign into a full +-lr move.  Measured with
+    # tools/step_repeatability.py (two EAGER runs against each other, every build switch on or off,
+    # labels identical, loss equal to 1e-5): after step 1 only that bias differs (by 2 lr on some
+    # channels); the second step's gradient then lands in one of a few populations, 1e-3 apart
+    # inside a population and 0.16 ... 0.86 (relative L2) between them.  So the second step is held
+    # to its loss and to bounded parameters only:
+    assert bool(torch.isfinite(graph[5]).all())
     assert float((eager[4] - graph[4]).abs().max()) <= 6e-3  # two Adam steps of lr 1e-3
-    assert float((eager[4] - graph[4]).norm() / eager[4].norm()) < 3e-3
+    assert float((eager[4] - graph[4]).norm() / eager[4].norm()) < 1e-2
     assert torch.allclose(eager[6], graph[6], rtol=1e-4, atol=1e-6)
     assert eager[7] == graph[7] == 2
 
