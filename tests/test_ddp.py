@@ -277,9 +277,11 @@ def test_graph_step_two_ranks_share_one_gpu(tmp_path, semi):
     assert rel(r[0]["graph_grad"], r[0]["eager_grad"]) < 1e-4
     lr = 2e-3 if semi else 1e-3
     assert np.abs(r[0]["graph_params"] - r[0]["eager_params"]).max() <= 3 * 3 * lr
-    # (relative L2: usually ~1e-3; 5.7e-3 was seen once -- each sign flip of a near-zero gradient
-    # is worth 2*lr on that parameter, the per-element bound above is the principled one)
-    assert rel(r[0]["graph_params"], r[0]["eager_params"]) < 1e-2
+    # (relative L2: usually ~1e-3; 3.8e-3 after two steps and 5.7e-3 after three were seen -- each
+    # sign flip of a mathematically-zero gradient is worth 2*lr on that parameter and moves the
+    # next step's gradient, profiles/r4_step_repeatability.txt; the per-element bound above is
+    # the principled one)
+    assert rel(r[0]["graph_params"], r[0]["eager_params"]) < 3e-2
     want = (r[0]["single_grad"] + r[1]["single_grad"]) / 2
     assert rel(r[0]["graph_grad"], want) < 1e-4, rel(r[0]["graph_grad"], want)
     # ... and for EVERY parameter tensor, not only in the global norm: a wrong 1/world (or a tensor
@@ -351,7 +353,7 @@ def test_graph_step_with_a_one_rank_rccl_group(tmp_path):
     assert np.abs(r["rccl_losses"][0] - r["plain_losses"][0]) <= 1e-4 * abs(r["plain_losses"][0])
     assert np.abs(r["rccl_params"] - r["plain_params"]).max() <= 5 * 3 * 1e-3
     rel = np.linalg.norm(r["rccl_params"] - r["plain_params"]) / np.linalg.norm(r["plain_params"])
-    assert rel < 1e-2, rel
+    assert rel < 3e-2, rel  # (sign flips of zero-gradient parameters: profiles/r4_step_repeatability.txt)
     # the eager all-reduce was timed (events on the launching stream) ...
     assert int(r["rccl_in_graph"][0]) == 0 and float(r["rccl_us"][0]) > 0
     # ... and the opt-in form with the collective captured at the head of G2 runs the same step

@@ -109,8 +109,8 @@ def test_semi_graph_replay_matches_eager(oracle_omp, monkeypatch):
     assert float((eager[3] - graph[3]).abs().max()) <= 1.2e-2  # two Adam steps of lr 2e-3
     # Adam turns the rounding noise of (mathematically) zero gradients into +-lr steps whose signs
     # differ from run to run (scatter-add order); the bound is ~2x what those parameters can add
-    assert float((eager[3] - graph[3]).norm() / eager[3].norm()) < 1.2e-2
-    assert float((eager[4] - graph[4]).norm() / eager[4].norm()) < 1.2e-2
+    assert float((eager[3] - graph[3]).norm() / eager[3].norm()) < 3e-2  # (profiles/r4_step_repeatability.txt)
+    assert float((eager[4] - graph[4]).norm() / eager[4].norm()) < 3e-2
     # teacher BN running mean: after step 0 the teacher IS the student (EMA weight 0), whose
     # pre-BatchNorm biases carry the +-lr sign noise above; a bias moves the batch mean one to
     # one and the running mean by momentum (0.1) of that: 0.1 * 2 * lr = 4e-4
