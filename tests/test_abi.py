@@ -152,3 +152,39 @@ def test_host_side_shape_gates_of_the_round4_entry_points():
     for b, m, k, r in ((8, 256, 256, 1024), (8, 128, 259, 768), (2, 79, 128, 256), (8, 128, 131, 3072)):
         need = ws(b, m, k, r)
         assert need >= b * m * k and need % (m * k) == 0  # whole partial blocks, one per cloud at least
+
+
+def test_weight_reduction_queue_host_logic():
+    """The queue behind mlp_defer_weight_reductions is host state: with nothing queued, switching it
+    on and off launches nothing and returns 0 (no device needed), and the Python context restores
+    the immediate mode whatever happens inside it."""
+    pkg = load_pkg()
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(pkg.__file__), "lib3dioumatch_hip.so"))
+    assert lib.mlp_flush_weight_reductions() == 0
+    assert lib.mlp_defer_weight_reductions(1) == 0
+    assert lib.mlp_flush_weight_reductions() == 0
+    assert lib.mlp_defer_weight_reductions(0) == 0
+    K = importlib.import_module("pointnet2._mlp_ext")
+    with K.deferred_weight_reductions():
+        assert K._queued_workspaces == []
+        with K.deferred_weight_reductions():       # nested: the outer context owns the queue
+            assert K._queued_workspaces == []
+    assert K._queued_workspaces is None
+    with pytest.raises(RuntimeError):
+        with K.deferred_weight_reductions():
+            raise RuntimeError("inside")
+    assert K._queued_workspaces is None            # back to immediate launches
+    with K.deferred_weight_reductions(False):      # disabled: nothing is queued
+        assert K._queued_workspaces is None
+
+
+def test_pregather_path_steps_aside_on_the_cpu():
+    """SharedMLP.pregather_ok is False for CPU tensors (the module then groups and convolves as the
+    reference does), without touching the HIP library."""
+    import torch
+    load_pkg()
+    pt = importlib.import_module("pointnet2.pytorch_utils")
+    mlp = pt.SharedMLP([3 + 8, 16, 16], bn=True)
+    xyz, new_xyz, feats = torch.rand(2, 64, 3), torch.rand(2, 16, 3), torch.rand(2, 8, 64)
+    assert mlp.pregather_ok(xyz, new_xyz, feats, 16, 8) is False
+    assert mlp.pregather_ok(xyz, new_xyz, None, 16, 8) is False
