@@ -85,6 +85,7 @@ _SIGNATURES = {
     "mlp_gemm_forward_stats_pool_supported": [_c_int, _c_int, _c_int, _c_int, _c_int],
     "mlp_gemm_forward_stats_pool": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c_int,
                                     _vp, _vp, _vp],
+    "mlp_bn_reset_tickets": [],
     "mlp_bn_pool_from_extrema": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_wgrad_first4_workspace_bytes": [_c_int, _c_int],
     "mlp_wgrad_first4": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

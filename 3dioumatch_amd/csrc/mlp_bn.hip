@@ -600,18 +600,42 @@ int slices_for(int r) {
 // cannot allocate: it shares the default array, which is safe as long as that graph is not
 // replayed beside another user of the default array -- the train step runs these kernels on its
 // main stream only).
+namespace {
+struct TicketKey {
+  int device; hipStream_t stream;
+  bool operator==(const TicketKey &o) const { return device == o.device && stream == o.stream; }
+};
+struct TicketKeyHash {
+  size_t operator()(const TicketKey &k) const {
+    return std::hash<const void *>()(k.stream) * 31u + (size_t)k.device;
+  }
+};
+std::mutex ticket_mu;
+std::unordered_map<TicketKey, int *, TicketKeyHash> ticket_table;   // (device, stream) -> own array
+std::unordered_map<int, int *> ticket_fallback;                     // device -> its bn_tickets symbol
+}  // namespace
+
+// The arrays are per DEVICE (the __device__ symbol has one instance per device: its address is
+// resolved with that device current -- the launch that follows runs there) and per stream.
 static int *tickets_for(hipStream_t stream) {
-  static std::mutex mu;
-  static std::unordered_map<hipStream_t, int *> table;
-  static int *fallback = nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  if (fallback == nullptr && hipGetSymbolAddress(reinterpret_cast<void **>(&fallback), HIP_SYMBOL(bn_tickets)) != hipSuccess)
-    return nullptr;
+  std::lock_guard<std::mutex> lock(ticket_mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  int *fallback = nullptr;
+  auto fb = ticket_fallback.find(dev);
+  if (fb != ticket_fallback.end()) {
+    fallback = fb->second;
+  } else {
+    if (hipGetSymbolAddress(reinterpret_cast<void **>(&fallback), HIP_SYMBOL(bn_tickets)) != hipSuccess)
+      return nullptr;
+    ticket_fallback.emplace(dev, fallback);
+  }
   if (stream == nullptr) return fallback;
-  auto it = table.find(stream);
-  if (it != table.end()) return it->second;
+  const TicketKey key = {dev, stream};
+  auto it = ticket_table.find(key);
+  if (it != ticket_table.end()) return it->second;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone || table.size() >= 64)
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone || ticket_table.size() >= 256)
     return fallback;
   int *buf = nullptr;
   // cleared ON the stream that will use it: a hipMemset on the null stream is not ordered before a
@@ -623,11 +647,34 @@ static int *tickets_for(hipStream_t stream) {
     (void)hipFree(buf);
     return fallback;
   }
-  table.emplace(stream, buf);
+  ticket_table.emplace(key, buf);
   return buf;
 }
 
 #define MLP_API extern "C" __attribute__((visibility("default")))
+
+// Zero every ticket array of the CURRENT device (after a faulted / aborted launch left a counter
+// non-zero: no workgroup would ever be "last" again).  Synchronises the device.  Returns 0 or a
+// HIP error.
+MLP_API int mlp_bn_reset_tickets(void) {
+  std::lock_guard<std::mutex> lock(ticket_mu);
+  int dev = 0;
+  hipError_t rc = hipGetDevice(&dev);
+  if (rc != hipSuccess) return (int)rc;
+  rc = hipDeviceSynchronize();
+  if (rc != hipSuccess) return (int)rc;
+  auto fb = ticket_fallback.find(dev);
+  if (fb != ticket_fallback.end()) {
+    rc = hipMemset(fb->second, 0, sizeof(int) * kMaxTicketChannels);
+    if (rc != hipSuccess) return (int)rc;
+  }
+  for (auto &kv : ticket_table) {
+    if (kv.first.device != dev) continue;
+    rc = hipMemset(kv.second, 0, sizeof(int) * kMaxTicketChannels);
+    if (rc != hipSuccess) return (int)rc;
+  }
+  return (int)hipDeviceSynchronize();
+}
 
 // number of floats of scratch the statistics kernels need
 MLP_API size_t mlp_bn_workspace_floats(int b, int c, int r) {

@@ -615,7 +615,10 @@ MLP_API int mlp_gemm_backward_fused_stats_parts(int b, int m, int k, int r) {
 MLP_API size_t mlp_gemm_backward_fused_workspace_floats(int b, int m, int k, int r) {
   FusedShape s;
   if (!fused_shape(m, k, &s) || r % s.tn != 0) return 0;
-  return (size_t)fused_workgroups(s, (long long)b * (r / s.tn)) * m * k;
+  // (the bf16-split kernel of the (128,128) layers writes one partial per ITS workgroup count)
+  const long long g0 = fused_workgroups(s, (long long)b * (r / s.tn));
+  const long long g1 = mlp_bwd_x6_workgroups(b, m, k, r, fused_cus());
+  return (size_t)(g0 > g1 ? g0 : g1) * m * k;
 }
 
 // dq (b,k,r) = W^T * P[b] and dw (m,k) = sum_b P[b] * Q[b]^T in one pass.

@@ -288,6 +288,11 @@ def three_nn_weights(dist2):
     return out
 
 
+def group_inverse_supported(n, m, ns):
+    """Does group_inverse() cover index arrays (B,m,ns) over n points?"""
+    return bool(_lib.pn2_group_inverse_supported(int(n), int(m), int(ns)))
+
+
 def group_inverse(idx, n):
     """Inverse of a grouping index array idx (B,m,ns) i32 with values < n: the positions of each
     cloud sorted by the point they refer to, packed (point << 16 | position) -> (B, entries) int32

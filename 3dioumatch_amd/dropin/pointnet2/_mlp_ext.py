@@ -268,9 +268,13 @@ def gemm_dgrad(w, dy=None, fly=None, pooled=None):
 _queued_workspaces = None  # not None: weight-gradient reductions are queued (see below)
 
 
-def _keep_until_flush(ws):
+def _keep_until_flush(*tensors):
+    """While weight-gradient reductions are queued, both the partial-sum workspace AND the dw the
+    queued reduction will write must stay allocated until the flush: autograd may drop a dw nobody
+    accumulates (frozen weight) and the caching allocator would hand its block to a live tensor,
+    which the flush would then overwrite."""
     if _queued_workspaces is not None:
-        _queued_workspaces.append(ws)
+        _queued_workspaces.extend(t for t in tensors if t is not None)
 
 
 @contextlib.contextmanager
@@ -278,7 +282,10 @@ def deferred_weight_reductions(enabled=True):
     """Inside this context the reductions that finish gemm_wgrad / gemm_backward_fused are queued
     and run as ONE launch at exit (include/mlp_hip.h: mlp_defer_weight_reductions).  The returned
     dw tensors are undefined until then -- for a backward pass whose weight gradients nobody reads
-    before the context ends (the train step: loss.backward(), then the gradient packing)."""
+    before the context ends (the train step: loss.backward(), then the gradient packing).
+    Contract: inside the context every fused weight is used ONCE per backward pass and carries no
+    gradient hook (autograd would sum / hand out undefined data); a weight that is frozen or whose
+    gradient autograd drops is fine -- its dw stays allocated until the flush."""
     global _queued_workspaces
     if not enabled or _queued_workspaces is not None:
         yield
@@ -312,7 +319,7 @@ def gemm_wgrad(m, k, x, xcoeff=None, dy=None, fly=None, pooled=None):
     with torch.cuda.device(x.device):
         ws = torch.empty(max(int(_lib.mlp_gemm_wgrad_workspace_floats(b, m, k, r)), 1),
                          dtype=torch.float32, device=x.device)
-        _keep_until_flush(ws)
+        _keep_until_flush(ws, dw)
         if dy is not None:
             rc = _lib.mlp_gemm_wgrad(b, m, k, r, 0, dy.data_ptr(), None, None, None, None, None,
                                      None, None, 0 if xcoeff is None else 1, x.data_ptr(),
@@ -379,7 +386,7 @@ def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None, n
     with torch.cuda.device(x.device):
         ws = torch.empty(max(int(_lib.mlp_gemm_backward_fused_workspace_floats(b, m, k, r)), 1),
                          dtype=torch.float32, device=x.device)
-        _keep_until_flush(ws)
+        _keep_until_flush(ws, dw)
         sp = torch.empty((k, parts, 2), dtype=torch.float32, device=x.device) if parts else None
         _L.check(_lib.mlp_gemm_backward_fused(b, m, k, r, w.data_ptr(), pmode, y.data_ptr(),
                                               dz.data_ptr(), _ptr(argmax), ns, scale.data_ptr(),
@@ -426,7 +433,7 @@ def gemm_backward_small(w, x, xcoeff=None, dy=None, fly=None, need_dx=True):
     with torch.cuda.device(x.device):
         ws = torch.empty(max(int(_lib.mlp_gemm_wgrad_workspace_floats(b, m, k, r)), 1),
                          dtype=torch.float32, device=x.device)
-        _keep_until_flush(ws)
+        _keep_until_flush(ws, dw)
         _L.check(_lib.mlp_gemm_backward_small(b, m, k, r, w.data_ptr(), pmode, p0.data_ptr(),
                                               _ptr(pdz), _ptr(sc), _ptr(sh), _ptr(mean),
                                               _ptr(invstd), _ptr(coef), qmode, x.data_ptr(),
@@ -595,6 +602,10 @@ def pregather_backward(fly, inverse, n):
     y, dz, scale, shift, mean, invstd, coef = fly
     _f32c(y, "y"); _f32c(dz, "dz")
     b, c, m, ns = y.shape
+    if (inverse.dtype != torch.int32 or not inverse.is_contiguous() or inverse.device != y.device
+            or tuple(inverse.shape) != (b, int(_lib.pn2_group_inverse_entries(m, ns)))):
+        raise RuntimeError("inverse is not the int32 group_inverse() of a (B,%d,%d) index array on %s"
+                           % (m, ns, y.device))
     out = torch.empty((b, c, n + m), dtype=torch.float32, device=y.device)
     with torch.cuda.device(y.device):
         _L.check(_lib.mlp_pregather_backward(b, c, n, m, ns, y.data_ptr(), dz.data_ptr(),

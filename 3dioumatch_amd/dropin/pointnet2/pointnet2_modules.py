@@ -185,12 +185,20 @@ class PointnetSAModuleVotes(nn.Module):
                                                                         self.nsample, lists)
                 else:
                     ball_idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+            # the inverse index serves the backward only: no-grad passes (teacher, inference) skip its
+            # sort kernel; `False` = not built (the shape is inside the fast backward's range)
+            need_bwd = torch.is_grad_enabled() and (
+                features.requires_grad or xyz.requires_grad or new_xyz.requires_grad
+                or any(p.requires_grad for p in self.mlp_module.parameters()))
             if ball_inv is None:
-                ball_inv = pointnet2_utils._ext.group_inverse(ball_idx, xyz.shape[1])
+                if need_bwd:
+                    ball_inv = pointnet2_utils._ext.group_inverse(ball_idx, xyz.shape[1])
+                elif pointnet2_utils._ext.group_inverse_supported(xyz.shape[1], self.npoint, self.nsample):
+                    ball_inv = False
             if ball_inv is not None:
                 scale = 1.0 / self.radius if self.normalize_xyz else 1.0
-                return new_xyz, self.mlp_module.forward_pregathered(xyz, new_xyz, features, ball_idx,
-                                                                    ball_inv, scale), inds
+                return new_xyz, self.mlp_module.forward_pregathered(
+                    xyz, new_xyz, features, ball_idx, None if ball_inv is False else ball_inv, scale), inds
         if ball_idx is not None and isinstance(self.grouper, pointnet2_utils.QueryAndGroup):
             grouped = self.grouper(xyz, new_xyz, features, ball_idx, None, ball_inv)
         elif lists is not None:

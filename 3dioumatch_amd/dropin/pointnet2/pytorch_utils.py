@@ -274,7 +274,11 @@ class _FusedMLPChain(Function):
                 # gradient of z_ext = W_0 . src_ext: the BatchNorm / ReLU backward of (y_0, dz) formed
                 # on the fly, scatter-added over idx and summed per group; then two GEMMs over
                 # the n + m points
-                dzx = K.pregather_backward(fly, ctx.pre[1], ctx.pre[2])
+                inverse = ctx.pre[1]
+                if inverse is None:  # forward ran without it (no gradient expected then): build it now
+                    from pointnet2 import _ext
+                    inverse = _ext.group_inverse(ctx.pre[0], ctx.pre[2])
+                dzx = K.pregather_backward(fly, inverse, ctx.pre[2])
                 pair = K.gemm_backward_small(w2, x, None, dy=dzx, need_dx=need_dx)
                 if pair is not None:
                     dx, grads[0] = pair[0], pair[1].view_as(w)

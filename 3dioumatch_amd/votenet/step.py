@@ -736,3 +736,33 @@ def flat_grads(module):
 
 def flat_params(module):
     return torch.cat([p.detach().reshape(-1) for p in module.parameters()])
+
+
+def shift_invariant_parameter_names(net):
+    """Names of the parameters whose gradient is mathematically zero wherever the pooled maxima are
+    positive: the bias of the LAST BatchNorm of every max-pooling set-abstraction module.  A
+    constant shift of a pooled channel survives max / interpolation / concatenation unchanged and
+    is removed by the batch-statistics BatchNorm behind the next 1x1 convolution, so what the
+    backward pass computes for it is round-off of either sign -- which Adam's first steps turn into
+    +-lr moves (profiles/r4_step_repeatability.txt).  Multi-step equivalence tests freeze them
+    (freeze_shift_invariant_parameters) so that the rest can be held to a tight bound."""
+    names = []
+    for mod_name, mod in net.named_modules():
+        mlp = getattr(mod, "mlp_module", None)
+        if mlp is None or getattr(mod, "pooling", None) != "max" or len(mlp) == 0:
+            continue
+        last = len(mlp) - 1
+        names.append("%s.mlp_module.layer%d.bn.bn.bias" % (mod_name, last))
+    have = dict(net.named_parameters())
+    return [n for n in names if n in have]
+
+
+def freeze_shift_invariant_parameters(net):
+    """requires_grad_(False) on shift_invariant_parameter_names(net): autograd then returns no
+    gradient for them, the gradient packing substitutes zeros and Adam leaves them where they are.
+    Call before the first step of a runner (the HIP graphs bake the set in).  -> the names."""
+    names = shift_invariant_parameter_names(net)
+    have = dict(net.named_parameters())
+    for n in names:
+        have[n].requires_grad_(False)
+    return names

@@ -77,6 +77,12 @@ def parse():
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="compute the FPS chain inline instead of one step ahead on a side stream")
+    ap.add_argument("--rotate", type=int, default=4,
+                    help="K distinct batches (seeds 100 .. 100+K-1) kept in pinned host memory; batch "
+                         "i+2 is copied to the device on a copy stream while step i runs, INSIDE the "
+                         "timed region (what a training loop with a DataLoader does, "
+                         "pretrain.py:310-347).  `value` is measured on this loop; 0 = only the "
+                         "resident-batch loop of rounds 1-4 (then `value` = `value_resident`)")
     return ap.parse_args()
 
 
@@ -409,23 +415,93 @@ def main():
             raise RuntimeError("non-finite loss during the timed steps")
         return elapsed, views
 
+    def rotating_loop(step, host_batches, steps, warmup):
+        """The timed loop of a training run that FEEDS data: K distinct batches in pinned host
+        memory, three device-side input sets; iteration i copies batch i+2 host -> device on a
+        copy stream (its set was last read by step i-1), prefetches the index chain of batch i+1
+        and runs step i.  Also returns the host time per iteration measured in a second pass with
+        the device idle-waited between iterations (Python + launch time only)."""
+        k = len(host_batches)
+        copy_stream = torch.cuda.Stream(device=device)
+        main = torch.cuda.current_stream(device)
+        sets = [{key: torch.empty_like(v, device=device) for key, v in host_batches[0].items()}
+                for _ in range(3)]
+        filled = [torch.cuda.Event() for _ in range(3)]
+        consumed = [torch.cuda.Event() for _ in range(3)]
+        h2d_bytes = sum(v.numel() * v.element_size() for v in host_batches[0].values())
+
+        def upload(i):  # batch i -> set i % 3, after that set's last reader
+            slot = i % 3
+            copy_stream.wait_event(consumed[slot])
+            with torch.cuda.stream(copy_stream):
+                for key, v in host_batches[i % k].items():
+                    sets[slot][key].copy_(v, non_blocking=True)
+                filled[slot].record(copy_stream)
+
+        def one(i, history):
+            upload(i + 2)
+            if pipelined:
+                main.wait_event(filled[(i + 1) % 3])
+                step.prefetch(views[(i + 1) % 3])
+            main.wait_event(filled[i % 3])
+            loss = step(views[i % 3])
+            consumed[i % 3].record(main)
+            history[i].copy_(loss.detach())
+
+        for ev in consumed:
+            ev.record(main)
+        views = [dict(sets[j]) for j in range(3)]
+        if "supervised_mask" in host_batches[0]:
+            # which samples are labeled is host-side control flow baked into the graphs: hand the
+            # runner a host copy so it never reads the (rewritten) device tensor back
+            masks = [tuple(int(v) for v in hb["supervised_mask"].tolist()) for hb in host_batches]
+            assert all(m_ == masks[0] for m_ in masks), "the rotating batches must share one layout"
+            for v in views:
+                v["supervised_mask_host"] = masks[0]
+        upload(0)
+        upload(1)
+        main.wait_event(filled[0])
+        if pipelined:
+            step.prefetch(views[0])
+        history = torch.zeros(warmup + 2 * steps, device=device)
+        for i in range(warmup):
+            one(i, history)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(warmup, warmup + steps):
+            one(i, history)
+        fence()
+        elapsed = time.perf_counter() - t0
+        # host time per iteration: the same calls with the device drained between iterations, so the
+        # host never waits on a full queue -- what one rank's Python + launches cost per step
+        host = 0.0
+        for i in range(warmup + steps, warmup + 2 * steps):
+            t1 = time.perf_counter()
+            one(i, history)
+            host += time.perf_counter() - t1
+            torch.cuda.synchronize()
+        fence()
+        if not bool(torch.isfinite(history).all()):
+            raise RuntimeError("non-finite loss during the timed steps")
+        # leave the runner as the resident loop expects it: no prefetched slot pending
+        if pipelined:
+            step(views[(warmup + 2 * steps) % 3])
+            fence()
+        return elapsed, host / steps, h2d_bytes
+
+    rotate = max(0, args.rotate)
+    elapsed_rot = host_ms = h2d_bytes = None
+    if rotate > 0:
+        def make(seed):
+            if args.workload == "semi":
+                return data.make_semi_batch(SEMI_LABELED, SEMI_UNLABELED, NPTS, cfg, seed=seed)
+            return data.make_batch(scenes, npts, cfg, seed=seed)
+        host_batches = [{key: v.pin_memory() for key, v in make(100 + rank * rotate + j).items()
+                         if torch.is_tensor(v)} for j in range(rotate)]
+        elapsed_rot, host_s, h2d_bytes = rotating_loop(step, host_batches, args.steps, args.warmup)
+        host_ms = host_s * 1e3
     elapsed, views = timed_loop(step, batch, args.steps, args.warmup)
     rccl = None
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # what the N > 1 line needs to be checked from outside: the collective's backend, the
-        # width of the process group, which device every rank drove, the gradient all-reduce's
-        # device time (median over the warm-up + timed steps of rank 0)
-        mine = torch.tensor([torch.cuda.current_device()], dtype=torch.int64,
-                            device=device if args.backend == "nccl" else "cpu")
-        ids = [torch.zeros_like(mine) for _ in range(world)]
-        torch.distributed.all_gather(ids, mine)
-        rccl = step.runner.exchange_report()
-        rccl["ranks_device_ids"] = [int(i.item()) for i in ids]
-        rccl["ranks_share_one_gpu"] = os.environ.get("BENCH_SHARE_GPU") == "1"
-
     # the same step with the index chain inline (not part of `value`): what the one-step-ahead
     # prefetch of the coordinate-only chain hides
     ms_inline = None
@@ -440,16 +516,32 @@ def main():
         ms_inline = (time.perf_counter() - t1) * 1e3 / extra
 
     if rank == 0:
-        ms = elapsed * 1e3 / args.steps
+        ms_res = elapsed * 1e3 / args.steps
+        timed = elapsed_rot if elapsed_rot is not None else elapsed  # the loop `value` is quoted on
+        ms = timed * 1e3 / args.steps
         out = {
             "metric": "scenes/sec train-step (ScanNet 40k pts, 256 proposals)" if args.workload != "sunrgbd"
             else "scenes/sec train-step (SUN RGB-D 20k pts, 256 proposals)",
-            "value": round(scenes * world * args.steps / elapsed, 3), "unit": "scenes/s",
+            "value": round(scenes * world * args.steps / timed, 3), "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3),
+            # the loop of rounds 1-4: ONE batch resident in HBM, replayed (no host -> device copy)
+            "value_resident": round(scenes * world * args.steps / elapsed, 3),
+            "ms_per_step_resident": round(ms_res, 3),
+            "rotate": rotate,
+            "host_ms_per_step": None if host_ms is None else round(host_ms, 3),
+            "h2d_bytes_per_step": h2d_bytes,
+            "timed_loop": ("%d distinct batches (seeds %d..%d) in pinned host memory, batch i+2 copied "
+                           "host -> device on a copy stream inside the timed region, index chain of "
+                           "batch i+1 prefetched, step i" % (rotate, 100 + rank * rotate,
+                                                             100 + rank * rotate + rotate - 1))
+            if rotate > 0 else "one batch resident in HBM, replayed",
             "ms_per_step_no_prefetch": None if ms_inline is None else round(ms_inline, 3),
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32",
+            "products": "3xbf16 split: every fp32 product of the shared-MLP GEMMs = 6 x "
+                        "v_mfma_f32_32x32x16_bf16 on an exact three-term split, fp32 accumulate",
+            "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload],
                        "per_gpu_batch": scenes, "global_batch": scenes * world, "num_points": npts,
                        "num_proposals": KPROP, "parallelism": "dp%d" % world,

@@ -172,6 +172,11 @@ int mlp_gemm_forward_stats_pool_supported(int b, int m, int k, int r, int ns);
 int mlp_gemm_forward_stats_pool(int b, int m, int k, int r, const float *w, const float *x,
                                 const float *scale, const float *shift, float *y, float *pairs,
                                 int ns, const float *gamma, float *ext, void *stream);
+/* Zero the "last workgroup finalizes" ticket counters of the current device (every stream's
+ * array) after a faulted or aborted launch left one non-zero; synchronises the device.  The
+ * reductions stand in for nn.BatchNorm2d's statistics (pytorch_utils.py:42-67); no reference
+ * counterpart. */
+int mlp_bn_reset_tickets(void);
 /* pooled, argmax, ymax (b,c,groups) as mlp_bn_relu_pool returns them, from ext
  * (replaces F.max_pool2d of pointnet2_modules.py:256-262 after BatchNorm + ReLU) */
 int mlp_bn_pool_from_extrema(int b, int c, int groups, const float *ext, const float *scale,

@@ -27,6 +27,12 @@ def test_bench_default_line_has_roofline_and_cpu_baseline():
     assert d["unit"] == "scenes/s" and d["value"] > 0 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
     assert abs(d["value"] - 8 * 1000.0 / d["ms_per_step"]) <= 0.02 * d["value"]
+    # `value` is measured on the loop that FEEDS data (--rotate 4: distinct batches from pinned host
+    # memory, the copy inside the timed region); the resident-batch loop of rounds 1-4 rides along
+    assert d["rotate"] == 4 and d["h2d_bytes_per_step"] > 8 * 40000 * 16
+    assert abs(d["value_resident"] - 8 * 1000.0 / d["ms_per_step_resident"]) <= 0.02 * d["value_resident"]
+    assert 0.7 * d["value_resident"] < d["value"] < 1.3 * d["value_resident"]
+    assert 0 < d["host_ms_per_step"] < 20 and "bf16" in d["products"]
     assert d["config"]["hip_graphs"] is True and "workload" in d["config"]
     roof = d["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
@@ -72,7 +78,7 @@ def test_bench_default_line_has_roofline_and_cpu_baseline():
 @pytest.mark.parametrize("workload,scenes", [("semi", 12), ("sunrgbd", 16)])
 def test_bench_other_workloads(workload, scenes):
     d = _run("--workload", workload, "--no-kernels", "--no-cpu-baseline")
-    assert "workloads" not in d
+    assert "workloads" not in d and d["rotate"] == 4 and d["host_ms_per_step"] > 0
     assert REQUIRED <= set(d) and d["config"]["per_gpu_batch"] == scenes
     assert d["config"]["hip_graphs"] is True and d["value"] > 0
 
@@ -97,7 +103,10 @@ def test_bench_two_ranks_line_is_self_verifying():
     rc = d["rccl"]
     assert rc["backend"] == "gloo" and rc["world_size"] == 2 and rc["ranks_device_ids"] == [0, 0]
     assert rc["ranks_share_one_gpu"] is True and rc["bytes"] > 4_000_000 and rc["in_graph"] is False
-    assert rc["samples"] == 4 and rc["allreduce_us"] > 0
+    # every step's all-reduce was timed: the feeding loop (1 warm-up + 3 timed + 3 host-time steps
+    # + the one that consumes the last prefetch) and the resident loop (1 + 3)
+    assert rc["samples"] == 8 + 4 and rc["allreduce_us"] > 0
+    assert d["rotate"] == 4 and d["value"] > 0 and d["value_resident"] > 0 and d["host_ms_per_step"] > 0
     # a process group narrower than --gpus is refused
     bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port + 1),

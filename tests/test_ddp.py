@@ -229,9 +229,14 @@ def _gpu_graph_worker(rank, world, port, out_dir, semi):
             unl = importlib.import_module("3dioumatch_amd.votenet.losses_unlabeled")
             filt = unl.default_config_dict(cfg, unlabeled_batch_size=2)
             filt.update(obj_threshold=0.3, cls_threshold=0.03, iou_threshold=0.2)
-            return V.SemiSupervisedStep(cfg, dev, world_size=w, num_proposal=K, graphs=graphs,
-                                        config_dict=filt)
-        return V.SupervisedStep(cfg, dev, world_size=w, num_proposal=K, graphs=graphs)
+            runner = V.SemiSupervisedStep(cfg, dev, world_size=w, num_proposal=K, graphs=graphs,
+                                          config_dict=filt)
+        else:
+            runner = V.SupervisedStep(cfg, dev, world_size=w, num_proposal=K, graphs=graphs)
+        # the parameters whose gradient is mathematically zero stay put (both arms): Adam would turn
+        # their round-off into +-lr moves of either sign and the multi-step comparison into noise
+        step_mod.freeze_shift_invariant_parameters(runner.net)
+        return runner
 
     out = {}
     for name, graphs in (("graph", True), ("eager", False)):
@@ -272,16 +277,14 @@ def test_graph_step_two_ranks_share_one_gpu(tmp_path, semi):
     assert np.array_equal(r[0]["graph_grad"], r[1]["graph_grad"])
     rel = lambda a, b: np.linalg.norm(a - b) / max(1e-12, np.linalg.norm(b))  # noqa: E731
     # graph replay == eager launches: the exchanged gradient of step 0 (same weights) agrees to
-    # the reordering of atomic sums; after three Adam steps the weights agree to what Adam makes
-    # of that (the sign of a near-zero gradient is a full +-lr step: bounded, not tiny)
+    # the reordering of atomic sums; with the zero-gradient parameters frozen
+    # (step.freeze_shift_invariant_parameters: the last BatchNorm bias of every pooling module,
+    # profiles/r4_step_repeatability.txt) the weights after three Adam steps agree too
     assert rel(r[0]["graph_grad"], r[0]["eager_grad"]) < 1e-4
     lr = 2e-3 if semi else 1e-3
     assert np.abs(r[0]["graph_params"] - r[0]["eager_params"]).max() <= 3 * 3 * lr
-    # (relative L2: usually ~1e-3; 3.8e-3 after two steps and 5.7e-3 after three were seen -- each
-    # sign flip of a mathematically-zero gradient is worth 2*lr on that parameter and moves the
-    # next step's gradient, profiles/r4_step_repeatability.txt; the per-element bound above is
-    # the principled one)
-    assert rel(r[0]["graph_params"], r[0]["eager_params"]) < 3e-2
+    print("params after 3 steps, graph vs eager: rel %.2e" % rel(r[0]["graph_params"], r[0]["eager_params"]))
+    assert rel(r[0]["graph_params"], r[0]["eager_params"]) < 1e-2
     want = (r[0]["single_grad"] + r[1]["single_grad"]) / 2
     assert rel(r[0]["graph_grad"], want) < 1e-4, rel(r[0]["graph_grad"], want)
     # ... and for EVERY parameter tensor, not only in the global norm: a wrong 1/world (or a tensor
@@ -316,6 +319,7 @@ def _rccl_worker(rank, world, port, out_dir):
         if with_group and not dist.is_initialized():
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         runner = V.SupervisedStep(cfg, dev, world_size=1, num_proposal=K, graphs=True)
+        importlib.import_module("3dioumatch_amd.votenet.step").freeze_shift_invariant_parameters(runner.net)
         runner.exchange_always = with_group
         runner.time_exchange = name == "rccl"
         runner.capture_exchange = name == "rccl_in_graph"  # the all-reduce as the first node of G2
@@ -353,7 +357,8 @@ def test_graph_step_with_a_one_rank_rccl_group(tmp_path):
     assert np.abs(r["rccl_losses"][0] - r["plain_losses"][0]) <= 1e-4 * abs(r["plain_losses"][0])
     assert np.abs(r["rccl_params"] - r["plain_params"]).max() <= 5 * 3 * 1e-3
     rel = np.linalg.norm(r["rccl_params"] - r["plain_params"]) / np.linalg.norm(r["plain_params"])
-    assert rel < 3e-2, rel  # (sign flips of zero-gradient parameters: profiles/r4_step_repeatability.txt)
+    print("params after 5 steps, one-rank rccl vs no group: rel %.2e" % rel)
+    assert rel < 1e-2, rel  # (the zero-gradient parameters are frozen in both arms)
     # the eager all-reduce was timed (events on the launching stream) ...
     assert int(r["rccl_in_graph"][0]) == 0 and float(r["rccl_us"][0]) > 0
     # ... and the opt-in form with the collective captured at the head of G2 runs the same step

@@ -617,6 +617,42 @@ def test_queued_weight_gradient_reductions_equal_immediate_ones():
         assert torch.equal(a, b)
 
 
+def test_deferred_reductions_with_a_frozen_weight():
+    """A SharedMLP whose middle convolution is frozen (requires_grad False) under
+    deferred_weight_reductions(): autograd drops that layer's dw as soon as the backward returns
+    it, the queued reduction still writes it at the flush -- so the tensor must stay allocated
+    until then (the caching allocator would otherwise hand the block to a live tensor
+    and the flush would overwrite it).  Everything else equals the immediate form bit for bit."""
+    pt = _mods()
+    K = importlib.import_module("pointnet2._mlp_ext")
+    torch.manual_seed(11)
+    mlp = pt.SharedMLP([128, 128, 128, 256], bn=True).to(DEV).train()
+    mlp[1].conv.weight.requires_grad_(False)
+    x0 = torch.randn(4, 128, 512, 32, device=DEV)
+    wgt = torch.randn(4, 256, 512, device=DEV)
+
+    def run(deferred):
+        x = x0.clone().requires_grad_(True)
+        mlp.zero_grad()
+        out = mlp.forward_pooled(x)
+        held = []
+        with K.deferred_weight_reductions(deferred):
+            (out * wgt).sum().backward()
+            # allocations while the reductions are still queued: each would receive the block of a
+            # dropped dw if it had been freed (128 x 128 floats = the frozen layer's gradient)
+            held = [torch.full((128, 128), 7.0, device=DEV) for _ in range(64)]
+        torch.cuda.synchronize()
+        assert all(bool((t == 7.0).all()) for t in held)
+        grads = [p.grad.clone() for p in mlp.parameters() if p.grad is not None]
+        return [x.grad.clone()] + grads
+
+    want, got = run(False), run(True)
+    assert mlp[1].conv.weight.grad is None
+    assert len(want) == len(got)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("b,n,c,m,ns,widths,scale,training", [
     (2, 2048, 128, 1024, 32, (128, 128, 256), 1.0, True),
     (3, 1024, 256, 512, 16, (128, 128, 256), 1.0 / 0.8, True),

@@ -89,6 +89,8 @@ def test_semi_graph_replay_matches_eager(oracle_omp, monkeypatch):
     for graphs in (False, True):
         runner = V.SemiSupervisedStep(cfg, dev, num_proposal=K, seed=4, graphs=graphs,
                                       config_dict=_loose_filter(V, cfg))
+        # (the zero-gradient parameters stay put in both arms: profiles/r4_step_repeatability.txt)
+        step_mod.freeze_shift_invariant_parameters(runner.net)
         torch.manual_seed(9)
         torch.cuda.manual_seed_all(9)
         first, second = dict(batches[0]), dict(batches[1])
@@ -107,10 +109,11 @@ def test_semi_graph_replay_matches_eager(oracle_omp, monkeypatch):
     assert abs(eager[0] - graph[0]) <= 1e-5 * max(1.0, abs(eager[0]))
     assert abs(eager[1] - graph[1]) <= 4e-2 * max(1.0, abs(eager[1]))
     assert float((eager[3] - graph[3]).abs().max()) <= 1.2e-2  # two Adam steps of lr 2e-3
-    # Adam turns the rounding noise of (mathematically) zero gradients into +-lr steps whose signs
-    # differ from run to run (scatter-add order); the bound is ~2x what those parameters can add
-    assert float((eager[3] - graph[3]).norm() / eager[3].norm()) < 3e-2  # (profiles/r4_step_repeatability.txt)
-    assert float((eager[4] - graph[4]).norm() / eager[4].norm()) < 3e-2
+    print("semi params after 2 steps, graph vs eager: student %.2e teacher %.2e" % (
+        float((eager[3] - graph[3]).norm() / eager[3].norm()),
+        float((eager[4] - graph[4]).norm() / eager[4].norm())))
+    assert float((eager[3] - graph[3]).norm() / eager[3].norm()) < 1.2e-2
+    assert float((eager[4] - graph[4]).norm() / eager[4].norm()) < 1.2e-2
     # teacher BN running mean: after step 0 the teacher IS the student (EMA weight 0), whose
     # pre-BatchNorm biases carry the +-lr sign noise above; a bias moves the batch mean one to
     # one and the running mean by momentum (0.1) of that: 0.1 * 2 * lr = 4e-4

@@ -201,6 +201,14 @@ def test_graph_replay_matches_eager(oracle_omp):
     for graphs in (False, True):
         runner = V.SupervisedStep(cfg, dev, world_size=1, num_proposal=K, seed=3, graphs=graphs)
         assert runner.graphs == graphs
+        # Parameters with a mathematically ZERO gradient (the bias of a pooling module's last
+        # BatchNorm: a constant shift passes max / interpolation and is removed by the next
+        # BatchNorm) receive round-off of either sign, which Adam's first step turns into +-lr and
+        # the second step's gradient into one of a few populations
+        # (profiles/r4_step_repeatability.txt).  Frozen in both arms, the steps AFTER the first can
+        # be compared as tightly as the first.
+        frozen = step_mod.freeze_shift_invariant_parameters(runner.net)
+        assert len(frozen) == 5
         torch.manual_seed(9)
         torch.cuda.manual_seed_all(9)
         first, second = dict(batches[0]), dict(batches[1])
@@ -214,7 +222,8 @@ def test_graph_replay_matches_eager(oracle_omp):
         results.append((loss0, float(loss1), inds0, ep1["aggregated_vote_inds"].cpu().clone(),
                         step_mod.flat_params(runner.net).cpu(), step_mod.flat_grads(runner.net).cpu(),
                         runner.net.backbone_net.sa1.mlp_module.layer0.bn.bn.running_mean.cpu().clone(),
-                        int(runner.net.pnet.bn1.num_batches_tracked), grads0))
+                        int(runner.net.pnet.bn1.num_batches_tracked), grads0,
+                        [(n, b.detach().cpu().clone()) for n, b in runner.net.named_buffers()]))
     eager, graph = results
     assert torch.equal(eager[2], graph[2]) and torch.equal(eager[3], graph[3])
     assert abs(eager[0] - graph[0]) <= 1e-5 * max(1.0, abs(eager[0]))
@@ -222,19 +231,18 @@ def test_graph_replay_matches_eager(oracle_omp):
     # same weights, same batch: the replayed graph's gradient IS the eager one up to the order of
     # the fp32 atomics (measured 6e-7)
     assert float((eager[8] - graph[8]).norm() / eager[8].norm()) < 1e-5
-    # After an Adam step the comparison is no longer a kernel check.  Some parameters have a
-    # mathematically ZERO gradient -- e.g. the bias of SA4's last BatchNorm on channels whose pooled
-    # maxima are positive: a constant shift of such a channel passes the interpolation and is
-    # removed by the next BatchNorm -- so what is computed for them is round-off, and Adam's first
-    # step turns round-off of either sign into a full +-lr move.  Measured with
-    # tools/step_repeatability.py (two EAGER runs against each other, every build switch on or off,
-    # labels identical, loss equal to 1e-5): after step 1 only that bias differs (by 2 lr on some
-    # channels); the second step's gradient then lands in one of a few populations, 1e-3 apart
-    # inside a population and 0.16 ... 0.86 (relative L2) between them.  So the second step is held
-    # to its loss and to bounded parameters only:
-    assert bool(torch.isfinite(graph[5]).all())
+    # the second step (after an Adam update, on another batch): gradient, parameters and the
+    # running statistics agree as the first step's do
+    g2 = float((eager[5] - graph[5]).norm() / eager[5].norm())
+    p2 = float((eager[4] - graph[4]).norm() / eager[4].norm())
+    print("graph vs eager: step-2 gradient rel %.2e, params after 2 steps rel %.2e" % (g2, p2))
+    assert g2 < 5e-2, g2
     assert float((eager[4] - graph[4]).abs().max()) <= 6e-3  # two Adam steps of lr 1e-3
-    assert float((eager[4] - graph[4]).norm() / eager[4].norm()) < 1e-2
+    assert p2 < 1e-2, p2
+    for key in ("running_mean", "running_var"):
+        for (n_e, b_e), (_, b_g) in zip(eager[9], graph[9]):
+            if n_e.endswith(key):
+                assert torch.allclose(b_e, b_g, rtol=2e-3, atol=2e-5), n_e
     assert torch.allclose(eager[6], graph[6], rtol=1e-4, atol=1e-6)
     assert eager[7] == graph[7] == 2
 
