@@ -536,6 +536,69 @@ def gemm_forward_bn_lin4(w, x4, w1, coeff1, gamma, beta, running_mean, running_v
     return y, out[0], out[1], out[2], out[3]
 
 
+def chain_lin4_supported(w0, w1, w2, x4, ns):
+    """Can layers 2 and 3 of a 4 -> 64 -> 64 -> 128 module run as ONE register-chained kernel
+    (csrc/mlp_chain.hip) on x4 (B,4,m,ns)?"""
+    if os.environ.get("MLP_CHAIN_FWD", "1") == "0":
+        return False
+    if tuple(w0.shape) != (64, 4) or tuple(w1.shape) != (64, 64) or tuple(w2.shape) != (128, 64):
+        return False
+    if x4.dim() != 4 or x4.shape[1] != 4 or x4.shape[3] != ns:
+        return False
+    if any(w.data_ptr() % 16 for w in (w0, w1, w2)):
+        return False
+    b = x4.shape[0]
+    r = x4.numel() // (b * 4)
+    return int(_lib.mlp_chain_lin4_parts(b, r, 128, int(ns), None)) > 0
+
+
+def chain_lin4_forward(x4, w0, coeff0, layer1, layer2, store=True):
+    """Layers 2 and 3 of a 4 -> 64 -> 64 -> 128 set-abstraction MLP in training mode, chained in
+    registers.  x4 (B,4,m,ns); w0 (64,4) and coeff0 = (scale, shift) of the virtual first layer;
+    layerN = (w, gamma, beta, running_mean, running_var, momentum, eps).
+    -> (y of layer 1 (B,64,m,ns), its (mean, invstd, scale, shift), y of layer 2 (B,128,m,ns), its
+    coefficients, ext = the extrema planes for pool_from_extrema); store=False: the y are None."""
+    _f32c(x4, "x4"); _f32c(w0, "w0")
+    b, _, m, ns = x4.shape
+    r = m * ns
+    w1, g1, be1, rm1, rv1, mom1, eps1 = layer1
+    w2, g2, be2, rm2, rv2, mom2, eps2 = layer2
+    _f32c(w1, "w1"); _f32c(w2, "w2")
+    import ctypes
+    cols = ctypes.c_int(0)
+    parts = int(_lib.mlp_chain_lin4_parts(b, r, 128, ns, ctypes.byref(cols)))
+    if parts <= 0:
+        raise RuntimeError("chain_lin4_forward: shape not covered")
+    dev = x4.device
+    pairs1 = torch.empty((parts, 64, 2), dtype=torch.float32, device=dev)
+    pairs2 = torch.empty((parts, 128, 2), dtype=torch.float32, device=dev)
+    img = torch.empty(int(_lib.mlp_chain_lin4_image_bytes()), dtype=torch.uint8, device=dev)
+    out1 = torch.empty((4, 64), dtype=torch.float32, device=dev)
+    out2 = torch.empty((4, 128), dtype=torch.float32, device=dev)
+    y1 = torch.empty((b, 64, m, ns), dtype=torch.float32, device=dev) if store else None
+    y2 = torch.empty((b, 128, m, ns), dtype=torch.float32, device=dev) if store else None
+    ext = torch.empty((2, b, 128, m), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = _stream(x4)
+        _L.check(_lib.mlp_chain_lin4_prepare(w0.data_ptr(), coeff0[0].data_ptr(), coeff0[1].data_ptr(),
+                                             w1.data_ptr(), w2.data_ptr(), img.data_ptr(), st),
+                 "mlp_chain_lin4_prepare")
+        _L.check(_lib.mlp_chain_lin4_stats(b, r, ns, x4.data_ptr(), img.data_ptr(), pairs1.data_ptr(), st),
+                 "mlp_chain_lin4_stats")
+        _L.check(_lib.mlp_chain_finalize(64, parts, cols.value, pairs1.data_ptr(), g1.data_ptr(),
+                                         be1.data_ptr(), float(eps1), float(mom1), _ptr(rm1), _ptr(rv1),
+                                         out1[0].data_ptr(), out1[1].data_ptr(), out1[2].data_ptr(),
+                                         out1[3].data_ptr(), st), "mlp_chain_finalize")
+        _L.check(_lib.mlp_chain_lin4_forward(b, r, ns, x4.data_ptr(), img.data_ptr(), out1[2].data_ptr(),
+                                             out1[3].data_ptr(), g2.data_ptr(), _ptr(y1), _ptr(y2),
+                                             pairs2.data_ptr(), ext.data_ptr(), st), "mlp_chain_lin4_forward")
+        _L.check(_lib.mlp_chain_finalize(128, parts, cols.value, pairs2.data_ptr(), g2.data_ptr(),
+                                         be2.data_ptr(), float(eps2), float(mom2), _ptr(rm2), _ptr(rv2),
+                                         out2[0].data_ptr(), out2[1].data_ptr(), out2[2].data_ptr(),
+                                         out2[3].data_ptr(), st), "mlp_chain_finalize")
+    return y1, (out1[0], out1[1], out1[2], out1[3]), y2, (out2[0], out2[1], out2[2], out2[3]), ext
+
+
 # ---- first layer of a set-abstraction module applied before the gather (csrc/mlp_pregather.hip) ----
 def pregather_supported(b, c, n, m, ns):
     return bool(_lib.mlp_pregather_supported(int(b), int(c), int(n), int(m), int(ns)))

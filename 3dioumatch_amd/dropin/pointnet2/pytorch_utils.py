@@ -166,10 +166,28 @@ class _FusedMLPChain(Function):
         virtual0 = (training and n_layers >= 3 and x.dim() == 4 and not ctx.needs_input_grad[0]
                     and K.lin4_supported(params[0].reshape(params[0].shape[0], -1),
                                          params[5].reshape(params[5].shape[0], -1), x))
+        # ... and layers 2 + 3 of that module (64 -> 64 -> 128, max-pooled) run as ONE register-chained
+        # kernel (csrc/mlp_chain.hip): layer 2's activation never leaves the registers, statistics
+        # and pooled extrema are in-lane reductions of the second GEMM's accumulators
+        chained = (virtual0 and pool and n_layers == 3 and
+                   K.chain_lin4_supported(params[0].reshape(params[0].shape[0], -1),
+                                          params[5].reshape(params[5].shape[0], -1),
+                                          params[10].reshape(params[10].shape[0], -1), x, x.shape[3]))
+        ext = None
         for i in range(n_layers):
             w, gamma, beta, rm, rv = params[5 * i:5 * i + 5]
             w2 = w.reshape(w.shape[0], -1)
-            ext = None
+            if chained and i >= 1:
+                if i == 2:
+                    continue
+                w0 = params[0].reshape(params[0].shape[0], -1)
+                lay = [(params[5 * q].reshape(params[5 * q].shape[0], -1),) + tuple(params[5 * q + 1:5 * q + 5])
+                       + (momenta[q], epss[q]) for q in (1, 2)]
+                y1, c1, y2, c2, ext = K.chain_lin4_forward(x, w0, cur_coeff, lay[0], lay[1])
+                ys += [y1, y2]
+                coefs += [c1, c2]
+                cur, cur_coeff = y2, (c2[2], c2[3])
+                continue
             if pre is not None and i == 0:
                 idx, _, npts = pre
                 z = K.gemm_forward(w2, x)  # over the n + m points, not the m * ns gathered columns

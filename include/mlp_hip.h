@@ -172,6 +172,39 @@ int mlp_gemm_forward_stats_pool_supported(int b, int m, int k, int r, int ns);
 int mlp_gemm_forward_stats_pool(int b, int m, int k, int r, const float *w, const float *x,
                                 const float *scale, const float *shift, float *y, float *pairs,
                                 int ns, const float *gamma, float *ext, void *stream);
+/* ---- a set-abstraction module's shared MLP as a register chain (csrc/mlp_chain.hip) -----------
+ * conv(1x1) -> BatchNorm -> ReLU -> conv(1x1) -> [statistics, max over nsample] for the SA1 shape
+ * 4 -> 64 -> 64 -> 128 (pytorch_utils.py:14-39,70-124; the max-pool of pointnet2_modules.py:256-262):
+ * layer 2's activation never leaves the registers between the two GEMMs, BatchNorm statistics and
+ * the pooled extrema are in-lane reductions of the second GEMM's accumulators.
+ * A workgroup covers 256 columns (4 waves x 2 tiles of 32): many small workgroups, one equal-count
+ * (mean, M2) pair per workgroup and channel.
+ * mlp_chain_lin4_parts: pairs per channel of a pass and the columns each covers; 0 = shape not
+ * covered (m3 = 128, ns 16 / 32 / 64, r % 256 == 0). */
+int mlp_chain_lin4_parts(int b, int r, int m3, int ns, int *cols_per_part);
+/* bytes of the weight-image scratch of mlp_chain_lin4_prepare (nn.Conv2d weights of
+ * pytorch_utils.py:70-124 as fragment-ordered bf16 images) */
+size_t mlp_chain_lin4_image_bytes(void);
+/* once per forward: w1 (64,4), sc1 / sh1 (64: layer 1's BatchNorm, mlp_first4_bn), w2 (64,64),
+ * w3 (128,64) -> img (16-byte aligned, mlp_chain_lin4_image_bytes()); the conv weights of
+ * pytorch_utils.py:14-39 */
+int mlp_chain_lin4_prepare(const float *w1, const float *sc1, const float *sh1, const float *w2,
+                           const float *w3, void *img, void *stream);
+/* statistics pass: pairs2 (parts, 64, 2) of y2 = w2 . relu(bn1(w1 . x4)), x4 (b,4,r); nothing else
+ * is written (the BatchNorm of pytorch_utils.py:42-67 needs them before layer 2's ReLU) */
+int mlp_chain_lin4_stats(int b, int r, int ns, const float *x4, const void *img, float *pairs2,
+                         void *stream);
+/* full pass: y2 (b,64,r) and y3 (b,128,r) (either may be NULL), pairs3 (parts,128,2), ext = 2 planes
+ * of (b,128,r/ns) as mlp_gemm_forward_stats_pool leaves them (pointnet2_modules.py:256-262) */
+int mlp_chain_lin4_forward(int b, int r, int ns, const float *x4, const void *img, const float *sc2,
+                           const float *sh2, const float *gamma3, float *y2, float *y3, float *pairs3,
+                           float *ext, void *stream);
+/* training-mode BatchNorm coefficients + running statistics of c channels from a pass's equal-count
+ * pairs, n_part columns each (nn.BatchNorm2d inside pytorch_utils.py:42-67) */
+int mlp_chain_finalize(int c, int parts, int n_part, const float *pairs, const float *gamma,
+                       const float *beta, float eps, float momentum, float *running_mean,
+                       float *running_var, float *mean, float *invstd, float *scale, float *shift,
+                       void *stream);
 /* Zero the "last workgroup finalizes" ticket counters of the current device (every stream's
  * array) after a faulted or aborted launch left one non-zero; synchronises the device.  The
  * reductions stand in for nn.BatchNorm2d's statistics (pytorch_utils.py:42-67); no reference
