@@ -176,7 +176,6 @@ __global__ void __launch_bounds__(256, FULL ? 2 : 4) chain_lin4_kernel(const Cha
   const float2 *c2h = c2tab + 4 * h;
   const char *w2lane = w2img + (h * M2 + l31) * 16;
   const char *w3lane = w3img + (h * M3 + l31) * 16;
-  const int gwave = (int)blockIdx.x * 4 + wave;
   constexpr int CB = FULL ? M3B : 2;  // channel blocks whose statistics this pass leaves
   RunStat st[CB];
 #pragma unroll

@@ -672,9 +672,26 @@ class SemiSupervisedStep(SupervisedStep):
     # the BN-momentum schedule touches the student only (train.py:234-237): inherited set_epoch
     # walks self.net
 
+    # The index chain depends on coordinates only -- not on either network's weights -- and its
+    # sampling kernels run ONE workgroup per cloud for ~3 ms: the student's (labeled + unlabeled) and
+    # the teacher's (unlabeled, other augmentation) clouds go through ONE chain of launches, side by
+    # side on 20 CUs, instead of two chains back to back (5.6 ms of fps_bucket_rounds per step).
+    batch_chains = os.environ.get("STEP_SEMI_ONE_CHAIN", "1") != "0"
+
     def _compute_geometry(self, inputs):
+        pc, ema = inputs["point_clouds"], inputs["ema_point_clouds"]
+        if self.batch_chains and pc.shape[1:] == ema.shape[1:] and pc.dtype == ema.dtype:
+            nb = pc.shape[0]
+            both = self.net.compute_geometry({"point_clouds": torch.cat([pc, ema], dim=0)})
+            geometry = {}
+            for k, v in both.items():
+                if not torch.is_tensor(v) or v.dim() == 0 or v.shape[0] != nb + ema.shape[0]:
+                    raise RuntimeError("geometry entry %r is not batched along dim 0" % k)
+                geometry[k] = v[:nb]
+                geometry["ema_" + k] = v[nb:]
+            return geometry
         geometry = dict(self.net.compute_geometry(inputs))
-        teacher = self.teacher.compute_geometry({"point_clouds": inputs["ema_point_clouds"]})
+        teacher = self.teacher.compute_geometry({"point_clouds": ema})
         geometry.update({"ema_" + k: v for k, v in teacher.items()})
         return geometry
 

@@ -208,7 +208,7 @@ def test_pooled_operand_mode_vs_materialised(b, m, k, groups, ns):
 
 
 @pytest.mark.parametrize("b,m,k,groups,ns,pooled", [
-    (2, 64, 64, 40, 64, False), (2, 128, 64, 36, 64, True), (3, 128, 128, 25, 32, False),
+    (2, 64, 64, 40, 64, False), (2, 128, 64, 36, 64, True), (3, 128, 64, 301, 64, True), (3, 128, 128, 25, 32, False),
     (2, 256, 128, 33, 32, True), (2, 128, 131, 40, 32, False), (5, 128, 259, 26, 16, False),
     (8, 128, 128, 512, 16, False), (1, 256, 128, 2048, 16, True), (2, 128, 128, 64, 64, True),
     (3, 128, 128, 256, 16, True)])
