@@ -107,11 +107,16 @@ def bn_relu_pool_backward(y, dpooled, argmax, ymax, gamma, scale, shift, mean, i
 
 
 def bn_relu_pool_backward_stats(y, dpooled, argmax, ymax, gamma, scale, shift, mean, invstd,
-                                training):
+                                training, ns=None):
     """-> dgamma, dbeta, coef (C,3) of the pooled last layer; dy itself is formed inside
-    gemm_dgrad / gemm_wgrad (pooled=...)."""
+    gemm_dgrad / gemm_wgrad (pooled=...).  y is only asked for its shape (B,C,m,ns): with ns given
+    it may be None (a layer whose raw output was never stored)."""
     _f32c(dpooled, "dpooled")
-    b, c, m, ns = y.shape
+    if ns is not None:
+        b, c, m = dpooled.shape
+        y = dpooled  # (never read: the statistics come from the pooled tensors)
+    else:
+        b, c, m, ns = y.shape
     small = torch.empty((5, c), dtype=torch.float32, device=y.device)
     with torch.cuda.device(y.device):
         ws = _ws(y, b, c, m)
@@ -552,12 +557,14 @@ def chain_lin4_supported(w0, w1, w2, x4, ns):
     return int(_lib.mlp_chain_lin4_parts(b, r, 128, int(ns), None)) > 0
 
 
-def chain_lin4_forward(x4, w0, coeff0, layer1, layer2, store=True):
+def chain_lin4_forward(x4, w0, coeff0, layer1, layer2, store=True, store_last=True):
     """Layers 2 and 3 of a 4 -> 64 -> 64 -> 128 set-abstraction MLP in training mode, chained in
     registers.  x4 (B,4,m,ns); w0 (64,4) and coeff0 = (scale, shift) of the virtual first layer;
     layerN = (w, gamma, beta, running_mean, running_var, momentum, eps).
     -> (y of layer 1 (B,64,m,ns), its (mean, invstd, scale, shift), y of layer 2 (B,128,m,ns), its
-    coefficients, ext = the extrema planes for pool_from_extrema); store=False: the y are None."""
+    coefficients, ext = the extrema planes for pool_from_extrema); store=False: the y are None;
+    store_last=False: only the last layer's raw output is not stored (its backward then runs
+    from the Gram matrix of its input, pool_gram_backward)."""
     _f32c(x4, "x4"); _f32c(w0, "w0")
     b, _, m, ns = x4.shape
     r = m * ns
@@ -576,7 +583,7 @@ def chain_lin4_forward(x4, w0, coeff0, layer1, layer2, store=True):
     out1 = torch.empty((4, 64), dtype=torch.float32, device=dev)
     out2 = torch.empty((4, 128), dtype=torch.float32, device=dev)
     y1 = torch.empty((b, 64, m, ns), dtype=torch.float32, device=dev) if store else None
-    y2 = torch.empty((b, 128, m, ns), dtype=torch.float32, device=dev) if store else None
+    y2 = torch.empty((b, 128, m, ns), dtype=torch.float32, device=dev) if (store and store_last) else None
     ext = torch.empty((2, b, 128, m), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         st = _stream(x4)
@@ -597,6 +604,50 @@ def chain_lin4_forward(x4, w0, coeff0, layer1, layer2, store=True):
                                          out2[0].data_ptr(), out2[1].data_ptr(), out2[2].data_ptr(),
                                          out2[3].data_ptr(), st), "mlp_chain_finalize")
     return y1, (out1[0], out1[1], out1[2], out1[3]), y2, (out2[0], out2[1], out2[2], out2[3]), ext
+
+
+def pool_gram_supported(w, y_in, ns):
+    """Can the backward of the pooled last layer (w (128,64) on y_in (B,64,m,ns)) run without that
+    layer's raw output (csrc/mlp_pool_gram.hip)?"""
+    if os.environ.get("MLP_POOL_GRAM", "1") == "0" or tuple(w.shape) != (128, 64):
+        return False
+    b = y_in.shape[0]
+    r = y_in.numel() // (b * 64)
+    return bool(_lib.mlp_pool_gram_supported(b, 128, 64, r, int(ns)))
+
+
+def pool_gram_backward(w, y_in, in_coeff, in_gamma, coef, coeff, dpooled, argmax, ymax, ns, training):
+    """Backward of a pooled last layer y = w . relu(bn(y_in)) from y_in and the pooled tensors alone.
+    y_in (B,64,m,ns) raw output of the layer below, in_coeff = its (mean, invstd, scale, shift),
+    in_gamma its BatchNorm weight; coef (128,3) and coeff = (mean, invstd, scale, shift) of THIS
+    layer's BatchNorm; dpooled / argmax / ymax (B,128,m).
+    -> (d relu(bn(y_in)) (B,64,m,ns), dw (128,64), below = (dgamma, dbeta, coef) of the layer below)."""
+    _f32c(w, "w"); _f32c(y_in, "y_in"); _f32c(dpooled, "dpooled"); _f32c(ymax, "ymax")
+    b = y_in.shape[0]
+    r = y_in.numel() // (b * 64)
+    dev = y_in.device
+    mean_i, invstd_i, scale_i, shift_i = in_coeff
+    mean, invstd, scale, shift = coeff
+    parts = int(_lib.mlp_pool_gram_parts(b, r))
+    dq = torch.empty_like(y_in)
+    dw = torch.empty((128, 64), dtype=torch.float32, device=dev)
+    sp = torch.empty((64, parts, 2), dtype=torch.float32, device=dev)
+    small = torch.empty((5, 64), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws = torch.empty(int(_lib.mlp_pool_gram_workspace_floats(b, r)), dtype=torch.float32, device=dev)
+        st = _stream(y_in)
+        _L.check(_lib.mlp_pool_gram_backward(b, r, int(ns), w.data_ptr(), y_in.data_ptr(), scale_i.data_ptr(),
+                                             shift_i.data_ptr(), mean_i.data_ptr(), invstd_i.data_ptr(),
+                                             coef.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                             mean.data_ptr(), invstd.data_ptr(), argmax.data_ptr(),
+                                             dpooled.data_ptr(), ymax.data_ptr(), dq.data_ptr(),
+                                             dw.data_ptr(), sp.data_ptr(), ws.data_ptr(), st),
+                 "mlp_pool_gram_backward")
+        _L.check(_lib.mlp_bn_backward_finalize(64, parts, float(b) * float(r), 1 if training else 0,
+                                               sp.data_ptr(), in_gamma.data_ptr(), invstd_i.data_ptr(),
+                                               small[0].data_ptr(), small[1].data_ptr(), small[2:].data_ptr(),
+                                               st), "mlp_bn_backward_finalize")
+    return dq, dw, (small[0], small[1], small[2:])
 
 
 # ---- first layer of a set-abstraction module applied before the gather (csrc/mlp_pregather.hip) ----

@@ -174,6 +174,7 @@ class _FusedMLPChain(Function):
                                           params[5].reshape(params[5].shape[0], -1),
                                           params[10].reshape(params[10].shape[0], -1), x, x.shape[3]))
         ext = None
+        gram_last = False
         for i in range(n_layers):
             w, gamma, beta, rm, rv = params[5 * i:5 * i + 5]
             w2 = w.reshape(w.shape[0], -1)
@@ -183,10 +184,17 @@ class _FusedMLPChain(Function):
                 w0 = params[0].reshape(params[0].shape[0], -1)
                 lay = [(params[5 * q].reshape(params[5 * q].shape[0], -1),) + tuple(params[5 * q + 1:5 * q + 5])
                        + (momenta[q], epss[q]) for q in (1, 2)]
-                y1, c1, y2, c2, ext = K.chain_lin4_forward(x, w0, cur_coeff, lay[0], lay[1])
+                # the LAST layer's raw output is not even stored when its backward can run from the
+                # Gram matrix of its input (csrc/mlp_pool_gram.hip): 537 MB at SA1
+                gram = K.pool_gram_supported(lay[1][0], x, x.shape[3])
+                y1, c1, y2, c2, ext = K.chain_lin4_forward(x, w0, cur_coeff, lay[0], lay[1],
+                                                           store_last=not gram)
+                if y2 is None:
+                    y2 = x.new_empty(0)  # never materialised
                 ys += [y1, y2]
                 coefs += [c1, c2]
                 cur, cur_coeff = y2, (c2[2], c2[3])
+                gram_last = gram
                 continue
             if pre is not None and i == 0:
                 idx, _, npts = pre
@@ -245,6 +253,8 @@ class _FusedMLPChain(Function):
         ctx.save_for_backward(x, *ys, *flat, *extra, *params)
         ctx.n_layers, ctx.pool, ctx.training = n_layers, pool, training
         ctx.moments = moments  # not None: the first layer is virtual (ys[0] is a placeholder)
+        ctx.gram_last = gram_last  # the last layer's raw output was not stored (ys[-1] is a placeholder)
+        ctx.ns = x.shape[3] if x.dim() == 4 else 0
         ctx.pre = pre
         return out
 
@@ -268,6 +278,17 @@ class _FusedMLPChain(Function):
             w, gamma = params[5 * i], params[5 * i + 1]
             w2 = w.reshape(w.shape[0], -1)
             mean, invstd, scale, shift = coefs[i]
+            if i == n - 1 and pool and ctx.gram_last:
+                # the layer's raw output does not exist: both products of its backward from the Gram
+                # matrix of its input and one sparse column per (channel, group)
+                dgamma, dbeta, coef = K.bn_relu_pool_backward_stats(
+                    None, dz, extra[0], extra[1], gamma, scale, shift, mean, invstd, training, ns=ctx.ns)
+                grads[5 * i + 1], grads[5 * i + 2] = dgamma, dbeta
+                dz, dw_last, below = K.pool_gram_backward(
+                    w2, ys[i - 1], coefs[i - 1], params[5 * (i - 1) + 1], coef, coefs[i], dz, extra[0],
+                    extra[1], ctx.ns, training)
+                grads[5 * i] = dw_last.view_as(w)
+                continue
             if i == n - 1 and pool:
                 # dz of the pooled layer is one value per (channel, group): the GEMM operand
                 # loads rebuild dy from y, dpooled and the arg-max, nothing dense is written

@@ -205,6 +205,29 @@ int mlp_chain_finalize(int c, int parts, int n_part, const float *pairs, const f
                        const float *beta, float eps, float momentum, float *running_mean,
                        float *running_var, float *mean, float *invstd, float *scale, float *shift,
                        void *stream);
+/* ---- backward of a max-pooled last layer WITHOUT its raw output (csrc/mlp_pool_gram.hip) -------
+ * For (m, k) = (128, 64) (SA1's last layer; pytorch_utils.py:14-39,70-124 with the max-pool of
+ * pointnet2_modules.py:256-262): dy3 = q y3 + p + S with y3 = w3 a2 turns both backward products
+ * into functions of the layer's input a2 = relu(bn2(y2)), the 64 x 64 matrices W3^T diag(q) W3 and
+ * a2 a2^T, and one sparse column per (channel, group) -- y3 is neither read nor stored.
+ * mlp_pool_gram_supported: 1 when the layer is covered (ns 16 / 32 / 64, r % 32 == 0). */
+int mlp_pool_gram_supported(int b, int m, int k, int r, int ns);
+/* per-workgroup partials = parts of stats_part (64, parts, 2) (the autograd of nn.BatchNorm2d,
+ * pytorch_utils.py:42-67) */
+int mlp_pool_gram_parts(int b, int r);
+/* floats of 16-byte aligned workspace of mlp_pool_gram_backward (autograd of nn.Conv2d,
+ * pytorch_utils.py:70-124) */
+size_t mlp_pool_gram_workspace_floats(int b, int r);
+/* dq (b,64,r) = gradient w.r.t. relu(bn2(y2)), dw3 (128,64), stats_part (64,parts,2) = layer 2's
+ * BatchNorm-backward sums; y2 (b,64,r) raw, (sc2, sh2, mean2, invstd2) layer 2's BatchNorm,
+ * coef3 (128,3) / (sc3, sh3, mean3, invstd3) layer 3's, argmax / dpooled / ymax (b,128,r/ns) the
+ * pooled tensors (autograd of pytorch_utils.py:14-39 + pointnet2_modules.py:256-262) */
+int mlp_pool_gram_backward(int b, int r, int ns, const float *w3, const float *y2, const float *sc2,
+                           const float *sh2, const float *mean2, const float *invstd2,
+                           const float *coef3, const float *sc3, const float *sh3, const float *mean3,
+                           const float *invstd3, const int *argmax, const float *dpooled,
+                           const float *ymax, float *dq, float *dw3, float *stats_part,
+                           float *workspace, void *stream);
 /* Zero the "last workgroup finalizes" ticket counters of the current device (every stream's
  * array) after a faulted or aborted launch left one non-zero; synchronises the device.  The
  * reductions stand in for nn.BatchNorm2d's statistics (pytorch_utils.py:42-67); no reference

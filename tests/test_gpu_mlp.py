@@ -590,6 +590,66 @@ def test_chained_forward_vs_layerwise(b, m, ns):
     assert not bool((got[5] == 5).any()) and not bool((want[5] == 5).any())
 
 
+@pytest.mark.parametrize("b,m,ns", [(8, 256, 64), (4, 300, 32), (2, 1024, 16), (3, 77, 64)])
+def test_pooled_backward_from_the_gram_matrix(b, m, ns):
+    """csrc/mlp_pool_gram.hip: the backward of a max-pooled last layer y3 = w3 . relu(bn(y2)) WITHOUT
+    y3 (dy3 = q y3 + p + S: da2 = (W3^T diag(q) W3) a2 + W3^T p + W3^T S, dW3 = diag(q) W3 (a2 a2^T) +
+    p (sum a2)^T + S a2^T) == the one-pass kernel that rebuilds dy3 from the stored y3: gradient
+    w.r.t. the layer's input, weight gradient, BatchNorm-backward sums of the layer below
+    (autograd of pytorch_utils.py:14-39,70-124 + pointnet2_modules.py:256-262)."""
+    load_pkg()
+    K = importlib.import_module("pointnet2._mlp_ext")
+    g = torch.Generator().manual_seed(b * 31 + m + ns)
+    y2 = (torch.randn(b, 64, m, ns, generator=g) * 1.3 + 0.2).to(DEV)
+    y2[:, :, :, 3] = y2[:, :, :, 1]  # duplicated columns, as ball_query pads: pool ties
+    w3 = (torch.randn(128, 64, generator=g) / 8).to(DEV)
+
+    def bn(c):
+        gamma = torch.rand(c, generator=g) + 0.5
+        gamma[::5] *= -1
+        return gamma.to(DEV), (torch.randn(c, generator=g) * 0.3).to(DEV)
+
+    g2, be2 = bn(64)
+    g3, be3 = bn(128)
+    z = lambda c: (torch.zeros(c, device=DEV), torch.ones(c, device=DEV))  # noqa: E731
+    c2 = K.bn_coefficients(y2, g2, be2, *z(64), 0.1, 1e-5, True)
+    assert K.pool_gram_supported(w3, y2, ns)
+    y3, mean3, invstd3, sc3, sh3, ext = K.gemm_forward_bn(w3, y2, (c2[2], c2[3]), g3, be3, *z(128), 0.1, 1e-5,
+                                                          pool=True)
+    if ext is None:
+        pooled, argmax, ymax = K.bn_relu_pool(y3, sc3, sh3)
+    else:
+        pooled, argmax, ymax = K.pool_from_extrema(ext, sc3, sh3)
+    dpooled = torch.randn(b, 128, m, generator=g).to(DEV)
+    dgamma, dbeta, coef3 = K.bn_relu_pool_backward_stats(y3, dpooled, argmax, ymax, g3, sc3, sh3, mean3,
+                                                         invstd3, True)
+    want = K.gemm_backward_fused(w3, y2, (c2[2], c2[3]),
+                                 pooled=(y3, dpooled, argmax, sc3, sh3, mean3, invstd3, coef3),
+                                 xstats=(c2[0], c2[1], g2, True))
+    if want is None:
+        want_dx = K.gemm_dgrad(w3, pooled=(y3, dpooled, argmax, sc3, sh3, mean3, invstd3, coef3))
+        want_dw = K.gemm_wgrad(128, 64, y2, (c2[2], c2[3]),
+                               pooled=(y3, dpooled, argmax, sc3, sh3, mean3, invstd3, coef3))
+        want_below = K.bn_relu_backward_stats(y2, want_dx.contiguous(), g2, c2[2], c2[3], c2[0], c2[1], True)
+    else:
+        want_dx, want_dw, want_below = want
+    dgamma_g, dbeta_g, coef_g = K.bn_relu_pool_backward_stats(None, dpooled, argmax, ymax, g3, sc3, sh3,
+                                                              mean3, invstd3, True, ns=ns)
+    assert torch.equal(coef_g, coef3) and torch.equal(dgamma_g, dgamma)
+    dx, dw, below = K.pool_gram_backward(w3, y2, c2, g2, coef3, (mean3, invstd3, sc3, sh3), dpooled, argmax,
+                                         ymax, ns, True)
+    rel = lambda a_, b_: float((a_ - b_).norm() / (b_.norm() + 1e-20))  # noqa: E731
+    print("gram backward vs stored-y3 backward: dx %.2e dw %.2e dgamma %.2e dbeta %.2e coef %.2e" % (
+        rel(dx, want_dx.view_as(dx)), rel(dw, want_dw), rel(below[0], want_below[0]),
+        rel(below[1], want_below[1]), rel(below[2], want_below[2])))
+    close(dx, want_dx.view_as(dx), 3e-5)
+    assert rel(dx, want_dx.view_as(dx)) < 2e-5
+    close(dw, want_dw, 1e-4)
+    assert rel(dw, want_dw) < 1e-4
+    for a_, b_ in zip(below, want_below):
+        close(a_, b_, 1e-4)
+
+
 def test_reductions_on_two_streams_at_once():
     """The BatchNorm reductions finalize in their last workgroup through per-channel ticket
     counters; launches on different streams may overlap and must not share counters (one array
