@@ -86,6 +86,15 @@ def parse():
     return ap.parse_args()
 
 
+def newest_profile(suffix):
+    """profiles/r<N>_<suffix> of the latest round that committed one (None if there is none)."""
+    for rnd in range(9, 0, -1):
+        path = os.path.join(ROOT, "profiles", "r%d_%s" % (rnd, suffix))
+        if os.path.exists(path):
+            return path
+    return None
+
+
 def build_step(V, cfg, device, world, local_rank, workload="pretrain"):
     if workload == "semi":
         runner = V.SemiSupervisedStep(cfg, device, world_size=world, num_proposal=KPROP, lr=2e-3,
@@ -291,6 +300,50 @@ def kernel_table(device):
                    "frac_of_fp32_mfma_peak": round(flops / (us * 1e-6) / 1e12 / F32_PEAK_TFLOPS, 4),
                    "hbm_GBps": round(nbytes / us / 1e3, 1),
                    "frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    # SA1's shared MLP as the step runs it since round 5: layers 2 + 3 chained in registers
+    # (csrc/mlp_chain.hip: statistics pass + full pass, y3 not stored) and the last layer's backward
+    # from the Gram matrix of its input (csrc/mlp_pool_gram.hip)
+    x4 = torch.randn(B, 4, m1, ns1, device=device)
+    w0 = torch.randn(64, 4, device=device) * 0.7
+    w1c = torch.randn(64, 64, device=device) / 8
+    w2c = torch.randn(128, 64, device=device) / 8
+    bnp = lambda c: [torch.rand(c, device=device) + 0.5, torch.randn(c, device=device) * 0.3,  # noqa: E731
+                     torch.zeros(c, device=device), torch.ones(c, device=device)]
+    p0, p1, p2 = bnp(64), bnp(64), bnp(128)
+    if K.chain_lin4_supported(w0, w1c, w2c, x4, ns1):
+        mom = K.first4_moments(x4)
+        c0 = K.first4_bn(mom, x4.numel() // 4, w0, p0[0], p0[1], p0[2], p0[3], 0.1, 1e-5)
+
+        def chain():
+            return K.chain_lin4_forward(x4, w0, (c0[2], c0[3]), (w1c, *p1, 0.1, 1e-5), (w2c, *p2, 0.1, 1e-5),
+                                        store_last=False)
+
+        us = time_op(chain, iters=5, warm=2)
+        cols = B * m1 * ns1
+        flops = 2.0 * cols * (64 * 64 * 2 + 128 * 64)  # layer 2 twice (statistics pass + full pass)
+        nbytes = 4.0 * cols * (4 * 2 + 64)              # x4 read twice, y2 written once
+        t["mlp_chain_fwd_sa1"] = {
+            "us": round(us, 2), "flops": int(flops), "bytes": int(nbytes),
+            "bound": "vector-instruction issue (4 cycles per wave instruction, ~1200 per 32-column tile "
+                     "against 144 MFMAs; profiles/r5_chain_pmc.json)",
+            "TFLOPs": round(flops / us * 1e-6, 1), "hbm_GBps": round(nbytes / us / 1e3, 1),
+            "frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "note": "replaces mlp_fwd 64x64 (lin4) + 128x64 with their statistics / pool epilogues: "
+                    "y3 (537 MB) is never written"}
+        y1c, c1c, _, c2c, extc = chain()
+        _, amax, ymax_ = K.pool_from_extrema(extc, c2c[2], c2c[3])
+        dpool = torch.randn(B, 128, m1, device=device)
+        _, _, coef3 = K.bn_relu_pool_backward_stats(None, dpool, amax, ymax_, p2[0], c2c[2], c2c[3], c2c[0],
+                                                    c2c[1], True, ns=ns1)
+        if K.pool_gram_supported(w2c, y1c, ns1):
+            us = time_op(lambda: K.pool_gram_backward(w2c, y1c, c1c, p1[0], coef3, c2c, dpool, amax, ymax_,
+                                                      ns1, True), iters=5, warm=2)
+            nbytes = 4.0 * cols * (64 + 64)  # y2 read once, d relu(bn(y2)) written once
+            t["mlp_gram_bwd_sa1_128x64"] = {
+                "us": round(us, 2), "bytes": int(nbytes), "bound": "hbm / per-chunk latency (one workgroup per CU)",
+                "hbm_GBps": round(nbytes / us / 1e3, 1),
+                "frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "backward of the pooled 64 -> 128 layer without y3: Gram matrix + sparse image"}
     # SA2's first layer applied before the gather (csrc/mlp_pregather.hip): gather of the small
     # GEMM's output with the BatchNorm moments / its backward (BN+ReLU backward on the fly, scatter
     # through the inverse index), at N = 2048 -> m = 1024 x ns = 32, 128 channels
@@ -502,6 +555,25 @@ def main():
         host_ms = host_s * 1e3
     elapsed, views = timed_loop(step, batch, args.steps, args.warmup)
     rccl = None
+    if world > 1:
+        # MAX over ranks of both timed loops (and of the host time per step)
+        t = torch.tensor([elapsed, elapsed_rot if elapsed_rot is not None else 0.0, host_ms or 0.0],
+                         device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t[0].item())
+        if elapsed_rot is not None:
+            elapsed_rot, host_ms = float(t[1].item()), float(t[2].item())
+        # what the N > 1 line needs to be checked from outside: the collective's backend, the
+        # width of the process group, which device every rank drove, the gradient all-reduce's
+        # device time (median over the warm-up + timed steps of rank 0)
+        mine = torch.tensor([torch.cuda.current_device()], dtype=torch.int64,
+                            device=device if args.backend == "nccl" else "cpu")
+        ids = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(ids, mine)
+        rccl = step.runner.exchange_report()
+        rccl["ranks_device_ids"] = [int(i.item()) for i in ids]
+        rccl["ranks_share_one_gpu"] = os.environ.get("BENCH_SHARE_GPU") == "1"
+
     # the same step with the index chain inline (not part of `value`): what the one-step-ahead
     # prefetch of the coordinate-only chain hides
     ms_inline = None
@@ -563,27 +635,27 @@ def main():
             # WRITE_SIZE in separate runs, gfx950 correction of the guide applied): measured by
             # tools/pair_bench.py --plain under the profiler, NOT by this run
             traffic, source = None, None
-            pmc = os.path.join(ROOT, "profiles", "r4_pair_pmc.json")
-            if os.path.exists(pmc):
+            pmc = newest_profile("pair_pmc.json")
+            if pmc:
                 traffic = json.load(open(pmc)).get("traffic_bytes_fused_kernel")
-                source = "profiles/r4_pair_pmc.json (separate rocprofv3 --pmc passes)"
+                source = "profiles/%s (separate rocprofv3 --pmc passes)" % os.path.basename(pmc)
             # VALU utilisation of the VALU-bound operators, from the committed
             # counter pass of tools/op_bench.py (tools/valu_util.py), not from this run
-            vu = os.path.join(ROOT, "profiles", "r4_ops_valu_util.json")
-            if os.path.exists(vu):
+            vu = newest_profile("ops_valu_util.json")
+            if vu:
                 busy = {k: v["valu_busy"] for k, v in json.load(open(vu))["kernels"].items()}
                 for op_name, kern in (("iou3d_2048x512", "pair_matrix_kernel<2>"),
                                       ("three_nn_gridconv", "three_nn_kernel"),
                                       ("ball_query_sa2", "ball_query_bf_kernel<2>")):
                     if op_name in table and kern in busy:
                         table[op_name]["valu_busy"] = busy[kern]
-                        table[op_name]["valu_busy_source"] = "profiles/r4_ops_valu_util.json (%s)" % kern
+                        table[op_name]["valu_busy_source"] = "profiles/%s (%s)" % (os.path.basename(vu), kern)
             # in-step duration of the kernels behind the table's entries, next to their standalone
             # `us` (committed rocprofv3 summary of the timed steps, tools/step_breakdown.py): a
             # kernel that behaves differently on the step's own data or beside the side stream
             # shows up here (round 3: the query kernel, 18 us standalone / 86 us in the step)
-            ss = os.path.join(ROOT, "profiles", "r4_train_step_timed_summary.csv")
-            if os.path.exists(ss):
+            ss = newest_profile("train_step_timed_summary.csv")
+            if ss:
                 import csv
                 rows = {r["kernel"]: r for r in csv.DictReader(open(ss))}
                 for op_name, kern in (
@@ -592,7 +664,8 @@ def main():
                         ("group_grad_sa2_c128", "group_points_grad_sorted_kernel<32>"),
                         ("group_inverse_sa2", "group_inverse_kernel"),
                         ("three_interpolate_gridconv", "three_interpolate_lds_kernel<8>"),
-                        ("mlp_fwd_sa1_128x64", "gemm_nn2_kernel<128, 128, 2, 2, 1, false, true, true, 64, true>"),
+                        ("mlp_chain_fwd_sa1", "chain_lin4_kernel<4, 64, true>"),
+                        ("mlp_gram_bwd_sa1_128x64", "pool_gram_bwd_kernel"),
                         ("pregather_bwd_sa2", "pregather_backward_kernel<32>")):
                     r_ = rows.get(kern)
                     if op_name in table and r_ is not None and float(r_["launches_per_step"]) > 0:
@@ -610,6 +683,13 @@ def main():
                           "duration = the slowest of cloud U(L), cloud R and the timed step's own "
                           "batch (here: %s)" % worst,
                 "algorithmic_bytes": PAIR_BYTES, "duration_us": round(layer_us, 2),
+                # how far this decomposition (one wave per centroid on cell lists) can go: a skeleton
+                # of the nine row loads + the stores of the pair alone (no tests, no ranking)
+                "floor": {"us": 13.0, "frac": round(PAIR_BYTES / 13.0e-6 / 1e9 / HBM_PEAK_GBS, 4),
+                          "source": "tools/micro/td_rate.py (profiles/r3_vector_memory_microbench.json: "
+                                    "12.8-13.3 us for 16 384 waves x 9 row loads + the pair's stores); the "
+                                    "kernel itself is instruction-issue bound: ~700 wave instructions per "
+                                    "centroid x 4 cycles x 16 centroids per SIMD = 18.7 us"},
                 "forms": {k: {"us": round(v, 2),
                               "frac": round(PAIR_BYTES / (v * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
                           for k, v in forms.items()},

@@ -40,4 +40,11 @@ run gemm_util rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CY
 python tools/mfma_util.py $P/gemm/g_counter_collection.csv $O/${TAG}_gemm_mfma_util.csv > /dev/null 2>&1
 run bwd_util rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $P/bwd -o g -- python tools/bwd_bench.py
 python tools/mfma_util.py $P/bwd/g_counter_collection.csv $O/${TAG}_bwd_mfma_util.csv > /dev/null 2>&1
-ls -la $O | head -40
+# -- SA1's chained forward and Gram backward (round 5)
+timeout 120 python tools/chain_bench.py $O/${TAG}_chain_bench.json > $O/chain_bench.log 2>&1; echo "chain_bench rc=$?"
+timeout 120 python tools/gram_bench.py $O/${TAG}_gram_bench.json > $O/gram_bench.log 2>&1; echo "gram_bench rc=$?"
+run chain_pmc rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d $P/chain -o p -- python tools/chain_bench.py
+python tools/pmc_kernel.py $P/chain/p_counter_collection.csv chain_lin4 $O/${TAG}_chain_pmc.json > /dev/null 2>&1
+run gram_pmc rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d $P/gram -o p -- python tools/gram_bench.py
+python tools/pmc_kernel.py $P/gram/p_counter_collection.csv "" $O/${TAG}_gram_pmc.json > /dev/null 2>&1
+ls -la $O | head -60
