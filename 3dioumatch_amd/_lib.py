@@ -39,6 +39,7 @@ _SIGNATURES = {
     "pn2_group_concat": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _vp, _vp,
                          _vp, _vp, _vp, _vp],
     "pn2_grid_bytes": [_c_int, _c_int],
+    "pn2_grid_launch_order": [_c_int, _c_int, _vp, _vp, _vp, _vp],
     "pn2_grid_build": [_c_int, _c_int, _c_float, _vp, _vp, _sz, _vp],
     "pn2_ball_query_prebuilt": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp, _sz, _vp],
     "pn2_query_and_group_prebuilt": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _vp,

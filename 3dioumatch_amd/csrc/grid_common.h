@@ -15,6 +15,9 @@ constexpr int kG = 32;                  // lattice cells per axis (periodic)
 constexpr int kLayerCells = kG * kG;    // cells of one z-layer
 constexpr int kCells = kG * kG * kG;
 constexpr int kStartStride = kCells + 32;  // ints per cloud in `start` (start[kCells] = n)
+// start[kOrderFor]: the number of centroids `order` of this cloud is a permutation for, 0 = none.
+// Written 0 by every builder of the lists, m by the sampling kernel that also knows the centroids.
+constexpr int kOrderFor = kCells + 1;
 constexpr int kChunks = 32;             // chunks a cloud is split into by the first build pass
 constexpr int kSegOff = kG + 1;         // layer offsets per chunk (+ total)
 constexpr int kGridMaxPoints = kChunks * 4096;  // the first pass keeps a chunk in registers
@@ -28,6 +31,10 @@ struct GridWs {
   int *segoff;    // [b][kChunks][kSegOff]        (scratch of the two-pass build)
   float4 *rec;    // [b][n]  records in cell order
   float4 *seg;    // [b][kChunks][chunk_pts]      (scratch of the two-pass build)
+  // [b][n] launch order of the centroids sampled from this cloud: longest query first (the query
+  // kernel's workgroup jj answers centroid order[jj]); keys of the counting sort behind it
+  int *order;
+  int *order_key;
   size_t bytes;
 };
 
@@ -40,6 +47,8 @@ inline GridWs grid_ws_layout(void *base, int b, int n) {
   w.segoff = reinterpret_cast<int *>(take(sizeof(int) * (size_t)b * kChunks * kSegOff));
   w.rec = reinterpret_cast<float4 *>(take(sizeof(float4) * (size_t)b * n));
   w.seg = reinterpret_cast<float4 *>(take(sizeof(float4) * (size_t)b * kChunks * grid_chunk_points(n)));
+  w.order = reinterpret_cast<int *>(take(sizeof(int) * (size_t)b * n));
+  w.order_key = reinterpret_cast<int *>(take(sizeof(int) * (size_t)b * n));
   w.bytes = off;
   return w;
 }
@@ -53,6 +62,31 @@ __device__ __forceinline__ int cell_coord(float v, float inv_side) {
 __device__ __forceinline__ int cell_id(float x, float y, float z, float inv_side) {
   return (((cell_coord(z, inv_side) & (kG - 1)) * kG + (cell_coord(y, inv_side) & (kG - 1))) * kG) +
          (cell_coord(x, inv_side) & (kG - 1));
+}
+
+// Cost class of a centroid's query (what grid_query_kernel will do for it, from the row lengths
+// alone): 0 = every one of its nine x-rows fits a wave (the single-load path), otherwise the
+// number of 64-record chunks its general path sweeps, capped at 63.
+__device__ inline int query_cost_class(const int *st, float cx, float cy, float cz, float inv_side) {
+  const int gx = cell_coord(cx, inv_side) & (kG - 1);
+  const int gy = cell_coord(cy, inv_side), gz = cell_coord(cz, inv_side);
+  const int xa = gx > 0 ? gx - 1 : 0, xb = gx < kG - 1 ? gx + 1 : kG - 1;
+  const bool seam = gx == 0 || gx == kG - 1;
+  bool fast = true;
+  int chunks = 0;
+  for (int r = 0; r < 9; ++r) {
+    const int rz = r / 3;
+    const int rowbase = (((gz + rz - 1) & (kG - 1)) * kG + ((gy + (r - 3 * rz) - 1) & (kG - 1))) * kG;
+    const int len = st[rowbase + xb + 1] - st[rowbase + xa];
+    int lenw = 0;
+    if (seam) {
+      const int c = rowbase + (gx == 0 ? kG - 1 : 0);
+      lenw = st[c + 1] - st[c];
+    }
+    fast = fast && len + lenw <= kWave;
+    chunks += ((len + kWave - 1) >> 6) + ((lenw + kWave - 1) >> 6);
+  }
+  return fast ? 0 : (chunks < 63 ? (chunks > 0 ? chunks : 1) : 63);
 }
 
 }  // namespace grid

@@ -212,7 +212,10 @@ grid_bin_kernel(int n, int chunk_pts, float inv_side, const int *__restrict__ se
     cnt_b[tid] = excl + va;
     int *st = start + (size_t)b * kStartStride;
     st[layer * kLayerCells + tid] = excl;
-    if (layer == kG - 1 && tid == kBuildThreads - 1) st[kCells] = excl + v;  // == n
+    if (layer == kG - 1 && tid == kBuildThreads - 1) {
+      st[kCells] = excl + v;  // == n
+      st[kOrderFor] = 0;      // these lists come without a launch order
+    }
   }
   __syncthreads();
   float4 *out = rec + (size_t)b * n;
@@ -287,7 +290,8 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
                   int nsample,
                   unsigned bucket_mul, const float *__restrict__ new_xyz,
                   const float *__restrict__ xyz, const int *__restrict__ start,
-                  const float4 *__restrict__ rec, int *__restrict__ idx, GroupOut g) {
+                  const float4 *__restrict__ rec, const int *__restrict__ order,
+                  int *__restrict__ idx, GroupOut g) {
   static_assert(MAXH <= 512, "hit list capacity");
   constexpr int TMAX = MAXH / kWave;
   constexpr int NH = MAXH >= 8 * kWave ? 4 : (MAXH >= 4 * kWave ? 2 : 1);  // nsample <= 64 * NH
@@ -306,8 +310,16 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
 
 #pragma unroll 1
   for (int cq = 0; cq < CPW; ++cq) {
-    const int j = ((wg - b * wg_per_cloud) * WPB + wave) * CPW + cq;
-    if (j >= m) return;  // whole wave
+    const int jj = ((wg - b * wg_per_cloud) * WPB + wave) * CPW + cq;
+    if (jj >= m) return;  // whole wave
+    // longest query first, when the sampling kernel that picked these centroids left the order
+    // behind (grid_common.h: start[kOrderFor] == m); any permutation gives the same rows
+    int j = jj;
+    {
+      const int for_m = st[kOrderFor];
+      const int oj = order[(size_t)b * n + (jj < n ? jj : 0)];
+      if (for_m == m && (unsigned)oj < (unsigned)m) j = oj;
+    }
 #ifdef GRID_PROBE
     const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime();
     unsigned long long probe_t1 = 0, probe_t2 = 0, probe_t3 = 0;  // starts known / list complete / ranked
@@ -685,6 +697,16 @@ size_t pn2_grid_layout_bytes(int b, int n) {
   return grid_ws_layout(nullptr, b, n).bytes;
 }
 
+// where a cell-list object keeps its launch order (byte offsets into the object)
+void pn2_grid_order_layout(int b, int n, size_t *start_off, size_t *order_off, int *start_stride,
+                           int *order_for_slot) {
+  const GridWs ws = grid_ws_layout(nullptr, b, n);
+  *start_stride = kStartStride;
+  *order_for_slot = kOrderFor;
+  *start_off = (size_t)(reinterpret_cast<char *>(ws.start) - (char *)nullptr);
+  *order_off = (size_t)(reinterpret_cast<char *>(ws.order) - (char *)nullptr);
+}
+
 // the two-pass build of the cell lists of `xyz` for `radius`
 int pn2_grid_build_launch(int b, int n, float radius, const float *xyz, void *workspace,
                           hipStream_t stream) {
@@ -723,7 +745,7 @@ static int grid_run(int b, int n, int m, float radius, int nsample, const float 
 #define GRID_QUERY(MAXH, GROUP)                                                                    \
   hipLaunchKernelGGL((grid_query_kernel<MAXH, 1, GROUP>), dim3((unsigned)m * (unsigned)b),         \
                      dim3(kWave), 0, stream, n, m, m, radius2, inv_side, nsample, bucket_mul,      \
-                     new_xyz, xyz, ws.start, ws.rec, idx, g)
+                     new_xyz, xyz, ws.start, ws.rec, ws.order, idx, g)
   if ((long long)m * b > 0x7fffffffll) return (int)hipErrorInvalidValue;
   if (nsample > 2 * kWave) { if (group) GRID_QUERY(512, true); else GRID_QUERY(512, false); }
   else if (nsample > kWave) { if (group) GRID_QUERY(256, true); else GRID_QUERY(256, false); }

@@ -716,6 +716,16 @@ PN2_API int pn2_query_and_group(int b, int n, int m, int c, float radius, int ns
 // pn2_furthest_point_sampling_grid), queried by any number of ball queries of the same radius
 PN2_API size_t pn2_grid_bytes(int b, int n) { return pn2_grid_layout_bytes(b, n); }
 
+void pn2_grid_order_layout(int b, int n, size_t *start_off, size_t *order_off, int *start_stride,
+                           int *order_for_slot);
+PN2_API int pn2_grid_launch_order(int b, int n, size_t *start_offset, int *start_stride,
+                                  int *order_for_slot, size_t *order_offset) {
+  if (pn2_grid_layout_bytes(b, n) == 0 || !start_offset || !start_stride || !order_for_slot || !order_offset)
+    return (int)hipErrorInvalidValue;
+  pn2_grid_order_layout(b, n, start_offset, order_offset, start_stride, order_for_slot);
+  return 0;
+}
+
 PN2_API int pn2_grid_build(int b, int n, float radius, const float *xyz, void *grid,
                            size_t grid_bytes, void *stream_) {
   const size_t need = pn2_grid_layout_bytes(b, n);

@@ -163,7 +163,10 @@ fps_bucket_setup_kernel(int n, size_t cloud_stride, const float *__restrict__ da
         gcnt[tid * 16 + q] = (unsigned)lo | ((unsigned)hi << 16);  // scatter cursors (n < 65536)
         run = hi + (int)(wds[q] >> 16);
       }
-      if (tid == kThreads - 1) grid_start[(size_t)blockIdx.x * grid::kStartStride + grid::kCells] = run;
+      if (tid == kThreads - 1) {
+        grid_start[(size_t)blockIdx.x * grid::kStartStride + grid::kCells] = run;
+        grid_start[(size_t)blockIdx.x * grid::kStartStride + grid::kOrderFor] = 0;  // no launch order yet
+      }
     }
     __syncthreads();
     float4 *rec = grid_rec + (size_t)blockIdx.x * n;
@@ -309,7 +312,9 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
                          const float *__restrict__ dataset, float4 *__restrict__ rec_all,
                          const int *__restrict__ pidx_all, const float *__restrict__ bbox_all,
                          const int *__restrict__ n_valid_in, int *__restrict__ idxs,
-                         int *__restrict__ first_tie_out, const int *__restrict__ prefix_first_tie) {
+                         int *__restrict__ first_tie_out, const int *__restrict__ prefix_first_tie,
+                         int *__restrict__ grid_start, int *__restrict__ grid_order,
+                         int *__restrict__ grid_order_key, float grid_inv_side) {
   static_assert(G == 2 || G == 4, "group of 2 or 4 buckets");
   constexpr int NG = 3;   // groups whose loads are issued together
   __shared__ __attribute__((aligned(16))) int2 slots[2][W];   // (bits of the wave's maximum, bucket id)
@@ -570,6 +575,42 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
   if (w == 0)
     for (int j = 1 + lane; j < m; j += kWave) out[j] = pidx[out[j]];
   if (tid == 0 && first_tie_out != nullptr) first_tie_out[blockIdx.x] = first_tie;
+
+  // ---- launch order for the ball queries around these picks (grid_common.h) ------------------
+  // The set-abstraction layer queries a ball around every pick right afterwards, one wave per
+  // centroid.  A centroid inside a dense cluster sweeps up to ~30 chunks of candidates (10 us
+  // against 3 for the usual one); dispatched last it is the tail of that launch.  The cell lists
+  // of the cloud are in place (the setup kernel's second workgroup), so the cost class of every
+  // query is 18 cached loads away: a counting sort by class, longest first -- the query kernel's
+  // workgroup jj answers centroid order[jj], and the long ones run under everyone else.
+  if (grid_order != nullptr && m <= n) {   // kernel arguments
+    __shared__ int o_cnt[kWave];
+    const int *st = grid_start + (size_t)blockIdx.x * grid::kStartStride;
+    int *ord = grid_order + (size_t)blockIdx.x * n;
+    int *key = grid_order_key + (size_t)blockIdx.x * n;
+    if (tid < kWave) o_cnt[tid] = 0;
+    __syncthreads();   // (also: wave 0's translated picks)
+    for (int jj = tid; jj < m; jj += W * kWave) {
+      const int p = out[jj];
+      const int k = grid::query_cost_class(st, pts[p * 3 + 0], pts[p * 3 + 1], pts[p * 3 + 2], grid_inv_side);
+      key[jj] = k;
+      atomicAdd(&o_cnt[k], 1);
+    }
+    __syncthreads();
+    if (w == 0) {   // exclusive scan from the longest class down: lane l <-> class 63 - l
+      const int c = o_cnt[kWave - 1 - lane];
+      int incl = c;
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const int o = __shfl_up(incl, off, kWave);
+        if (lane >= off) incl += o;
+      }
+      o_cnt[kWave - 1 - lane] = incl - c;
+    }
+    __syncthreads();
+    for (int jj = tid; jj < m; jj += W * kWave) ord[atomicAdd(&o_cnt[key[jj]], 1)] = jj;
+    if (tid == 0) grid_start[(size_t)blockIdx.x * grid::kStartStride + grid::kOrderFor] = m;
+  }
 }
 
 }  // namespace
@@ -612,7 +653,7 @@ int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, vo
   int *pidx = reinterpret_cast<int *>(rec + (size_t)b * stride);
   float *bbox = reinterpret_cast<float *>(pidx + (size_t)b * stride);
   int *n_valid = reinterpret_cast<int *>(bbox + (size_t)b * (stride / kWave) * 8);
-  int *g_start = nullptr;
+  int *g_start = nullptr, *g_order = nullptr, *g_order_key = nullptr;
   float4 *g_rec = nullptr;
   float g_inv = 0.f;
   if (grid != nullptr) {  // also leave the cell lists for ball queries of grid_radius behind
@@ -620,6 +661,8 @@ int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, vo
     const grid::GridWs ws = grid::grid_ws_layout(grid, b, n);
     g_start = ws.start;
     g_rec = ws.rec;
+    g_order = ws.order;
+    g_order_key = ws.order_key;
     g_inv = grid::grid_inv_side(grid_radius);
   }
   hipLaunchKernelGGL(fps_bucket_setup_kernel, dim3(b, grid != nullptr ? 2 : 1), dim3(kThreads), 0, stream,
@@ -628,7 +671,8 @@ int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, vo
   const int per_wave = ((int)(stride / kWave) + WV - 1) / WV;   // buckets per wave
 #define FPS_ROUNDS(META)                                                                       \
   hipLaunchKernelGGL((fps_bucket_rounds_kernel<WV, META, FPS_BUCKET_GROUP>), dim3(b), dim3(WV * kWave), 0, \
-                     stream, n, m, log2bs, stride, dataset, rec, pidx, bbox, n_valid, idxs, first_tie_out, prefix_first_tie)
+                     stream, n, m, log2bs, stride, dataset, rec, pidx, bbox, n_valid, idxs, first_tie_out, prefix_first_tie,  \
+                     g_start, g_order, g_order_key, g_inv)
   if (per_wave <= kWave) FPS_ROUNDS(1);
   else if (per_wave <= 2 * kWave) FPS_ROUNDS(2);
   else FPS_ROUNDS(3);

@@ -433,6 +433,21 @@ class CellLists(object):
         if xyz.device != self.buf.device:
             raise RuntimeError("cell lists live on %s" % self.buf.device)
 
+    def launch_order(self):
+        """(order_for (B,) int32, order (B,N) int32, cell_start (B, cells + 1) int32): the order in
+        which the query kernels answer the centroids the sampling kernel picked -- longest query
+        first -- valid for `order_for` centroids per cloud, 0 = none
+        (include/pn2_hip.h pn2_grid_launch_order).  Views of the object's own memory."""
+        import ctypes
+        so, oo = ctypes.c_size_t(), ctypes.c_size_t()
+        stride, slot = ctypes.c_int(), ctypes.c_int()
+        _L.check(_lib.pn2_grid_launch_order(self.b, self.n, ctypes.byref(so), ctypes.byref(stride),
+                                            ctypes.byref(slot), ctypes.byref(oo)), "grid_launch_order")
+        start = self.buf[so.value:so.value + 4 * stride.value * self.b].view(torch.int32)
+        start = start.view(self.b, stride.value)
+        order = self.buf[oo.value:oo.value + 4 * self.n * self.b].view(torch.int32).view(self.b, self.n)
+        return start[:, slot.value], order, start[:, :slot.value]
+
 
 def grid_supported(b, n):
     return int(_lib.pn2_grid_bytes(int(b), int(n))) > 0

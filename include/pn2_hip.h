@@ -137,6 +137,17 @@ int pn2_group_concat(int b, int n, int m, int c, float radius, int nsample, int 
  * n > 131072): use pn2_ball_query (the reference allocates nothing, ball_query.cpp:24-33) */
 size_t pn2_grid_bytes(int b, int n);
 
+/* Launch order of the ball queries (an addition without a reference counterpart: the reference's
+ * query_ball_point_kernel, ball_query_gpu.cu:14-49, answers centroid blockIdx-major in the order
+ * given).  pn2_furthest_point_sampling_grid knows both the lists and the centroids it picked, and
+ * leaves a permutation of 0..m-1 in the object, longest query first; the query kernels follow it
+ * when they are asked for the same number of centroids (any permutation gives the same rows).
+ * This call tells where: cloud i's int32 row of cells starts at
+ * start_offset + 4 * start_stride * i bytes, its entry [order_for_slot] holds the m the order is
+ * for (0: none), and its order at order_offset + 4 * n * i bytes. */
+int pn2_grid_launch_order(int b, int n, size_t *start_offset, int *start_stride,
+                          int *order_for_slot, size_t *order_offset);
+
 /* build the cell lists of xyz (b,n,3) for balls of `radius` into grid (pn2_grid_bytes bytes);
  * the stand-alone form of what query_ball_point_kernel_wrapper's replacement does internally
  * (ball_query.cpp:9-11) */

@@ -288,6 +288,52 @@ def test_north_star_pair_on_the_step_and_room_clouds(ext, oracle_omp, synth, kin
         assert ((d2 < r * r).sum(1) * 8).max() > 192
 
 
+def test_launch_order_left_by_the_sampling_kernel(ext, oracle_omp, synth):
+    """The sampling kernel leaves, next to the cell lists, the order in which the query kernel
+    answers the centroids it picked: a permutation of 0..m-1 per cloud, sorted by the query's
+    cost class (0: every x-row of the 3x3 neighbourhood fits a wave; otherwise the number of
+    64-record chunks of the general path), longest first -- recomputed here from the cell
+    offsets.  Lists built any other way carry no order; a query for another number of
+    centroids ignores it; rows are the oracle's in every case."""
+    import bench
+    b, n, m, r, ns = 2, 40000, 2048, 0.2, 64
+    xyz = bench.pair_cloud("step")[:b].numpy().copy()
+    d_xyz = dev(xyz)
+    fps, lists = ext.furthest_point_sampling_with_grid(d_xyz, m, r)
+    order_for, order, start = (t.cpu().numpy() for t in lists.launch_order())
+    assert list(order_for) == [m] * b and start.shape[1] == 32 ** 3 + 1
+    new_xyz = ext.gather_points(d_xyz.transpose(1, 2).contiguous(), fps).transpose(1, 2).contiguous()
+    cen = new_xyz.cpu().numpy()
+    inv_side = np.float32(1.0) / (np.float32(r) * np.float32(1.001))
+    heavy = 0
+    for i in range(b):
+        assert np.array_equal(np.sort(order[i, :m]), np.arange(m))
+        g = np.floor(cen[i] * inv_side).astype(np.int64)
+        gx, gy, gz = g[:, 0] & 31, g[:, 1], g[:, 2]
+        xa, xb = np.maximum(gx - 1, 0), np.minimum(gx + 1, 31)
+        seam = (gx == 0) | (gx == 31)
+        fast = np.ones(m, bool)
+        chunks = np.zeros(m, np.int64)
+        for rz in range(3):
+            for ry in range(3):
+                base = (((gz + rz - 1) & 31) * 32 + ((gy + ry - 1) & 31)) * 32
+                ln = start[i][base + xb + 1] - start[i][base + xa]
+                wrap = base + np.where(gx == 0, 31, 0)
+                lw = np.where(seam, start[i][wrap + 1] - start[i][wrap], 0)
+                fast &= ln + lw <= 64
+                chunks += (ln + 63) // 64 + (lw + 63) // 64
+        cls = np.where(fast, 0, np.clip(chunks, 1, 63))
+        along = cls[order[i, :m]]
+        assert np.all(along[:-1] >= along[1:])
+        heavy += int((cls > 0).sum())
+    assert heavy > 100   # (the dense clusters of this cloud are what the order is for)
+    want = oracle_omp.ball_query(cen, xyz, r, ns)
+    assert np.array_equal(ext.ball_query_prebuilt(new_xyz, d_xyz, r, ns, lists).cpu().numpy(), want)
+    fewer = new_xyz[:, :777].contiguous()
+    assert np.array_equal(ext.ball_query_prebuilt(fewer, d_xyz, r, ns, lists).cpu().numpy(), want[:, :777])
+    assert list(ext.build_grid(d_xyz, r).launch_order()[0].cpu().numpy()) == [0] * b
+
+
 def test_ballquery_general_path_bucket_refinement(ext, oracle_omp, synth):
     """n = 80 000 (index buckets of 2048) with 3000 CONSECUTIVE indices packed into one cell and
     2000 more into its neighbour: one bucket alone overflows the hit list, so the adaptive cut
