@@ -393,14 +393,12 @@ class SupervisedStep(object):
         self._refresh_lr()
 
     # ---------------------------------------------------------------- geometry prefetch
-    def prefetch_geometry(self, batch):
-        """Launch the coordinate-only index computations (FPS chain, ball queries) of `batch`
-        on a side stream; the step that later consumes `batch` waits for them.  Call it for
-        batch i+1 right before running the step on batch i: the serial FPS rounds then overlap
-        the dense kernels of step i instead of heading step i+1's critical path."""
+    def side_stream(self):
+        """The stream the prefetched index chains run on (None on CPU).  It has slack -- the chain
+        is ~4 ms of a ~6 ms step -- so a feeding loop can put its host -> device copies on it too,
+        instead of on a stream of its own that may land on the main stream's hardware queue."""
         if self.device.type != "cuda":
-            batch["geometry"] = self._compute_geometry(batch)
-            return
+            return None
         if self._side is None:
             # ONE side stream per device for every runner of the process: HIP maps streams onto a
             # few hardware queues, and a third runner's fresh stream was seen to share the main
@@ -410,6 +408,17 @@ class SupervisedStep(object):
             if key not in _SIDE_STREAMS:
                 _SIDE_STREAMS[key] = torch.cuda.Stream(device=self.device)
             self._side = _SIDE_STREAMS[key]
+        return self._side
+
+    def prefetch_geometry(self, batch):
+        """Launch the coordinate-only index computations (FPS chain, ball queries) of `batch`
+        on a side stream; the step that later consumes `batch` waits for them.  Call it for
+        batch i+1 right before running the step on batch i: the serial FPS rounds then overlap
+        the dense kernels of step i instead of heading step i+1's critical path."""
+        if self.device.type != "cuda":
+            batch["geometry"] = self._compute_geometry(batch)
+            return
+        self.side_stream()
         main = torch.cuda.current_stream(self.device)
         if self.graphs and self._ensure_captured(batch):
             slot = self._slots[self._turn]
