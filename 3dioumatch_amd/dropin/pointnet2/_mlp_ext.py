@@ -412,6 +412,22 @@ def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None, n
     return dx, dw, below
 
 
+def small_backward_prefers_dy(w, y):
+    """True when the backward of the layer y = w x (y (B,M,...) behind BatchNorm + ReLU) is faster
+    with dy WRITTEN once (bn_relu_backward: sums + apply, two launches) and the pair launch reading
+    it, than with dy formed inside the pair launch's operand loads: in the small regime every one
+    of the K/64 row tiles of the data gradient and every tile of the weight gradient re-forms the
+    same dy tile (6 instructions + the bf16 split per element, up to 8 times over).  Measured
+    (tools/small_bwd_form_bench.py): 256 x 512 at 8 x 1024 columns 105 -> 83 us, 256 x 256 60 -> 48,
+    at 8 x 512 columns 39 -> 37, 128 x 128 at 8 x 256 columns 19.5 = 19.4.  MLP_SMALL_BWD_DY_COLS:
+    least number of columns (default 4096, 0 = never)."""
+    m, k = w.shape
+    b = y.shape[0]
+    r = y.numel() // (b * m)
+    least = int(os.environ.get("MLP_SMALL_BWD_DY_COLS", "4096"))
+    return least > 0 and b * r >= least and bool(_lib.mlp_gemm_backward_small_supported(b, m, k, r, 0, 0))
+
+
 def gemm_backward_small(w, x, xcoeff=None, dy=None, fly=None, need_dx=True):
     """Both backward GEMMs of a SMALL layer (FP modules, heads, pre-gather first layers) in one
     launch: -> (dx (B,K,...) or None, dw (M,K)), or None when the layer is outside the small

@@ -297,16 +297,22 @@ class _FusedMLPChain(Function):
                 dy_tensor, fly = None, None
                 pooled = (ys[i], dz, extra[0], scale, shift, mean, invstd, coef)
             else:
-                pooled = None
+                pooled, dy_tensor = None, None
                 if below is not None:  # left behind by the fused backward GEMM of layer i+1
                     dgamma, dbeta, coef = below
                 elif i == 0 and ctx.moments is not None:
                     raise RuntimeError("the virtual first layer's BatchNorm sums must come from the "
                                        "fused backward kernel of the second layer")
+                elif K.small_backward_prefers_dy(w2, ys[i]) and not (ctx.pre is not None and i == 0):
+                    # a small layer: dy written once and read by the pair launch, instead of
+                    # re-formed by each of its tiles (_mlp_ext.small_backward_prefers_dy)
+                    dy_tensor, dgamma, dbeta = K.bn_relu_backward(ys[i], dz, gamma, scale, shift, mean,
+                                                                  invstd, training)
+                    coef = None
                 else:
                     dgamma, dbeta, coef = K.bn_relu_backward_stats(ys[i], dz, gamma, scale, shift,
                                                                    mean, invstd, training)
-                dy_tensor, fly = None, (ys[i], dz, scale, shift, mean, invstd, coef)
+                fly = None if dy_tensor is not None else (ys[i], dz, scale, shift, mean, invstd, coef)
             grads[5 * i + 1], grads[5 * i + 2] = dgamma, dbeta
             m, k = w2.shape
             if ctx.pre is not None and i == 0:
@@ -332,14 +338,16 @@ class _FusedMLPChain(Function):
             # both GEMMs from one pass over (y_i, dz) where the shape allows
             src_stats = None if i == 0 else (coefs[i - 1][0], coefs[i - 1][1],
                                              params[5 * (i - 1) + 1], training)
-            both = K.gemm_backward_fused(w2, src, src_coeff, fly, pooled, src_stats,
-                                         need_dx=i > 0 or need_dx, lin_w=lin_w)
+            both = None
+            if dy_tensor is None:
+                both = K.gemm_backward_fused(w2, src, src_coeff, fly, pooled, src_stats,
+                                             need_dx=i > 0 or need_dx, lin_w=lin_w)
             if lin_w is not None and both is None:
                 raise RuntimeError("the virtual first layer needs the fused backward kernel of the second")
             below = None
             if both is None and pooled is None and lin_w is None and (i > 0 or need_dx):
                 # the small layers: both GEMMs in one launch (no BatchNorm sums for the layer below)
-                pair = K.gemm_backward_small(w2, src, src_coeff, fly=fly)
+                pair = K.gemm_backward_small(w2, src, src_coeff, dy=dy_tensor, fly=fly)
                 if pair is not None:
                     both = (pair[0], pair[1], None)
             if both is not None:

@@ -78,31 +78,39 @@ class _HeadChain(Function):
             dwm = K.gemm_wgrad(wm.shape[0], wm.shape[1], src, src_coeff, **grad)
             return dwm, (K.gemm_dgrad(wm, **grad) if need_dx else None)
 
+        def through_bn(wm, y, dz, gamma, scale, shift, mean, invstd):
+            """BatchNorm + ReLU backward of (y, dz) as the gradient operand of the layer's GEMMs:
+            (dgamma, dbeta, coef, operand keywords) -- dy written once where the pair launch would
+            otherwise re-form it in every tile (_mlp_ext.small_backward_prefers_dy), else on the fly"""
+            if K.small_backward_prefers_dy(wm, y):
+                dy, dg, dbe = K.bn_relu_backward(y, dz, gamma, scale, shift, mean, invstd, training)
+                return dg, dbe, None, dict(dy=dy)
+            dg, dbe, coef = K.bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, training)
+            return dg, dbe, coef, dict(fly=(y, dz, scale, shift, mean, invstd, coef))
+
         dw3, dz2 = both(w3m, y2, (scale2, shift2), dy=dy3)
         dw3 = dw3.view_as(w3)
-        dg2, dbe2, coef2 = K.bn_relu_backward_stats(y2, dz2, g2, scale2, shift2, mean2, invstd2,
-                                                    training)
-        fly2 = (y2, dz2, scale2, shift2, mean2, invstd2, coef2)
-        dw2, dz1 = both(w2m, y1, (scale1, shift1), fly=fly2)
+        dg2, dbe2, coef2, grad2 = through_bn(w2m, y2, dz2, g2, scale2, shift2, mean2, invstd2)
+        dw2, dz1 = both(w2m, y1, (scale1, shift1), **grad2)
         dw2 = dw2.view_as(w2)
-        dg1, dbe1, coef1 = K.bn_relu_backward_stats(y1, dz1, g1, scale1, shift1, mean1, invstd1,
-                                                    training)
-        fly1 = (y1, dz1, scale1, shift1, mean1, invstd1, coef1)
-        dw1, dx = both(w1m, x, None, need_dx=ctx.needs_input_grad[0], fly=fly1)
+        dg1, dbe1, coef1, grad1 = through_bn(w1m, y1, dz1, g1, scale1, shift1, mean1, invstd1)
+        dw1, dx = both(w1m, x, None, need_dx=ctx.needs_input_grad[0], **grad1)
         dw1 = dw1.view_as(w1)
         dx = dx.view_as(x) if dx is not None else None
 
-        def dbias(present, coef, dbeta):
+        def dbias(present, coef, dbeta, gamma, invstd):
             if not present:
                 return None
             # training: sum(dy) vanishes identically; eval: dy = gamma*invstd*dz_masked
             if training:
                 from pointnet2 import pytorch_utils
                 return None if pytorch_utils.zero_grads_as_none else torch.zeros_like(dbeta)
+            if coef is None:  # (dy was materialised: no coefficient table)
+                return gamma.detach() * invstd * dbeta
             return coef.reshape(-1)[0::3] * dbeta  # coef is [C][3]
 
-        db2 = dbias(ctx.has_bias[1], coef2, dbe2)
-        db1 = dbias(ctx.has_bias[0], coef1, dbe1)
+        db2 = dbias(ctx.has_bias[1], coef2, dbe2, g2, invstd2)
+        db1 = dbias(ctx.has_bias[0], coef1, dbe1, g1, invstd1)
         return (dx, None, None, None, None, None, dw1, db1, dg1, dbe1, None, None, dw2, db2, dg2,
                 dbe2, None, None, dw3, db3)
 

@@ -545,9 +545,15 @@ class SupervisedStep(object):
                 slot["geometry"] = body_geometry(slot)
         self._geo_keys = sorted(k for k, v in self._slots[0]["geometry"].items() if torch.is_tensor(v))
         self._cur_geometry = {k: self._slots[0]["geometry"][k].clone() for k in self._geo_keys}
+        # Without a gradient exchange nothing separates the backward pass from the update: ONE graph
+        # (the host-side learning-rate refresh of _before_apply moves in front of it -- only the
+        # update kernel reads that scalar).  STEP_ONE_GRAPH=0: two graphs as with an exchange.
+        self._merged = not self._exchanges() and os.environ.get("STEP_ONE_GRAPH", "1") != "0"
         self._g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g1, **mode):
             self._loss, self._end_points = body_step()
+            if self._merged:
+                self._apply()
         self._exchange_in_graph = False
         if self.capture_exchange and self._exchanges() and torch.distributed.get_backend() == "nccl":
             try:  # the collective as the first node of G2 (the zero gradient makes it harmless here)
@@ -560,7 +566,9 @@ class SupervisedStep(object):
                 sys.stderr.write("SupervisedStep: all-reduce not capturable (%s: %s); it stays an "
                                  "eager launch between the graphs\n" % (type(err).__name__, err))
                 torch.cuda.synchronize(dev)
-        if not self._exchange_in_graph:
+        if self._merged:
+            self._g2 = None
+        elif not self._exchange_in_graph:
             self._g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g2, **mode):
                 self._apply()
@@ -622,11 +630,15 @@ class SupervisedStep(object):
             slot["graph"].replay()
         slot["token"] = -1
         self._stage_copies(slot)
-        self._g1.replay()
-        if not self._exchange_in_graph:
-            self._exchange_gradients()
-        self._before_apply()
-        self._g2.replay()
+        if self._merged:
+            self._before_apply()
+            self._g1.replay()
+        else:
+            self._g1.replay()
+            if not self._exchange_in_graph:
+                self._exchange_gradients()
+            self._before_apply()
+            self._g2.replay()
         batch.pop("geometry", None)
         return self._loss, self._end_points
 
