@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib3dioumatch_hip.so")
+LIB_PATH = os.path.join(_HERE, "lib3dioumatch_hip%s.so" % os.environ.get("PN2_LIB_SUFFIX", ""))  # (build.py)
 
 _c_int, _c_float, _vp, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 

@@ -13,8 +13,12 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "lib3dioumatch_hip.so")
-OBJ = os.path.join(HERE, "build")
+# PN2_BUILD_SUFFIX=_x: a second library lib3dioumatch_hip_x.so (objects in build_x/) next to the
+# product, loaded instead of it when PN2_LIB_SUFFIX=_x (A/B of a compile-time switch inside ONE
+# gpurun call: both libraries travel with the snapshot)
+SUFFIX = os.environ.get("PN2_BUILD_SUFFIX", "")
+OUT = os.path.join(HERE, "lib3dioumatch_hip%s.so" % SUFFIX)
+OBJ = os.path.join(HERE, "build" + SUFFIX)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-munsafe-fp-atomics", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
