@@ -236,7 +236,7 @@ LOSS_HD void loss_proposal(const LossArgs &a, const SceneView &sv, int b, int k,
     const float s0 = lt_at(a.obj, b, k, 0), s1 = lt_at(a.obj, b, k, 1);
     const float m = s0 > s1 ? s0 : s1;
     const float lse = m + logf(expf(s0 - m) + expf(s1 - m));
-    const float scale = 0.5f * kLossWeight * mask * w;
+    const float scale = (a.consistency ? 0.0f : 0.5f * kLossWeight) * mask * w;  // (a statistic only there)
     a.g_obj[bk * 2] = scale * (expf(s0 - lse) - (label == 0 ? 1.0f : 0.0f));
     a.g_obj[bk * 2 + 1] = scale * (expf(s1 - lse) - (label == 1 ? 1.0f : 0.0f));
     acc[ACC_CE_MASK] += w * (lse - (label ? s1 : s0)) * mask;
@@ -285,6 +285,7 @@ LOSS_HD void loss_proposal(const LossArgs &a, const SceneView &sv, int b, int k,
                                       a.g_sem + bk * a.NC, &top);
     acc[ACC_CLSACC] += obj * (top == cl ? 1.0f : 0.0f);
   }
+  if (a.consistency) return;  // (loss_helper_unlabeled.py:292-361 has no IoU term)
   // IoU estimation: sigmoid(score of the class of the best-overlapping GT box) vs that IoU
   const int rows = a.has_jitter ? 2 * a.K : a.K;
   {
@@ -370,6 +371,10 @@ LOSS_HD void loss_stats(const LossArgs &a, const float *acc) {
   st[ST_JIT] = a.has_jitter ? acc[ACC_JITHUB] / (total + 1e-6f) : 0.0f;
   st[ST_LOSS] = kLossWeight * (st[ST_VOTE] + 0.5f * st[ST_OBJ] + st[ST_BOX] + 0.1f * st[ST_SEM] +
                                st[ST_IOU] + st[ST_JIT]);
+  if (a.consistency) {  // get_pseudo_detection_loss, loss_helper_unlabeled.py:350-358
+    st[ST_VOTE] = st[ST_IOU] = st[ST_JIT] = 0.0f;
+    st[ST_LOSS] = kLossWeight * (st[ST_BOX] + 0.1f * st[ST_SEM]);
+  }
   st[ST_POS_RATIO] = cnt / total;
   st[ST_NEG_RATIO] = acc[ACC_MASK] / total - st[ST_POS_RATIO];
   st[ST_OBJ_ACC] = acc[ACC_OBJACC] / (acc[ACC_MASK] + 1e-6f);

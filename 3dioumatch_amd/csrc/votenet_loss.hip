@@ -146,7 +146,8 @@ __global__ void __launch_bounds__(kLossBlock) loss_finalize_kernel(LossArgs a) {
 }
 
 bool valid(const VnLossArgs *a) {
-  return a && a->B > 0 && a->K > 0 && a->G > 0 && a->S > 0 && a->VF > 0 && a->NH > 0 && a->NS > 0 &&
+  if (a && a->consistency && (a->S != 0 || a->VF != 0)) return false;  // no vote term there
+  return a && a->B > 0 && a->K > 0 && a->G > 0 && (a->consistency || (a->S > 0 && a->VF > 0)) && a->NH > 0 && a->NS > 0 &&
          a->NC > 0 && (a->NI == 1 || a->NI == a->NC) && a->G <= kMaxG && a->K <= kMaxK &&
          a->B <= 65535;
 }

@@ -28,7 +28,7 @@ _GRADS = ("g_obj", "g_center", "g_h_scores", "g_h_resn", "g_s_scores", "g_s_resn
 
 class VnLossArgs(ctypes.Structure):  # field order == include/loss_hip.h
     _fields_ = ([(n, _c_int) for n in ("B", "K", "G", "S", "VF", "N", "NH", "NS", "NC", "NI",
-                                       "has_jitter")] +
+                                       "has_jitter", "consistency")] +
                 [(n, _vp) for n in ("center_label", "box_label_mask", "heading_class_label",
                                     "heading_residual_label", "size_class_label",
                                     "size_residual_label", "sem_cls_label", "vote_label",
@@ -237,4 +237,118 @@ def get_labeled_loss_fused(end_points, dataset_config, supervised_inds=None):
     loss = stats[ST_LOSS]
     end_points['detection_loss'] = loss
     end_points['loss'] = loss
+    return loss, end_points
+
+
+_CONSISTENCY_GRADS = ("g_center", "g_h_scores", "g_h_resn", "g_s_scores", "g_s_resn", "g_sem")
+_CONSISTENCY_KEYS = {
+    'unlabeled_objectness_loss': ST_OBJ, 'unlabeled_pos_ratio': ST_POS_RATIO,
+    'unlabeled_neg_ratio': ST_NEG_RATIO, 'unlabeled_center_loss': ST_CENTER,
+    'unlabeled_heading_cls_loss': ST_HCLS, 'unlabeled_heading_reg_loss': ST_HREG,
+    'unlabeled_size_cls_loss': ST_SCLS, 'unlabeled_size_reg_loss': ST_SREG,
+    'unlabeled_sem_cls_loss': ST_SEM, 'unlabeled_box_loss': ST_BOX,
+}
+
+
+class _FusedConsistencyLoss(torch.autograd.Function):
+    """The consistency loss on pseudo labels (losses_unlabeled.get_pseudo_detection_loss) with the
+    kernels of the supervised loss (VnLossArgs.consistency = 1): ONE call, two launches, where the
+    tensor version is ~90 small kernels forward and as many backward."""
+
+    @staticmethod
+    def forward(ctx, labels, config, agg_xyz, obj, center, h_scores, h_resn, s_scores, s_resn, sem):
+        dev = center.device
+        nb, k = center.shape[:2]
+        g = labels['center'].shape[1]
+        a = VnLossArgs()
+        a.B, a.K, a.G, a.S, a.VF, a.N = nb, k, g, 0, 0, 0
+        a.NH, a.NS, a.NC, a.NI = h_scores.shape[2], s_scores.shape[2], sem.shape[2], 1
+        a.has_jitter, a.consistency = 0, 1
+        keep = []
+
+        def ptr(t):
+            keep.append(t)
+            return t.data_ptr()
+        for field, key, dt in (('center_label', 'center', torch.float32), ('box_label_mask', 'mask', torch.float32),
+                               ('heading_class_label', 'heading_class', torch.int64),
+                               ('heading_residual_label', 'heading_residual', torch.float32),
+                               ('size_class_label', 'size_class', torch.int64),
+                               ('size_residual_label', 'size_residual', torch.float32),
+                               ('sem_cls_label', 'sem_cls', torch.int64)):
+            t = labels[key]
+            if t.dtype != dt or t.shape[0] != nb:
+                raise RuntimeError("pseudo label %s must be %s with %d scenes" % (key, dt, nb))
+            setattr(a, field, ptr(t.contiguous()))
+        a.mean_size = ptr(config.mean_size(dev).contiguous())
+        preds = {"agg_xyz": agg_xyz, "obj": obj, "center": center, "h_scores": h_scores, "h_resn": h_resn,
+                 "s_scores": s_scores, "s_resn": s_resn, "sem": sem}
+        for name, t in preds.items():
+            if t.dtype != torch.float32 or t.device != dev:
+                raise RuntimeError("%s must be a float32 tensor on %s" % (name, dev))
+            keep.append(t)
+            setattr(a, name, _view(t))
+        for name in ("iou", "iou_jit", "seed_xyz", "vote_xyz", "jit_center", "jit_size", "jit_heading"):
+            setattr(a, name, _view(center))  # unused in this mode
+        f32 = dict(dtype=torch.float32, device=dev)
+        stats = torch.empty(ST_COUNT, **f32)
+        objectness_label = torch.empty((nb, k), dtype=torch.int64, device=dev)
+        objectness_mask = torch.empty((nb, k), **f32)
+        object_assignment = torch.empty((nb, k), dtype=torch.int64, device=dev)
+        gt_nearest = torch.empty((nb, g), dtype=torch.int32, device=dev)
+        a.stats, a.objectness_label = ptr(stats), ptr(objectness_label)
+        a.objectness_mask, a.object_assignment = ptr(objectness_mask), ptr(object_assignment)
+        a.gt_nearest = ptr(gt_nearest)
+        a.partials = ptr(torch.empty(max(1, _scratch_floats(a, dev)), **f32))
+        shapes = [(nb, k, 2), (nb, k, 3), (nb, k, a.NH), (nb, k, a.NH), (nb, k, a.NS), (nb, k, a.NS, 3),
+                  (nb, k, a.NC)]
+        sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+        flat = torch.empty(sum(sizes), **f32)  # every element is written by the kernel
+        off = 0
+        for name, n in zip(("g_obj",) + _CONSISTENCY_GRADS, sizes):
+            setattr(a, name, flat.data_ptr() + 4 * off)
+            off += n
+        keep.append(flat)
+        _launch("votenet_loss_forward_backward", a, dev)
+        ctx.flat, ctx.shapes, ctx.sizes = flat, shapes, sizes
+        ctx.mark_non_differentiable(objectness_label, objectness_mask, object_assignment)
+        return stats, objectness_label, objectness_mask, object_assignment
+
+    @staticmethod
+    def backward(ctx, g_stats, *unused):
+        first = ctx.sizes[0]  # (the objectness rows are zeros: no gradient)
+        scaled = ctx.flat[first:] * g_stats[ST_LOSS]
+        out, off = [], 0
+        for sh, n in zip(ctx.shapes[1:], ctx.sizes[1:]):
+            out.append(scaled[off:off + n].view(sh))
+            off += n
+        return (None, None, None, None) + tuple(out)
+
+
+def get_pseudo_detection_loss_fused(end_points, labeled_num, config):
+    """Same contract as losses_unlabeled.get_pseudo_detection_loss (same end_points keys)."""
+    tail = slice(labeled_num, None)
+    mask = end_points['unlabeled_box_label_mask']
+    center = end_points['unlabeled_center_label'][:, :, 0:3]
+    # (the reference masks the centres of empty slots in place, loss_helper_unlabeled.py:150-152)
+    center = torch.where((1 - mask).unsqueeze(-1).bool(), torch.full_like(center, -1000), center)
+    end_points['unlabeled_center_label'] = center
+    labels = {'center': center, 'mask': mask.float(),
+              'heading_class': end_points['unlabeled_heading_class_label'],
+              'heading_residual': end_points['unlabeled_heading_residual_label'],
+              'size_class': end_points['unlabeled_size_class_label'],
+              'size_residual': end_points['unlabeled_size_residual_label'],
+              'sem_cls': end_points['unlabeled_sem_cls_label']}
+    stats, obj_label, obj_mask, assignment = _FusedConsistencyLoss.apply(
+        labels, config, end_points['aggregated_vote_xyz'][tail], end_points['objectness_scores'][tail],
+        end_points['center'][tail], end_points['heading_scores'][tail],
+        end_points['heading_residuals_normalized'][tail], end_points['size_scores'][tail],
+        end_points['size_residuals_normalized'][tail], end_points['sem_cls_scores'][tail])
+    log = stats.detach()
+    for key, i in _CONSISTENCY_KEYS.items():
+        end_points[key] = log[i]
+    end_points['unlabeled_objectness_label'] = obj_label
+    end_points['unlabeled_objectness_mask'] = obj_mask
+    end_points['unlabeled_object_assignment'] = assignment
+    loss = stats[ST_LOSS]
+    end_points['unlabeled_detection_loss'] = loss
     return loss, end_points

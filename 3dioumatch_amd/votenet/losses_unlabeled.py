@@ -13,6 +13,8 @@ synchronise); here everything stays on the device with static shapes -- the NMS 
 semi-supervised step can be captured in a HIP graph.  The batch layout is the reference loader's:
 labeled samples first, then the unlabeled ones (train.py:321-325), `labeled_num` known on the host.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -183,7 +185,13 @@ def compute_box_and_sem_cls_loss(end_points, labeled_num, config):
 
 
 def get_pseudo_detection_loss(end_points, labeled_num, config):
-    """10 * (box + 0.1 * sem_cls) on the unlabeled samples (:292-361)."""
+    """10 * (box + 0.1 * sem_cls) on the unlabeled samples (:292-361).  On the GPU: the kernels of
+    the supervised loss in their consistency mode (fused_loss.get_pseudo_detection_loss_fused;
+    VOTENET_FUSED_LOSS=0 or VOTENET_FUSED_CONSISTENCY=0 keep the tensor operations below)."""
+    from . import fused_loss
+    if fused_loss.enabled() and os.environ.get("VOTENET_FUSED_CONSISTENCY", "1") != "0" and \
+            fused_loss.available(end_points['center'].device) and end_points['center'].dim() == 3:
+        return fused_loss.get_pseudo_detection_loss_fused(end_points, labeled_num, config)
     obj_loss, obj_label, obj_mask, assignment = compute_objectness_loss(end_points, labeled_num)
     end_points['unlabeled_objectness_loss'] = obj_loss
     end_points['unlabeled_objectness_label'] = obj_label

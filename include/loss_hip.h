@@ -29,6 +29,12 @@ typedef struct VnLossArgs {
                               seeds, votes per seed, points per scene */
   int NH, NS, NC, NI;      /* heading bins, size clusters, classes, IoU channels (1 or NC) */
   int has_jitter;
+  int consistency;         /* 1: the consistency loss of the semi-supervised stage on pseudo labels
+                              (models/loss_helper_unlabeled.py:137-361): the labels are the pseudo
+                              boxes (centres of empty slots already at -1000), there is no vote term
+                              (S = VF = 0, vote / seed arguments unused) and no IoU term (iou
+                              arguments unused, g_iou* not written), the objectness term is a
+                              statistic only (g_obj = 0): loss = 10 (box + 0.1 sem_cls) */
   /* labels (loss_helper_labeled.py end_points keys): contiguous, first B scenes are read */
   const float *center_label;             /* (.,G,3) */
   const float *box_label_mask;           /* (.,G)   */

@@ -195,3 +195,78 @@ def test_gpu_kernels_labeled_scenes_first(oracle_omp, monkeypatch):
     cfg = V.scannet_config()
     ref, got = _both_paths(V, cfg, dev, monkeypatch, extra={"labeled_num": B - 1})
     _compare(ref, got, 5e-5)
+
+
+def _consistency_both_paths(tag, dev, monkeypatch, nms=None):
+    """get_unlabeled_loss on the reference's golden inputs, tensor operations (flag 0) and the
+    fused kernels in consistency mode (flag 1): (loss, end_points, input gradients) each."""
+    V = importlib.import_module("3dioumatch_amd.votenet")
+    U = importlib.import_module("3dioumatch_amd.votenet.losses_unlabeled")
+    if nms is not None:
+        monkeypatch.setattr(U, "_lhs_nms", nms)
+    g = golden("unlabeled_loss_ref.npz")
+    cfg = V.scannet_config() if tag == "scannet" else V.sunrgbd_config()
+    keys = ("center", "heading_residuals_normalized", "size_residuals_normalized", "sem_cls_scores",
+            "heading_scores", "size_scores", "objectness_scores")
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("VOTENET_FUSED_LOSS", flag)
+        ep = {k.split("::", 1)[1]: torch.from_numpy(g[k]).to(dev) for k in g.files
+              if k.startswith(tag + "_in_ep::")}
+        ema = {k.split("::", 1)[1]: torch.from_numpy(g[k]).to(dev) for k in g.files
+               if k.startswith(tag + "_in_ema::")}
+        for k in keys:
+            ep[k].requires_grad_(True)
+        ep["labeled_num"] = int(ep["supervised_mask"].sum())
+        loss, ep = U.get_unlabeled_loss(ep, ema, cfg, U.default_config_dict(cfg, dataset=tag,
+                                                                            unlabeled_batch_size=3))
+        loss.backward()
+        out.append((loss.detach(), ep, {k: (ep[k].grad.detach().clone() if ep[k].grad is not None
+                                            else torch.zeros_like(ep[k])) for k in keys}))
+    return out
+
+
+def _compare_consistency(ref, got, tol):
+    (l0, e0, g0), (l1, e1, g1) = ref, got
+    assert abs(float(l0) - float(l1)) <= tol * max(1.0, abs(float(l0)))
+    for key in ("unlabeled_objectness_label", "unlabeled_objectness_mask", "unlabeled_object_assignment"):
+        assert np.array_equal(e0[key].cpu().numpy().astype(np.float64), e1[key].cpu().numpy().astype(np.float64)), key
+    for key in ("unlabeled_objectness_loss", "unlabeled_pos_ratio", "unlabeled_neg_ratio",
+                "unlabeled_center_loss", "unlabeled_heading_cls_loss", "unlabeled_heading_reg_loss",
+                "unlabeled_size_cls_loss", "unlabeled_size_reg_loss", "unlabeled_sem_cls_loss",
+                "unlabeled_box_loss", "unlabeled_detection_loss"):
+        a, b = float(e0[key].detach()), float(e1[key].detach())
+        assert abs(a - b) <= tol * max(1.0, abs(a)), (key, a, b)
+    assert np.array_equal(e0["unlabeled_center_label"].cpu().numpy(), e1["unlabeled_center_label"].cpu().numpy())
+    whole = float(torch.sqrt(sum((v.double() ** 2).sum() for v in g0.values())))
+    assert whole > 0
+    for name in g0:
+        err = float((g0[name] - g1[name]).norm()) / max(0.01 * whole, float(g0[name].norm()))
+        assert err <= 20 * tol, (name, err)
+    assert float(g1["objectness_scores"].abs().max()) == 0.0  # a statistic only: no gradient
+
+
+@pytest.mark.parametrize("tag", ["scannet", "sunrgbd"])
+def test_host_build_consistency_loss_matches_tensor_ops(tag, oracle, host_build, monkeypatch):
+    """The consistency loss on pseudo labels through the supervised loss' functions in their
+    consistency mode (loss_core.h compiled for the host) == losses_unlabeled's tensor operations
+    with autograd, on the inputs of the reference's golden vectors: labels, every logged term,
+    the loss, and the gradient w.r.t. each head output."""
+    from test_unlabeled_loss import _oracle_nms
+    load_pkg()
+    fused = importlib.import_module("3dioumatch_amd.votenet.fused_loss")
+    monkeypatch.setattr(fused, "_HOST_BUILD", host_build)
+    calls = []
+    real_launch = fused._launch
+    monkeypatch.setattr(fused, "_launch", lambda name, a, d: (calls.append(name), real_launch(name, a, d)))
+    ref, got = _consistency_both_paths(tag, torch.device("cpu"), monkeypatch, _oracle_nms(oracle))
+    assert calls == ["votenet_loss_forward_backward"]  # the fused path ran, once
+    _compare_consistency(ref, got, 2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["scannet", "sunrgbd"])
+def test_gpu_consistency_loss_matches_tensor_ops(tag, oracle_omp, monkeypatch):
+    _setup(True, oracle_omp)
+    ref, got = _consistency_both_paths(tag, torch.device("cuda:0"), monkeypatch)
+    _compare_consistency(ref, got, 5e-5)

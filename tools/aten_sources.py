@@ -2,7 +2,7 @@
 TorchDispatchMode records every aten call on CUDA tensors with the innermost frame inside this
 repository (forward, loss and the Python bodies of the custom autograd functions; the mode is
 re-entered in the autograd worker thread through a hook on the engine's first function).
-    python tools/aten_sources.py"""
+    python tools/aten_sources.py [semi]"""
 import collections
 import importlib
 import os
@@ -19,8 +19,14 @@ V = importlib.import_module("3dioumatch_amd.votenet")
 data = importlib.import_module("3dioumatch_amd.votenet.data")
 dev = torch.device("cuda:0")
 cfg = V.scannet_config()
-runner = V.SupervisedStep(cfg, dev, world_size=1, num_proposal=256, graphs=False)
-batch = data.make_batch(8, 40000, cfg, seed=100, device=dev)
+SEMI = len(sys.argv) > 1 and sys.argv[1] == "semi"
+if SEMI:
+    runner = V.SemiSupervisedStep(cfg, dev, world_size=1, num_proposal=256, graphs=False)
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v)
+             for k, v in data.make_semi_batch(4, 8, 40000, cfg, seed=100).items()}
+else:
+    runner = V.SupervisedStep(cfg, dev, world_size=1, num_proposal=256, graphs=False)
+    batch = data.make_batch(8, 40000, cfg, seed=100, device=dev)
 SKIP = ("aten::view", "aten::_unsafe_view", "aten::reshape", "aten::transpose", "aten::permute", "aten::slice",
         "aten::select", "aten::expand", "aten::unsqueeze", "aten::squeeze", "aten::detach", "aten::alias",
         "aten::as_strided", "aten::t", "aten::empty", "aten::empty_like", "aten::empty_strided", "aten::size",
