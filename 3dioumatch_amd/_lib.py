@@ -127,6 +127,8 @@ _SIGNATURES = {
     "mlp_flush_weight_reductions": [],
     "lhs_nms3d_aabb": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _c_int, _c_int, _vp,
                        _vp],
+    "lhs_pseudo_select": [_vp, _vp],
+    "lhs_pseudo_finish": [_vp, _vp],
     "lhs_nms_samecls": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _c_int, _vp, _vp],
     "iou3d_boxes_overlap_bev": [_c_int, _vp, _c_int, _vp, _vp, _vp],
     "iou3d_boxes_iou_bev": [_c_int, _vp, _c_int, _vp, _vp, _vp],

@@ -233,18 +233,42 @@ def get_unlabeled_loss(end_points, ema_end_points, config, config_dict):
     if labeled_num is None:
         labeled_num = int(torch.count_nonzero(end_points['supervised_mask']))
     tail = slice(labeled_num, None)
-    (label_mask, center_label, sem_cls_label, heading_label, heading_residual_label, size_label,
-     size_residual_label, false_center_label, iou_label) = get_pseudo_labels(
-        end_points, ema_end_points, labeled_num, ema_end_points['center'][tail],
-        ema_end_points['sem_cls_scores'][tail], ema_end_points['objectness_scores'][tail],
-        ema_end_points['heading_scores'][tail], ema_end_points['heading_residuals'][tail],
-        ema_end_points['size_scores'][tail], ema_end_points['size_residuals'][tail],
-        ema_end_points['aggregated_vote_xyz'][tail], config_dict)
-
     aug = [end_points[k][tail] for k in ('flip_x_axis', 'flip_y_axis', 'rot_mat', 'scale')]
-    center_label = trans_center(center_label, *aug)
-    false_center_label = trans_center(false_center_label, *aug)
-    size_residual_label = trans_size(size_label, size_residual_label, aug[3], config)
+    fused = None
+    if ema_end_points['center'].is_cuda and os.environ.get("VOTENET_FUSED_PSEUDO_LABELS", "1") != "0":
+        from . import pseudo_nms
+        if pseudo_nms.pseudo_labels_supported(ema_end_points['center'][tail], aug[3]) and \
+                _lhs_nms.__module__ == __name__:  # (tests substitute the NMS: the tensor form calls it)
+            fused = pseudo_nms.pseudo_labels_gpu(
+                ema_end_points['objectness_scores'][tail], ema_end_points['sem_cls_scores'][tail],
+                ema_end_points['iou_scores'][tail], ema_end_points['heading_scores'][tail],
+                ema_end_points['heading_residuals'][tail], ema_end_points['size_scores'][tail],
+                ema_end_points['size_residuals'][tail], ema_end_points['center'][tail],
+                ema_end_points['aggregated_vote_xyz'][tail], config.mean_size(aug[3].device), aug[0], aug[1],
+                aug[2], aug[3], config_dict['obj_threshold'], config_dict['cls_threshold'],
+                config_dict['iou_threshold'],
+                (config_dict['nms_iou'], config_dict['use_old_type_nms']) if config_dict['use_lhs'] else None)
+    if fused is not None:
+        # two launches around the NMS kernel: selection, labels, and the transforms into the student's
+        # frame (votenet/pseudo_nms.py pseudo_labels_gpu)
+        end_points['pseudo_gt_ratio'] = fused['pseudo_gt_ratio']
+        label_mask, center_label, false_center_label = (fused[k] for k in ('label_mask', 'center_label',
+                                                                            'false_center_label'))
+        sem_cls_label, heading_label, size_label = (fused[k] for k in ('sem_cls_label', 'heading_label',
+                                                                       'size_label'))
+        heading_residual_label, size_residual_label, iou_label = (
+            fused[k] for k in ('heading_residual_label', 'size_residual_label', 'iou_label'))
+    else:
+        (label_mask, center_label, sem_cls_label, heading_label, heading_residual_label, size_label,
+         size_residual_label, false_center_label, iou_label) = get_pseudo_labels(
+            end_points, ema_end_points, labeled_num, ema_end_points['center'][tail],
+            ema_end_points['sem_cls_scores'][tail], ema_end_points['objectness_scores'][tail],
+            ema_end_points['heading_scores'][tail], ema_end_points['heading_residuals'][tail],
+            ema_end_points['size_scores'][tail], ema_end_points['size_residuals'][tail],
+            ema_end_points['aggregated_vote_xyz'][tail], config_dict)
+        center_label = trans_center(center_label, *aug)
+        false_center_label = trans_center(false_center_label, *aug)
+        size_residual_label = trans_size(size_label, size_residual_label, aug[3], config)
     if config_dict['dataset'] == 'sunrgbd':
         heading_label, heading_residual_label = trans_angle(
             heading_label, heading_residual_label, aug[0], aug[1], end_points['rot_angle'][tail],

@@ -57,3 +57,90 @@ def nms3d_aabb_gpu(center, size, heading, score, cls, thresh, old_type=False, sa
                                      picked.data_ptr(), _L.current_stream_ptr(score.device)),
                  "lhs_nms3d_aabb")
     return picked.bool()
+
+
+import ctypes  # noqa: E402
+
+_c_int, _c_float, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+
+class LhsPseudoArgs(ctypes.Structure):  # field order == include/lhs_hip.h
+    _fields_ = ([(n, _c_int) for n in ("S", "K", "NC", "NI", "NH", "NS")] +
+                [(n, _c_float) for n in ("obj_threshold", "cls_threshold", "iou_threshold")] +
+                [("use_nms", _c_int)] +
+                [(n, _vp) for n in ("objectness", "sem_cls", "iou", "heading_scores", "heading_residuals",
+                                    "size_scores", "size_residuals", "center", "vote_xyz", "mean_size",
+                                    "flip_x", "flip_y", "rot_mat", "scale", "box_center", "box_size",
+                                    "box_heading", "box_score", "passed", "negative", "false_xyz", "picked",
+                                    "label_mask", "center_label", "false_center_label", "sem_cls_label",
+                                    "heading_label", "size_label", "heading_residual_label",
+                                    "size_residual_label", "iou_label", "pseudo_gt_ratio")])
+
+
+def pseudo_labels_supported(pred_center, scale):
+    """The two-launch form covers GPU tensors, 64 <= K <= 1024 proposals and a per-axis scale (S,1,3)."""
+    return pred_center.is_cuda and 64 <= pred_center.shape[1] <= 1024 and \
+        tuple(scale.shape) == (pred_center.shape[0], 1, 3)
+
+
+def pseudo_labels_gpu(objectness, sem_cls, iou_scores, heading_scores, heading_residuals, size_scores,
+                      size_residuals, center, vote_xyz, mean_size, flip_x, flip_y, rot_mat, scale,
+                      obj_threshold, cls_threshold, iou_threshold, nms=None):
+    """get_pseudo_labels + trans_center / trans_size of losses_unlabeled.py as two launches around
+    the NMS kernel (include/lhs_hip.h lhs_pseudo_select / lhs_pseudo_finish).  `nms`: None, or
+    (iou threshold, old_type) for lhs_nms_samecls on the selected boxes.  Returns a dict with
+    label_mask, center_label, false_center_label, sem_cls_label, heading_label,
+    heading_residual_label, size_label, size_residual_label, iou_label, pseudo_gt_ratio."""
+    dev = center.device
+    s, k = center.shape[:2]
+    f32 = dict(dtype=torch.float32, device=dev)
+    i64 = dict(dtype=torch.int64, device=dev)
+    keep = []
+
+    def inp(t, dt):
+        if t.dtype != dt or t.device != dev:
+            raise RuntimeError("pseudo_labels_gpu: expected %s tensors on %s" % (dt, dev))
+        t = t.detach().contiguous()
+        keep.append(t)
+        return t.data_ptr()
+    a = LhsPseudoArgs()
+    a.S, a.K = s, k
+    a.NC, a.NI, a.NH, a.NS = sem_cls.shape[2], iou_scores.shape[2], heading_scores.shape[2], size_scores.shape[2]
+    a.obj_threshold, a.cls_threshold, a.iou_threshold = float(obj_threshold), float(cls_threshold), float(iou_threshold)
+    a.use_nms = 1 if nms is not None else 0
+    for name, t in (("objectness", objectness), ("sem_cls", sem_cls), ("iou", iou_scores),
+                    ("heading_scores", heading_scores), ("heading_residuals", heading_residuals),
+                    ("size_scores", size_scores), ("size_residuals", size_residuals), ("center", center),
+                    ("vote_xyz", vote_xyz), ("mean_size", mean_size), ("rot_mat", rot_mat), ("scale", scale)):
+        setattr(a, name, inp(t, torch.float32))
+    a.flip_x, a.flip_y = inp(flip_x, torch.int64), inp(flip_y, torch.int64)
+    n = 64
+    out = {"label_mask": torch.empty((s, n), **i64), "center_label": torch.empty((s, n, 3), **f32),
+           "false_center_label": torch.empty((s, n, 3), **f32), "sem_cls_label": torch.empty((s, n), **i64),
+           "heading_label": torch.empty((s, n), **i64), "size_label": torch.empty((s, n), **i64),
+           "heading_residual_label": torch.empty((s, n), **f32),
+           "size_residual_label": torch.empty((s, n, 3), **f32), "iou_label": torch.empty((s, n), **f32),
+           "pseudo_gt_ratio": torch.empty((), **f32)}
+    box_center = torch.empty((s, n, 3), **f32)
+    box_size = torch.empty((s, n, 3), dtype=torch.float64, device=dev)
+    box_heading = torch.empty((s, n), dtype=torch.float64, device=dev)
+    box_score = torch.empty((s, n), **f32)
+    flags = torch.empty((2, s, n), dtype=torch.int32, device=dev)
+    false_xyz = torch.empty((s, n, 3), **f32)
+    a.box_center, a.box_size, a.box_heading = box_center.data_ptr(), box_size.data_ptr(), box_heading.data_ptr()
+    a.box_score, a.passed, a.negative = box_score.data_ptr(), flags[0].data_ptr(), flags[1].data_ptr()
+    a.false_xyz = false_xyz.data_ptr()
+    for name, t in out.items():
+        setattr(a, name, t.data_ptr())
+    stream = _L.current_stream_ptr(dev)
+    with torch.cuda.device(dev):
+        _L.check(_lib.lhs_pseudo_select(ctypes.byref(a), stream), "lhs_pseudo_select")
+        picked = None
+        if nms is not None:
+            picked = torch.zeros((s, n), dtype=torch.int32, device=dev)
+            _L.check(_lib.lhs_nms_samecls(s, n, box_center.data_ptr(), box_size.data_ptr(), box_heading.data_ptr(),
+                                          box_score.data_ptr(), out["sem_cls_label"].data_ptr(), float(nms[0]),
+                                          1 if nms[1] else 0, picked.data_ptr(), stream), "lhs_nms_samecls")
+            a.picked = picked.data_ptr()
+        _L.check(_lib.lhs_pseudo_finish(ctypes.byref(a), stream), "lhs_pseudo_finish")
+    return out
