@@ -127,6 +127,8 @@ _SIGNATURES = {
     "mlp_flush_weight_reductions": [],
     "lhs_nms3d_aabb": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _c_int, _c_int, _vp,
                        _vp],
+    "votenet_decode_scores": [_c_int] * 5 + [_vp] * 13,
+    "votenet_decode_scores_grad": [_c_int] * 5 + [_vp] * 13,
     "lhs_pseudo_select": [_vp, _vp],
     "lhs_pseudo_finish": [_vp, _vp],
     "lhs_nms_samecls": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _c_int, _vp, _vp],

@@ -177,3 +177,124 @@ int votenet_loss_forward_backward(const VnLossArgs *args, void *stream) {
   hipLaunchKernelGGL(loss_finalize_kernel, grid, dim3(kLossBlock), 0, (hipStream_t)stream, *args);
   return (int)hipGetLastError();
 }
+
+
+// ---- decode_scores (models/proposal_module.py:24-54) and its backward -----------------------------
+// A lane per proposal: its column of the head output (b, c, k) -- coalesced along k -- in, the rows
+// of the nine named predictions out.
+namespace {
+
+struct DecodeArgs {
+  int b, k, nh, ns, nc;
+  const float *net, *agg_xyz, *mean_size;
+  float *objectness, *center, *heading_scores, *heading_resn, *heading_res, *size_scores, *size_resn,
+      *size_res, *sem_cls;
+};
+
+__device__ __forceinline__ float softplus1(float x) {  // F.softplus: beta 1, threshold 20
+  return x > 20.0f ? x : log1pf(expf(x));
+}
+
+__global__ void __launch_bounds__(256) decode_scores_kernel(DecodeArgs a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)a.b * a.k) return;
+  const int bi = (int)(i / a.k), ki = (int)(i % a.k);
+  const int c_total = 5 + 2 * a.nh + 4 * a.ns + a.nc;
+  const float *col = a.net + ((long long)bi * c_total) * a.k + ki;
+  auto at = [&](int c) { return col[(long long)c * a.k]; };
+  int c = 0;
+  a.objectness[i * 2] = at(0); a.objectness[i * 2 + 1] = at(1);
+  c = 2;
+  for (int d = 0; d < 3; ++d) a.center[i * 3 + d] = a.agg_xyz[i * 3 + d] + at(c + d);
+  c += 3;
+  for (int j = 0; j < a.nh; ++j) a.heading_scores[i * a.nh + j] = at(c + j);
+  c += a.nh;
+  const float per = (float)(M_PI / (double)a.nh);   // np.pi / nh as a Python float, then fp32
+  for (int j = 0; j < a.nh; ++j) {
+    const float v = at(c + j);
+    a.heading_resn[i * a.nh + j] = v;
+    a.heading_res[i * a.nh + j] = v * per;
+  }
+  c += a.nh;
+  for (int j = 0; j < a.ns; ++j) a.size_scores[i * a.ns + j] = at(c + j);
+  c += a.ns;
+  for (int j = 0; j < a.ns * 3; ++j) {
+    const float v = softplus1(at(c + j)) - 1.0f;
+    a.size_resn[i * a.ns * 3 + j] = v;
+    a.size_res[i * a.ns * 3 + j] = v * a.mean_size[j];
+  }
+  c += a.ns * 3;
+  for (int j = 0; j < a.nc; ++j) a.sem_cls[i * a.nc + j] = at(c + j);
+}
+
+struct DecodeGradArgs {
+  int b, k, nh, ns, nc;
+  const float *net, *mean_size;
+  const float *g_objectness, *g_center, *g_heading_scores, *g_heading_resn, *g_heading_res,
+      *g_size_scores, *g_size_resn, *g_size_res, *g_sem_cls;
+  float *d_net;
+};
+
+__global__ void __launch_bounds__(256) decode_scores_grad_kernel(DecodeGradArgs a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)a.b * a.k) return;
+  const int bi = (int)(i / a.k), ki = (int)(i % a.k);
+  const int c_total = 5 + 2 * a.nh + 4 * a.ns + a.nc;
+  const long long base = ((long long)bi * c_total) * a.k + ki;
+  auto put = [&](int c, float v) { a.d_net[base + (long long)c * a.k] = v; };
+  auto get = [&](const float *g, long long j) { return g ? g[j] : 0.0f; };
+  put(0, get(a.g_objectness, i * 2)); put(1, get(a.g_objectness, i * 2 + 1));
+  int c = 2;
+  for (int d = 0; d < 3; ++d) put(c + d, get(a.g_center, i * 3 + d));
+  c += 3;
+  for (int j = 0; j < a.nh; ++j) put(c + j, get(a.g_heading_scores, i * a.nh + j));
+  c += a.nh;
+  const float per = (float)(M_PI / (double)a.nh);
+  for (int j = 0; j < a.nh; ++j)
+    put(c + j, get(a.g_heading_resn, i * a.nh + j) + get(a.g_heading_res, i * a.nh + j) * per);
+  c += a.nh;
+  for (int j = 0; j < a.ns; ++j) put(c + j, get(a.g_size_scores, i * a.ns + j));
+  c += a.ns;
+  for (int j = 0; j < a.ns * 3; ++j) {
+    const float x = a.net[base + (long long)(c + j) * a.k];
+    const float slope = x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));   // softplus' = sigmoid
+    const float g = get(a.g_size_resn, i * a.ns * 3 + j) + get(a.g_size_res, i * a.ns * 3 + j) * a.mean_size[j];
+    put(c + j, g * slope);
+  }
+  c += a.ns * 3;
+  for (int j = 0; j < a.nc; ++j) put(c + j, get(a.g_sem_cls, i * a.nc + j));
+}
+
+}  // namespace
+
+extern "C" __attribute__((visibility("default")))
+int votenet_decode_scores(int b, int k, int nh, int ns, int nc, const float *net, const float *agg_xyz,
+                          const float *mean_size, float *objectness, float *center,
+                          float *heading_scores, float *heading_resn, float *heading_res,
+                          float *size_scores, float *size_resn, float *size_res, float *sem_cls,
+                          void *stream) {
+  if (b <= 0 || k <= 0) return 0;
+  if (nh <= 0 || ns <= 0 || nc <= 0) return (int)hipErrorInvalidValue;
+  const DecodeArgs a = {b, k, nh, ns, nc, net, agg_xyz, mean_size, objectness, center, heading_scores,
+                        heading_resn, heading_res, size_scores, size_resn, size_res, sem_cls};
+  hipLaunchKernelGGL(decode_scores_kernel, dim3((unsigned)(((long long)b * k + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" __attribute__((visibility("default")))
+int votenet_decode_scores_grad(int b, int k, int nh, int ns, int nc, const float *net,
+                               const float *mean_size, const float *g_objectness, const float *g_center,
+                               const float *g_heading_scores, const float *g_heading_resn,
+                               const float *g_heading_res, const float *g_size_scores,
+                               const float *g_size_resn, const float *g_size_res, const float *g_sem_cls,
+                               float *d_net, void *stream) {
+  if (b <= 0 || k <= 0) return 0;
+  if (nh <= 0 || ns <= 0 || nc <= 0) return (int)hipErrorInvalidValue;
+  const DecodeGradArgs a = {b, k, nh, ns, nc, net, mean_size, g_objectness, g_center, g_heading_scores,
+                            g_heading_resn, g_heading_res, g_size_scores, g_size_resn, g_size_res,
+                            g_sem_cls, d_net};
+  hipLaunchKernelGGL(decode_scores_grad_kernel, dim3((unsigned)(((long long)b * k + 255) / 256)), dim3(256),
+                     0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}

@@ -47,9 +47,70 @@ class VotingModule(nn.Module):
         return vote_xyz, vote_features.transpose(2, 1).contiguous()
 
 
+class _DecodeScores(torch.autograd.Function):
+    """decode_scores as one launch each way (include/loss_hip.h votenet_decode_scores): the nine
+    named predictions as contiguous (B,K,.) tensors from the head output (B,C,K)."""
+
+    @staticmethod
+    def forward(ctx, net, agg_xyz, mean_size, nh, ns, nc):
+        _L = _fused_front_end()
+        net, agg = net.contiguous(), agg_xyz.contiguous()
+        b, _, k = net.shape
+        f32 = dict(dtype=torch.float32, device=net.device)
+        outs = [torch.empty((b, k, 2), **f32), torch.empty((b, k, 3), **f32), torch.empty((b, k, nh), **f32),
+                torch.empty((b, k, nh), **f32), torch.empty((b, k, nh), **f32), torch.empty((b, k, ns), **f32),
+                torch.empty((b, k, ns, 3), **f32), torch.empty((b, k, ns, 3), **f32),
+                torch.empty((b, k, nc), **f32)]
+        with torch.cuda.device(net.device):
+            _L.check(_L.lib.votenet_decode_scores(
+                b, k, nh, ns, nc, net.data_ptr(), agg.data_ptr(), mean_size.data_ptr(),
+                *[o.data_ptr() for o in outs], torch.cuda.current_stream(net.device).cuda_stream),
+                "votenet_decode_scores")
+        ctx.save_for_backward(net, mean_size)
+        ctx.dims = (nh, ns, nc)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        _L = _fused_front_end()
+        net, mean_size = ctx.saved_tensors
+        nh, ns, nc = ctx.dims
+        b, _, k = net.shape
+        grads = [g.contiguous() if g is not None else None for g in grads]
+        d_net = torch.empty_like(net)
+        with torch.cuda.device(net.device):
+            _L.check(_L.lib.votenet_decode_scores_grad(
+                b, k, nh, ns, nc, net.data_ptr(), mean_size.data_ptr(),
+                *[g.data_ptr() if g is not None else None for g in grads], d_net.data_ptr(),
+                torch.cuda.current_stream(net.device).cuda_stream), "votenet_decode_scores_grad")
+        return d_net, grads[1], None, None, None, None
+
+
+def _decode_fused(net, mean_size, width):
+    import os
+    _L = _fused_front_end()
+    return (os.environ.get("VOTENET_FUSED_DECODE", "1") != "0" and net.is_cuda and net.dtype == torch.float32
+            and _L is not None and hasattr(_L.lib, "votenet_decode_scores") and net.shape[1] == width
+            and mean_size.is_cuda and mean_size.is_contiguous())
+
+
 def decode_scores(net, end_points, num_class, num_heading_bin, num_size_cluster, mean_size):
     """Split the proposal head output (B, C, K) into the named predictions
     (proposal_module.py:24-54); mean_size is a (num_size_cluster, 3) tensor."""
+    nh, ns = num_heading_bin, num_size_cluster
+    if _decode_fused(net, mean_size, 5 + nh * 2 + ns * 4 + num_class):
+        (objectness, center, heading_scores, hrn, hr, size_scores, srn, sr, sem) = _DecodeScores.apply(
+            net, end_points['aggregated_vote_xyz'], mean_size, nh, ns, num_class)
+        end_points['objectness_scores'] = objectness
+        end_points['center'] = center
+        end_points['heading_scores'] = heading_scores
+        end_points['heading_residuals_normalized'] = hrn
+        end_points['heading_residuals'] = hr
+        end_points['size_scores'] = size_scores
+        end_points['size_residuals_normalized'] = srn
+        end_points['size_residuals'] = sr
+        end_points['sem_cls_scores'] = sem
+        return end_points
     t = net.transpose(2, 1)
     b, k = t.shape[:2]
     nh, ns = num_heading_bin, num_size_cluster

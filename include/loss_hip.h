@@ -106,6 +106,28 @@ int votenet_channel_normalize(int b, int c, int n, const float *x, float *y, flo
 int votenet_channel_normalize_grad(int b, int c, int n, const float *y, const float *norm,
                                    const float *dy, float *dx, void *stream);
 
+/* replaces decode_scores (models/proposal_module.py:24-54): the proposal head's output net
+ * (b, c, k), c = 2 + 3 + 2 nh + 4 ns + nc, split into the named predictions, each a contiguous
+ * (b,k,.) tensor: objectness (2), center = agg_xyz + offset (3), heading_scores (nh),
+ * heading_residuals_normalized (nh), heading_residuals = normalized * pi/nh (nh), size_scores (ns),
+ * size_residuals_normalized = softplus(.) - 1 (ns,3), size_residuals = normalized * mean_size
+ * (ns,3), sem_cls_scores (nc) -- one launch instead of five tensor kernels and the strided copies
+ * their consumers make. */
+int votenet_decode_scores(int b, int k, int nh, int ns, int nc, const float *net,
+                          const float *agg_xyz, const float *mean_size, float *objectness,
+                          float *center, float *heading_scores, float *heading_resn,
+                          float *heading_res, float *size_scores, float *size_resn, float *size_res,
+                          float *sem_cls, void *stream);
+/* its backward (autograd of models/proposal_module.py:24-54): d_net (b,c,k) from the gradients of
+ * the nine outputs (any of them NULL = zero); the gradient of agg_xyz is g_center itself */
+int votenet_decode_scores_grad(int b, int k, int nh, int ns, int nc, const float *net,
+                               const float *mean_size, const float *g_objectness,
+                               const float *g_center, const float *g_heading_scores,
+                               const float *g_heading_resn, const float *g_heading_res,
+                               const float *g_size_scores, const float *g_size_resn,
+                               const float *g_size_res, const float *g_sem_cls, float *d_net,
+                               void *stream);
+
 /* decoded boxes of the proposals + one jittered copy of each, training forward (no gradient flows
  * through them): replaces VoteNet.calculate_bbox and the jitter of forward_with_pred_jitter,
  * models/votenet_iou_branch.py:111-137 and :157-172.  center (b,k,3), size_scores (b,k,ns),

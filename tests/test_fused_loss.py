@@ -270,3 +270,49 @@ def test_gpu_consistency_loss_matches_tensor_ops(tag, oracle_omp, monkeypatch):
     _setup(True, oracle_omp)
     ref, got = _consistency_both_paths(tag, torch.device("cuda:0"), monkeypatch)
     _compare_consistency(ref, got, 5e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["scannet", "sunrgbd"])
+def test_decode_scores_kernel_matches_tensor_ops(tag, monkeypatch):
+    """votenet_decode_scores / _grad == decode_scores in tensor operations
+    (models/proposal_module.py:24-54): the nine predictions bit for bit except softplus (1 ulp),
+    and the gradient of a random functional of all of them w.r.t. the head output and the
+    aggregated vote positions; some outputs unused (their gradient is None), softplus arguments
+    beyond its threshold of 20."""
+    load_pkg()
+    V = importlib.import_module("3dioumatch_amd.votenet")
+    heads = importlib.import_module("3dioumatch_amd.votenet.heads")
+    dev = torch.device("cuda:0")
+    cfg = V.scannet_config() if tag == "scannet" else V.sunrgbd_config()
+    nh, ns, nc = cfg.num_heading_bin, cfg.num_size_cluster, cfg.num_class
+    g = torch.Generator().manual_seed(nh + ns)
+    b, k = 3, 70
+    width = 5 + 2 * nh + 4 * ns + nc
+    net0 = (torch.randn(b, width, k, generator=g) * 3).to(dev)
+    net0[0, 5 + 2 * nh + ns, :5] = 25.0    # softplus' linear branch
+    agg0 = torch.randn(b, k, 3, generator=g).to(dev)
+    keys = ("objectness_scores", "center", "heading_scores", "heading_residuals_normalized",
+            "heading_residuals", "size_scores", "size_residuals_normalized", "size_residuals", "sem_cls_scores")
+    weights = {}
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("VOTENET_FUSED_DECODE", flag)
+        net, agg = net0.clone().requires_grad_(True), agg0.clone().requires_grad_(True)
+        ep = heads.decode_scores(net, {"aggregated_vote_xyz": agg}, nc, nh, ns, cfg.mean_size(dev))
+        total = 0.0
+        for key in keys:
+            if key in ("heading_scores", "size_residuals"):
+                continue  # unused outputs: no gradient arrives for them
+            if key not in weights:
+                weights[key] = torch.randn(ep[key].shape, generator=g).to(dev)
+            total = total + (ep[key] * weights[key]).sum()
+        total.backward()
+        res.append(({key: ep[key].detach() for key in keys}, net.grad.clone(), agg.grad.clone()))
+    (o0, gn0, ga0), (o1, gn1, ga1) = res
+    for key in keys:
+        assert o1[key].is_contiguous() and o0[key].shape == o1[key].shape, key
+        tol = 2e-6 if key.startswith("size_residuals") else 0.0
+        assert float((o0[key] - o1[key]).abs().max()) <= tol * max(1.0, float(o0[key].abs().max())), key
+    assert float((gn0 - gn1).abs().max()) <= 2e-6 * float(gn0.abs().max())
+    assert torch.equal(ga0, ga1)
