@@ -520,11 +520,14 @@ class SupervisedStep(object):
         def body_geometry(slot):
             return self._compute_geometry(slot["inputs"])
 
-        def body_step():
+        def make_inputs():
             inputs = dict(self._cur)
             inputs["geometry"] = self._cur_geometry
             inputs.update(host_info)
-            return self._forward_backward(inputs)
+            return inputs
+
+        def body_step():
+            return self._forward_backward(make_inputs())
 
         warm = torch.cuda.Stream(device=dev)
         warm.wait_stream(torch.cuda.current_stream(dev))
@@ -549,11 +552,7 @@ class SupervisedStep(object):
         # (the host-side learning-rate refresh of _before_apply moves in front of it -- only the
         # update kernel reads that scalar).  STEP_ONE_GRAPH=0: two graphs as with an exchange.
         self._merged = not self._exchanges() and os.environ.get("STEP_ONE_GRAPH", "1") != "0"
-        self._g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g1, **mode):
-            self._loss, self._end_points = body_step()
-            if self._merged:
-                self._apply()
+        self._capture_step(make_inputs, mode)
         self._exchange_in_graph = False
         if self.capture_exchange and self._exchanges() and torch.distributed.get_backend() == "nccl":
             try:  # the collective as the first node of G2 (the zero gradient makes it harmless here)
@@ -590,6 +589,17 @@ class SupervisedStep(object):
                 [slot["geometry"][k] for k in self._geo_keys]
         torch.cuda.synchronize(dev)
         self._captured = sig
+
+    def _capture_step(self, make_inputs, mode):
+        """forward + loss + backward (+ the update when nothing separates them) as self._g1"""
+        self._g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g1, **mode):
+            self._loss, self._end_points = self._forward_backward(make_inputs())
+            if self._merged:
+                self._apply()
+
+    def _replay_step(self):
+        self._g1.replay()
 
     def _stage_copies(self, slot):
         """slot -> the buffers G1 reads: one launch for all ~46 tensors (a table of pointers that
@@ -632,9 +642,9 @@ class SupervisedStep(object):
         self._stage_copies(slot)
         if self._merged:
             self._before_apply()
-            self._g1.replay()
+            self._replay_step()
         else:
-            self._g1.replay()
+            self._replay_step()
             if not self._exchange_in_graph:
                 self._exchange_gradients()
             self._before_apply()
@@ -689,6 +699,8 @@ class SemiSupervisedStep(SupervisedStep):
         self.ema_decay = ema_decay
         self.config_dict = config_dict or default_config_dict(cfg, dataset=dataset)
         self._ema_weight = torch.zeros((), device=device)  # 1 - a, read by the update graph
+        self._teacher_stream = None
+        self._gt = None
 
     # the BN-momentum schedule touches the student only (train.py:234-237): inherited set_epoch
     # walks self.net
@@ -726,21 +738,28 @@ class SemiSupervisedStep(SupervisedStep):
     def _state(self):
         return super()._state() + [b for b in self.teacher.buffers()] + [self.flat_teacher]
 
-    def _forward_backward(self, batch):
-        from .losses_unlabeled import get_unlabeled_loss
+    # ---- the step in three pieces: the two forward passes meet only in the consistency loss ----
+    def _geometries(self, batch):
+        geometry = batch.get("geometry")
+        if geometry is None:
+            return None, None
+        return ({k: v for k, v in geometry.items() if not k.startswith("ema_")},
+                {k[4:]: v for k, v in geometry.items() if k.startswith("ema_")})
+
+    def _teacher_forward(self, batch):
+        with deferred_bn_counters(), torch.no_grad():
+            return self.teacher({"point_clouds": batch["ema_point_clouds"],
+                                 "geometry": self._geometries(batch)[1]}, mode="jitter")
+
+    def _student_forward(self, batch):
         for p in self._params:
             p.grad = None
-        geometry = batch.get("geometry")
-        student_geo = teacher_geo = None
-        if geometry is not None:
-            student_geo = {k: v for k, v in geometry.items() if not k.startswith("ema_")}
-            teacher_geo = {k[4:]: v for k, v in geometry.items() if k.startswith("ema_")}
         with deferred_bn_counters():
-            with torch.no_grad():
-                ema_end_points = self.teacher({"point_clouds": batch["ema_point_clouds"],
-                                               "geometry": teacher_geo}, mode="jitter")
-            end_points = self.model({"point_clouds": batch["point_clouds"],
-                                     "geometry": student_geo}, mode="jitter")
+            return self.model({"point_clouds": batch["point_clouds"],
+                               "geometry": self._geometries(batch)[0]}, mode="jitter")
+
+    def _losses_backward(self, end_points, ema_end_points, batch):
+        from .losses_unlabeled import get_unlabeled_loss
         end_points.update({k: v for k, v in batch.items()
                            if torch.is_tensor(v) and k not in ("point_clouds", "ema_point_clouds")})
         labeled = batch.get("labeled_num")
@@ -757,6 +776,59 @@ class SemiSupervisedStep(SupervisedStep):
             loss.backward()
         self._pack_gradients()
         return loss, end_points
+
+    def _forward_backward(self, batch):
+        ema_end_points = self._teacher_forward(batch)
+        end_points = self._student_forward(batch)
+        return self._losses_backward(end_points, ema_end_points, batch)
+
+    # Captured, the teacher's pass is a graph of its own, replayed on its own stream next to the
+    # student's forward graph: two chains of mostly small kernels fill each other's gaps (5.5 ->
+    # 4.5 ms for the two forward passes, tools/two_forward_graphs.py).  As two separately launched
+    # graphs -- as parallel branches of ONE captured graph the same kernels took 3.5 ms LONGER
+    # (profiles/r5_step_experiments.json).  STEP_SEMI_SPLIT_GRAPHS=0: one graph, one stream.
+    split_graphs = os.environ.get("STEP_SEMI_SPLIT_GRAPHS", "1") != "0"
+
+    def _capture_step(self, make_inputs, mode):
+        if not self.split_graphs:
+            self._gt = None
+            return super()._capture_step(make_inputs, mode)
+        dev = self.device
+        if self._teacher_stream is None:
+            self._teacher_stream = torch.cuda.Stream(device=dev)
+        ts = self._teacher_stream
+        cur = torch.cuda.current_stream(dev)
+        # once eagerly ON that stream: per-stream state of the kernel library (the BatchNorm ticket
+        # counters) must exist before a capture, and must not be the one the student's graph uses
+        ts.wait_stream(cur)
+        with torch.cuda.stream(ts):
+            self._teacher_forward(make_inputs())
+        cur.wait_stream(ts)
+        torch.cuda.synchronize(dev)
+        self._gt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._gt, stream=ts, **mode):
+            self._ema_end_points = self._teacher_forward(make_inputs())
+        self._g1a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g1a, **mode):
+            inputs = make_inputs()
+            student = self._student_forward(inputs)
+        self._g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g1, pool=self._g1a.pool(), **mode):
+            self._loss, self._end_points = self._losses_backward(student, self._ema_end_points, inputs)
+            if self._merged:
+                self._apply()
+
+    def _replay_step(self):
+        if self._gt is None:
+            return super()._replay_step()
+        main = torch.cuda.current_stream(self.device)
+        ts = self._teacher_stream
+        ts.wait_stream(main)  # the inputs are staged
+        with torch.cuda.stream(ts):
+            self._gt.replay()
+        self._g1a.replay()
+        main.wait_stream(ts)
+        self._g1.replay()
 
     def _before_apply(self):
         self.global_step += 1

@@ -188,63 +188,72 @@ def test_geometry_prefetch_is_equivalent(use_gpu, oracle_omp):
 
 @pytest.mark.gpu
 def test_graph_replay_matches_eager(oracle_omp):
-    """The three HIP graphs of SupervisedStep (index chain / forward+loss+backward / Adam)
-    replay exactly the eager step: same indices and loss, same parameters after two steps on
-    two different batches (the second one prefetched), same BatchNorm statistics."""
+    """The HIP graphs of SupervisedStep (index chain / forward+loss+backward+Adam) replay exactly
+    the eager step, over two steps on two different batches (the second one prefetched):
+      step 1 (same initial weights): indices, loss, gradient (to the order of the fp32 atomics),
+              parameters and BatchNorm statistics after the update;
+      step 2: the eager runner first takes over the graph runner's weights, so that both arms
+              evaluate the second batch at THE SAME point -- the step is a discontinuous function
+              of its weights at round-off scale (a max-pool arg-max or a ball-query membership can
+              flip on 1e-7: with each arm continuing from its own step-1 result, about one run in
+              six lands in another branch, eager against eager just the same, step-2 gradients 13 %
+              apart; tools/step_repeatability.py --freeze) -- and is held to the bounds of step 1."""
     V, dev = _setup(True, oracle_omp)
     cfg = V.scannet_config()
     data = importlib.import_module("3dioumatch_amd.votenet.data")
     step_mod = importlib.import_module("3dioumatch_amd.votenet.step")
     batches = [{k: v.to(dev) for k, v in data.make_batch(B, N, cfg, seed=s, num_objects=5).items()}
                for s in (44, 45)]
-    results = []
+    runners = {}
     for graphs in (False, True):
         runner = V.SupervisedStep(cfg, dev, world_size=1, num_proposal=K, seed=3, graphs=graphs)
         assert runner.graphs == graphs
         # Parameters with a mathematically ZERO gradient (the bias of a pooling module's last
         # BatchNorm: a constant shift passes max / interpolation and is removed by the next
-        # BatchNorm) receive round-off of either sign, which Adam's first step turns into +-lr and
-        # the second step's gradient into one of a few populations
-        # (profiles/r4_step_repeatability.txt).  Frozen in both arms, the steps AFTER the first can
-        # be compared as tightly as the first.
+        # BatchNorm) receive round-off of either sign, which Adam's first step turns into +-lr
+        # (profiles/r4_step_repeatability.txt): frozen in both arms.
         frozen = step_mod.freeze_shift_invariant_parameters(runner.net)
         assert len(frozen) == 5
-        torch.manual_seed(9)
-        torch.cuda.manual_seed_all(9)
-        first, second = dict(batches[0]), dict(batches[1])
-        runner.prefetch_geometry(first)
-        runner.prefetch_geometry(second)
-        loss0, ep0 = runner(first)
-        loss0, inds0 = float(loss0), ep0["aggregated_vote_inds"].cpu().clone()
-        grads0 = step_mod.flat_grads(runner.net).cpu().clone()
-        loss1, ep1 = runner(second)
+        runners[graphs] = runner
+
+    def one_step(graphs, batch, seed):
+        runner = runners[graphs]
+        torch.manual_seed(seed)
+        torch.cuda.manual_seed_all(seed)
+        view = dict(batch)
+        runner.prefetch_geometry(view)
+        loss, ep = runner(view)
         assert runner.graphs == graphs  # the capture did not fall back
-        results.append((loss0, float(loss1), inds0, ep1["aggregated_vote_inds"].cpu().clone(),
-                        step_mod.flat_params(runner.net).cpu(), step_mod.flat_grads(runner.net).cpu(),
-                        runner.net.backbone_net.sa1.mlp_module.layer0.bn.bn.running_mean.cpu().clone(),
-                        int(runner.net.pnet.bn1.num_batches_tracked), grads0,
-                        [(n, b.detach().cpu().clone()) for n, b in runner.net.named_buffers()]))
-    eager, graph = results
-    assert torch.equal(eager[2], graph[2]) and torch.equal(eager[3], graph[3])
-    assert abs(eager[0] - graph[0]) <= 1e-5 * max(1.0, abs(eager[0]))
-    assert abs(eager[1] - graph[1]) <= 1e-3 * max(1.0, abs(eager[1]))
-    # same weights, same batch: the replayed graph's gradient IS the eager one up to the order of
-    # the fp32 atomics (measured 6e-7)
-    assert float((eager[8] - graph[8]).norm() / eager[8].norm()) < 1e-5
-    # the second step (after an Adam update, on another batch): gradient, parameters and the
-    # running statistics agree as the first step's do
-    g2 = float((eager[5] - graph[5]).norm() / eager[5].norm())
-    p2 = float((eager[4] - graph[4]).norm() / eager[4].norm())
-    print("graph vs eager: step-2 gradient rel %.2e, params after 2 steps rel %.2e" % (g2, p2))
-    assert g2 < 5e-2, g2
-    assert float((eager[4] - graph[4]).abs().max()) <= 6e-3  # two Adam steps of lr 1e-3
-    assert p2 < 1e-2, p2
-    for key in ("running_mean", "running_var"):
-        for (n_e, b_e), (_, b_g) in zip(eager[9], graph[9]):
-            if n_e.endswith(key):
-                assert torch.allclose(b_e, b_g, rtol=2e-3, atol=2e-5), n_e
-    assert torch.allclose(eager[6], graph[6], rtol=1e-4, atol=1e-6)
-    assert eager[7] == graph[7] == 2
+        return {"loss": float(loss), "inds": ep["aggregated_vote_inds"].cpu().clone(),
+                "grad": step_mod.flat_grads(runner.net).cpu().clone(),
+                "params": step_mod.flat_params(runner.net).cpu().clone(),
+                "buffers": [(n, b.detach().cpu().clone()) for n, b in runner.net.named_buffers()]}
+
+    def compare(eager, graph, tag):
+        assert torch.equal(eager["inds"], graph["inds"]), tag
+        assert abs(eager["loss"] - graph["loss"]) <= 1e-5 * max(1.0, abs(eager["loss"])), tag
+        # same weights, same batch: the replayed graph's gradient IS the eager one up to the order of
+        # the fp32 atomics (measured 5e-7 .. 7e-7)
+        g = float((eager["grad"] - graph["grad"]).norm() / eager["grad"].norm())
+        p = float((eager["params"] - graph["params"]).abs().max())
+        print("graph vs eager, %s: gradient rel %.2e, parameters max abs %.2e" % (tag, g, p))
+        assert g < 1e-5, (tag, g)
+        # one Adam step of lr 1e-3 on gradients that agree to 1e-6: the update direction
+        # g / (sqrt(v) + eps) is round-off sensitive only where a gradient entry is ~1e-8 itself
+        assert p <= 2e-4, (tag, p)
+        assert float((eager["params"] - graph["params"]).norm() / eager["params"].norm()) < 1e-4, tag
+        for (n_e, b_e), (_, b_g) in zip(eager["buffers"], graph["buffers"]):
+            if n_e.endswith("running_mean") or n_e.endswith("running_var"):
+                assert torch.allclose(b_e, b_g, rtol=1e-4, atol=2e-6), (tag, n_e)
+            elif n_e.endswith("num_batches_tracked"):
+                assert int(b_e) == int(b_g), (tag, n_e)
+
+    first = [one_step(g, batches[0], 9) for g in (False, True)]
+    compare(first[0], first[1], "step 1")
+    runners[False].flat_params.data.copy_(runners[True].flat_params.data)
+    second = [one_step(g, batches[1], 10) for g in (False, True)]
+    compare(second[0], second[1], "step 2")
+    assert int(runners[True].net.pnet.bn1.num_batches_tracked) == 2
 
 
 @pytest.mark.gpu

@@ -24,6 +24,8 @@ B, N, K = T.B, T.N, T.K
 batches = [{k: v.to(dev) for k, v in data.make_batch(B, N, cfg, seed=s, num_objects=5).items()} for s in (44, 45)]
 def run(graphs):
     runner = V.SupervisedStep(cfg, dev, world_size=1, num_proposal=K, seed=3, graphs=graphs)
+    if "--freeze" in sys.argv:  # as tests/test_train_step.py does: the known zero-gradient parameters
+        step_mod.freeze_shift_invariant_parameters(runner.net)
     torch.manual_seed(9); torch.cuda.manual_seed_all(9)
     first, second = dict(batches[0]), dict(batches[1])
     runner.prefetch_geometry(first); runner.prefetch_geometry(second)
@@ -51,5 +53,7 @@ for i in range(6):
         print("     params after step 1: " + "; ".join("%s max %.1e rel %.1e" % (n, m, r) for m, r, n in w))
         print("  %s run: g2 rel %.2e  label / mask / assignment entries differing from ref: %s  (positives %d vs %d)" % (
             tag, rel(x[3], ref[3]), dl, int(x[6][0].sum()), int(ref[6][0].sum())))
+        if rel(x[3], ref[3]) > 1e-2 and "--explain" in sys.argv:
+            explain(x)
     print("eager-eager: g1 %.2e g2 %.2e p %.2e | eager-graph: g1 %.2e g2 %.2e p %.2e" % (
         rel(e[2], ref[2]), rel(e[3], ref[3]), rel(e[4], ref[4]), rel(g[2], ref[2]), rel(g[3], ref[3]), rel(g[4], ref[4])))
