@@ -115,6 +115,12 @@ _SIGNATURES = {
     "mlp_bn_backward_finalize": [_c_int, _c_int, ctypes.c_double, _c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _vp],
     "mlp_gemm_backward_small_supported": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int],
+    "mlp_weight_image_elems": [_c_int, _c_int],
+    "mlp_weight_images_build": [_c_int, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mlp_gemm_image_supported": [_c_int, _c_int],
+    "mlp_gemm_forward_img": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp],
+    "mlp_gemm_backward_small_img": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_gemm_backward_small": [_c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_pregather_supported": [_c_int, _c_int, _c_int, _c_int, _c_int],
@@ -152,7 +158,7 @@ _SIGNATURES = {
     "iou3d_nms": [_vp, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp],
     "iou3d_boxes_iou_bev_cpu": [_c_int, _vp, _c_int, _vp, _vp],
 }
-_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_grid_bytes": _sz, "pn2_fps_workspace_bytes": _sz, "mlp_bn_workspace_floats": _sz, "mlp_gemm_wgrad_workspace_floats": _sz, "mlp_wgrad_first4_workspace_bytes": _sz, "mlp_gemm_backward_fused_workspace_floats": _sz, "mlp_bn_finalize_pairs_scratch_bytes": _sz, "mlp_chain_lin4_image_bytes": _sz, "mlp_pool_gram_workspace_floats": _sz, "pn2_error_string": ctypes.c_char_p}
+_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_grid_bytes": _sz, "pn2_fps_workspace_bytes": _sz, "mlp_bn_workspace_floats": _sz, "mlp_gemm_wgrad_workspace_floats": _sz, "mlp_wgrad_first4_workspace_bytes": _sz, "mlp_gemm_backward_fused_workspace_floats": _sz, "mlp_bn_finalize_pairs_scratch_bytes": _sz, "mlp_chain_lin4_image_bytes": _sz, "mlp_weight_image_elems": _sz, "mlp_pool_gram_workspace_floats": _sz, "pn2_error_string": ctypes.c_char_p}
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -594,11 +594,25 @@ constexpr int KS = 64;  // K chunk of the small variant
 
 // X6: the chunk's 16 k-rows of a wave are ONE bf16 MFMA step; fragments gathered as eight 4-byte
 // reads per row block and split in registers (mlp_operand.h)
-template <int MODE, bool A_TRANS, bool X6>
+// A operand as a ready bf16 image (X6 only; mlp_weight_images_build): the three planes of the exact
+// split of A as [plane][row][reduction index], rows and reduction padded with zeros to multiples
+// of 64 -- for the forward the weight itself, for the data gradient its transpose.  A lane's MFMA
+// fragment (row lane & 31, eight consecutive reduction indices) is ONE 16-byte load per plane,
+// requested a chunk ahead; the 64 x 64 weight tile is then neither staged through LDS nor split
+// by every one of the layer's ~128 workgroups (88 + ~60 of the ~250 vector instructions per wave
+// and chunk that bound this kernel).
+struct AImage {
+  const unsigned short *p;   // nullptr: A is read as fp32 and split here
+  int pitch;                 // reduction indices per row (multiple of 64)
+  size_t plane;              // elements per plane
+};
+
+template <int MODE, bool A_TRANS, bool X6, bool AIMG = false>
 __device__ __forceinline__ void gemm_nn_small_body(int blk_x, int blk_y, int blk_z, int m_total, int k_total,
                                                    int r, const float *__restrict__ a, int lda,
                                                    OperandB opb, float *__restrict__ c,
-                                                   size_t b_stride_in, size_t b_stride_out) {
+                                                   size_t b_stride_in, size_t b_stride_out,
+                                                   const AImage img = AImage{nullptr, 0, 0}) {
   constexpr int TM = 64, TN = 64, LDA = TM + 1;
   constexpr int STAGE = KS * LDA + KS * TN, REDUCE = 4 * 16 * 64;
   __shared__ __attribute__((aligned(16))) float lds[STAGE > REDUCE ? STAGE : REDUCE];
@@ -620,14 +634,18 @@ __device__ __forceinline__ void gemm_nn_small_body(int blk_x, int blk_y, int blk
   float areg[16], bx[16], bdz[16];
   RowCoef rc;
   bool brow_ok = false;
+  static_assert(!AIMG || X6, "images feed the bf16 form only");
+  const bf16x8 *img8 = reinterpret_cast<const bf16x8 *>(img.p);
   auto fetch = [&](int k0) {
+    if constexpr (!AIMG) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int t = tid + e * 256;
-      const int kk = A_TRANS ? t / TM : t % KS, mm = A_TRANS ? t % TM : t / KS;
-      const int gm = m0 + mm, gk = k0 + kk;
-      const size_t at = A_TRANS ? (size_t)gk * lda + gm : (size_t)gm * lda + gk;
-      areg[e] = (gm < m_total && gk < k_total) ? a[at] : 0.f;
+      for (int e = 0; e < 16; ++e) {
+        const int t = tid + e * 256;
+        const int kk = A_TRANS ? t / TM : t % KS, mm = A_TRANS ? t % TM : t / KS;
+        const int gm = m0 + mm, gk = k0 + kk;
+        const size_t at = A_TRANS ? (size_t)gk * lda + gm : (size_t)gm * lda + gk;
+        areg[e] = (gm < m_total && gk < k_total) ? a[at] : 0.f;
+      }
     }
     const int gk = k0 + bkk;
     brow_ok = gk < k_total;
@@ -637,11 +655,26 @@ __device__ __forceinline__ void gemm_nn_small_body(int blk_x, int blk_y, int blk
   };
   fetch(0);
   for (int k0 = 0; k0 < k_total; k0 += KS) {
-    __syncthreads();
+    // (image form: this chunk's weight fragments are requested here, ahead of the barrier and the
+    //  staging of B, and used after them)
+    Split3 sa_img[2];
+    if constexpr (AIMG) {
+      const int k0w = wave * (KS / 4) + 8 * (lane >> 5);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int t = tid + e * 256;
-      As[(A_TRANS ? t / TM : t % KS) * LDA + (A_TRANS ? t % TM : t / KS)] = areg[e];
+      for (int i = 0; i < 2; ++i) {
+        const size_t at = ((size_t)(m0 + i * 32 + (lane & 31)) * img.pitch + k0 + k0w) >> 3;
+        sa_img[i].hi = img8[at];
+        sa_img[i].mid = img8[at + (img.plane >> 3)];
+        sa_img[i].lo = img8[at + 2 * (img.plane >> 3)];
+      }
+    }
+    __syncthreads();
+    if constexpr (!AIMG) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int t = tid + e * 256;
+        As[(A_TRANS ? t / TM : t % KS) * LDA + (A_TRANS ? t % TM : t / KS)] = areg[e];
+      }
     }
 #pragma unroll
     for (int i = 0; i < 16; i += 4) {
@@ -658,12 +691,16 @@ __device__ __forceinline__ void gemm_nn_small_body(int blk_x, int blk_y, int blk
       static_assert(KS / 4 == 16, "a wave's share of the chunk is one 16-deep MFMA step");
       const int k0w = wave * (KS / 4) + 8 * (lane >> 5);
       Split3 sa[2], sb[2];
+      if constexpr (AIMG) {
+        sa[0] = sa_img[0]; sa[1] = sa_img[1];
+      } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float v[8];
+        for (int i = 0; i < 2; ++i) {
+          float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = As[(k0w + e) * LDA + i * 32 + (lane & 31)];
-        sa[i] = split3(v);
+          for (int e = 0; e < 8; ++e) v[e] = As[(k0w + e) * LDA + i * 32 + (lane & 31)];
+          sa[i] = split3(v);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -728,13 +765,13 @@ __device__ __forceinline__ void gemm_nn_small_body(int blk_x, int blk_y, int blk
     }
 }
 
-template <int MODE, bool A_TRANS, bool X6 = false>
+template <int MODE, bool A_TRANS, bool X6 = false, bool AIMG = false>
 __global__ void __launch_bounds__(256, (X6 && A_TRANS) ? 2 : 1)
 gemm_nn_small_kernel(int m_total, int k_total, int r, const float *__restrict__ a, int lda,
                      OperandB opb, float *__restrict__ c, size_t b_stride_in,
-                     size_t b_stride_out) {
-  gemm_nn_small_body<MODE, A_TRANS, X6>((int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, m_total,
-                                        k_total, r, a, lda, opb, c, b_stride_in, b_stride_out);
+                     size_t b_stride_out, AImage img) {
+  gemm_nn_small_body<MODE, A_TRANS, X6, AIMG>((int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, m_total,
+                                              k_total, r, a, lda, opb, c, b_stride_in, b_stride_out, img);
 }
 
 // Partial wgrad: for one cloud b and one slice of R,
@@ -1031,9 +1068,10 @@ struct SmallPairArgs {
   int wkx, wmy, per, slices;    // weight-gradient grid (x over k, y over m) and slicing
   const float *w;               // (m, k)
   float *dq, *part;
+  AImage wt_img;                // the transposed weight as a bf16 image (or none)
 };
 
-template <int PMODE, int QMODE, bool X6D>
+template <int PMODE, int QMODE, bool X6D, bool AIMG = false>
 __global__ void __launch_bounds__(256, 2)
 gemm_small_backward_pair_kernel(SmallPairArgs t, OperandB opp, OperandB opq) {
   const int id = (int)blockIdx.x;
@@ -1041,8 +1079,8 @@ gemm_small_backward_pair_kernel(SmallPairArgs t, OperandB opp, OperandB opq) {
     const int bx = id % t.dgx, by = (id / t.dgx) % t.dgy, bz = id / (t.dgx * t.dgy);
     // dQ (k rows) = W^T (k x m, read transposed) . P (m rows): the small kernel's (m_total, k_total)
     // are (k, m) here
-    gemm_nn_small_body<PMODE, true, X6D>(bx, by, bz, t.k, t.m, t.r, t.w, t.k, opp, t.dq,
-                                         (size_t)t.m * t.r, (size_t)t.k * t.r);
+    gemm_nn_small_body<PMODE, true, X6D, AIMG>(bx, by, bz, t.k, t.m, t.r, t.w, t.k, opp, t.dq,
+                                               (size_t)t.m * t.r, (size_t)t.k * t.r, t.wt_img);
   } else {
     const int wid = id - t.nd;
     BlockId blk;
@@ -1152,21 +1190,26 @@ void launch_stats(bool a_vec, int r, int b, hipStream_t stream, int rows, int k,
 
 template <int MODE, bool A_TRANS = false>
 int launch_nn(int b, int m, int k, int r, const float *a, int lda, const OperandB &op, float *c,
-              size_t in_stride, size_t out_stride, hipStream_t stream, float *stats = nullptr) {
+              size_t in_stride, size_t out_stride, hipStream_t stream, float *stats = nullptr,
+              const AImage img = AImage{nullptr, 0, 0}) {
   // (read per call so that the tests can steer both kernels; a getenv costs nothing next to a launch)
   const char *env = getenv("MLP_SMALL_GEMM_COLS");
   const long long small_cols = env ? atoll(env) : 16384;
   if ((long long)b * r <= small_cols) {  // a few hundred columns per cloud: latency-bound regime
     // (measured, tools/small_gemm_bench.py: the transposed form with a plain operand gains from the
     //  split at two workgroups per CU, 20 -> 15.6 us; with the on-the-fly dY operand it spills and does not)
-    if (gemm_x6() && (!A_TRANS || MODE == OP_DIRECT))
+    if (gemm_x6() && (!A_TRANS || MODE == OP_DIRECT) && img.p != nullptr)
+      hipLaunchKernelGGL((gemm_nn_small_kernel<MODE, A_TRANS, true, true>),
+                         dim3(pn2_ceil_div(r, 64), pn2_ceil_div(m, 64), b), dim3(256), 0, stream, m,
+                         k, r, a, lda, op, c, in_stride, out_stride, img);
+    else if (gemm_x6() && (!A_TRANS || MODE == OP_DIRECT))
       hipLaunchKernelGGL((gemm_nn_small_kernel<MODE, A_TRANS, true>),
                          dim3(pn2_ceil_div(r, 64), pn2_ceil_div(m, 64), b), dim3(256), 0, stream, m,
-                         k, r, a, lda, op, c, in_stride, out_stride);
+                         k, r, a, lda, op, c, in_stride, out_stride, AImage{nullptr, 0, 0});
     else
       hipLaunchKernelGGL((gemm_nn_small_kernel<MODE, A_TRANS>),
                          dim3(pn2_ceil_div(r, 64), pn2_ceil_div(m, 64), b), dim3(256), 0, stream, m,
-                         k, r, a, lda, op, c, in_stride, out_stride);
+                         k, r, a, lda, op, c, in_stride, out_stride, AImage{nullptr, 0, 0});
     return pn2_launch_status();
   }
   // rows are covered by 256-row tiles, then one smaller tile for the remainder
@@ -1222,9 +1265,91 @@ int launch_nn(int b, int m, int k, int r, const float *a, int lda, const Operand
   return pn2_launch_status();
 }
 
+// ---- bf16 images of the weights (AImage) ---------------------------------------------------------
+// One launch for every weight of the table: workgroup = one 64 x 64 tile of one weight; the exact
+// three-term split of mlp_operand.h per element (bit for bit what split3 produces in the kernels
+// that split on the fly), written in BOTH orders: [plane][m][k] for the forward, [plane][k][m] for
+// the data gradient.
+constexpr int kImageBatch = 24;
+struct ImageBatch {
+  int n;
+  int first_tile[kImageBatch + 1];
+  int m[kImageBatch], k[kImageBatch];
+  const float *w[kImageBatch];
+  unsigned short *img[kImageBatch], *img_t[kImageBatch];
+};
+
+__host__ __device__ inline int pad64(int v) { return (v + 63) & ~63; }
+
+__global__ void __launch_bounds__(256) weight_images_kernel(const ImageBatch t) {
+  __shared__ unsigned short tile[3][64][66];
+  int e = 0;
+  while (e + 1 < t.n && (int)blockIdx.x >= t.first_tile[e + 1]) ++e;
+  const int local = (int)blockIdx.x - t.first_tile[e];
+  const int m = t.m[e], k = t.k[e], mp = pad64(m), kp = pad64(k);
+  const int tiles_k = kp / 64;
+  const int r0 = (local / tiles_k) * 64, c0 = (local % tiles_k) * 64;
+  const float *w = t.w[e];
+  const size_t plane = (size_t)mp * kp;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int rr = i >> 6, cc = i & 63;
+    const float x = (r0 + rr < m && c0 + cc < k) ? w[(size_t)(r0 + rr) * k + c0 + cc] : 0.f;
+    const float h = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffff0000u);
+    const float r1 = x - h;                                   // exact
+    const float md = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1) & 0xffff0000u);
+    const float lo = r1 - md;                                 // exact, at most 8 significant bits
+    tile[0][rr][cc] = (unsigned short)(__builtin_bit_cast(unsigned, h) >> 16);
+    tile[1][rr][cc] = (unsigned short)(__builtin_bit_cast(unsigned, md) >> 16);
+    tile[2][rr][cc] = (unsigned short)(__builtin_bit_cast(unsigned, lo) >> 16);
+  }
+  __syncthreads();
+  for (int i = tid; i < 3 * 64 * 64; i += 256) {
+    const int pl = i >> 12, rr = (i >> 6) & 63, cc = i & 63;
+    t.img[e][pl * plane + (size_t)(r0 + rr) * kp + c0 + cc] = tile[pl][rr][cc];     // [m][k]
+    t.img_t[e][pl * plane + (size_t)(c0 + rr) * mp + r0 + cc] = tile[pl][cc][rr];   // [k][m]
+  }
+}
+
 }  // namespace
 
 #define MLP_API extern "C" __attribute__((visibility("default")))
+
+// elements (2 bytes each) of ONE image of an (m, k) weight: three planes, both dimensions padded to 64
+MLP_API size_t mlp_weight_image_elems(int m, int k) {
+  if (m <= 0 || k <= 0) return 0;
+  return (size_t)3 * pad64(m) * pad64(k);
+}
+
+// n weights w[i] (m[i], k[i]) -> img[i] (forward order) and img_t[i] (transposed), each
+// mlp_weight_image_elems(m[i], k[i]) 2-byte elements, 16-byte aligned.  The arrays are HOST arrays
+// of DEVICE pointers / sizes; one launch per 24 weights.
+MLP_API int mlp_weight_images_build(int n, const void *const *w, const int *m, const int *k,
+                                    void *const *img, void *const *img_t, void *stream_) {
+  if (n <= 0) return 0;
+  if (!w || !m || !k || !img || !img_t) return (int)hipErrorInvalidValue;
+  hipStream_t stream = (hipStream_t)stream_;
+  for (int base = 0; base < n; base += kImageBatch) {
+    ImageBatch t = {};
+    t.n = n - base < kImageBatch ? n - base : kImageBatch;
+    int tiles = 0;
+    for (int i = 0; i < t.n; ++i) {
+      const int j = base + i;
+      if (m[j] <= 0 || k[j] <= 0 || !w[j] || !img[j] || !img_t[j] ||
+          (reinterpret_cast<size_t>(img[j]) & 15) || (reinterpret_cast<size_t>(img_t[j]) & 15))
+        return (int)hipErrorInvalidValue;
+      t.first_tile[i] = tiles;
+      t.m[i] = m[j]; t.k[i] = k[j];
+      t.w[i] = reinterpret_cast<const float *>(w[j]);
+      t.img[i] = reinterpret_cast<unsigned short *>(img[j]);
+      t.img_t[i] = reinterpret_cast<unsigned short *>(img_t[j]);
+      tiles += (pad64(m[j]) / 64) * (pad64(k[j]) / 64);
+    }
+    t.first_tile[t.n] = tiles;
+    hipLaunchKernelGGL(weight_images_kernel, dim3(tiles), dim3(256), 0, stream, t);
+  }
+  return pn2_launch_status();
+}
 
 // mode: 0 = X given directly, 1 = X = relu(bn(Yprev)) via (scale, shift)
 int mlp_reduce_partials(int count, int parts, const float *part, float *out, hipStream_t stream) {
@@ -1294,6 +1419,32 @@ MLP_API int mlp_gemm_forward(int b, int m, int k, int r, const float *w, const f
   if (mode == OP_DIRECT)
     return launch_nn<OP_DIRECT>(b, m, k, r, w, k, op, y, in_stride, out_stride, (hipStream_t)stream_);
   return launch_nn<OP_BNRELU>(b, m, k, r, w, k, op, y, in_stride, out_stride, (hipStream_t)stream_);
+}
+
+// 1 when the layer runs on the small 64 x 64 kernel in its bf16 form, i.e. when
+// mlp_gemm_forward_img / mlp_gemm_backward_small_img can take their weight from an image
+MLP_API int mlp_gemm_image_supported(int b, int r) {
+  static const bool off = getenv("MLP_WEIGHT_IMAGES") && atoi(getenv("MLP_WEIGHT_IMAGES")) == 0;
+  const char *env = getenv("MLP_SMALL_GEMM_COLS");
+  const long long small_cols = env ? atoll(env) : 16384;
+  return !off && b > 0 && r > 0 && (long long)b * r <= small_cols && gemm_x6();
+}
+
+// mlp_gemm_forward with the weight ALSO given as the bf16 image mlp_weight_images_build made of it
+// (img: the [plane][m][k] order): same result bit for bit, the kernel neither stages nor splits w
+MLP_API int mlp_gemm_forward_img(int b, int m, int k, int r, const float *w, const void *img,
+                                 const float *x, int mode, const float *scale, const float *shift,
+                                 float *y, void *stream_) {
+  if (b <= 0 || m <= 0 || k <= 0 || r <= 0) return 0;
+  if (!img || !mlp_gemm_image_supported(b, r)) return (int)hipErrorInvalidValue;
+  OperandB op = {x, nullptr, scale, shift, nullptr, nullptr, nullptr};
+  const size_t in_stride = (size_t)k * r, out_stride = (size_t)m * r;
+  const AImage ai = {reinterpret_cast<const unsigned short *>(img), pad64(k), (size_t)pad64(m) * pad64(k)};
+  if (mode == OP_DIRECT)
+    return launch_nn<OP_DIRECT>(b, m, k, r, w, k, op, y, in_stride, out_stride, (hipStream_t)stream_,
+                                nullptr, ai);
+  return launch_nn<OP_BNRELU>(b, m, k, r, w, k, op, y, in_stride, out_stride, (hipStream_t)stream_,
+                              nullptr, ai);
 }
 
 // Can the forward GEMM of this shape leave BatchNorm partials behind?  Returns the number of
@@ -1445,12 +1596,12 @@ MLP_API int mlp_gemm_backward_small_supported(int b, int m, int k, int r, int pm
 // from (y, dz) and the BatchNorm / ReLU backward constants (pmode 2); Q = x (qmode 0) or
 // relu(x*xscale + xshift) (qmode 1).  dq == NULL: the weight gradient alone.
 // workspace: mlp_gemm_wgrad_workspace_floats(b, m, k, r) floats.
-MLP_API int mlp_gemm_backward_small(int b, int m, int k, int r, const float *w, int pmode,
-                                    const float *dy_or_y, const float *dz, const float *scale,
-                                    const float *shift, const float *mean, const float *invstd,
-                                    const float *coef, int qmode, const float *x,
-                                    const float *xscale, const float *xshift, float *dq, float *dw,
-                                    float *workspace, void *stream_) {
+static int backward_small_impl(int b, int m, int k, int r, const float *w, const void *wt_img, int pmode,
+                               const float *dy_or_y, const float *dz, const float *scale,
+                               const float *shift, const float *mean, const float *invstd,
+                               const float *coef, int qmode, const float *x,
+                               const float *xscale, const float *xshift, float *dq, float *dw,
+                               float *workspace, void *stream_) {
   if (!mlp_gemm_backward_small_supported(b, m, k, r, pmode, qmode)) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
   OperandB P = {dy_or_y, dz, scale, shift, mean, invstd, coef};
@@ -1464,11 +1615,19 @@ MLP_API int mlp_gemm_backward_small(int b, int m, int k, int r, const float *w, 
   t.slices = (r + t.per - 1) / t.per;
   t.wkx = pn2_ceil_div(k, 64); t.wmy = pn2_ceil_div(m, 64);
   t.w = w; t.dq = dq; t.part = workspace;
+  // the data-gradient half reads W^T: rows k, reduction over m
+  t.wt_img = AImage{reinterpret_cast<const unsigned short *>(wt_img), pad64(m), (size_t)pad64(k) * pad64(m)};
   const int nw = t.wkx * t.wmy * b * t.slices;
   const dim3 grid((unsigned)(t.nd + nw));
 #define PAIR(PM, QM, X6D)                                                                        \
   hipLaunchKernelGGL((gemm_small_backward_pair_kernel<PM, QM, X6D>), grid, dim3(256), 0, stream, t, P, Q)
-  if (pmode == OP_DIRECT && qmode == OP_DIRECT) PAIR(OP_DIRECT, OP_DIRECT, true);
+  if (pmode == OP_DIRECT && wt_img != nullptr) {
+    if (qmode == OP_DIRECT)
+      hipLaunchKernelGGL((gemm_small_backward_pair_kernel<OP_DIRECT, OP_DIRECT, true, true>), grid, dim3(256), 0, stream, t, P, Q);
+    else
+      hipLaunchKernelGGL((gemm_small_backward_pair_kernel<OP_DIRECT, OP_BNRELU, true, true>), grid, dim3(256), 0, stream, t, P, Q);
+  }
+  else if (pmode == OP_DIRECT && qmode == OP_DIRECT) PAIR(OP_DIRECT, OP_DIRECT, true);
   else if (pmode == OP_DIRECT) PAIR(OP_DIRECT, OP_BNRELU, true);
   else if (qmode == OP_DIRECT) PAIR(OP_DY, OP_DIRECT, false);
   else PAIR(OP_DY, OP_BNRELU, false);
@@ -1476,6 +1635,30 @@ MLP_API int mlp_gemm_backward_small(int b, int m, int k, int r, const float *w, 
   const int rc = pn2_launch_status();
   if (rc) return rc;
   return mlp_reduce_weight_partials(m * k, b * t.slices, workspace, dw, stream);
+}
+
+MLP_API int mlp_gemm_backward_small(int b, int m, int k, int r, const float *w, int pmode,
+                                    const float *dy_or_y, const float *dz, const float *scale,
+                                    const float *shift, const float *mean, const float *invstd,
+                                    const float *coef, int qmode, const float *x,
+                                    const float *xscale, const float *xshift, float *dq, float *dw,
+                                    float *workspace, void *stream_) {
+  return backward_small_impl(b, m, k, r, w, nullptr, pmode, dy_or_y, dz, scale, shift, mean, invstd, coef,
+                             qmode, x, xscale, xshift, dq, dw, workspace, stream_);
+}
+
+// mlp_gemm_backward_small with the TRANSPOSED weight also given as the bf16 image
+// mlp_weight_images_build made of it (img_t: the [plane][k][m] order), read by the data-gradient
+// half when the gradient operand is given (pmode 0); same results bit for bit
+MLP_API int mlp_gemm_backward_small_img(int b, int m, int k, int r, const float *w, const void *img_t,
+                                        int pmode, const float *dy_or_y, const float *dz,
+                                        const float *scale, const float *shift, const float *mean,
+                                        const float *invstd, const float *coef, int qmode,
+                                        const float *x, const float *xscale, const float *xshift,
+                                        float *dq, float *dw, float *workspace, void *stream_) {
+  if (!img_t || !mlp_gemm_image_supported(b, r)) return (int)hipErrorInvalidValue;
+  return backward_small_impl(b, m, k, r, w, img_t, pmode, dy_or_y, dz, scale, shift, mean, invstd, coef,
+                             qmode, x, xscale, xshift, dq, dw, workspace, stream_);
 }
 
 MLP_API int mlp_gemm_dgrad_pooled_nt(int b, int m, int k, int groups, int ns, const float *w,

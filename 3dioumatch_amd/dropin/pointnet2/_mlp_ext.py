@@ -136,6 +136,81 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+class WeightImages(object):
+    """bf16 images of a set of weights for the SMALL layers' kernels (include/mlp_hip.h
+    mlp_weight_images_build): the exact three-term split of every weight, written once per
+    optimizer step by refresh() -- ONE launch -- in the two orders forward and data gradient read,
+    instead of being redone by every workgroup of every small GEMM.  Inside `with
+    weight_images(obj):` gemm_forward / gemm_backward_small find a weight's images by its address and
+    use them where the layer runs on the small kernel; results are the same bit for bit.  The caller
+    owns the freshness: refresh() after every update of the weights (the train step's optimizer
+    writes them through raw pointers -- there is no version counter to key a cache on)."""
+
+    def __init__(self, weights):
+        import ctypes
+        ws = [w for w in weights if w.is_cuda and w.dtype == torch.float32 and w.dim() >= 2
+              and w.is_contiguous()]
+        self.entries = {}
+        self._keep = ws
+        if not ws:
+            self.n = 0
+            return
+        dev = ws[0].device
+        dims = [(w.shape[0], w.numel() // w.shape[0]) for w in ws]
+        elems = [int(_lib.mlp_weight_image_elems(m, k)) for m, k in dims]
+        offs, total = [], 0
+        for e in elems:
+            offs.append(total)
+            total += 2 * ((e + 7) // 8 * 8)
+        self.buf = torch.empty(total, dtype=torch.int16, device=dev)
+        base = self.buf.data_ptr()
+        n = self.n = len(ws)
+        self._w = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+        self._m = (ctypes.c_int * n)(*[m for m, _ in dims])
+        self._k = (ctypes.c_int * n)(*[k for _, k in dims])
+        img = [base + 2 * o for o in offs]
+        img_t = [base + 2 * (o + (e + 7) // 8 * 8) for o, e in zip(offs, elems)]
+        self._img = (ctypes.c_void_p * n)(*img)
+        self._img_t = (ctypes.c_void_p * n)(*img_t)
+        for w, (m, k), a, t in zip(ws, dims, img, img_t):
+            self.entries[w.data_ptr()] = (m, k, a, t)
+        self.device = dev
+
+    def refresh(self):
+        if self.n:
+            with torch.cuda.device(self.device):
+                _L.check(_lib.mlp_weight_images_build(self.n, self._w, self._m, self._k, self._img,
+                                                      self._img_t, _stream(self.buf)),
+                         "mlp_weight_images_build")
+
+
+_ACTIVE_IMAGES = []
+
+
+@contextlib.contextmanager
+def weight_images(*sets):
+    """gemm_forward / gemm_backward_small take the weights of `sets` (WeightImages) from their images."""
+    global _ACTIVE_IMAGES
+    previous = _ACTIVE_IMAGES
+    _ACTIVE_IMAGES = previous + [s for s in sets if s is not None and s.n]
+    try:
+        yield
+    finally:
+        _ACTIVE_IMAGES = previous
+
+
+def _image_of(w, b, r):
+    """(forward image, transposed image) addresses of w, or None"""
+    if not _ACTIVE_IMAGES:
+        return None
+    for s in _ACTIVE_IMAGES:
+        e = s.entries.get(w.data_ptr())
+        if e is not None and (e[0], e[1]) == (w.shape[0], w.numel() // w.shape[0]) and \
+                _lib.mlp_gemm_image_supported(int(b), int(r)):
+            return e[2], e[3]
+    return None
+
+
 def gemm_forward(w, x, coeff=None):
     """y (B,M,R) = w (M,K) @ x (B,K,R); with coeff=(scale, shift) the operand is
     relu(x*scale[k] + shift[k]) formed on the fly (x is then the previous layer's conv output)."""
@@ -145,6 +220,13 @@ def gemm_forward(w, x, coeff=None):
     m = w.shape[0]
     y = torch.empty((b, m) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
     scale, shift = coeff if coeff is not None else (None, None)
+    image = _image_of(w, b, r)
+    if image is not None:
+        with torch.cuda.device(x.device):
+            _L.check(_lib.mlp_gemm_forward_img(b, m, k, r, w.data_ptr(), image[0], x.data_ptr(),
+                                               0 if coeff is None else 1, _ptr(scale), _ptr(shift),
+                                               y.data_ptr(), _stream(x)), "mlp_gemm_forward_img")
+        return y
     with torch.cuda.device(x.device):
         _L.check(_lib.mlp_gemm_forward(b, m, k, r, w.data_ptr(), x.data_ptr(),
                                        0 if coeff is None else 1, _ptr(scale), _ptr(shift),
@@ -455,6 +537,13 @@ def gemm_backward_small(w, x, xcoeff=None, dy=None, fly=None, need_dx=True):
         ws = torch.empty(max(int(_lib.mlp_gemm_wgrad_workspace_floats(b, m, k, r)), 1),
                          dtype=torch.float32, device=x.device)
         _keep_until_flush(ws, dw)
+        image = _image_of(w, b, r) if (pmode == 0 and need_dx) else None
+        if image is not None:
+            _L.check(_lib.mlp_gemm_backward_small_img(
+                b, m, k, r, w.data_ptr(), image[1], pmode, p0.data_ptr(), _ptr(pdz), _ptr(sc), _ptr(sh),
+                _ptr(mean), _ptr(invstd), _ptr(coef), qmode, x.data_ptr(), _ptr(xs), _ptr(xh), _ptr(dx),
+                dw.data_ptr(), ws.data_ptr(), _stream(x)), "mlp_gemm_backward_small_img")
+            return dx, dw
         _L.check(_lib.mlp_gemm_backward_small(b, m, k, r, w.data_ptr(), pmode, p0.data_ptr(),
                                               _ptr(pdz), _ptr(sc), _ptr(sh), _ptr(mean),
                                               _ptr(invstd), _ptr(coef), qmode, x.data_ptr(),

@@ -235,16 +235,37 @@ class SupervisedStep(object):
                 self.optimizer.param_groups[0]["lr"] = float(saved["lr"])
 
     # ---------------------------------------------------------------- the step, eagerly
+    # bf16 images of the convolution weights for the small layers' kernels, rebuilt by ONE launch at
+    # the head of every forward pass (pointnet2/_mlp_ext.py WeightImages); STEP_WEIGHT_IMAGES=0: off
+    use_weight_images = os.environ.get("STEP_WEIGHT_IMAGES", "1") != "0"
+
+    def _images_of(self, net, slot):
+        """the WeightImages of `net` (made on first use; None without a GPU)"""
+        if not self.use_weight_images or self.device.type != "cuda":
+            return None
+        cache = self.__dict__.setdefault("_weight_images", {})
+        if slot not in cache:
+            from pointnet2 import _mlp_ext as K
+            cache[slot] = K.WeightImages([p.data for p in net.parameters()
+                                          if p.dim() >= 3 and p.shape[0] <= 512
+                                          and p.numel() // p.shape[0] <= 512])
+        return cache[slot]
+
     def _forward_backward(self, batch):
+        from pointnet2 import _mlp_ext as K
         for p in self._params:
             p.grad = None
-        with deferred_bn_counters():
-            end_points = self.model(batch, mode="jitter")
-        end_points.update({k: v for k, v in batch.items()
-                           if torch.is_tensor(v) or k in ("all_supervised", "labeled_num")})
-        loss, end_points = get_labeled_loss(end_points, self.cfg, {"dataset_config": self.cfg})
-        with zero_grads_none(), deferred_weight_reductions(self.defer_weight_reductions):
-            loss.backward()
+        images = self._images_of(self.net, "student")
+        with K.weight_images(images):
+            if images is not None:
+                images.refresh()
+            with deferred_bn_counters():
+                end_points = self.model(batch, mode="jitter")
+            end_points.update({k: v for k, v in batch.items()
+                               if torch.is_tensor(v) or k in ("all_supervised", "labeled_num")})
+            loss, end_points = get_labeled_loss(end_points, self.cfg, {"dataset_config": self.cfg})
+            with zero_grads_none(), deferred_weight_reductions(self.defer_weight_reductions):
+                loss.backward()
         self._pack_gradients()
         return loss, end_points
 
@@ -747,14 +768,22 @@ class SemiSupervisedStep(SupervisedStep):
                 {k[4:]: v for k, v in geometry.items() if k.startswith("ema_")})
 
     def _teacher_forward(self, batch):
-        with deferred_bn_counters(), torch.no_grad():
+        from pointnet2 import _mlp_ext as K
+        images = self._images_of(self.teacher, "teacher")
+        with K.weight_images(images), deferred_bn_counters(), torch.no_grad():
+            if images is not None:
+                images.refresh()
             return self.teacher({"point_clouds": batch["ema_point_clouds"],
                                  "geometry": self._geometries(batch)[1]}, mode="jitter")
 
     def _student_forward(self, batch):
+        from pointnet2 import _mlp_ext as K
         for p in self._params:
             p.grad = None
-        with deferred_bn_counters():
+        images = self._images_of(self.net, "student")
+        with K.weight_images(images), deferred_bn_counters():
+            if images is not None:
+                images.refresh()
             return self.model({"point_clouds": batch["point_clouds"],
                                "geometry": self._geometries(batch)[0]}, mode="jitter")
 
@@ -772,7 +801,10 @@ class SemiSupervisedStep(SupervisedStep):
                                                         self.config_dict)
         loss = detection_loss + unlabeled_loss * self.unlabeled_loss_weight
         end_points["loss"] = loss
-        with zero_grads_none(), deferred_weight_reductions(self.defer_weight_reductions):
+        from pointnet2 import _mlp_ext as K
+        # (the student's images were rebuilt at the head of its forward pass)
+        with K.weight_images(self._images_of(self.net, "student")), zero_grads_none(), \
+                deferred_weight_reductions(self.defer_weight_reductions):
             loss.backward()
         self._pack_gradients()
         return loss, end_points

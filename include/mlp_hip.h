@@ -288,6 +288,27 @@ int mlp_gemm_backward_small(int b, int m, int k, int r, const float *w, int pmod
                             const float *coef, int qmode, const float *x, const float *xscale,
                             const float *xshift, float *dq, float *dw, float *workspace,
                             void *stream);
+/* bf16 images of the weights of the SMALL layers (FP modules, heads, pre-gather first layers;
+ * b*r <= 16384 columns).  Their 64 x 64-tile kernels compute fp32 products as six bf16 MFMAs on an
+ * exact three-term split of both operands; every one of a layer's ~128 workgroups split the same
+ * weight tile again.  mlp_weight_images_build writes that split ONCE per optimizer step for all
+ * weights of a table, in the two orders the forward convolution (pytorch_utils.py:70-124) and its
+ * backward-input read; mlp_gemm_forward_img / mlp_gemm_backward_small_img are mlp_gemm_forward /
+ * mlp_gemm_backward_small that take the image next to the fp32 weight -- same results bit for bit.
+ * An image is mlp_weight_image_elems(m, k) 2-byte elements (three planes, both dimensions padded
+ * to multiples of 64), 16-byte aligned.  w / m / k / img / img_t of the build call: HOST arrays. */
+size_t mlp_weight_image_elems(int m, int k);
+int mlp_weight_images_build(int n, const void *const *w, const int *m, const int *k,
+                            void *const *img, void *const *img_t, void *stream);
+int mlp_gemm_image_supported(int b, int r);
+int mlp_gemm_forward_img(int b, int m, int k, int r, const float *w, const void *img, const float *x,
+                         int mode, const float *scale, const float *shift, float *y, void *stream);
+int mlp_gemm_backward_small_img(int b, int m, int k, int r, const float *w, const void *img_t,
+                                int pmode, const float *dy_or_y, const float *dz, const float *scale,
+                                const float *shift, const float *mean, const float *invstd,
+                                const float *coef, int qmode, const float *x, const float *xscale,
+                                const float *xshift, float *dq, float *dw, float *workspace,
+                                void *stream);
 /* partials per channel in stats_part; 0 when the layer leaves none (sizing helper for the
  * BatchNorm backward of pytorch_utils.py:42-50) */
 int mlp_gemm_backward_fused_stats_parts(int b, int m, int k, int r);

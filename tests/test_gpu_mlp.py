@@ -874,3 +874,50 @@ def test_small_backward_pair_vs_two_gemms(b, m, k, r):
             none, dw_only = K.gemm_backward_small(w, x, xcoeff, need_dx=False, **grad)
             assert none is None
             assert torch.equal(dw_only, dw)
+
+
+@pytest.mark.parametrize("b,m,k,r", [(8, 256, 512, 1024), (8, 259, 256, 1024), (3, 79, 128, 256),
+                                     (2, 128, 131, 100), (1, 64, 20, 36), (8, 128, 259, 768)])
+def test_small_gemms_from_weight_images(b, m, k, r, monkeypatch):
+    """The small layers' kernels with their weight taken from the bf16 images that ONE launch
+    writes for a whole set of weights (mlp_weight_images_build; WeightImages) == the same kernels
+    splitting the fp32 weight tile in every workgroup: forward (plain and BatchNorm + ReLU'ed
+    input) and the pair launch of the backward (data gradient through the TRANSPOSED image, weight
+    gradient untouched), bit for bit; ragged rows / columns / reduction lengths (zero padding of
+    the images); a weight that is not in the set, a layer outside the small regime and an update
+    of the weight without refresh() behave as documented."""
+    load_pkg()
+    K = importlib.import_module("pointnet2._mlp_ext")
+    g = torch.Generator().manual_seed(m * 7 + k + r)
+    w = (torch.randn(m, k, 1, 1, generator=g) / k ** 0.5).to(DEV)
+    other = (torch.randn(m, k, 1, generator=g) / k ** 0.5).to(DEV)
+    w2 = w.reshape(m, k)
+    x = torch.randn(b, k, r, generator=g).to(DEV)
+    dy = torch.randn(b, m, r, generator=g).to(DEV)
+    ck = ((torch.rand(k, generator=g) + 0.5).to(DEV), (torch.randn(k, generator=g) * 0.3).to(DEV))
+    images = K.WeightImages([w, torch.ones(7, device=DEV), other])   # (1-D tensors are skipped)
+    assert images.n == 2
+    images.refresh()
+    calls = []
+    real = K._lib.mlp_gemm_forward_img
+    want = [K.gemm_forward(w2, x), K.gemm_forward(w2, x, ck), K.gemm_backward_small(w2, x, ck, dy=dy),
+            K.gemm_backward_small(w2, x, None, dy=dy)]
+    with K.weight_images(images):
+        assert K._image_of(w2, b, r) is not None
+        got = [K.gemm_forward(w2, x), K.gemm_forward(w2, x, ck), K.gemm_backward_small(w2, x, ck, dy=dy),
+               K.gemm_backward_small(w2, x, None, dy=dy)]
+        stranger = torch.randn(m, k, device=DEV)
+        assert K._image_of(stranger, b, r) is None
+        assert torch.equal(K.gemm_forward(stranger, x), K.gemm_forward(stranger, x))
+        assert K._image_of(w2, 64, 1024) is None          # 65536 columns: not the small kernel
+    assert K._image_of(w2, b, r) is None                    # outside the context
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    for (dx_g, dw_g), (dx_w, dw_w) in zip(got[2:], want[2:]):
+        assert torch.equal(dx_g, dx_w) and torch.equal(dw_g, dw_w)
+    # the images are a snapshot: an in-place update shows only after refresh()
+    w.mul_(2.0)
+    with K.weight_images(images):
+        stale = K.gemm_forward(w2, x)
+        images.refresh()
+        fresh = K.gemm_forward(w2, x)
+    assert torch.equal(stale, want[0]) and torch.equal(fresh, K.gemm_forward(w2, x))
