@@ -721,6 +721,7 @@ class SemiSupervisedStep(SupervisedStep):
         self.config_dict = config_dict or default_config_dict(cfg, dataset=dataset)
         self._ema_weight = torch.zeros((), device=device)  # 1 - a, read by the update graph
         self._teacher_stream = None
+        self._teacher_replay = None
         self._gt = None
 
     # the BN-momentum schedule touches the student only (train.py:234-237): inherited set_epoch
@@ -849,12 +850,43 @@ class SemiSupervisedStep(SupervisedStep):
             self._loss, self._end_points = self._losses_backward(student, self._ema_end_points, inputs)
             if self._merged:
                 self._apply()
+        self._pick_teacher_replay_stream()
+
+    def _pick_teacher_replay_stream(self):
+        """HIP maps streams onto a few hardware queues in creation order; a stream that shares the
+        main stream's queue runs the teacher's graph AFTER the student's instead of beside it (seen
+        when this runner is the third of a process: 10.9 instead of 9.8 ms per step).  A graph can be
+        replayed on any stream, so the pair of forward graphs is timed on a few and the fastest
+        keeps the job (every side effect of these replays is undone with the capture's)."""
+        dev = self.device
+        self._teacher_replay = self._teacher_stream
+        if os.environ.get("STEP_SEMI_TEACHER_PROBE", "1") == "0":
+            return
+        cur = torch.cuda.current_stream(dev)
+        candidates = [self._teacher_stream] + [torch.cuda.Stream(device=dev) for _ in range(3)]
+        times = []
+        for s in candidates:
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for rep in range(3):
+                if rep == 1:
+                    torch.cuda.synchronize(dev)
+                    t0.record(cur)
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    self._gt.replay()
+                self._g1a.replay()
+                cur.wait_stream(s)
+            t1.record(cur)
+            torch.cuda.synchronize(dev)
+            times.append(t0.elapsed_time(t1) / 2)
+        self._teacher_probe_ms = times
+        self._teacher_replay = candidates[times.index(min(times))]
 
     def _replay_step(self):
         if self._gt is None:
             return super()._replay_step()
         main = torch.cuda.current_stream(self.device)
-        ts = self._teacher_stream
+        ts = self._teacher_replay
         ts.wait_stream(main)  # the inputs are staged
         with torch.cuda.stream(ts):
             self._gt.replay()

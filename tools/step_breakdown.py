@@ -1,5 +1,6 @@
 """Per-step kernel breakdown from a rocprofv3 --kernel-trace csv of bench.py: the timed steps are
-delimited by the once-per-step loss_finalize kernel; prints time per kernel per step, busiest first.
+delimited by the once-per-step optimizer kernel (adam_update_kernel; the loss' finalize kernel runs
+twice per semi-supervised step since round 5); prints time per kernel per step, busiest first.
 
     python tools/step_breakdown.py <kernel_trace.csv> [steps=20] [top=40] [out.csv]
 """
@@ -25,7 +26,7 @@ def short(n):
 names = [short(r["Kernel_Name"]) for r in rows]
 st = [int(r["Start_Timestamp"]) for r in rows]
 en = [int(r["End_Timestamp"]) for r in rows]
-adam = [i for i, n in enumerate(names) if n.startswith("loss_finalize_kernel")]
+adam = [i for i, n in enumerate(names) if n.startswith("adam_update_kernel")]
 lo, hi = adam[-steps - 1] + 1, adam[-1] + 1
 tot, cnt = collections.Counter(), collections.Counter()
 for i in range(lo, hi):
