@@ -299,7 +299,7 @@ LOSS_HD void loss_proposal(const LossArgs &a, const SceneView &sv, int b, int k,
     acc[ACC_IOUACC] += fabsf(x);
     acc[ACC_IOUACC_OBJ] += fabsf(x) * obj;
     acc[ACC_IOUHUB] += huber1(x);
-    const float s = kLossWeight / (float)(a.B * a.K) * huber1_grad(x) * p * (1.0f - p);
+    const float s = a.grad_scale * kLossWeight / (float)(a.B * a.K) * huber1_grad(x) * p * (1.0f - p);
     for (int j = 0; j < a.NI; ++j) a.g_iou[bk * a.NI + j] = j == sel ? s : 0.0f;
   }
   if (a.has_jitter) {
@@ -310,7 +310,7 @@ LOSS_HD void loss_proposal(const LossArgs &a, const SceneView &sv, int b, int k,
     const float x = p - lab;
     acc[ACC_JITACC] += fabsf(x);
     acc[ACC_JITHUB] += huber1(x);
-    const float s = kLossWeight / ((float)(a.B * a.K) + 1e-6f) * huber1_grad(x) * p * (1.0f - p);
+    const float s = a.grad_scale * kLossWeight / ((float)(a.B * a.K) + 1e-6f) * huber1_grad(x) * p * (1.0f - p);
     for (int j = 0; j < a.NI; ++j) a.g_iou_jit[bk * a.NI + j] = j == sel ? s : 0.0f;
   }
 }
@@ -393,11 +393,11 @@ LOSS_HD void loss_stats(const LossArgs &a, const float *acc) {
 // slot whose nearest prediction is this proposal
 LOSS_HD void finalize_proposal(const LossArgs &a, const SceneView &sv, int b, int k, const float *acc) {
   const long long bk = (long long)b * a.K + k;
-  const float so = 1.0f / (acc[ACC_MASK] + 1e-6f), sp = 1.0f / (acc[ACC_POS] + 1e-6f);
+  const float so = a.grad_scale / (acc[ACC_MASK] + 1e-6f), sp = a.grad_scale / (acc[ACC_POS] + 1e-6f);
   a.g_obj[bk * 2] *= so;
   a.g_obj[bk * 2 + 1] *= so;
   float back[3] = {0.0f, 0.0f, 0.0f};
-  const float sb = kLossWeight / (acc[ACC_BLM] + 1e-6f) * 2.0f;
+  const float sb = a.grad_scale * kLossWeight / (acc[ACC_BLM] + 1e-6f) * 2.0f;
   for (int g = 0; g < a.G; ++g)
     if (sv.nearest[g] == k)
       for (int d = 0; d < 3; ++d)
@@ -413,7 +413,7 @@ LOSS_HD void finalize_proposal(const LossArgs &a, const SceneView &sv, int b, in
 LOSS_HD void vote_grad(const LossArgs &a, int b, int s, int arg, float mask, const float *acc) {
   const int p = a.seed_inds[b * a.seed_inds_stride + s];
   const long long row = (long long)b * a.N + p;
-  const float scale = kLossWeight * mask / (acc[ACC_VMASK] + 1e-6f);
+  const float scale = a.grad_scale * kLossWeight * mask / (acc[ACC_VMASK] + 1e-6f);
   for (int j = 0; j < a.VF; ++j)
     for (int c = 0; c < 3; ++c) {
       float v = 0.0f;

@@ -225,7 +225,7 @@ def default_config_dict(config, dataset='scannet', unlabeled_batch_size=8):
             'view_stats': False}
 
 
-def get_unlabeled_loss(end_points, ema_end_points, config, config_dict):
+def get_unlabeled_loss(end_points, ema_end_points, config, config_dict, labels_only=False):
     """Pseudo labels from the EMA teacher -> transformed into the student's augmented frame ->
     consistency loss.  `labeled_num`: end_points['labeled_num'] (host int) or, as the reference
     does, the number of non-zero entries of supervised_mask (a device sync)."""
@@ -283,4 +283,6 @@ def get_unlabeled_loss(end_points, ema_end_points, config, config_dict):
     end_points['unlabeled_size_residual_label'] = size_residual_label
     end_points['unlabeled_false_center_label'] = false_center_label
     end_points['unlabeled_iou_label'] = iou_label
+    if labels_only:  # (the caller computes the loss together with the supervised one)
+        return None, end_points
     return get_pseudo_detection_loss(end_points, labeled_num, config)

@@ -796,12 +796,21 @@ class SemiSupervisedStep(SupervisedStep):
         if labeled is None:
             labeled = self._host_info(batch)["labeled_num"]
         end_points["labeled_num"] = labeled
-        detection_loss, end_points = get_labeled_loss(end_points, self.cfg,
-                                                      {"dataset_config": self.cfg})
-        unlabeled_loss, end_points = get_unlabeled_loss(end_points, ema_end_points, self.cfg,
-                                                        self.config_dict)
-        loss = detection_loss + unlabeled_loss * self.unlabeled_loss_weight
-        end_points["loss"] = loss
+        from . import fused_loss
+        if fused_loss.semi_loss_supported(end_points, labeled):
+            # both losses as ONE autograd node over one gradient buffer per head output
+            # (fused_loss._FusedSemiLoss); the pseudo labels first, without their loss
+            _, end_points = get_unlabeled_loss(end_points, ema_end_points, self.cfg, self.config_dict,
+                                               labels_only=True)
+            loss, end_points = fused_loss.get_semi_loss_fused(end_points, self.cfg, labeled,
+                                                              self.unlabeled_loss_weight)
+        else:
+            detection_loss, end_points = get_labeled_loss(end_points, self.cfg,
+                                                          {"dataset_config": self.cfg})
+            unlabeled_loss, end_points = get_unlabeled_loss(end_points, ema_end_points, self.cfg,
+                                                            self.config_dict)
+            loss = detection_loss + unlabeled_loss * self.unlabeled_loss_weight
+            end_points["loss"] = loss
         from pointnet2 import _mlp_ext as K
         # (the student's images were rebuilt at the head of its forward pass)
         with K.weight_images(self._images_of(self.net, "student")), zero_grads_none(), \

@@ -35,6 +35,10 @@ typedef struct VnLossArgs {
                               (S = VF = 0, vote / seed arguments unused) and no IoU term (iou
                               arguments unused, g_iou* not written), the objectness term is a
                               statistic only (g_obj = 0): loss = 10 (box + 0.1 sem_cls) */
+  float grad_scale;        /* every gradient output is d(grad_scale * stats[VN_ST_LOSS]) / d(prediction):
+                              1 for the loss alone; w where the caller's objective adds this loss
+                              with weight w (train.py:333: detection_loss + 2.0 * unlabeled_loss)
+                              and wants ONE gradient buffer for the sum */
   /* labels (loss_helper_labeled.py end_points keys): contiguous, first B scenes are read */
   const float *center_label;             /* (.,G,3) */
   const float *box_label_mask;           /* (.,G)   */

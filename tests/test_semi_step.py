@@ -118,3 +118,39 @@ def test_semi_graph_replay_matches_eager(oracle_omp, monkeypatch):
     # pre-BatchNorm biases carry the +-lr sign noise above; a bias moves the batch mean one to
     # one and the running mean by momentum (0.1) of that: 0.1 * 2 * lr = 4e-4
     assert torch.allclose(eager[5], graph[5], rtol=3e-3, atol=5e-4)
+
+
+@pytest.mark.gpu
+def test_one_loss_node_for_both_losses(oracle_omp, monkeypatch):
+    """fused_loss._FusedSemiLoss (the supervised loss on the labeled scenes and the consistency loss
+    on the unlabeled ones writing ONE gradient buffer per head output, the consistency rows
+    pre-scaled by the loss weight) == the two separate autograd nodes on slices of the head outputs:
+    same loss, same logged terms and labels, same parameter gradients (to the order of the fp32
+    atomics), from the same initial state and noise."""
+    V, dev = _setup(True, oracle_omp, monkeypatch)
+    cfg = V.scannet_config()
+    step_mod = importlib.import_module("3dioumatch_amd.votenet.step")
+    batch = {k: v.to(dev) for k, v in V.make_semi_batch(LAB, UNL, N, cfg, seed=3, num_objects=5).items()}
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("VOTENET_FUSED_SEMI_LOSS", flag)
+        runner = V.SemiSupervisedStep(cfg, dev, num_proposal=K, seed=4, graphs=False,
+                                      config_dict=_loose_filter(V, cfg))
+        torch.manual_seed(1)
+        torch.cuda.manual_seed_all(1)
+        view = dict(batch)
+        view["labeled_num"] = LAB
+        loss, ep = runner._forward_backward(view)
+        res.append((float(loss), ep, runner.flat_grad.clone()))
+    (l0, e0, g0), (l1, e1, g1) = res
+    assert int(e1["unlabeled_box_label_mask"].sum()) > 0
+    assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0))
+    for key in ("detection_loss", "unlabeled_detection_loss", "vote_loss", "objectness_loss", "box_loss",
+                "iou_loss", "unlabeled_box_loss", "unlabeled_center_loss", "unlabeled_sem_cls_loss",
+                "unlabeled_objectness_loss", "pos_ratio", "unlabeled_pos_ratio"):
+        a, b = float(e0[key]), float(e1[key])
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (key, a, b)
+    for key in ("objectness_label", "object_assignment", "unlabeled_objectness_label",
+                "unlabeled_object_assignment"):
+        assert torch.equal(e0[key], e1[key]), key
+    assert float((g0 - g1).norm() / g0.norm()) < 1e-5
