@@ -872,6 +872,7 @@ class SemiSupervisedStep(SupervisedStep):
         if os.environ.get("STEP_SEMI_TEACHER_PROBE", "1") == "0":
             return
         cur = torch.cuda.current_stream(dev)
+        side = self.side_stream()
         candidates = [self._teacher_stream] + [torch.cuda.Stream(device=dev) for _ in range(3)]
         times = []
         for s in candidates:
@@ -880,6 +881,12 @@ class SemiSupervisedStep(SupervisedStep):
                 if rep == 1:
                     torch.cuda.synchronize(dev)
                     t0.record(cur)
+                # as in the running loop: the next batch's index chain (4 ms of serial sampling
+                # rounds) is in flight on the prefetch stream -- a candidate that shares ITS queue
+                # would run the teacher behind it
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    self._slots[0]["graph"].replay()
                 s.wait_stream(cur)
                 with torch.cuda.stream(s):
                     self._gt.replay()
@@ -890,6 +897,9 @@ class SemiSupervisedStep(SupervisedStep):
             times.append(t0.elapsed_time(t1) / 2)
         self._teacher_probe_ms = times
         self._teacher_replay = candidates[times.index(min(times))]
+        if os.environ.get("STEP_DEBUG"):
+            sys.stderr.write("teacher replay stream probe (ms per pair of forward graphs): %s\n"
+                             % ", ".join("%.3f" % t for t in times))
 
     def _replay_step(self):
         if self._gt is None:
