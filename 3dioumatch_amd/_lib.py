@@ -24,6 +24,8 @@ _SIGNATURES = {
     "pn2_group_points_grad": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
     "pn2_three_nn": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "pn2_three_interpolate": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "pn2_three_interpolate_affine_supported": [_c_int, _c_int, _c_int],
+    "pn2_three_interpolate_affine": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pn2_three_interpolate_grad": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "pn2_three_nn_weights": [ctypes.c_longlong, _vp, _vp, _vp],
     "pn2_multi_copy": [_c_int, _vp, ctypes.c_longlong, _vp],

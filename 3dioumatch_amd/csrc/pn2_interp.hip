@@ -149,6 +149,59 @@ three_interpolate_lds_kernel(int c, int m, int n, const float *__restrict__ poin
   }
 }
 
+// three_interpolate_lds_kernel + an affine term in three more inputs per query:
+//   out[b][l][j] = sum_q w[b][j][q] * points[b][l][idx[b][j][q]] + aw[l] . ax[b][:, j]
+// What it is for: a 1x1 convolution W over cat([ax (3 rows), interpolate(f)]) commutes with the
+// interpolation -- W[:, 3:] . interpolate(f) = interpolate(W[:, 3:] . f) -- so the layer's GEMM runs
+// over the m source points instead of the n >> m queries and this kernel writes the layer's output
+// directly (the IoU branch's first layer, grid_conv_module.py:87-110: n = 64 grid points per box).
+template <int CPW>
+__global__ void __launch_bounds__(256)
+three_interpolate_affine_lds_kernel(int c, int m, int n, const float *__restrict__ points,
+                                    const int *__restrict__ idx, const float *__restrict__ weight,
+                                    const float *__restrict__ aw, const float *__restrict__ ax,
+                                    float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float rows[];
+  const BlockId blk = xcd_block_id();
+  const int b = blk.z, l0 = blk.y * CPW;
+  const int nc = c - l0 < CPW ? c - l0 : CPW;
+  const float *src = points + ((size_t)b * c + l0) * m;
+  for (int t = threadIdx.x; t < nc * m; t += 256) rows[t] = src[t];
+  __syncthreads();
+  const int j0 = (blk.x * 256 + threadIdx.x) * 4;
+  if (j0 >= n) return;
+  const int4 *ib = reinterpret_cast<const int4 *>(idx + ((size_t)b * n + j0) * 3);
+  const float4 *wb = reinterpret_cast<const float4 *>(weight + ((size_t)b * n + j0) * 3);
+  const int4 i0 = ib[0], i1 = ib[1], i2 = ib[2];
+  const float4 w0 = wb[0], w1 = wb[1], w2 = wb[2];
+  const int ii[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
+  const float ww[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+  const float *axb = ax + (size_t)b * 3 * n + j0;
+  const float4 x0 = *reinterpret_cast<const float4 *>(axb), x1 = *reinterpret_cast<const float4 *>(axb + n),
+               x2 = *reinterpret_cast<const float4 *>(axb + 2 * (size_t)n);
+  const float xs[4][3] = {{x0.x, x1.x, x2.x}, {x0.y, x1.y, x2.y}, {x0.z, x1.z, x2.z}, {x0.w, x1.w, x2.w}};
+#pragma unroll
+  for (int cc = 0; cc < CPW; ++cc) {
+    if (cc < nc) {
+      const float *row = rows + cc * m;
+      const float a0 = aw[(l0 + cc) * 3], a1 = aw[(l0 + cc) * 3 + 1], a2 = aw[(l0 + cc) * 3 + 2];
+      float r[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float interp = __fadd_rn(__fadd_rn(__fmul_rn(row[ii[3 * t]], ww[3 * t]),
+                                                 __fmul_rn(row[ii[3 * t + 1]], ww[3 * t + 1])),
+                                       __fmul_rn(row[ii[3 * t + 2]], ww[3 * t + 2]));
+        const float affine = __fadd_rn(__fadd_rn(__fmul_rn(a0, xs[t][0]), __fmul_rn(a1, xs[t][1])),
+                                       __fmul_rn(a2, xs[t][2]));
+        r[t] = __fadd_rn(affine, interp);
+      }
+      typedef float ti_f4 __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(ti_f4{r[0], r[1], r[2], r[3]},
+                                  reinterpret_cast<ti_f4 *>(out + ((size_t)b * c + l0 + cc) * n + j0));
+    }
+  }
+}
+
 // Scatter-add with the CPW destination rows privatised in LDS (ds_add_f32), written back once:
 // no global atomics and no pre-zeroing (the global-atomic kernel below remains for large m).
 template <int CPW>
@@ -269,6 +322,26 @@ static int interpolate_grad_run(int b, int c, int n, int m, const float *grad_ou
   dim3 grid(pn2_ceil_div(n, 256), interp_channel_groups(c), b);
   hipLaunchKernelGGL(three_interpolate_grad_kernel, grid, dim3(256), 0, stream, c, n, m, grad_out,
                      g_bstride, idx, weight, grad_points);
+  return pn2_launch_status();
+}
+
+PN2_API int pn2_three_interpolate_affine_supported(int c, int m, int n) {
+  return c > 0 && m > 0 && m <= 2048 && n >= 4 && n % 4 == 0;
+}
+
+PN2_API int pn2_three_interpolate_affine(int b, int c, int m, int n, const float *points, const int *idx,
+                                         const float *weight, const float *affine_w,
+                                         const float *affine_x, float *out, void *stream_) {
+  if (b <= 0) return 0;
+  if (!pn2_three_interpolate_affine_supported(c, m, n) || !affine_w || !affine_x ||
+      (reinterpret_cast<size_t>(out) & 15) || (reinterpret_cast<size_t>(affine_x) & 15) ||
+      (reinterpret_cast<size_t>(idx) & 15) || (reinterpret_cast<size_t>(weight) & 15))
+    return (int)hipErrorInvalidValue;
+  constexpr int CPW = 8;
+  dim3 grid(pn2_ceil_div(n, 1024), pn2_ceil_div(c, CPW), b);
+  hipLaunchKernelGGL(three_interpolate_affine_lds_kernel<CPW>, grid, dim3(256),
+                     sizeof(float) * (size_t)CPW * m, (hipStream_t)stream_, c, m, n, points, idx, weight,
+                     affine_w, affine_x, out);
   return pn2_launch_status();
 }
 

@@ -348,6 +348,33 @@ def three_interpolate_into(points, idx, weight, out, channel0):
     return out
 
 
+def three_interpolate_affine_supported(c, m, n):
+    return bool(_lib.pn2_three_interpolate_affine_supported(int(c), int(m), int(n)))
+
+
+def three_interpolate_affine(points, idx, weight, affine_w, affine_x):
+    """three_interpolate(points (B,C,m), idx, weight) + affine_w (C,3) . affine_x (B,3,n) -> (B,C,n):
+    the output of a 1x1 convolution over cat([3 coordinate rows, interpolated features]) when
+    `points` is that convolution's feature part applied to the SOURCE points
+    (include/pn2_hip.h pn2_three_interpolate_affine).  No gradient."""
+    for t, name in ((points, "points"), (weight, "weight"), (affine_w, "affine_w"), (affine_x, "affine_x")):
+        _chk_f32(t, name)
+    _chk_i32(idx, "idx")
+    _chk_dev(points, (idx, "idx"), (weight, "weight"), (affine_w, "affine_w"), (affine_x, "affine_x"))
+    b, c, m = points.shape
+    n = idx.shape[1]
+    if tuple(affine_w.shape) != (c, 3) or tuple(affine_x.shape) != (b, 3, n) or \
+            not three_interpolate_affine_supported(c, m, n):
+        raise RuntimeError("three_interpolate_affine: affine_w (C,3), affine_x (B,3,n), m <= 2048, n % 4 == 0")
+    out = torch.empty((b, c, n), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        _L.check(_lib.pn2_three_interpolate_affine(b, c, m, n, points.data_ptr(), idx.data_ptr(),
+                                                   weight.data_ptr(), affine_w.data_ptr(),
+                                                   affine_x.data_ptr(), out.data_ptr(), _stream(points)),
+                 "three_interpolate_affine")
+    return out
+
+
 def three_interpolate_grad_from(grad, channel0, c, idx, weight, m):
     """three_interpolate_grad of channels [channel0, channel0 + c) of the contiguous
     (B, C_total, n) gradient `grad` (read in place, no slice copy) -> (B, c, m)."""

@@ -196,6 +196,22 @@ class _FusedMLPChain(Function):
                 cur, cur_coeff = y2, (c2[2], c2[3])
                 gram_last = gram
                 continue
+            if pre is not None and isinstance(pre[0], str) and i == 0:
+                # ("interp", idx, weight, rel, shape): the layer's input is cat([rel (3 rows),
+                # three_interpolate(x)]) over n >> m queries and the convolution commutes with the
+                # interpolation: GEMM over the m source points, then ONE kernel interpolates its output
+                # and adds the coordinate rows' part (no-grad passes only: the weight gradient would
+                # need the interpolated input after all)
+                from pointnet2 import _ext
+                _, q_idx, q_weight, rel, shape = pre
+                z = K.gemm_forward(w2[:, 3:].contiguous(), x)
+                y = _ext.three_interpolate_affine(z, q_idx, q_weight, w2[:, :3].contiguous(), rel).view(shape)
+                mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, momenta[0], epss[0],
+                                                               training)
+                ys.append(y)
+                coefs.append((mean, invstd, scale, shift))
+                cur, cur_coeff = y, (scale, shift)
+                continue
             if pre is not None and i == 0:
                 idx, _, npts = pre
                 z = K.gemm_forward(w2, x)  # over the n + m points, not the m * ns gathered columns
@@ -261,6 +277,8 @@ class _FusedMLPChain(Function):
     @staticmethod
     def backward(ctx, dout):
         from pointnet2 import _mlp_ext as K
+        if ctx.pre is not None and isinstance(ctx.pre[0], str):
+            raise RuntimeError("the interpolation-commuted first layer is a forward-only form")
         n, pool, training = ctx.n_layers, ctx.pool, ctx.training
         saved = ctx.saved_tensors
         x, ys = saved[0], saved[1:1 + n]
@@ -529,6 +547,26 @@ class SharedMLP(nn.Sequential):
         _ext.group_inverse; -> (B, C', m)."""
         src = _PackPoints.apply(xyz, new_xyz, features, float(scale))
         return self._run(src, pool=True, pre=(idx, inverse, xyz.shape[1]))
+
+    def interp_first_ok(self, features, idx):
+        """forward_pooled_interp covers: no gradient recording, the MFMA chain, two layers or more,
+        shapes of the affine interpolation kernel."""
+        from pointnet2 import _ext
+        layers = list(self)
+        return (not torch.is_grad_enabled() and os.environ.get("PN2_INTERP_FIRST", "1") != "0"
+                and _mfma_enabled() and len(layers) >= 2 and features.is_cuda and features.dim() == 3
+                and features.dtype == torch.float32 and hasattr(_ext, "three_interpolate_affine")
+                and layers[0].conv.weight.shape[1] == features.shape[1] + 3
+                and _ext.three_interpolate_affine_supported(layers[0].conv.weight.shape[0],
+                                                            features.shape[2], idx.shape[1]))
+
+    def forward_pooled_interp(self, features, idx, weight, rel, npoint, nsample):
+        """forward_pooled(cat([rel, three_interpolate(features, idx, weight)]).view(B, 3 + C, npoint,
+        nsample)) without that tensor: features (B,C,m) of the source points, idx / weight
+        (B, npoint*nsample, 3), rel (B, 3, npoint*nsample).  No-grad passes only (interp_first_ok)."""
+        shape = (features.shape[0], list(self)[0].conv.weight.shape[0], npoint, nsample)
+        return self._run(features.contiguous(), pool=True,
+                         pre=("interp", idx.contiguous(), weight.contiguous(), rel.contiguous(), shape))
 
     def forward_pooled(self, x):
         """max over the last axis of forward(x): (B, C, npoint, nsample) -> (B, C', npoint)."""

@@ -266,17 +266,30 @@ class GridConv(nn.Module):
             # interpolation into channels 3.. -- grid_conv_module.py:64-107 was ~20 tensor kernels
             _L = _fused_front_end()
             c = origin_features.shape[1]
-            feats = torch.empty((b, 3 + c, k * g3), dtype=torch.float32, device=size.device)
             whole = torch.empty((b, k * g3, 3), dtype=torch.float32, device=size.device)
             ctr, sz, hd = center.detach().contiguous(), size.detach().contiguous(), heading.detach().contiguous()
+            # no-grad passes (the EMA teacher, evaluation): the first layer of the shared MLP commutes
+            # with the interpolation (SharedMLP.forward_pooled_interp): only the 3 rows of relative
+            # coordinates are formed here, the (3 + C, K*64) input tensor never is
+            commute = getattr(self.mlp_before_iou, "interp_first_ok", None) is not None and \
+                (k * g3) % 4 == 0 and origin_xyz.shape[1] <= 2048 and not torch.is_grad_enabled()
+            rows = 3 if commute else 3 + c
+            feats = torch.empty((b, rows, k * g3), dtype=torch.float32, device=size.device)
             with torch.cuda.device(size.device):
                 _L.check(_L.lib.votenet_gridconv_points(
-                    b, k, 3 + c, self._unit_grid(size.device).data_ptr(), ctr.data_ptr(), sz.data_ptr(),
+                    b, k, rows, self._unit_grid(size.device).data_ptr(), ctr.data_ptr(), sz.data_ptr(),
                     hd.data_ptr(), whole.data_ptr(), feats.data_ptr(),
                     torch.cuda.current_stream(size.device).cuda_stream), "votenet_gridconv_points")
             idx, weight = pointnet2_utils.three_nn_with_weights(whole, origin_xyz)
-            pointnet2_utils._ext.three_interpolate_into(origin_features, idx, weight, feats, 3)
-            iou_features = self.mlp_before_iou.forward_pooled(feats.view(b, -1, k, g3))
+            if commute and self.mlp_before_iou.interp_first_ok(origin_features, idx):
+                iou_features = self.mlp_before_iou.forward_pooled_interp(origin_features, idx, weight, feats,
+                                                                         k, g3)
+            else:
+                if commute:  # (the shared MLP declined: the full input after all)
+                    rel, feats = feats, torch.empty((b, 3 + c, k * g3), dtype=torch.float32, device=size.device)
+                    feats[:, :3].copy_(rel)
+                pointnet2_utils._ext.three_interpolate_into(origin_features, idx, weight, feats, 3)
+                iou_features = self.mlp_before_iou.forward_pooled(feats.view(b, -1, k, g3))
             net = head_chain(iou_features, self.conv1_iou, self.bn1_iou, self.conv2_iou, self.bn2_iou,
                              self.conv3_iou)
             end_points['iou_scores'] = net.transpose(2, 1)[:, :, -self.iou_size:]

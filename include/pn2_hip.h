@@ -87,6 +87,17 @@ int pn2_three_nn(int b, int n, int m, const float *unknown, const float *known, 
 int pn2_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
                           const float *weight, float *out, void *stream);
 
+/* three_interpolate (interpolate.cpp:47-75, K8 interpolate_gpu.cu:77-117) plus an affine term in
+ * three more inputs per query: out (b,c,n) = interpolate(points (b,c,m), idx, weight) +
+ * affine_w (c,3) . affine_x (b,3,n).  For a 1x1 convolution over cat([3 coordinate rows,
+ * interpolated features]) (models/grid_conv_module.py:87-110): the convolution commutes with the
+ * interpolation, so the GEMM runs over the m source points and this call writes the layer's output.
+ * m <= 2048, n a multiple of 4, 16-byte aligned idx / weight / affine_x / out. */
+int pn2_three_interpolate_affine_supported(int c, int m, int n);
+int pn2_three_interpolate_affine(int b, int c, int m, int n, const float *points, const int *idx,
+                                 const float *weight, const float *affine_w, const float *affine_x,
+                                 float *out, void *stream);
+
 /* replaces three_interpolate_grad_kernel_wrapper (interpolate.cpp:14-17,
  * interpolate_gpu.cu:121-159) -- the INTENDED scatter-add.  The reference's pybind layer
  * never reaches that launcher (interpolate.cpp:95 dispatches the forward kernel instead,

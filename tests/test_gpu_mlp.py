@@ -921,3 +921,56 @@ def test_small_gemms_from_weight_images(b, m, k, r, monkeypatch):
         images.refresh()
         fresh = K.gemm_forward(w2, x)
     assert torch.equal(stale, want[0]) and torch.equal(fresh, K.gemm_forward(w2, x))
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_first_layer_commuted_with_the_interpolation(training, monkeypatch):
+    """SharedMLP.forward_pooled_interp (no-grad passes of the IoU branch, grid_conv_module.py:87-110):
+    W0 . cat([rel, interpolate(f)]) computed as interpolate(W0[:, 3:] . f) + W0[:, :3] . rel -- the
+    GEMM over the 1024 seeds instead of the 16384 grid points, one kernel for interpolation + the
+    coordinate rows (pn2_three_interpolate_affine, also checked alone against torch) -- == the shared
+    MLP on the materialised input: pooled features to 1e-4 of their range, running statistics too."""
+    P = _mods()
+    ext = importlib.import_module("pointnet2._ext")
+    g = torch.Generator().manual_seed(5)
+    b, c, s, k, g3 = 3, 256, 1024, 40, 64
+    n = k * g3
+    f = torch.randn(b, c, s, generator=g).to(DEV)
+    idx = torch.randint(0, s, (b, n, 3), generator=g, dtype=torch.int32).to(DEV)
+    wt = torch.rand(b, n, 3, generator=g)
+    wt = (wt / wt.sum(-1, keepdim=True)).to(DEV)
+    rel = torch.randn(b, 3, n, generator=g).to(DEV)
+    # the kernel alone
+    z = torch.randn(b, 128, s, generator=g).to(DEV)
+    aw = torch.randn(128, 3, generator=g).to(DEV)
+    got = ext.three_interpolate_affine(z, idx, wt, aw, rel)
+    gathered = torch.gather(z.unsqueeze(2).expand(b, 128, n, s), 3, idx.long().unsqueeze(1).expand(b, 128, n, 3))
+    want = (gathered * wt.unsqueeze(1)).sum(-1) + torch.einsum("cd,bdn->bcn", aw, rel)
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    # the module
+    torch.manual_seed(0)
+    outs = []
+    for commuted in (False, True):
+        torch.manual_seed(0)
+        mlp = P.SharedMLP([c + 3, 128, 128, 128], bn=True).to(DEV)
+        mlp.train(training)
+        with torch.no_grad():
+            if commuted:
+                assert mlp.interp_first_ok(f, idx)
+                out = mlp.forward_pooled_interp(f, idx, wt, rel, k, g3)
+            else:
+                feats = torch.empty(b, 3 + c, n, device=DEV)
+                feats[:, :3] = rel
+                ext.three_interpolate_into(f, idx, wt, feats, 3)
+                out = mlp.forward_pooled(feats.view(b, 3 + c, k, g3))
+        outs.append((out, [bb.clone() for bb in mlp.buffers()]))
+    (o0, b0), (o1, b1) = outs
+    assert o0.shape == o1.shape == (b, 128, k)
+    assert float((o0 - o1).abs().max()) <= 1e-4 * max(1.0, float(o0.abs().max()))
+    for x, y in zip(b0, b1):
+        assert torch.allclose(x.float(), y.float(), rtol=1e-4, atol=1e-5)
+    # with gradients recorded the commuted form declines
+    assert not mlp.interp_first_ok(f, idx)
+    monkeypatch.setenv("PN2_INTERP_FIRST", "0")
+    with torch.no_grad():
+        assert not mlp.interp_first_ok(f, idx)
