@@ -277,11 +277,21 @@ class _FusedMLPChain(Function):
     @staticmethod
     def backward(ctx, dout):
         from pointnet2 import _mlp_ext as K
-        if ctx.pre is not None and isinstance(ctx.pre[0], str):
-            raise RuntimeError("the interpolation-commuted first layer is a forward-only form")
         n, pool, training = ctx.n_layers, ctx.pool, ctx.training
         saved = ctx.saved_tensors
         x, ys = saved[0], saved[1:1 + n]
+        pre_gather = ctx.pre
+        if ctx.pre is not None and isinstance(ctx.pre[0], str):
+            # the interpolation-commuted first layer: its weight gradient needs the layer's real
+            # input cat([rel, interpolate(x)]) -- formed here, once, instead of in the forward pass
+            # (the layer's input carries no gradient: asserted by interp_first_ok)
+            from pointnet2 import _ext
+            _, q_idx, q_weight, rel, shape = ctx.pre
+            feats = torch.empty((x.shape[0], 3 + x.shape[1], rel.shape[2]), dtype=torch.float32, device=x.device)
+            feats[:, :3].copy_(rel)
+            _ext.three_interpolate_into(x, q_idx, q_weight, feats, 3)
+            x = feats.view(x.shape[0], 3 + x.shape[1], shape[2], shape[3])
+            pre_gather = None
         flat = saved[1 + n:1 + 5 * n]
         coefs = [flat[4 * i:4 * i + 4] for i in range(n)]  # mean, invstd, scale, shift
         pos = 1 + 5 * n
@@ -321,7 +331,7 @@ class _FusedMLPChain(Function):
                 elif i == 0 and ctx.moments is not None:
                     raise RuntimeError("the virtual first layer's BatchNorm sums must come from the "
                                        "fused backward kernel of the second layer")
-                elif K.small_backward_prefers_dy(w2, ys[i]) and not (ctx.pre is not None and i == 0):
+                elif K.small_backward_prefers_dy(w2, ys[i]) and not (pre_gather is not None and i == 0):
                     # a small layer: dy written once and read by the pair launch, instead of
                     # re-formed by each of its tiles (_mlp_ext.small_backward_prefers_dy)
                     dy_tensor, dgamma, dbeta = K.bn_relu_backward(ys[i], dz, gamma, scale, shift, mean,
@@ -333,15 +343,15 @@ class _FusedMLPChain(Function):
                 fly = None if dy_tensor is not None else (ys[i], dz, scale, shift, mean, invstd, coef)
             grads[5 * i + 1], grads[5 * i + 2] = dgamma, dbeta
             m, k = w2.shape
-            if ctx.pre is not None and i == 0:
+            if pre_gather is not None and i == 0:
                 # gradient of z_ext = W_0 . src_ext: the BatchNorm / ReLU backward of (y_0, dz) formed
                 # on the fly, scatter-added over idx and summed per group; then two GEMMs over
                 # the n + m points
-                inverse = ctx.pre[1]
+                inverse = pre_gather[1]
                 if inverse is None:  # forward ran without it (no gradient expected then): build it now
                     from pointnet2 import _ext
-                    inverse = _ext.group_inverse(ctx.pre[0], ctx.pre[2])
-                dzx = K.pregather_backward(fly, inverse, ctx.pre[2])
+                    inverse = _ext.group_inverse(pre_gather[0], pre_gather[2])
+                dzx = K.pregather_backward(fly, inverse, pre_gather[2])
                 pair = K.gemm_backward_small(w2, x, None, dy=dzx, need_dx=need_dx)
                 if pair is not None:
                     dx, grads[0] = pair[0], pair[1].view_as(w)
@@ -549,11 +559,14 @@ class SharedMLP(nn.Sequential):
         return self._run(src, pool=True, pre=(idx, inverse, xyz.shape[1]))
 
     def interp_first_ok(self, features, idx):
-        """forward_pooled_interp covers: no gradient recording, the MFMA chain, two layers or more,
-        shapes of the affine interpolation kernel."""
+        """forward_pooled_interp covers: features without gradient, the MFMA chain, two layers or
+        more, shapes of the affine interpolation kernel."""
         from pointnet2 import _ext
         layers = list(self)
-        return (not torch.is_grad_enabled() and os.environ.get("PN2_INTERP_FIRST", "1") != "0"
+        recording = torch.is_grad_enabled()
+        if recording and (features.requires_grad or os.environ.get("PN2_INTERP_FIRST_TRAIN", "1") == "0"):
+            return False  # (a gradient w.r.t. the features would need the scatter form)
+        return (os.environ.get("PN2_INTERP_FIRST", "1") != "0"
                 and _mfma_enabled() and len(layers) >= 2 and features.is_cuda and features.dim() == 3
                 and features.dtype == torch.float32 and hasattr(_ext, "three_interpolate_affine")
                 and layers[0].conv.weight.shape[1] == features.shape[1] + 3
@@ -563,7 +576,9 @@ class SharedMLP(nn.Sequential):
     def forward_pooled_interp(self, features, idx, weight, rel, npoint, nsample):
         """forward_pooled(cat([rel, three_interpolate(features, idx, weight)]).view(B, 3 + C, npoint,
         nsample)) without that tensor: features (B,C,m) of the source points, idx / weight
-        (B, npoint*nsample, 3), rel (B, 3, npoint*nsample).  No-grad passes only (interp_first_ok)."""
+        (B, npoint*nsample, 3), rel (B, 3, npoint*nsample); none of them with a gradient
+        (interp_first_ok).  In a training pass the layer's real input is formed once, in the backward
+        pass, for the weight gradient."""
         shape = (features.shape[0], list(self)[0].conv.weight.shape[0], npoint, nsample)
         return self._run(features.contiguous(), pool=True,
                          pre=("interp", idx.contiguous(), weight.contiguous(), rel.contiguous(), shape))

@@ -268,11 +268,12 @@ class GridConv(nn.Module):
             c = origin_features.shape[1]
             whole = torch.empty((b, k * g3, 3), dtype=torch.float32, device=size.device)
             ctr, sz, hd = center.detach().contiguous(), size.detach().contiguous(), heading.detach().contiguous()
-            # no-grad passes (the EMA teacher, evaluation): the first layer of the shared MLP commutes
-            # with the interpolation (SharedMLP.forward_pooled_interp): only the 3 rows of relative
-            # coordinates are formed here, the (3 + C, K*64) input tensor never is
+            # the first layer of the shared MLP commutes with the interpolation
+            # (SharedMLP.forward_pooled_interp): only the 3 rows of relative coordinates are formed
+            # here; the (3 + C, K*64) input tensor is not (a training pass forms it in its backward,
+            # for the layer's weight gradient)
             commute = getattr(self.mlp_before_iou, "interp_first_ok", None) is not None and \
-                (k * g3) % 4 == 0 and origin_xyz.shape[1] <= 2048 and not torch.is_grad_enabled()
+                (k * g3) % 4 == 0 and origin_xyz.shape[1] <= 2048
             rows = 3 if commute else 3 + c
             feats = torch.empty((b, rows, k * g3), dtype=torch.float32, device=size.device)
             with torch.cuda.device(size.device):

@@ -969,8 +969,30 @@ def test_first_layer_commuted_with_the_interpolation(training, monkeypatch):
     assert float((o0 - o1).abs().max()) <= 1e-4 * max(1.0, float(o0.abs().max()))
     for x, y in zip(b0, b1):
         assert torch.allclose(x.float(), y.float(), rtol=1e-4, atol=1e-5)
-    # with gradients recorded the commuted form declines
-    assert not mlp.interp_first_ok(f, idx)
+    # a pass that records gradients: same output, and the parameters' gradients agree (the layer's
+    # input is then formed in the backward pass, for the weight gradient); features WITH a gradient
+    # are declined (that gradient would need the scatter form)
+    assert not mlp.interp_first_ok(f.clone().requires_grad_(True), idx)
+    if training:
+        probe = torch.randn(b, 128, k, generator=g).to(DEV)
+        grads = []
+        for commuted in (False, True):
+            torch.manual_seed(0)
+            mlp = P.SharedMLP([c + 3, 128, 128, 128], bn=True).to(DEV).train()
+            if commuted:
+                assert mlp.interp_first_ok(f, idx)
+                out = mlp.forward_pooled_interp(f, idx, wt, rel, k, g3)
+            else:
+                feats = torch.empty(b, 3 + c, n, device=DEV)
+                feats[:, :3] = rel
+                ext.three_interpolate_into(f, idx, wt, feats, 3)
+                out = mlp.forward_pooled(feats.view(b, 3 + c, k, g3))
+            (out * probe).sum().backward()
+            grads.append({name: p_.grad.clone() for name, p_ in mlp.named_parameters()})
+        whole = float(torch.sqrt(sum((v.double() ** 2).sum() for v in grads[0].values())))
+        for name in grads[0]:
+            err = float((grads[0][name] - grads[1][name]).norm()) / max(0.01 * whole, float(grads[0][name].norm()))
+            assert err <= 2e-3, (name, err)
     monkeypatch.setenv("PN2_INTERP_FIRST", "0")
     with torch.no_grad():
         assert not mlp.interp_first_ok(f, idx)
