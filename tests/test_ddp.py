@@ -280,13 +280,17 @@ def test_graph_step_two_ranks_share_one_gpu(tmp_path, semi):
     # the reordering of atomic sums; with the zero-gradient parameters frozen
     # (step.freeze_shift_invariant_parameters: the last BatchNorm bias of every pooling module,
     # profiles/r4_step_repeatability.txt) the weights after three Adam steps agree too
-    assert rel(r[0]["graph_grad"], r[0]["eager_grad"]) < 1e-4
+    # (the semi-supervised gradient adds the consistency terms against a second forward pass: one
+    # max-pool winner changing between two near-tied neighbours moves it by ~1e-4 -- 1.18e-4 measured
+    # once in eight runs -- so its bound is 1e-3; a wrong 1/world or a missing tensor is >= 1e-2)
+    g_tol = 1e-3 if semi else 1e-4
+    assert rel(r[0]["graph_grad"], r[0]["eager_grad"]) < g_tol
     lr = 2e-3 if semi else 1e-3
     assert np.abs(r[0]["graph_params"] - r[0]["eager_params"]).max() <= 3 * 3 * lr
     print("params after 3 steps, graph vs eager: rel %.2e" % rel(r[0]["graph_params"], r[0]["eager_params"]))
     assert rel(r[0]["graph_params"], r[0]["eager_params"]) < 1e-2
     want = (r[0]["single_grad"] + r[1]["single_grad"]) / 2
-    assert rel(r[0]["graph_grad"], want) < 1e-4, rel(r[0]["graph_grad"], want)
+    assert rel(r[0]["graph_grad"], want) < g_tol, rel(r[0]["graph_grad"], want)
     # ... and for EVERY parameter tensor, not only in the global norm: a wrong 1/world (or a tensor
     # left out of the exchange) on a small tensor would be a 100 % error there and invisible above
     worst, off, floor = 0.0, 0, 1e-4 * np.linalg.norm(want)
