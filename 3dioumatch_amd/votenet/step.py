@@ -836,10 +836,11 @@ class SemiSupervisedStep(SupervisedStep):
             self._gt = None
             return super()._capture_step(make_inputs, mode)
         dev = self.device
-        if self._teacher_stream is None:
-            self._teacher_stream = torch.cuda.Stream(device=dev)
-        ts = self._teacher_stream
         cur = torch.cuda.current_stream(dev)
+        if self._teacher_stream is None:
+            self._teacher_stream = self._stream_apart_from(
+                cur, self._side, torch.cuda.graph.default_capture_stream)
+        ts = self._teacher_stream
         # once eagerly ON that stream: per-stream state of the kernel library (the BatchNorm ticket
         # counters) must exist before a capture, and must not be the one the student's graph uses
         ts.wait_stream(cur)
@@ -860,6 +861,20 @@ class SemiSupervisedStep(SupervisedStep):
             if self._merged:
                 self._apply()
         self._pick_teacher_replay_stream()
+
+    def _stream_apart_from(self, *others):
+        """A stream whose HANDLE is none of `others`'.  torch.cuda.Stream() hands out the streams of
+        a pool of 32 round-robin, so the seventh graph runner of a process got, as its teacher
+        stream, the very stream torch.cuda.graph captures on by default: the teacher's and the
+        student's graphs then shared one array of BatchNorm ticket counters (the kernel library
+        keys them by stream) and, replayed side by side, corrupted each other's statistics (seen
+        once in sixteen runs of tools/semi_step_branches.py with a second process on the GPU)."""
+        taken = {s.cuda_stream for s in others if s is not None}
+        for _ in range(64):
+            stream = torch.cuda.Stream(device=self.device)
+            if stream.cuda_stream not in taken:
+                return stream
+        raise RuntimeError("no stream apart from %d others in 64 draws" % len(taken))
 
     def _pick_teacher_replay_stream(self):
         """HIP maps streams onto a few hardware queues in creation order; a stream that shares the

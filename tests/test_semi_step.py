@@ -154,3 +154,31 @@ def test_one_loss_node_for_both_losses(oracle_omp, monkeypatch):
                 "unlabeled_object_assignment"):
         assert torch.equal(e0[key], e1[key]), key
     assert float((g0 - g1).norm() / g0.norm()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_teacher_stream_apart_from_the_capture_stream(oracle_omp, monkeypatch):
+    """torch.cuda.Stream() deals the 32 streams of a pool round-robin: the teacher's graph must not
+    be captured on the handle torch.cuda.graph captures the student's graphs on (the BatchNorm
+    ticket counters are per stream; the seventh graph runner of a process drew exactly that one).
+    _stream_apart_from keeps drawing until the handle is none of those it was given."""
+    V, dev = _setup(True, oracle_omp, monkeypatch)
+    cfg = V.scannet_config()
+    runner = V.SemiSupervisedStep(cfg, dev, num_proposal=K, seed=4, graphs=False,
+                                  config_dict=_loose_filter(V, cfg))
+    drawn = [torch.cuda.Stream(device=dev) for _ in range(70)]
+    by_handle = {s.cuda_stream: s for s in drawn}
+    assert len(by_handle) >= 2  # a pool, not a fresh stream per call: handles repeat
+    assert len(by_handle) < len(drawn)
+    free = drawn[5].cuda_stream
+    others = [s for h, s in by_handle.items() if h != free]
+    for _ in range(3):
+        assert runner._stream_apart_from(None, *others).cuda_stream == free
+    # ... and a captured runner's teacher stream is not the default capture stream
+    runner = V.SemiSupervisedStep(cfg, dev, num_proposal=K, seed=4, graphs=True,
+                                  config_dict=_loose_filter(V, cfg))
+    batch = {k: v.to(dev) for k, v in V.make_semi_batch(LAB, UNL, N, cfg, seed=5, num_objects=5).items()}
+    runner(batch)
+    assert runner.graphs and runner._gt is not None
+    assert runner._teacher_stream.cuda_stream != torch.cuda.graph.default_capture_stream.cuda_stream
+    assert runner._teacher_stream.cuda_stream != torch.cuda.current_stream(dev).cuda_stream
