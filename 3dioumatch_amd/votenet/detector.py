@@ -147,13 +147,20 @@ class VoteNet(nn.Module):
         """Predicted boxes + one jittered copy of each go through the IoU branch together
         (votenet_iou_branch.py:157-181): K -> 2K boxes."""
         end_points = self.forward_backbone(inputs)
-        fused = self._bbox_jitter_fused(end_points)
+        # inputs['jitter_noise']: the two standard-normal (B, K, 3) tensors of this pass, drawn by
+        # the caller (a step runner that replays two forward graphs side by side draws them ahead
+        # of both: graph replays share one device-side offset per generator, votenet/step.py)
+        noise = inputs.get('jitter_noise')
+        fused = self._bbox_jitter_fused(end_points, noise)
         if fused is not None:
             return fused
         center, size, heading = self.calculate_bbox(end_points)
         k = heading.shape[1]
-        center_jitter = center + size * torch.randn(size.shape, device=size.device) * 0.3
-        size_jitter = size + size * torch.randn(size.shape, device=size.device) * 0.3
+        if noise is None:  # the two draws of the reference, in its order
+            noise = (torch.randn(size.shape, device=size.device),
+                     torch.randn(size.shape, device=size.device))
+        center_jitter = center + size * noise[0] * 0.3
+        size_jitter = size + size * noise[1] * 0.3
         size_jitter = torch.clamp(size_jitter, min=1e-8)
         heading_jitter = heading.clone()
         all_center = torch.cat([center, center_jitter], dim=1)
@@ -168,7 +175,7 @@ class VoteNet(nn.Module):
         end_points['jitter_heading'] = heading_jitter
         return end_points
 
-    def _bbox_jitter_fused(self, end_points):
+    def _bbox_jitter_fused(self, end_points, noise=None):
         """calculate_bbox + the jitter as ONE kernel (votenet_bbox_jitter) on the GPU: nothing flows
         back through these tensors in the training forward (they feed the detached IoU branch and
         the IoU labels).  Returns the completed end_points, or None where the kernel is not there."""
@@ -189,8 +196,16 @@ class VoteNet(nn.Module):
         nh = self.num_heading_bin
         dev = center.device
         # the two draws of the reference, in its order (votenet_iou_branch.py:161-162)
-        noise_c = torch.randn((b, k, 3), device=dev)
-        noise_s = torch.randn((b, k, 3), device=dev)
+        if noise is None:
+            noise_c = torch.randn((b, k, 3), device=dev)
+            noise_s = torch.randn((b, k, 3), device=dev)
+        else:
+            noise_c, noise_s = noise
+            for t in (noise_c, noise_s):
+                if t.shape != (b, k, 3) or t.dtype != torch.float32 or t.device != dev or \
+                        not t.is_contiguous():
+                    raise ValueError("jitter_noise: two contiguous float32 (%d, %d, 3) tensors on %s"
+                                     % (b, k, dev))
         c = center.detach().contiguous()
         ss, sr = size_scores.detach().contiguous(), size_residuals.detach().contiguous()
         hs = end_points['heading_scores'].detach().contiguous()

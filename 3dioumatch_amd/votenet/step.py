@@ -775,7 +775,8 @@ class SemiSupervisedStep(SupervisedStep):
             if images is not None:
                 images.refresh()
             return self.teacher({"point_clouds": batch["ema_point_clouds"],
-                                 "geometry": self._geometries(batch)[1]}, mode="jitter")
+                                 "geometry": self._geometries(batch)[1],
+                                 "jitter_noise": batch.get("_teacher_noise")}, mode="jitter")
 
     def _student_forward(self, batch):
         from pointnet2 import _mlp_ext as K
@@ -786,7 +787,8 @@ class SemiSupervisedStep(SupervisedStep):
             if images is not None:
                 images.refresh()
             return self.model({"point_clouds": batch["point_clouds"],
-                               "geometry": self._geometries(batch)[0]}, mode="jitter")
+                               "geometry": self._geometries(batch)[0],
+                               "jitter_noise": batch.get("_student_noise")}, mode="jitter")
 
     def _losses_backward(self, end_points, ema_end_points, batch):
         from .losses_unlabeled import get_unlabeled_loss
@@ -841,6 +843,28 @@ class SemiSupervisedStep(SupervisedStep):
             self._teacher_stream = self._stream_apart_from(
                 cur, self._side, torch.cuda.graph.default_capture_stream)
         ts = self._teacher_stream
+        # No random draw inside the two forward graphs: torch keeps ONE device-side (seed, offset)
+        # pair per generator and every graph replay fills it on the replaying stream -- of two
+        # graphs replayed side by side, both draw from whichever fill landed last (the student drew
+        # its box jitter from the teacher's offset in one run of three with another process on the
+        # GPU, the teacher from the student's otherwise; profiles/r5_semi_step_branches.txt).  The
+        # four noise tensors are drawn on the main stream ahead of the fork, in the eager step's
+        # order (teacher's two, student's two: the same numbers), into buffers the graphs read.
+        probe = make_inputs()
+        k = self.net.num_proposal
+        shape = lambda key: (probe[key].shape[0], k, 3)  # noqa: E731
+        self._noise = {name: tuple(torch.empty(shape(key), dtype=torch.float32, device=dev)
+                                   for _ in range(2))
+                       for name, key in (("_teacher_noise", "ema_point_clouds"),
+                                         ("_student_noise", "point_clouds"))}
+        self._draw_noise()
+        plain_inputs = make_inputs
+
+        def make_inputs():
+            inputs = plain_inputs()
+            inputs.update(self._noise)
+            return inputs
+
         # once eagerly ON that stream: per-stream state of the kernel library (the BatchNorm ticket
         # counters) must exist before a capture, and must not be the one the student's graph uses
         ts.wait_stream(cur)
@@ -916,10 +940,16 @@ class SemiSupervisedStep(SupervisedStep):
             sys.stderr.write("teacher replay stream probe (ms per pair of forward graphs): %s\n"
                              % ", ".join("%.3f" % t for t in times))
 
+    def _draw_noise(self):
+        for pair in (self._noise["_teacher_noise"], self._noise["_student_noise"]):
+            for t in pair:
+                t.normal_()
+
     def _replay_step(self):
         if self._gt is None:
             return super()._replay_step()
         main = torch.cuda.current_stream(self.device)
+        self._draw_noise()
         ts = self._teacher_replay
         ts.wait_stream(main)  # the inputs are staged
         with torch.cuda.stream(ts):

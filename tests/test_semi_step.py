@@ -182,3 +182,41 @@ def test_teacher_stream_apart_from_the_capture_stream(oracle_omp, monkeypatch):
     assert runner.graphs and runner._gt is not None
     assert runner._teacher_stream.cuda_stream != torch.cuda.graph.default_capture_stream.cuda_stream
     assert runner._teacher_stream.cuda_stream != torch.cuda.current_stream(dev).cuda_stream
+
+
+@pytest.mark.parametrize("use_gpu", [pytest.param(False, id="cpu-hostlogic"),
+                                     pytest.param(True, id="gpu-hip", marks=pytest.mark.gpu)])
+def test_jitter_noise_from_the_caller(use_gpu, oracle_omp, monkeypatch):
+    """forward_with_pred_jitter with inputs['jitter_noise'] = the two standard-normal tensors the
+    pass would have drawn itself (votenet_iou_branch.py:161-162, in that order) is the same pass:
+    what lets the semi-supervised runner draw the noise of its two forward graphs ahead of both."""
+    V, dev = _setup(use_gpu, oracle_omp, monkeypatch)
+    cfg = V.scannet_config()
+    step_mod = importlib.import_module("3dioumatch_amd.votenet.step")
+    data = importlib.import_module("3dioumatch_amd.votenet.data")
+    net = step_mod.build_detector(cfg, num_proposal=K, seed=4).to(dev).train()
+    pc = data.make_batch(2, N, cfg, seed=3, num_objects=5)["point_clouds"].to(dev)
+
+    def seed():
+        torch.manual_seed(11)
+        if use_gpu:
+            torch.cuda.manual_seed_all(11)
+
+    seed()
+    with torch.no_grad():
+        drawn = net({"point_clouds": pc}, mode="jitter")
+    seed()
+    noise = (torch.randn((2, K, 3), device=dev), torch.randn((2, K, 3), device=dev))
+    with torch.no_grad():
+        given = net({"point_clouds": pc, "jitter_noise": noise}, mode="jitter")
+    for key in ("jitter_center", "jitter_size", "iou_scores", "iou_scores_jitter"):
+        # (two passes of the GPU forward differ by the order of their fp32 atomics)
+        assert torch.allclose(drawn[key], given[key], rtol=1e-3, atol=1e-4), key
+    # (other noise is another pass: the check above is not vacuous)
+    other = (noise[1], noise[0])
+    with torch.no_grad():
+        swapped = net({"point_clouds": pc, "jitter_noise": other}, mode="jitter")
+    assert not torch.allclose(drawn["jitter_center"], swapped["jitter_center"], rtol=1e-3, atol=1e-4)
+    if use_gpu:
+        with pytest.raises(ValueError):
+            net({"point_clouds": pc, "jitter_noise": (noise[0][:1], noise[1])}, mode="jitter")

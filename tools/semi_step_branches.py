@@ -10,7 +10,8 @@ end points that differs at all (the first one in the network's order names the d
 Findings (round 5, profiles/r5_semi_step_branches.txt): alone on the GPU every run agrees to 4e-7.
 With a second copy of this script running beside it: (1) jitter_center / jitter_size of the graph
 runner differ in every entry in ~1 run of 9 -- the replay fills torch's per-generator (seed, offset)
-pair once per graph, on two streams, and the later fill serves both graphs; (2) before
+pair once per graph, on two streams, and the later fill serves both graphs (since then the
+runner draws the noise ahead of the graphs: expect none); (2) before
 SemiSupervisedStep._stream_apart_from, the 7th graph runner's teacher stream WAS torch's default
 capture stream (a pool of 32 handles, round-robin): shared BatchNorm tickets, gradient 1e6 apart.
 
