@@ -291,14 +291,12 @@ def test_graph_step_two_ranks_share_one_gpu(tmp_path, semi):
     # the reordering of atomic sums; with the zero-gradient parameters frozen
     # (step.freeze_shift_invariant_parameters: the last BatchNorm bias of every pooling module,
     # profiles/r4_step_repeatability.txt) the weights after three Adam steps agree too
-    # (semi-supervised: until the runner drew its box-jitter noise ahead of its two forward graphs,
-    # their concurrent replays raced on torch's one device-side (seed, offset) pair per generator
-    # and, with this test's second process on the GPU, the student drew from the teacher's offset in
-    # about one run of three -- gradient 1.2e-4 .. 1.4e-4 apart (tools/semi_step_branches.py,
-    # profiles/r5_semi_step_branches.txt).  The bounds below were set for that and have not been
-    # re-tightened since the fix (no GPU time left in the round to repeat the run often enough);
-    # a wrong 1 / world or a missing tensor is >= 1e-2)
-    g_tol = 1e-3 if semi else 1e-4
+    # (semi-supervised: the runner draws its box-jitter noise on the main stream AHEAD of its two
+    # forward graphs -- inputs["jitter_noise"] -- so the concurrent replays no longer share torch's
+    # one device-side (seed, offset) pair per generator; tools/semi_step_branches.py in two
+    # processes, profiles/r6_semi_step_branches.txt: every run on one branch.  Same bounds as the
+    # supervised arm: a wrong 1 / world or a missing tensor is >= 1e-2)
+    g_tol = 1e-4
     assert rel(r[0]["graph_grad"], r[0]["eager_grad"]) < g_tol
     lr = 2e-3 if semi else 1e-3
     assert np.abs(r[0]["graph_params"] - r[0]["eager_params"]).max() <= 3 * 3 * lr
@@ -315,13 +313,7 @@ def test_graph_step_two_ranks_share_one_gpu(tmp_path, semi):
         off += int(n_el)
     errs = np.sort(np.array(errs))[::-1]
     assert off == want.size
-    if semi:
-        # the other jitter draw (above) landed in the IoU branch's tensors (six of them 0.1 .. 0.7
-        # of their own norm apart): nine tensors in ten must hold the bound here; the supervised
-        # variant runs the same exchange with no exception allowed
-        assert np.mean(errs < 2e-2) >= 0.9, errs[:12]
-    else:
-        assert errs[0] < 2e-2, errs[:6]
+    assert errs[0] < 2e-2, errs[:6]
     assert np.isfinite(r[0]["graph_loss"]) and r[0]["graph_loss"] != r[1]["graph_loss"]
 
 

@@ -27,6 +27,30 @@ def close(a, b, tol=1e-4):
     assert np.abs(a - b).max() <= tol * scale, float(np.abs(a - b).max())
 
 
+def _rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def _f64_twin(ref):
+    """nn.Sequential of the same modules in float64: the TRUTH both fp32 paths are measured against."""
+    import copy
+    twin = copy.deepcopy(ref).double()
+    twin.train(ref.training)
+    return twin
+
+
+def _grad_bound(got, ref32, truth, floor=2e-3):
+    """tests/test_train_step.py:84-131's rule for a gradient that is a sum with ReLU / arg-max gates
+    within rounding of a tie: ANY fp32 evaluation sits rel(ref32, truth) away from the float64
+    value (its own round-off and its own flipped gates), so the kernel's result may be three times
+    that + `floor` away from the truth -- tight where the sum is well conditioned and never looser
+    than what fp32 torch itself resolves.  (Before round 6: a blanket rel < 3e-2 against ref32.)"""
+    e_ref, e_got = _rel(ref32, truth), _rel(got, truth)
+    assert e_got <= floor + 3 * e_ref, (e_got, e_ref)
+    return e_got, e_ref
+
+
 @pytest.mark.parametrize("shape", [(2, 7, 33, 5), (2, 16, 40, 16), (3, 64, 100, 64),
                                    (2, 8, 50, 32), (2, 5, 1000, 1), (1, 3, 7, 8), (4, 128, 64, 4)])
 @pytest.mark.parametrize("training", [True, False])
@@ -304,9 +328,19 @@ def test_fused_chain_vs_sequential(widths, shape, training):
         # every element agrees tightly, and the dense sums agree in relative L2.
         d = (x1.grad - x2.grad).abs()
         assert float((d > 5e-4 * max(1.0, float(x2.grad.abs().max()))).float().mean()) < 2e-3
-        for (n1, p1), (n2, p2) in zip(mlp.named_parameters(), ref.named_parameters()):
-            rel = float((p1.grad - p2.grad).norm() / (p2.grad.norm() + 1e-12))
-            assert rel < 3e-2, (n1, rel)
+        # weight / BatchNorm gradients: against the float64 evaluation of the same modules
+        ref64 = _f64_twin(ref)  # (training: batch statistics; eval: the running ones, unchanged)
+        ref64.zero_grad()
+        x3 = x1.detach().double().requires_grad_(True)
+        z64 = torch.nn.Sequential.forward(ref64, x3)
+        want64 = torch.max(z64, dim=3)[0] if pool else z64
+        (want64 * wgt.double()).sum().backward()
+        worst = 0.0
+        for (n1, p1), (n2, p2), (n3, p3) in zip(mlp.named_parameters(), ref.named_parameters(),
+                                                ref64.named_parameters()):
+            e_got, e_ref = _grad_bound(p1.grad, p2.grad, p3.grad)
+            worst = max(worst, e_got / (2e-3 + 3 * e_ref))
+        print("chain vs float64: worst gradient at %.2f of its bound" % worst)
         for (n1, b1), (n2, b2) in zip(mlp.named_buffers(), ref.named_buffers()):
             close(b1.float(), b2.float(), 2e-4)
 
@@ -509,6 +543,7 @@ def test_virtual_first_layer_chain_vs_sequential(pool, monkeypatch):
     assert calls, "the first layer was materialised"
     monkeypatch.setenv("MLP_FIRST4_VIRTUAL", "0")
     out2 = twin.forward_pooled(x) if pool else twin(x)
+    ref64 = _f64_twin(ref)  # (before the forward pass moves the running statistics)
     z = torch.nn.Sequential.forward(ref, x)
     want = torch.max(z, dim=3)[0] if pool else z
     close(out, out2, 1e-5)
@@ -517,14 +552,16 @@ def test_virtual_first_layer_chain_vs_sequential(pool, monkeypatch):
     (out * wgt).sum().backward()
     (out2 * wgt).sum().backward()
     (want * wgt).sum().backward()
-    for (n1, p1), (n2, p2), (n3, p3) in zip(mlp.named_parameters(), twin.named_parameters(),
-                                            ref.named_parameters()):
+    z64 = torch.nn.Sequential.forward(ref64, x.double())
+    ((torch.max(z64, dim=3)[0] if pool else z64) * wgt.double()).sum().backward()
+    for (n1, p1), (n2, p2), (n3, p3), (n4, p4) in zip(mlp.named_parameters(), twin.named_parameters(),
+                                                      ref.named_parameters(), ref64.named_parameters()):
         rel = float((p1.grad - p2.grad).norm() / (p2.grad.norm() + 1e-12))
         # virtual (+ layers 2 and 3 chained in registers, csrc/mlp_chain.hip) vs materialised,
         # layer by layer: other forward kernels, so ReLU masks within rounding of 0 may differ
         assert rel < 6e-3, (n1, rel)
-        rel = float((p1.grad - p3.grad).norm() / (p3.grad.norm() + 1e-12))
-        assert rel < 3e-2, (n1, rel)   # vs torch (mask flips at rounding level, as in the chain test)
+        # vs torch: both fp32 results against the float64 evaluation (_grad_bound)
+        _grad_bound(p1.grad, p3.grad, p4.grad)
     for (n1, b1), (n2, b2) in zip(mlp.named_buffers(), ref.named_buffers()):
         close(b1.float(), b2.float(), 2e-4)
 
@@ -648,6 +685,85 @@ def test_pooled_backward_from_the_gram_matrix(b, m, ns):
     assert rel(dw, want_dw) < 1e-4
     for a_, b_ in zip(below, want_below):
         close(a_, b_, 1e-4)
+
+
+@pytest.mark.parametrize("b,m,ns", [(8, 2048, 64), (2, 256, 32)])
+def test_sa1_chain_and_gram_vs_float64_torch(b, m, ns):
+    """An INDEPENDENT check of the round-5 SA1 kernels at the step's real shape (B = 8, m = 2048,
+    ns = 64: VERDICT r5 weak item 13): csrc/mlp_chain.hip's forward (layers 2 + 3 chained in
+    registers, last raw output not stored) and csrc/mlp_pool_gram.hip's backward (from the Gram
+    matrix of the layer's input) against a float64 torch evaluation of the reference's module --
+    Conv2d 1x1 (no bias) + BatchNorm2d (batch statistics) + ReLU, three times, then the max over
+    nsample (pytorch_utils.py:14-39,70-124, pointnet2_modules.py:256-262) -- and its autograd."""
+    load_pkg()
+    K = importlib.import_module("pointnet2._mlp_ext")
+    g = torch.Generator().manual_seed(7 * b + m + ns)
+    x = (torch.randn(b, 4, m, ns, generator=g) * 1.5 + 0.4).to(DEV)
+    w = [(torch.randn(64, 4, generator=g) * 0.7).to(DEV), (torch.randn(64, 64, generator=g) / 8).to(DEV),
+         (torch.randn(128, 64, generator=g) / 8).to(DEV)]
+
+    def bn(c):
+        gamma = torch.rand(c, generator=g) + 0.5
+        gamma[::5] *= -1
+        return gamma.to(DEV), (torch.randn(c, generator=g) * 0.3).to(DEV)
+
+    gb = [bn(64), bn(64), bn(128)]
+    eps = 1e-5
+    assert K.chain_lin4_supported(w[0], w[1], w[2], x, ns) and K.pool_gram_supported(w[2], x.new_empty(b, 64, m, ns), ns)
+    rs = [[torch.zeros(c, device=DEV), torch.ones(c, device=DEV)] for c in (64, 64, 128)]
+    c0 = K.first4_bn(K.first4_moments(x), x.numel() // 4, w[0], gb[0][0], gb[0][1], rs[0][0], rs[0][1], 0.1, eps)
+    y1, c1, y2, c2, ext = K.chain_lin4_forward(
+        x, w[0], (c0[2], c0[3]), (w[1], gb[1][0], gb[1][1], rs[1][0], rs[1][1], 0.1, eps),
+        (w[2], gb[2][0], gb[2][1], rs[2][0], rs[2][1], 0.1, eps), store_last=False)
+    assert y2 is None, "the last raw output was stored"
+    pooled, argmax, ymax = K.pool_from_extrema(ext, c2[2], c2[3])
+    dpooled = torch.randn(b, 128, m, generator=g).to(DEV)
+    dgamma2, dbeta2, coef2 = K.bn_relu_pool_backward_stats(None, dpooled, argmax, ymax, gb[2][0], c2[2], c2[3],
+                                                           c2[0], c2[1], True, ns=ns)
+    da1, dw2, below = K.pool_gram_backward(w[2], y1, c1, gb[1][0], coef2, c2, dpooled, argmax, ymax, ns, True)
+
+    # ---- the same module in float64 ----
+    W = [t.double().requires_grad_(True) for t in w]
+    G = [(ga.double().requires_grad_(True), be.double().requires_grad_(True)) for ga, be in gb]
+
+    def layer(inp, i):
+        y = torch.einsum("oc,bcmn->bomn", W[i], inp)
+        mean = y.mean(dim=(0, 2, 3), keepdim=True)
+        var = y.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+        a = torch.relu((y - mean) / torch.sqrt(var + eps) * G[i][0].view(1, -1, 1, 1) + G[i][1].view(1, -1, 1, 1))
+        return y, mean.flatten(), (1.0 / torch.sqrt(var + eps)).flatten(), a
+
+    y0_64, _, _, a0 = layer(x.double(), 0)
+    y1_64, mean1, inv1, a1 = layer(a0, 1)
+    a1.retain_grad()
+    y2_64, mean2, inv2, a2 = layer(a1, 2)
+    pooled64, argmax64 = a2.max(dim=3)
+    # forward: raw output of layer 2 of the module, both layers' batch statistics, the pooled tensor
+    close(y1, y1_64, 2e-5)
+    close(c1[0], mean1, 2e-5); close(c1[1], inv1, 2e-5)
+    close(c2[0], mean2, 2e-5); close(c2[1], inv2, 2e-5)
+    close(pooled, pooled64, 2e-5)
+    # the arg-max: where it differs from float64's the rivals are within fp32 rounding of one another
+    flips = argmax.long() != argmax64
+    assert float(flips.float().mean()) < 1e-3, float(flips.float().mean())
+    at_kernel = torch.gather(a2, 3, argmax.long().unsqueeze(-1)).squeeze(-1)
+    assert float((pooled64 - at_kernel).abs().max()) <= 2e-5 * float(pooled64.abs().max())
+    # backward through the KERNEL's winners (a flipped winner is another, equally valid subgradient)
+    (at_kernel * dpooled.double()).sum().backward()
+    n_flips = int(flips.sum())
+    rel = lambda a_, b_: float((a_.double() - b_).norm() / (b_.norm() + 1e-300))  # noqa: E731
+    print("chain + gram vs float64 [%d x %d x %d]: %d arg-max flips of %d; da1 %.2e dw2 %.2e dgamma2 %.2e "
+          "dbeta2 %.2e dgamma1 %.2e dbeta1 %.2e" % (b, m, ns, n_flips, flips.numel(), rel(da1, a1.grad),
+                                                    rel(dw2, W[2].grad), rel(dgamma2, G[2][0].grad),
+                                                    rel(dbeta2, G[2][1].grad), rel(below[0], G[1][0].grad),
+                                                    rel(below[1], G[1][1].grad)))
+    # (ReLU gates within rounding of 0 may differ between fp32 and float64: single elements)
+    assert rel(da1, a1.grad) < 2e-4
+    d = (da1.double() - a1.grad).abs()
+    assert float((d > 1e-4 * float(a1.grad.abs().max())).float().mean()) < 1e-4
+    assert rel(dw2, W[2].grad) < 2e-4
+    assert rel(dgamma2, G[2][0].grad) < 2e-4 and rel(dbeta2, G[2][1].grad) < 2e-4
+    assert rel(below[0], G[1][0].grad) < 5e-4 and rel(below[1], G[1][1].grad) < 5e-4
 
 
 def test_reductions_on_two_streams_at_once():
@@ -810,6 +926,7 @@ def test_pregathered_first_layer_vs_grouped(b, n, c, m, ns, widths, scale, train
             mod.bias.data.normal_(0, 0.3)
     mlp_b = copy.deepcopy(mlp_a)
     mlp_a.train(training); mlp_b.train(training)
+    mlp_64 = _f64_twin(mlp_a)
     assert mlp_b.pregather_ok(xyz, new_xyz, feats[1], m, ns)
     # the reference's grouped tensor
     li = idx.long()
@@ -829,13 +946,22 @@ def test_pregathered_first_layer_vs_grouped(b, n, c, m, ns, widths, scale, train
         # test_fused_chain_vs_sequential): almost every element agrees tightly, the sums in L2
         d = (feats[1].grad - feats[0].grad).abs()
         assert float((d > 5e-4 * max(1.0, float(feats[0].grad.abs().max()))).float().mean()) < 2e-3
-        rel = float((feats[1].grad - feats[0].grad).norm() / feats[0].grad.norm())
-        assert rel < 3e-2, rel
-        rel = float((xyzs[1].grad - xyzs[0].grad).norm() / xyzs[0].grad.norm())
-        assert rel < 3e-2, rel  # scatter over idx + (through the centroids) minus the group sums
-        for (na, pa), (nb, pb) in zip(mlp_a.named_parameters(), mlp_b.named_parameters()):
-            rel = float((pb.grad - pa.grad).norm() / (pa.grad.norm() + 1e-12))
-            assert rel < 3e-2, (na, rel)
+        # ... measured against the float64 evaluation of the reference's formulation (_grad_bound:
+        # each fp32 path has its own flipped gates; neither is the other's truth)
+        x64 = xyzs[0].detach().double().requires_grad_(True)
+        f64 = feats[0].detach().double().requires_grad_(True)
+        gx64 = torch.gather(x64.transpose(1, 2).unsqueeze(2).expand(b, 3, m, n), 3,
+                            li.unsqueeze(1).expand(b, 3, m, ns))
+        gx64 = (gx64 - x64[:, pick].transpose(1, 2).unsqueeze(-1)) * scale
+        gf64 = torch.gather(f64.unsqueeze(2).expand(b, c, m, n), 3, li.unsqueeze(1).expand(b, c, m, ns))
+        z64 = torch.nn.Sequential.forward(mlp_64, torch.cat([gx64, gf64], dim=1))
+        torch.max(z64, dim=3)[0].backward(dout.double())
+        _grad_bound(feats[1].grad, feats[0].grad, f64.grad)
+        # scatter over idx + (through the centroids) minus the group sums
+        _grad_bound(xyzs[1].grad, xyzs[0].grad, x64.grad)
+        for (na, pa), (nb, pb), (nc, pc) in zip(mlp_a.named_parameters(), mlp_b.named_parameters(),
+                                                mlp_64.named_parameters()):
+            _grad_bound(pb.grad, pa.grad, pc.grad)
     for (na, ba), (nb, bb) in zip(mlp_a.named_buffers(), mlp_b.named_buffers()):
         close(bb.float(), ba.float(), 2e-5)
 
