@@ -48,6 +48,19 @@
 __device__ unsigned long long grid_probe_t[16384 * 8];
 #endif
 
+#ifndef GRID_CPW
+#define GRID_CPW 1
+#endif
+#ifndef GRID_KERNEL_ATTR
+#define GRID_KERNEL_ATTR
+#endif
+#ifndef GRID_ASM_ROWS
+#define GRID_ASM_ROWS 1  // 0: the compiler's single-load path everywhere (A/B, tools/micro/README.md)
+#endif
+typedef int grid_i32x4 __attribute__((ext_vector_type(4)));
+typedef float grid_f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) char *grid_lds_ptr;
+
 namespace {
 
 using namespace grid;
@@ -243,10 +256,10 @@ struct GroupOut {      // fused gather (GROUP kernels only)
 // LDS of one wave (= one centroid at a time)
 template <int MAXH>
 struct alignas(16) WaveLds {
-  float4 list[MAXH];          // records (x, y, z, index) of the hits, in arrival order
-  unsigned tmp[MAXH];         // indices grouped by bucket (order inside a bucket: arrival)
-  // perm[rank] = list position of the hit with that rank (a byte up to 256 hits)
-  typename std::conditional<(MAXH > 256), unsigned short, unsigned char>::type perm[MAXH];
+  // records (x, y, z, index) of the hits, in arrival order; after the ranking its first nsample
+  // slots are reused for the records in RANK order (every lane has its records in registers by then)
+  float4 list[MAXH];
+  unsigned tmp[MAXH + 4];     // indices grouped by bucket (order inside a bucket: arrival) + 4 sentinels
   int cnt[kWave];             // hits per index bucket
   int off[kWave];             // exclusive prefix of cnt
 #ifdef GRID_LDS_PAD
@@ -284,49 +297,81 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
 // offsets, and a hit's rank inside its bucket (1-2 elements for a ball of a shuffled cloud) is a
 // count of smaller indices among the bucket's elements.  rank -> output slot directly, for any
 // number of hits, so nsample in (64, 128] needs no second pass.
+// The kernel's parameter list as ONE struct: the kernarg segment has its layout, and the fields
+// only the epilogue needs (output pointers, the gather's parameters) are read from the segment
+// where they are used instead of sitting in scalar registers for the whole kernel -- this kernel
+// is admitted at min(8, 800 / (ceil(sgpr / 16) * 16 + 16)) waves per SIMD (MI355X_MICROARCH.md
+// "Residency"): 8 only up to 80 scalar registers, and rounds 1-5 ran it at 6 without knowing.
+struct QueryArgs {
+  int n, m, wg_per_cloud;
+  unsigned wg_per_cloud_inv;
+  float radius2, inv_side;
+  int nsample;
+  unsigned bucket_mul;
+  const float *new_xyz, *xyz;
+  const int *start;
+  const float4 *rec;
+  const int *order;
+  int *idx;
+  GroupOut g;
+};
+
+__device__ __forceinline__ const QueryArgs *kernarg_segment() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (const QueryArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+  return nullptr;
+#endif
+}
+
 template <int MAXH, int WPB, bool GROUP>
-__global__ void __launch_bounds__(WPB * kWave)
-grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
-                  int nsample,
-                  unsigned bucket_mul, const float *__restrict__ new_xyz,
-                  const float *__restrict__ xyz, const int *__restrict__ start,
-                  const float4 *__restrict__ rec, const int *__restrict__ order,
-                  int *__restrict__ idx, GroupOut g) {
+__global__ void __launch_bounds__(WPB * kWave) GRID_KERNEL_ATTR
+grid_query_kernel(const QueryArgs a) {
   static_assert(MAXH <= 512, "hit list capacity");
   constexpr int TMAX = MAXH / kWave;
   constexpr int NH = MAXH >= 8 * kWave ? 4 : (MAXH >= 4 * kWave ? 2 : 1);  // nsample <= 64 * NH
-  constexpr int CPW = 1;
+  constexpr int CPW = GRID_CPW;  // centroids per wave: jj = wave, wave + waves per cloud, ...
   __shared__ WaveLds<MAXH> lds[WPB];
+  const int n = a.n, m = a.m, wg_per_cloud = a.wg_per_cloud, nsample = a.nsample;
+  const float radius2 = a.radius2, inv_side = a.inv_side;
+  const unsigned bucket_mul = a.bucket_mul;
   // 1-D grid, XCD-contiguous: cloud = id / wg_per_cloud (one division per workgroup)
   const int wg = xcd_contiguous_block((int)blockIdx.x, (int)gridDim.x);
-  const int b = wg / wg_per_cloud;
-  const int lane = lane_id();
+  // (floor(2^32 / d) as the multiplier is at most one short of the quotient for ids < 2^31)
+  int b = (int)__umulhi((unsigned)wg, a.wg_per_cloud_inv);
+  if (wg - b * wg_per_cloud >= wg_per_cloud) ++b;
+  const int lane0 = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));  // an SGPR
   WaveLds<MAXH> &L = lds[wave];
-  const float *pts = xyz + (size_t)b * n * 3;
-  const int *st = start + (size_t)b * kStartStride;
-  const float4 *cloud = rec + (size_t)b * n;
-  const size_t plane = (size_t)m * nsample;
+  const int first = (wg - b * wg_per_cloud) * WPB + wave;
 
 #pragma unroll 1
   for (int cq = 0; cq < CPW; ++cq) {
-    const int jj = ((wg - b * wg_per_cloud) * WPB + wave) * CPW + cq;
+    const int jj = first + cq * wg_per_cloud * WPB;
     if (jj >= m) return;  // whole wave
+    // Every centroid starts from the cloud number and the lane id alone: with more than one
+    // centroid per wave nothing derived from them is carried around the loop (the compiler
+    // hoisted ~40 such values and the kernel fell from 8 waves per SIMD to 4)
+    int lane = lane0;
+    if (CPW > 1) asm volatile("" : "+v"(lane));
+    const int *st = a.start + (size_t)b * kStartStride;
+    const float4 *cloud = a.rec + (size_t)b * n;
+    L.cnt[lane] = 0;  // the ranking's bucket counters (a wave's LDS operations execute in order)
     // longest query first, when the sampling kernel that picked these centroids left the order
     // behind (grid_common.h: start[kOrderFor] == m); any permutation gives the same rows
     int j = jj;
     {
       const int for_m = st[kOrderFor];
-      const int oj = order[(size_t)b * n + (jj < n ? jj : 0)];
+      const int oj = a.order[(size_t)b * n + (jj < n ? jj : 0)];
       if (for_m == m && (unsigned)oj < (unsigned)m) j = oj;
     }
 #ifdef GRID_PROBE
     const unsigned long long probe_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long probe_rt0 = __builtin_amdgcn_s_memrealtime() & 0xffffffffffull;  // 100 MHz, chip-wide
     unsigned long long probe_t1 = 0, probe_t2 = 0, probe_t3 = 0;  // starts known / list complete / ranked
     int probe_sweeps = 0, probe_chunks = 0;
 #endif
-    const float *ctr = new_xyz + ((size_t)b * m + j) * 3;
-    int *row = idx + ((size_t)b * m + j) * nsample;
+    const float *ctr = a.new_xyz + ((size_t)b * m + j) * 3;
     const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
     const int gx = __builtin_amdgcn_readfirstlane(cell_coord(cx, inv_side)) & (kG - 1);
     const int gy = __builtin_amdgcn_readfirstlane(cell_coord(cy, inv_side));
@@ -338,44 +383,46 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
     //  first len lanes from one and the next len1 lanes from the other)
     const int xa = gx > 0 ? gx - 1 : 0, xb = gx < kG - 1 ? gx + 1 : kG - 1;
     const bool seam = gx == 0 || gx == kG - 1;
-    bool fast;
+    bool fast, wrapped = false;
     int total = 0;
     int vrow, lrow, vwrap = 0, lwrap = 0;  // lane q < 9: start / length of row q and of its wrapped cell
-    // two copies of the same code, so that the wave of an interior centroid (the usual one)
-    // executes nothing of the seam's second range
-    auto nine_rows = [&](auto seam_tag) {
+    {
+      // lanes 0..8 fetch the row starts, lanes 16..24 the row ends: ONE vector load and lane reads
+      // instead of 18 scalar loads with their scalar address arithmetic (the scalar unit is shared
+      // by the CU's four SIMDs and was this kernel's busiest resource)
+      const int rr9 = lane & 15;
+      const int r = rr9 < 9 ? rr9 : 0;
+      const int rz = (r * 11) >> 5;              // r / 3 for r < 9
+      const int rowbase = (((gz + rz - 1) & (kG - 1)) * kG + ((gy + (r - 3 * rz) - 1) & (kG - 1))) * kG;
+      const int v = st[rowbase + ((lane & 16) ? xb + 1 : xa)];
+      int w = 0;
+      if (seam) w = st[rowbase + (gx == 0 ? kG - 1 : 0) + ((lane & 16) ? 1 : 0)];  // wave-uniform
+      // lane q < 9: row q's length (its end sits 16 lanes up: row_shl needs same-row lanes, so
+      // the end is fetched with one LDS-free permute through the upper half of the row pair)
+      const int lenv = __shfl_down(v, 16, kWave) - v;
+      int lenw = 0;
+      if (seam) lenw = __shfl_down(w, 16, kWave) - w;
+      const bool owner = rr9 < 9 && (lane & 48) == 0;  // lanes 0..8
+      // the single-load path: every row (both of its ranges) inside ONE load, and below 64 records
+      // (the row's lane mask is s_bfm_b64(len): a width of 64 reads as 0)
+      fast = __builtin_amdgcn_ballot_w64(owner && lenv + lenw >= kWave) == 0ull;
+      if (seam) wrapped = __builtin_amdgcn_ballot_w64(owner && lenw != 0) != 0ull;
+      vrow = v; lrow = lenv; vwrap = w; lwrap = lenw;
+    }
+    // the compiler's version of the single-load path: both ranges of a seam centroid's rows in one
+    // load (SEAM), and the whole path when GRID_ASM_ROWS == 0
+    auto one_load_rows = [&](auto seam_tag) -> int {
       constexpr bool SEAM = decltype(seam_tag)::value;
       int s0[9], len[9], s1[9], len1[9];
-      {
-        // lanes 0..8 fetch the row starts, lanes 16..24 the row ends: ONE vector load and 18 lane
-        // reads instead of 18 scalar loads with their scalar address arithmetic (the scalar unit
-        // is shared by the CU's four SIMDs and was this kernel's busiest resource)
-        const int rr9 = lane & 15;
-        const int r = rr9 < 9 ? rr9 : 0;
-        const int rz = (r * 11) >> 5;              // r / 3 for r < 9
-        const int rowbase = (((gz + rz - 1) & (kG - 1)) * kG + ((gy + (r - 3 * rz) - 1) & (kG - 1))) * kG;
-        const int v = st[rowbase + ((lane & 16) ? xb + 1 : xa)];
-        int w = 0;
-        if (SEAM) w = st[rowbase + (gx == 0 ? kG - 1 : 0) + ((lane & 16) ? 1 : 0)];
-        // lane q < 9: row q's length (its end sits 16 lanes up: row_shl needs same-row lanes, so
-        // the end is fetched with one LDS-free permute through the upper half of the row pair)
-        const int lenv = __shfl_down(v, 16, kWave) - v;
-        int lenw = 0;
-        if (SEAM) lenw = __shfl_down(w, 16, kWave) - w;
-        fast = __builtin_amdgcn_ballot_w64(rr9 < 9 && (lane & 48) == 0 && lenv + lenw > kWave) == 0ull;
-        vrow = v; lrow = lenv;
-        if (SEAM) { vwrap = w; lwrap = lenw; }
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          s0[q] = __builtin_amdgcn_readlane(v, q);
-          len[q] = __builtin_amdgcn_readlane(lenv, q);
-          if (SEAM) {
-            s1[q] = __builtin_amdgcn_readlane(w, q);
-            len1[q] = __builtin_amdgcn_readlane(lenw, q);
-          }
+      for (int q = 0; q < 9; ++q) {
+        s0[q] = __builtin_amdgcn_readlane(vrow, q);
+        len[q] = __builtin_amdgcn_readlane(lrow, q);
+        if (SEAM) {
+          s1[q] = __builtin_amdgcn_readlane(vwrap, q);
+          len1[q] = __builtin_amdgcn_readlane(lwrap, q);
         }
       }
-      if (!fast) return;
       // all nine loads are in flight before the first test (one L2 round trip for ~400
       // candidates); lanes past the end of a row read the cloud's last record (always valid)
       // and are masked out of the hit test
@@ -391,24 +438,125 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
       }
       bool hit[9];
       int at[9];
+      int tot = 0;
 #pragma unroll
       for (int r = 0; r < 9; ++r) {  // branch-free
         const bool near = sqdist3(cx, cy, cz, q[r].x, q[r].y, q[r].z) < radius2;
         hit[r] = near & (lane < len[r]);
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit[r]);
-        at[r] = total + mask_rank(mask);
-        total += __popcll(mask);
+        at[r] = tot + mask_rank(mask);
+        tot += __popcll(mask);
       }
-      if (total <= MAXH) {
+      if (tot <= MAXH) {
 #pragma unroll
         for (int r = 0; r < 9; ++r)
           if (hit[r]) L.list[at[r]] = q[r];
       } else {
         fast = false;
       }
+      return tot;
     };
-    if (!seam) nine_rows(std::false_type{});
-    else nine_rows(std::true_type{});
+    if (fast && !wrapped) {
+#if GRID_ASM_ROWS
+      // ---- nine loads, nine tests, the hit list: one hand-scheduled block ---------------------
+      // The compiler's version of this (round 5) spent 13 vector instructions per row on the test
+      // (cross-row packing with register shuffles, a v_cndmask + v_cmp per ballot of a combined
+      // predicate), 3 on the load address and 8 scalar ones on the list slot and the branch
+      // around the write.  Here a row is: the lane mask of its length straight into EXEC
+      // (s_bfm_b64), (x, y) as ONE packed subtract and ONE packed multiply -- each operation
+      // rounded as in sqdist3, the order of the sum unchanged --, v_cmpx leaves EXEC = the hits,
+      // under which the record goes to the list at (scalar running address) + 16 * mbcnt; the
+      // address of the load is (descriptor of the cloud's records) + lane * 16 + scalar row start,
+      // no vector arithmetic at all.  10 vector + 4 scalar instructions per row.
+      // Lanes beyond the cloud's end read zeros (descriptor bounds), lanes beyond the row are
+      // outside EXEC.  More than MAXH hits spill over the list's end into tmp / cnt / off (rebuilt
+      // by whoever needs them) and beyond the workgroup's LDS (dropped by the hardware's bounds
+      // check): the general path below then starts from scratch.  One wave per workgroup.
+      static_assert(WPB == 1, "the list may overflow into a neighbour's LDS");
+      {
+        const unsigned long long ca = (unsigned long long)cloud;
+        grid_i32x4 rsrc;
+        rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ca);
+        rsrc.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(ca >> 32) & 0xFFFFu));  // stride 0: raw buffer
+        rsrc.z = n * 16;
+        rsrc.w = 0x00020000;
+        grid_f32x2 cxy;
+        cxy.x = cx; cxy.y = cy;
+        const unsigned lds_list = (unsigned)(unsigned long long)(grid_lds_ptr)(char *)&L.list[0];
+        const int start16 = vrow << 4, lane16 = lane << 4;
+        unsigned at;
+      // gfx950 wait states the assembler does not insert (MI300 ISA guide 4.5; LLVM's
+      // GCNHazardRecognizer sees none of this block): a VALU read of an SGPR / VCC a VALU wrote
+      // needs 2 instructions in between (v_cmpx -> v_mbcnt: the two scalar instructions of the
+      // running address sit there), v_readlane of a VGPR a VALU just wrote 1, v_readlane after a
+      // VALU write of EXEC 4 (six instructions follow the v_cmpx), a VMEM read of an SGPR a VALU
+      // wrote 5 (the row starts are read nine instructions ahead of their loads).
+#define GRID_ROW(R, Q0, Q1, Q2, Q3, WAIT, CUR, NEXT)                                               \
+        "v_readlane_b32 %2, %13, " #R "\n"                                                          \
+        "s_bfm_b64 exec, %2, 0\n"                                                                   \
+        "s_waitcnt vmcnt(" #WAIT ")\n"                                                              \
+        "v_pk_add_f32 v[24:25], %16, v[" #Q0 ":" #Q1 "] neg_lo:[0,1] neg_hi:[0,1]\n"                \
+        "v_sub_f32 v26, %17, v" #Q2 "\n"                                                            \
+        "v_pk_mul_f32 v[24:25], v[24:25], v[24:25]\n"                                               \
+        "v_mul_f32 v26, v26, v26\n"                                                                 \
+        "v_add_f32 v24, v24, v25\n"                                                                 \
+        "v_add_f32 v24, v24, v26\n"                                                                 \
+        "v_cmpx_gt_f32 vcc, %18, v24\n"                                                             \
+        "s_bcnt1_i32_b64 %2, vcc\n"                                                                 \
+        "s_lshl4_add_u32 " NEXT ", %2, " CUR "\n"                                                   \
+        "v_mbcnt_lo_u32_b32 v24, vcc_lo, 0\n"                                                       \
+        "v_mbcnt_hi_u32_b32 v24, vcc_hi, v24\n"                                                     \
+        "v_lshl_add_u32 v24, v24, 4, " CUR "\n"                                                     \
+        "ds_write_b128 v24, v[" #Q0 ":" #Q3 "]\n"
+        unsigned at2, stmp, so0, so1, so2, so3, so4, so5, so6, so7, so8;  // scalar temporaries of the block
+        asm volatile(
+            "s_mov_b32 %1, %19\n"
+            "v_readlane_b32 %3, %12, 0\n"
+            "v_readlane_b32 %4, %12, 1\n"
+            "v_readlane_b32 %5, %12, 2\n"
+            "v_readlane_b32 %6, %12, 3\n"
+            "v_readlane_b32 %7, %12, 4\n"
+            "v_readlane_b32 %8, %12, 5\n"
+            "v_readlane_b32 %9, %12, 6\n"
+            "v_readlane_b32 %10, %12, 7\n"
+            "v_readlane_b32 %11, %12, 8\n"
+            "buffer_load_dwordx4 v[28:31], %14, %15, %3 offen\n"
+            "buffer_load_dwordx4 v[32:35], %14, %15, %4 offen\n"
+            "buffer_load_dwordx4 v[36:39], %14, %15, %5 offen\n"
+            "buffer_load_dwordx4 v[40:43], %14, %15, %6 offen\n"
+            "buffer_load_dwordx4 v[44:47], %14, %15, %7 offen\n"
+            "buffer_load_dwordx4 v[48:51], %14, %15, %8 offen\n"
+            "buffer_load_dwordx4 v[52:55], %14, %15, %9 offen\n"
+            "buffer_load_dwordx4 v[56:59], %14, %15, %10 offen\n"
+            "buffer_load_dwordx4 v[60:63], %14, %15, %11 offen\n"
+            GRID_ROW(0, 28, 29, 30, 31, 8, "%1", "%0")
+            GRID_ROW(1, 32, 33, 34, 35, 7, "%0", "%1")
+            GRID_ROW(2, 36, 37, 38, 39, 6, "%1", "%0")
+            GRID_ROW(3, 40, 41, 42, 43, 5, "%0", "%1")
+            GRID_ROW(4, 44, 45, 46, 47, 4, "%1", "%0")
+            GRID_ROW(5, 48, 49, 50, 51, 3, "%0", "%1")
+            GRID_ROW(6, 52, 53, 54, 55, 2, "%1", "%0")
+            GRID_ROW(7, 56, 57, 58, 59, 1, "%0", "%1")
+            GRID_ROW(8, 60, 61, 62, 63, 0, "%1", "%0")
+            "s_mov_b64 exec, -1\n"
+            : "=&s"(at), "=&s"(at2), "=&s"(stmp), "=&s"(so0), "=&s"(so1), "=&s"(so2), "=&s"(so3),
+              "=&s"(so4), "=&s"(so5), "=&s"(so6), "=&s"(so7), "=&s"(so8)
+            : "v"(start16), "v"(lrow), "v"(lane16), "s"(rsrc), "s"(cxy), "s"(cz), "s"(radius2),
+              "s"(lds_list)
+            : "memory", "vcc", "scc", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32",
+              "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44",
+              "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56",
+              "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+#undef GRID_ROW
+        total = (int)((at - lds_list) >> 4);
+      }
+      if (total > MAXH) fast = false;
+#else
+      total = one_load_rows(std::false_type{});
+#endif
+    } else if (fast) {
+      total = one_load_rows(std::true_type{});
+    }
 #ifdef GRID_PROBE
     probe_t1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -574,20 +722,26 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
         }
       }
       __builtin_amdgcn_s_setprio(0);
+      L.cnt[lane] = 0;  // (the counting sweeps used the ranking's counters)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
 
 #ifdef GRID_PROBE
     probe_t2 = __builtin_amdgcn_s_memtime();
 #endif
+    // the epilogue's arguments, from the kernarg segment (see QueryArgs)
+    const QueryArgs *ka = kernarg_segment();
+    asm volatile("" : "+s"(ka));  // (not hoisted, not merged with the argument loads at the head)
+    int *row = ka->idx + ((size_t)b * m + j) * nsample;
     // rr[h]: the record (x, y, z, index) of slot h * 64 + lane of the row
     float4 rr[NH];
     if (total > 0) {
       const int have = total < nsample ? total : nsample;
       {
         // ---- rank the hits by index ----------------------------------------------------------
-        L.cnt[lane] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        // (L.cnt is zero here: cleared at the head of the kernel / after the general path)
+        float mx[TMAX], my[TMAX], mz[TMAX];  // this lane's hits: from here on the list itself is free
         unsigned key[TMAX];
         int bk[TMAX], slot[TMAX];
 #pragma unroll
@@ -596,7 +750,9 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
           if (t * kWave < total) {  // wave-uniform: whole passes beyond the list are skipped
             const int e = t * kWave + lane;
             if (e < total) {
-              key[t] = __builtin_bit_cast(unsigned, L.list[e].w);
+              const float4 mine = L.list[e];
+              mx[t] = mine.x; my[t] = mine.y; mz[t] = mine.z;
+              key[t] = __builtin_bit_cast(unsigned, mine.w);
               bk[t] = (int)__umulhi(key[t], bucket_mul);  // < 64 for every index < n
               slot[t] = atomicAdd(&L.cnt[bk[t]], 1);
             }
@@ -604,28 +760,44 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        {
-          const int c = L.cnt[lane];
-          L.off[lane] = wave_inclusive_scan(c) - c;
-        }
+        const int c = L.cnt[lane];
+        L.off[lane] = wave_inclusive_scan(c) - c;
+        // buckets of more than four hits (index-clustered balls) take the loop below as well
+        const bool deep = __builtin_amdgcn_ballot_w64(c > 4) != 0ull;
+        // four sentinels behind the last key: a bucket's successors in `tmp` are larger keys
+        // (buckets are monotone in the index) or these
+        if (lane < 4) L.tmp[total + lane] = 0xffffffffu;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int t = 0; t < TMAX; ++t)
           if (t * kWave < total && bk[t] >= 0) {
-            slot[t] += L.off[bk[t]];
-            L.tmp[slot[t]] = key[t];
+            const int o = L.off[bk[t]];
+            L.tmp[o + slot[t]] = key[t];
+            slot[t] = o;  // from here on: the bucket's first position
           }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int t = 0; t < TMAX; ++t)
           if (t * kWave < total && bk[t] >= 0) {
-            const int o = L.off[bk[t]], sz = L.cnt[bk[t]];
+            // rank = the bucket's first position + the smaller keys among the four entries from
+            // there on (straight-line: no loop, no bucket size, one LDS round trip)
+            const int o = slot[t];
             int rank = o;
+            rank += L.tmp[o + 0] < key[t] ? 1 : 0;
+            rank += L.tmp[o + 1] < key[t] ? 1 : 0;
+            rank += L.tmp[o + 2] < key[t] ? 1 : 0;
+            rank += L.tmp[o + 3] < key[t] ? 1 : 0;
+            if (deep) {  // wave-uniform, rare
+              const int sz = L.cnt[bk[t]];
 #pragma clang loop vectorize(disable) unroll(disable)
-            for (int u = 0; u < sz; ++u) rank += L.tmp[o + u] < key[t] ? 1 : 0;
-            if (rank < have) L.perm[rank] = (decltype(L.perm[0] + 0))(t * kWave + lane);
+              for (int u = 4; u < sz; ++u) rank += L.tmp[o + u] < key[t] ? 1 : 0;
+            }
+            // the record goes to slot `rank` of the list's own storage: every lane read its
+            // records above, and a wave's LDS operations execute in program order
+            if (rank < have)
+              L.list[rank] = make_float4(mx[t], my[t], mz[t], __builtin_bit_cast(float, key[t]));
           }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -633,15 +805,17 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         const int s = h * kWave + lane;
-        const int e = L.perm[s < have ? s : 0];  // tail: first hit
-        rr[h] = L.list[e];
+        rr[h] = L.list[s < have ? s : 0];  // tail: first hit
         if (s < nsample) __builtin_nontemporal_store(__builtin_bit_cast(int, rr[h].w), &row[s]);
       }
     } else {  // no hit: the reference's zero-initialised row -> point 0 everywhere
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         if (h * kWave + lane < nsample) row[h * kWave + lane] = 0;
-        if (GROUP) rr[h] = make_float4(pts[0], pts[1], pts[2], 0.f);
+        if (GROUP) {
+          const float *pts = ka->xyz + (size_t)b * n * 3;
+          rr[h] = make_float4(pts[0], pts[1], pts[2], 0.f);
+        }
       }
     }
 #ifdef GRID_PROBE
@@ -649,6 +823,8 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
 #endif
     if (GROUP) {
       // ---- fused gather: slot s of centroid j in every channel --------------------------------
+      const GroupOut g = ka->g;
+      const size_t plane = (size_t)m * nsample;
       float *ob = g.out + (size_t)b * g.ctot * plane + (size_t)j * nsample;
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
@@ -673,7 +849,10 @@ grid_query_kernel(int n, int m, int wg_per_cloud, float radius2, float inv_side,
       if (lane == 0) {
         unsigned long long *o = grid_probe_t + ((size_t)b * m + j) * 8;
         o[0] = probe_t0; o[1] = t1; o[2] = (unsigned long long)probe_sweeps << 32 | (unsigned)probe_chunks;
-        o[3] = (unsigned long long)total; o[4] = probe_t1; o[5] = probe_t2; o[6] = probe_t3;
+        o[3] = (unsigned long long)total | (probe_rt0 << 16); o[4] = probe_t1; o[5] = probe_t2; o[6] = probe_t3;
+        // where the wave ran: HW_ID (wave slot, SIMD, CU, SE) and the XCD
+        o[7] = (unsigned long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32;
       }
     }
 #endif
@@ -740,12 +919,16 @@ static int grid_run(int b, int n, int m, float radius, int nsample, const float 
   if (group) g = *group;
   // bucket of an index = floor(index * 64 / n), as a multiply-high
   const unsigned bucket_mul = (unsigned)(((unsigned long long)64 << 32) / (unsigned long long)n);
+  // cloud of a workgroup = id / m as a multiply-high: floor(2^32 / m) (m = 1: all ones)
+  const int wpc = (m + GRID_CPW - 1) / GRID_CPW;  // waves (= workgroups) per cloud
+  const unsigned wpc_inv = wpc > 1 ? (unsigned)(0x100000000ull / (unsigned long long)wpc) : 0xffffffffu;
   // one wave per workgroup: a finished centroid frees its slot at once (18.35 vs 18.63 us with
   // four waves per workgroup, round 2)
+  const QueryArgs qa = {n, m, wpc, wpc_inv, radius2, inv_side, nsample, bucket_mul, new_xyz, xyz,
+                        ws.start, ws.rec, ws.order, idx, g};
 #define GRID_QUERY(MAXH, GROUP)                                                                    \
-  hipLaunchKernelGGL((grid_query_kernel<MAXH, 1, GROUP>), dim3((unsigned)m * (unsigned)b),         \
-                     dim3(kWave), 0, stream, n, m, m, radius2, inv_side, nsample, bucket_mul,      \
-                     new_xyz, xyz, ws.start, ws.rec, ws.order, idx, g)
+  hipLaunchKernelGGL((grid_query_kernel<MAXH, 1, GROUP>), dim3((unsigned)wpc * (unsigned)b),       \
+                     dim3(kWave), 0, stream, qa)
   if ((long long)m * b > 0x7fffffffll) return (int)hipErrorInvalidValue;
   if (nsample > 2 * kWave) { if (group) GRID_QUERY(512, true); else GRID_QUERY(512, false); }
   else if (nsample > kWave) { if (group) GRID_QUERY(256, true); else GRID_QUERY(256, false); }

@@ -21,10 +21,12 @@ import bench  # noqa: E402
 import importlib  # noqa: E402
 
 CSRC = os.path.join(ROOT, "3dioumatch_amd", "csrc")
-so = os.path.join(HERE, "libgrid_probe.so")
+# GRID_PROBE_FLAGS="-DGRID_CPW=2 ...": the probed build of a kernel variant (GRID_PROBE_TAG names its library)
+so = os.path.join(HERE, "libgrid_probe%s.so" % os.environ.get("GRID_PROBE_TAG", ""))
 if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(CSRC, "pn2_ball_grid.hip")):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared",
                            "-fPIC", "-ffp-contract=off", "-DGRID_PROBE", "-I", CSRC,
+                           *os.environ.get("GRID_PROBE_FLAGS", "").split(),
                            os.path.join(HERE, "grid_probe.hip"), "-o", so])
 if "--build-only" in sys.argv:
     sys.exit(0)

@@ -12,7 +12,9 @@ Two forms of the same work (38 516 736 algorithmic bytes):
     rocprofv3 --kernel-trace --stats ... -- python tools/pair_bench.py 20
     rocprofv3 --kernel-trace --pmc FETCH_SIZE ... -- python tools/pair_bench.py 5 --plain
     rocprofv3 --kernel-trace --pmc WRITE_SIZE ... -- python tools/pair_bench.py 5 --plain
-(--plain: eager launches only, no graph capture -- what the counter passes want.)
+(--plain: eager launches only, no graph capture -- what the counter passes want;
+ --only layer|fused|api: that form alone, so that a rocprofv3 stats / counter file holds ONE form
+ per kernel name -- `fused` and `layer` launch the same kernel.)
 """
 import importlib
 import json
@@ -31,6 +33,7 @@ import bench  # noqa: E402  (time_op: events around a HIP-graph replay)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 iters = int(args[0]) if args else 20
 plain = "--plain" in sys.argv
+only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
 out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
 
 B, N, M, NS, R = 8, 40000, 2048, 64, 0.2
@@ -70,9 +73,12 @@ def build_only():
 
 if plain:
     for _ in range(iters):
-        api()
-        fused()
-        layer()
+        if only in (None, "api"):
+            api()
+        if only in (None, "fused"):
+            fused()
+        if only in (None, "layer"):
+            layer()
     if "--ablate" in sys.argv:  # counter passes of the timing ablations (kernel names differ)
         for a in ("1", "2"):
             os.environ["PN2_GRID_ABLATE"] = a
@@ -85,6 +91,8 @@ else:
     res = {"shape": {"B": B, "N": N, "m": M, "nsample": NS, "radius": R}, "cloud": cloud,
            "algorithmic_bytes": bench.PAIR_BYTES}
     for name, fn in (("api", api), ("fused", fused), ("layer", layer), ("build_only", build_only)):
+        if only is not None and name != only:
+            continue
         us = bench.time_op(fn, iters=iters, warm=3)
         res[name + "_us"] = round(us, 2)
         res[name + "_frac_of_8TBs"] = round(bench.PAIR_BYTES / (us * 1e-6) / 8e12, 4)
