@@ -46,6 +46,8 @@ _SIGNATURES = {
     "pn2_ball_query_prebuilt": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp, _sz, _vp],
     "pn2_query_and_group_prebuilt": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _vp,
                                      _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "pn2_query_and_group_picks": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_int, _vp,
+                                  _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "pn2_fps_grid_supported": [_c_int],
     "pn2_furthest_point_sampling_grid": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _sz, _c_float, _vp,
                                          _sz, _vp],

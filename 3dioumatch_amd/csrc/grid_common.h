@@ -21,6 +21,9 @@ constexpr int kOrderFor = kCells + 1;
 constexpr int kChunks = 32;             // chunks a cloud is split into by the first build pass
 constexpr int kSegOff = kG + 1;         // layer offsets per chunk (+ total)
 constexpr int kGridMaxPoints = kChunks * 4096;  // the first pass keeps a chunk in registers
+// Query plans (below): 16 words per centroid, room for n / 8 centroids per cloud
+constexpr int kPlanWords = 16;
+__host__ __device__ inline int grid_plan_capacity(int n) { return n / 8; }
 
 __host__ __device__ inline int grid_chunk_points(int n) {
   return (((n + kChunks - 1) / kChunks) + 3) & ~3;
@@ -35,6 +38,8 @@ struct GridWs {
   // kernel's workgroup jj answers centroid order[jj]); keys of the counting sort behind it
   int *order;
   int *order_key;
+  // [b][n / 8][16] query plans of the centroids sampled from this cloud, in launch order
+  unsigned *plan;
   size_t bytes;
 };
 
@@ -49,6 +54,7 @@ inline GridWs grid_ws_layout(void *base, int b, int n) {
   w.seg = reinterpret_cast<float4 *>(take(sizeof(float4) * (size_t)b * kChunks * grid_chunk_points(n)));
   w.order = reinterpret_cast<int *>(take(sizeof(int) * (size_t)b * n));
   w.order_key = reinterpret_cast<int *>(take(sizeof(int) * (size_t)b * n));
+  w.plan = reinterpret_cast<unsigned *>(take(sizeof(unsigned) * kPlanWords * (size_t)b * grid_plan_capacity(n)));
   w.bytes = off;
   return w;
 }
@@ -65,7 +71,7 @@ __device__ __forceinline__ int cell_id(float x, float y, float z, float inv_side
 }
 
 // Cost class of a centroid's query (what grid_query_kernel will do for it, from the row lengths
-// alone): 0 = every one of its nine x-rows fits a wave (the single-load path), otherwise the
+// alone): 0 = every one of its nine x-rows is shorter than a wave (the single-load path), otherwise the
 // number of 64-record chunks its general path sweeps, capped at 63.
 __device__ inline int query_cost_class(const int *st, float cx, float cy, float cz, float inv_side) {
   const int gx = cell_coord(cx, inv_side) & (kG - 1);
@@ -83,10 +89,62 @@ __device__ inline int query_cost_class(const int *st, float cx, float cy, float 
       const int c = rowbase + (gx == 0 ? kG - 1 : 0);
       lenw = st[c + 1] - st[c];
     }
-    fast = fast && len + lenw <= kWave;
+    fast = fast && len + lenw < kWave;
     chunks += ((len + kWave - 1) >> 6) + ((lenw + kWave - 1) >> 6);
   }
   return fast ? 0 : (chunks < 63 ? (chunks > 0 ? chunks : 1) : 63);
+}
+
+// The QUERY PLAN of a centroid: everything grid_query_kernel's wave needs before its nine row loads,
+// as ONE 64-byte scalar load -- written by the kernel that knows both the centroids and the lists
+// (the sampling kernel, next to the launch order; entry jj of a cloud = the centroid its
+// workgroup jj answers).  Without it the wave walks order -> centroid -> cell coordinates ->
+// row offsets: three dependent trips to the L2 and ~45 vector + ~90 scalar instructions.
+//   words 0..8 : byte offset of row r's first record in the cloud's record array (start * 16)
+//   word  9    : lengths of rows 0..4, six bits each (a length above 63 is stored as 63)
+//   word 10    : lengths of rows 5..8, six bits each; bits 24..: 0 = the single-load path applies
+//                (every row shorter than 64 records, no wrapped cell), else the wave computes
+//                its rows itself (general path / seam)
+//   word 11    : centroid j | m << 16 (the m it was made for: a wave that finds another m here
+//                does not use the plan)
+//   words 12..14: the centroid's coordinates; word 15: the query's cost class
+__device__ inline void write_query_plan(unsigned *rec, const int *st, float cx, float cy, float cz,
+                                        float inv_side, int j, int m, int cost) {
+  const int gx = cell_coord(cx, inv_side) & (kG - 1);
+  const int gy = cell_coord(cy, inv_side), gz = cell_coord(cz, inv_side);
+  const int xa = gx > 0 ? gx - 1 : 0, xb = gx < kG - 1 ? gx + 1 : kG - 1;
+  const bool seam = gx == 0 || gx == kG - 1;
+  unsigned w[kPlanWords];
+  unsigned lens[2] = {0u, 0u};
+  bool single = true;
+  for (int r = 0; r < 9; ++r) {
+    const int rz = r / 3;
+    const int rowbase = (((gz + rz - 1) & (kG - 1)) * kG + ((gy + (r - 3 * rz) - 1) & (kG - 1))) * kG;
+    const int s0 = st[rowbase + xa];
+    const int len = st[rowbase + xb + 1] - s0;
+    int lenw = 0;
+    if (seam) {
+      const int c = rowbase + (gx == 0 ? kG - 1 : 0);
+      lenw = st[c + 1] - st[c];
+    }
+    single = single && len < kWave && lenw == 0;
+    w[r] = (unsigned)s0 * 16u;
+    const unsigned l6 = (unsigned)(len < 63 ? len : 63);
+    if (r < 5) lens[0] |= l6 << (6 * r);
+    else lens[1] |= l6 << (6 * (r - 5));
+  }
+  w[9] = lens[0];
+  w[10] = lens[1] | (single ? 0u : 1u << 24);
+  w[11] = (unsigned)j | (unsigned)m << 16;
+  w[12] = __builtin_bit_cast(unsigned, cx);
+  w[13] = __builtin_bit_cast(unsigned, cy);
+  w[14] = __builtin_bit_cast(unsigned, cz);
+  w[15] = (unsigned)cost;
+  uint4 *o = reinterpret_cast<uint4 *>(rec);
+  o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  o[2] = make_uint4(w[8], w[9], w[10], w[11]);
+  o[3] = make_uint4(w[12], w[13], w[14], w[15]);
 }
 
 }  // namespace grid

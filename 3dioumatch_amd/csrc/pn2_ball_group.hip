@@ -756,6 +756,14 @@ PN2_API int pn2_query_and_group_prebuilt(int b, int n, int m, int c, float radiu
                               idx, out, const_cast<void *>(grid), grid_bytes, 1, stream_);
 }
 
+PN2_API int pn2_query_and_group_picks(int b, int n, int m, int c, float radius, int nsample,
+                                      int normalize_xyz, const float *new_xyz, const float *xyz,
+                                      const float *features, int *idx, float *out,
+                                      const void *grid, size_t grid_bytes, void *stream_) {
+  return query_and_group_impl(b, n, m, c, radius, nsample, normalize_xyz, new_xyz, xyz, features,
+                              idx, out, const_cast<void *>(grid), grid_bytes, 2, stream_);
+}
+
 // ---- inverse index of an index array (group_points_gpu.cu:48-69 does a same-address atomic per
 // element instead) ------------------------------------------------------------------------------
 PN2_API int pn2_group_inverse_supported(int n, int npoints, int nsample) {

@@ -314,7 +314,8 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
                          const int *__restrict__ n_valid_in, int *__restrict__ idxs,
                          int *__restrict__ first_tie_out, const int *__restrict__ prefix_first_tie,
                          int *__restrict__ grid_start, int *__restrict__ grid_order,
-                         int *__restrict__ grid_order_key, float grid_inv_side) {
+                         int *__restrict__ grid_order_key, unsigned *__restrict__ grid_plan,
+                         float grid_inv_side) {
   static_assert(G == 2 || G == 4, "group of 2 or 4 buckets");
   constexpr int NG = 3;   // groups whose loads are issued together
   __shared__ __attribute__((aligned(16))) int2 slots[2][W];   // (bits of the wave's maximum, bucket id)
@@ -608,7 +609,20 @@ fps_bucket_rounds_kernel(int n, int m, int log2bs, size_t cloud_stride,
       o_cnt[kWave - 1 - lane] = incl - c;
     }
     __syncthreads();
-    for (int jj = tid; jj < m; jj += W * kWave) ord[atomicAdd(&o_cnt[key[jj]], 1)] = jj;
+    // ... and, at the same position, the query's PLAN (grid_common.h): row offsets, row lengths,
+    // the centroid itself -- the query wave's whole head as one 64-byte load
+    const int plan_cap = grid::grid_plan_capacity(n);
+    unsigned *plan = grid_plan != nullptr && m <= plan_cap && m < 65536
+                         ? grid_plan + (size_t)blockIdx.x * plan_cap * grid::kPlanWords : nullptr;
+    for (int jj = tid; jj < m; jj += W * kWave) {
+      const int pos = atomicAdd(&o_cnt[key[jj]], 1);
+      ord[pos] = jj;
+      if (plan != nullptr) {
+        const int p = out[jj];
+        grid::write_query_plan(plan + (size_t)pos * grid::kPlanWords, st, pts[p * 3 + 0], pts[p * 3 + 1],
+                               pts[p * 3 + 2], grid_inv_side, jj, m, key[jj]);
+      }
+    }
     if (tid == 0) grid_start[(size_t)blockIdx.x * grid::kStartStride + grid::kOrderFor] = m;
   }
 }
@@ -654,6 +668,7 @@ int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, vo
   float *bbox = reinterpret_cast<float *>(pidx + (size_t)b * stride);
   int *n_valid = reinterpret_cast<int *>(bbox + (size_t)b * (stride / kWave) * 8);
   int *g_start = nullptr, *g_order = nullptr, *g_order_key = nullptr;
+  unsigned *g_plan = nullptr;
   float4 *g_rec = nullptr;
   float g_inv = 0.f;
   if (grid != nullptr) {  // also leave the cell lists for ball queries of grid_radius behind
@@ -663,6 +678,7 @@ int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, vo
     g_rec = ws.rec;
     g_order = ws.order;
     g_order_key = ws.order_key;
+    g_plan = ws.plan;
     g_inv = grid::grid_inv_side(grid_radius);
   }
   hipLaunchKernelGGL(fps_bucket_setup_kernel, dim3(b, grid != nullptr ? 2 : 1), dim3(kThreads), 0, stream,
@@ -672,7 +688,7 @@ int pn2_fps_bucket_try(int b, int n, int m, int log2bs, const float *dataset, vo
 #define FPS_ROUNDS(META)                                                                       \
   hipLaunchKernelGGL((fps_bucket_rounds_kernel<WV, META, FPS_BUCKET_GROUP>), dim3(b), dim3(WV * kWave), 0, \
                      stream, n, m, log2bs, stride, dataset, rec, pidx, bbox, n_valid, idxs, first_tie_out, prefix_first_tie,  \
-                     g_start, g_order, g_order_key, g_inv)
+                     g_start, g_order, g_order_key, g_plan, g_inv)
   if (per_wave <= kWave) FPS_ROUNDS(1);
   else if (per_wave <= 2 * kWave) FPS_ROUNDS(2);
   else FPS_ROUNDS(3);

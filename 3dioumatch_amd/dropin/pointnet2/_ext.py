@@ -450,9 +450,32 @@ class CellLists(object):
     """Cell lists of one (B,N,3) cloud for ball queries of one radius (include/pn2_hip.h
     pn2_grid_*): built once, queried by ball_query / query_and_group via `grid=`."""
 
-    def __init__(self, buf, b, n, radius):
+    def __init__(self, buf, b, n, radius, picks=None):
         self.buf, self.b, self.n, self.radius = buf, b, n, float(radius)
         self.event = None  # recorded on the building stream when the lists enter _ext's cache
+        # the index tensor of the sampling call that left these lists behind (its kernel also left
+        # a query plan per pick, include/pn2_hip.h pn2_query_and_group_picks), and the centroid
+        # tensor a caller has declared to be the cloud gathered at exactly those indices
+        self.picks = picks
+        self._centroids = None
+
+    def mark_centroids(self, new_xyz, inds):
+        """Declare that new_xyz (B,m,3) is the cloud gathered at `inds`, the picks of the sampling
+        call that produced these lists (what a set-abstraction layer computes,
+        pointnet2_modules.py:236-245): query_and_group(new_xyz, ..., grid=self) may then start
+        every query from the plan the sampling kernel left.  Any other tensor, or one modified in
+        place afterwards, takes the ordinary path."""
+        import weakref
+        if self.picks is None or inds is not self.picks or new_xyz.shape[1] != inds.shape[1]:
+            return
+        self._centroids = (weakref.ref(new_xyz), _tensor_version(new_xyz), new_xyz.data_ptr())
+
+    def centroids_are_picks(self, new_xyz):
+        if self._centroids is None:
+            return False
+        ref, version, ptr = self._centroids
+        return ref() is new_xyz and version is not None and _tensor_version(new_xyz) == version and \
+            new_xyz.data_ptr() == ptr
 
     def check(self, xyz, radius):
         if tuple(xyz.shape[:2]) != (self.b, self.n) or float(radius) != self.radius:
@@ -518,7 +541,7 @@ def furthest_point_sampling_with_grid(points, nsamples, radius):
                                                        float(radius), gbuf.data_ptr(), gbytes,
                                                        _stream(points)),
                  "furthest_point_sampling_grid")
-    return out, CellLists(gbuf, b, n, radius)
+    return out, CellLists(gbuf, b, n, radius, picks=out)
 
 
 def furthest_point_sampling_ties(points, nsamples, radius=None):
@@ -550,7 +573,7 @@ def furthest_point_sampling_ties(points, nsamples, radius=None):
             b, n, nsamples, points.data_ptr(), out.data_ptr(), ws.data_ptr(), need,
             float(radius) if with_lists else 0.0, gbuf.data_ptr() if with_lists else None, gbytes,
             ties.data_ptr(), _stream(points)), "furthest_point_sampling_ties")
-    return out, (CellLists(gbuf, b, n, radius) if with_lists else None), ties
+    return out, (CellLists(gbuf, b, n, radius, picks=out) if with_lists else None), ties
 
 
 def furthest_point_sampling_prefix(points, nsamples, first_tie):
@@ -626,12 +649,12 @@ def query_and_group(new_xyz, xyz, features, radius, nsample, normalize_xyz, idx=
     if grid is not None and nsample <= 256:
         grid.check(xyz, radius)
         with torch.cuda.device(new_xyz.device):
-            _L.check(_lib.pn2_query_and_group_prebuilt(b, n, m, c, float(radius), nsample,
-                                                       1 if normalize_xyz else 0,
-                                                       new_xyz.data_ptr(), xyz.data_ptr(), fptr,
-                                                       idx.data_ptr(), out.data_ptr(),
-                                                       grid.buf.data_ptr(), grid.buf.numel(),
-                                                       _stream(new_xyz)),
+            # (the layer's own centroids: every query starts from the plan its sampling kernel left)
+            entry = _lib.pn2_query_and_group_picks if grid.centroids_are_picks(new_xyz) \
+                else _lib.pn2_query_and_group_prebuilt
+            _L.check(entry(b, n, m, c, float(radius), nsample, 1 if normalize_xyz else 0,
+                           new_xyz.data_ptr(), xyz.data_ptr(), fptr, idx.data_ptr(), out.data_ptr(),
+                           grid.buf.data_ptr(), grid.buf.numel(), _stream(new_xyz)),
                      "query_and_group_prebuilt")
         return idx, out
     with torch.cuda.device(new_xyz.device):

@@ -42,6 +42,8 @@ def _sample_centroids(xyz, npoint, inds=None, radius=None):
     flipped = xyz.transpose(1, 2).contiguous()
     new_xyz = pointnet2_utils.gather_operation(flipped, inds).transpose(1, 2).contiguous()
     pointnet2_utils.remember_head(new_xyz, first_tie)
+    if lists is not None:  # the centroids are this sampling call's picks: its query plans apply
+        lists.mark_centroids(new_xyz, inds)
     return (new_xyz, inds, lists) if radius is not None else (new_xyz, inds)
 
 

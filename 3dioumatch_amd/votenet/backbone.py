@@ -66,6 +66,8 @@ class Pointnet2Backbone(nn.Module):
                                                        inds).transpose(1, 2).contiguous()
             geometry["sa%d_inds" % i] = inds
             geometry["sa%d_new_xyz" % i] = new_xyz
+            if lists is not None:  # the centroids are this sampling call's picks: its query plans apply
+                lists.mark_centroids(new_xyz, inds)
             if i == 1 and lists is not None and sa.nsample <= 256 and sa.use_xyz and \
                     sa.pooling == 'max' and (in_features is None or in_features.shape[1] <= 8):
                 idx, grouped = pointnet2_utils._ext.query_and_group(

@@ -191,6 +191,8 @@ def kernel_table(device):
     valu("fps_40000_2048_with_cell_lists", us, B * (m1 - 1) * NPTS, "dist_updates",
          "the same kernel also leaving SA1's cell lists behind")
     new_xyz = ext.gather_points(flipped, inds).transpose(1, 2).contiguous()
+    # the layer's own centroids (pointnet2_modules.py:236-245): the sampling kernel's query plans apply
+    lists.mark_centroids(new_xyz, inds)
     hbm("gather_3x2048", time_op(lambda: ext.gather_points(flipped, inds)), 4 * B * m1 + 8 * B * 3 * m1)
     bq_bytes = 12 * B * NPTS + 12 * B * m1 + 4 * B * m1 * ns1
     gx_bytes = 4 * B * 3 * NPTS + 4 * B * m1 * ns1 + 4 * B * 3 * m1 * ns1
@@ -211,6 +213,8 @@ def kernel_table(device):
 
     forms = {
         "layer": time_op(lambda: ext.query_and_group(new_xyz, xyz, feat, 0.2, ns1, True, None, lists)),
+        # the same kernel without the sampling kernel's query plans (centroids not known to be its picks)
+        "layer_no_plan": time_op(lambda: ext.query_and_group(new_xyz.clone(), xyz, feat, 0.2, ns1, True, None, lists)),
         "self_contained": time_op(lambda: ext.query_and_group(new_xyz, xyz, feat, 0.2, ns1, True)),
         "reference_api_3_calls": time_op(api),
     }
@@ -227,6 +231,7 @@ def kernel_table(device):
         xk = pair_cloud(kind).to(device)
         ik, lk = ext.furthest_point_sampling_with_grid(xk, m1, 0.2)
         nk = ext.gather_points(xk.transpose(1, 2).contiguous(), ik).transpose(1, 2).contiguous()
+        lk.mark_centroids(nk, ik)
         forms["layer_cloud_" + kind] = time_op(
             lambda: ext.query_and_group(nk, xk, feat, 0.2, ns1, True, None, lk))
     # the same kernel with its inputs and outputs rotating through 12 distinct sets (12 x 26 MB >
@@ -237,6 +242,7 @@ def kernel_table(device):
         xq = torch.from_numpy(synth.cloud_uniform(B, NPTS, synth.cube_side(NPTS, 0.2, 64), seed=10 + q)).to(device)
         iq, lq = ext.furthest_point_sampling_with_grid(xq, m1, 0.2)
         nq = ext.gather_points(xq.transpose(1, 2).contiguous(), iq).transpose(1, 2).contiguous()
+        lq.mark_centroids(nq, iq)
         sets.append((nq, xq, torch.rand(B, 1, NPTS, device=device), lq))
     keep = []
 

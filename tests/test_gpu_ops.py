@@ -291,7 +291,7 @@ def test_north_star_pair_on_the_step_and_room_clouds(ext, oracle_omp, synth, kin
 def test_launch_order_left_by_the_sampling_kernel(ext, oracle_omp, synth):
     """The sampling kernel leaves, next to the cell lists, the order in which the query kernel
     answers the centroids it picked: a permutation of 0..m-1 per cloud, sorted by the query's
-    cost class (0: every x-row of the 3x3 neighbourhood fits a wave; otherwise the number of
+    cost class (0: every x-row of the 3x3 neighbourhood is shorter than a wave; otherwise the number of
     64-record chunks of the general path), longest first -- recomputed here from the cell
     offsets.  Lists built any other way carry no order; a query for another number of
     centroids ignores it; rows are the oracle's in every case."""
@@ -320,7 +320,7 @@ def test_launch_order_left_by_the_sampling_kernel(ext, oracle_omp, synth):
                 ln = start[i][base + xb + 1] - start[i][base + xa]
                 wrap = base + np.where(gx == 0, 31, 0)
                 lw = np.where(seam, start[i][wrap + 1] - start[i][wrap], 0)
-                fast &= ln + lw <= 64
+                fast &= ln + lw < 64
                 chunks += (ln + 63) // 64 + (lw + 63) // 64
         cls = np.where(fast, 0, np.clip(chunks, 1, 63))
         along = cls[order[i, :m]]
@@ -332,6 +332,55 @@ def test_launch_order_left_by_the_sampling_kernel(ext, oracle_omp, synth):
     fewer = new_xyz[:, :777].contiguous()
     assert np.array_equal(ext.ball_query_prebuilt(fewer, d_xyz, r, ns, lists).cpu().numpy(), want[:, :777])
     assert list(ext.build_grid(d_xyz, r).launch_order()[0].cpu().numpy()) == [0] * b
+
+
+@pytest.mark.parametrize("kind,shift,ns,c", [("step", 0.0, 64, 1), ("U", 0.0, 64, 1), ("R", 0.0, 64, 3),
+                                             ("step", -1.7, 64, 0), ("U", -0.3, 128, 1), ("step", 0.0, 16, 8)])
+def test_query_plans_left_by_the_sampling_kernel(ext, oracle_omp, synth, kind, shift, ns, c):
+    """include/pn2_hip.h pn2_query_and_group_picks: when the centroids ARE the picks of the sampling
+    call that left the cell lists (what a set-abstraction layer computes, pointnet2_modules.py:
+    236-250), every query wave starts from the 64-byte plan that kernel wrote -- row offsets, row
+    lengths, centroid, launch position.  Rows and grouped tensor: bit-for-bit those of the call
+    that knows nothing about the centroids, and the oracle's (ball_query_gpu.cu:14-49,
+    group_points_gpu.cu:13-33).  Clouds with dense clusters (general path inside a planned launch),
+    walls at x = 0 and negative coordinates (wrapped seam cells), nsample 16 / 64 / 128."""
+    import bench
+    b, n, m, r = 2, 40000, 2048, 0.2
+    xyz = bench.pair_cloud(kind)[:b].numpy().copy() + np.float32(shift)
+    d_xyz = dev(xyz)
+    feat = torch.rand(b, c, n, device=d_xyz.device) if c else None
+    fps, lists = ext.furthest_point_sampling_with_grid(d_xyz, m, r)
+    new_xyz = ext.gather_points(d_xyz.transpose(1, 2).contiguous(), fps).transpose(1, 2).contiguous()
+    assert not lists.centroids_are_picks(new_xyz)
+    lists.mark_centroids(new_xyz, fps)
+    assert lists.centroids_are_picks(new_xyz) and not lists.centroids_are_picks(new_xyz.clone())
+    idx_p, grouped_p = ext.query_and_group(new_xyz, d_xyz, feat, r, ns, True, None, lists)   # plans
+    other = new_xyz.clone()
+    idx_o, grouped_o = ext.query_and_group(other, d_xyz, feat, r, ns, True, None, lists)     # no plans
+    want = oracle_omp.ball_query(new_xyz.cpu().numpy(), xyz, r, ns)
+    assert np.array_equal(idx_o.cpu().numpy(), want)
+    assert np.array_equal(idx_p.cpu().numpy(), want)
+    assert np.array_equal(bits(grouped_p.cpu().numpy()), bits(grouped_o.cpu().numpy()))
+    # a centroid tensor modified in place is no longer "the picks": the ordinary path answers it
+    new_xyz[:, 5] += 0.01
+    assert not lists.centroids_are_picks(new_xyz)
+    idx_m, _ = ext.query_and_group(new_xyz, d_xyz, feat, r, ns, True, None, lists)
+    assert np.array_equal(idx_m.cpu().numpy(), oracle_omp.ball_query(new_xyz.cpu().numpy(), xyz, r, ns))
+
+
+def test_query_plans_need_room(ext, oracle_omp, synth):
+    """More centroids than the object has plans for (m > n / 8): the sampling kernel writes none and
+    pn2_query_and_group_picks is pn2_query_and_group_prebuilt."""
+    b, n, m, r, ns = 2, 8192, 2048, 0.25, 32
+    xyz = synth.cloud_uniform(b, n, synth.cube_side(n, r, ns), seed=5)
+    d_xyz = dev(xyz)
+    fps, lists = ext.furthest_point_sampling_with_grid(d_xyz, m, r)
+    if lists is None:
+        pytest.skip("no cell lists for this cloud size")
+    new_xyz = ext.gather_points(d_xyz.transpose(1, 2).contiguous(), fps).transpose(1, 2).contiguous()
+    lists.mark_centroids(new_xyz, fps)
+    idx, _ = ext.query_and_group(new_xyz, d_xyz, None, r, ns, True, None, lists)
+    assert np.array_equal(idx.cpu().numpy(), oracle_omp.ball_query(new_xyz.cpu().numpy(), xyz, r, ns))
 
 
 def test_ballquery_general_path_bucket_refinement(ext, oracle_omp, synth):

@@ -59,12 +59,17 @@ def fused():
     ext.query_and_group(new_xyz, xyz, feat, R, NS, True)
 
 
-_, LISTS = ext.furthest_point_sampling_with_grid(xyz, M, R)  # the SA layer's own sampling call
+# the SA layer's own sampling call and its centroids (pointnet2_modules.py:236-245)
+LINDS, LISTS = ext.furthest_point_sampling_with_grid(xyz, M, R)
+LNEW = ext.gather_points(flipped, LINDS).transpose(1, 2).contiguous()
+assert torch.equal(LNEW, new_xyz)
+if "--no-plan" not in sys.argv:
+    LISTS.mark_centroids(LNEW, LINDS)
 
 
 def layer():
     """as the set-abstraction layer runs it: cell lists left behind by the sampling kernel"""
-    ext.query_and_group(new_xyz, xyz, feat, R, NS, True, None, LISTS)
+    ext.query_and_group(LNEW, xyz, feat, R, NS, True, None, LISTS)
 
 
 def build_only():
