@@ -34,7 +34,7 @@ lib = ctypes.CDLL(so)
 lib.grid_probe_ws.restype = ctypes.c_size_t
 lib.grid_probe_ws.argtypes = [ctypes.c_int] * 4
 lib.grid_probe_run.argtypes = [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_int] + [ctypes.c_void_p] * 6 + \
-    [ctypes.c_size_t, ctypes.c_void_p]
+    [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
 lib.grid_probe_read.argtypes = [ctypes.c_void_p]
 importlib.import_module("3dioumatch_amd")
 ext = importlib.import_module("pointnet2._ext")
@@ -43,16 +43,23 @@ B, N, M, NS, R = 8, 40000, 2048, 64, 0.2
 res = {}
 for kind in ("U", "R", "step"):
     xyz = bench.pair_cloud(kind).to(dev)
-    inds = ext.furthest_point_sampling(xyz, M)
+    # --layer: on the cell lists, launch order and query plans the layer's own sampling call leaves
+    layer = "--layer" in sys.argv
+    if layer:
+        inds, lists = ext.furthest_point_sampling_with_grid(xyz, M, R)
+    else:
+        inds = ext.furthest_point_sampling(xyz, M)
     new_xyz = ext.gather_points(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
     feat = torch.rand(B, 1, N, device=dev)
     idx = torch.zeros(B, M, NS, dtype=torch.int32, device=dev)
     out = torch.zeros(B, 4, M, NS, device=dev)
     nbytes = lib.grid_probe_ws(B, N, M, NS)
-    ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    ws = lists.buf if layer else torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    assert ws.numel() >= nbytes
     for _ in range(3):
         rc = lib.grid_probe_run(B, N, M, 1, R, NS, new_xyz.data_ptr(), xyz.data_ptr(), feat.data_ptr(),
-                                idx.data_ptr(), out.data_ptr(), ws.data_ptr(), nbytes, None)
+                                idx.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), None,
+                                2 if layer else 0)
         assert rc == 0, rc
         torch.cuda.synchronize()
     t = np.zeros((16384, 8), np.uint64)
@@ -63,11 +70,14 @@ for kind in ("U", "R", "step"):
     t = t.astype(np.int64)
     CLK = 2300.0  # s_memtime ticks per us (profiles/r3_instruction_costs.json); the counter's base
     #               differs from CU to CU, so only differences inside one wave / one CU are used
-    sweeps, chunks, hits = t[:, 2] >> 32, t[:, 2] & 0xffffffff, t[:, 3]
+    sweeps, chunks, hits = t[:, 2] >> 32, t[:, 2] & 0xffffff, t[:, 3] & 0xffff
+    path = (t[:, 2] >> 24) & 0xff
     d = lambda x, y: (t[:, x] - t[:, y]) / CLK  # noqa: E731
     total, s_start, s_sweep, s_rank, s_out = d(1, 0), d(4, 0), d(5, 4), d(6, 5), d(1, 6)
     r = {"classes": {}}
-    for name, msk in (("fast", sweeps == 0), ("general_1_8_chunks", (sweeps > 0) & (chunks <= 8)),
+    for name, msk in (("plan_one_pass", path == 1), ("plan_two_passes", path == 2),
+                      ("computed_single_load", path == 3), ("computed_seam", path == 4),
+                      ("fast", sweeps == 0), ("general_1_8_chunks", (sweeps > 0) & (chunks <= 8)),
                       ("general_9_16_chunks", (sweeps > 0) & (chunks > 8) & (chunks <= 16)),
                       ("general_17_24_chunks", (sweeps > 0) & (chunks > 16) & (chunks <= 24)),
                       ("general_over_24_chunks", (sweeps > 0) & (chunks > 24))):
