@@ -21,8 +21,8 @@ constexpr int kOrderFor = kCells + 1;
 constexpr int kChunks = 32;             // chunks a cloud is split into by the first build pass
 constexpr int kSegOff = kG + 1;         // layer offsets per chunk (+ total)
 constexpr int kGridMaxPoints = kChunks * 4096;  // the first pass keeps a chunk in registers
-// Query plans (below): 32 words per centroid, room for n / 8 centroids per cloud
-constexpr int kPlanWords = 32;
+// Query plans (below): 36 words per centroid, room for n / 8 centroids per cloud
+constexpr int kPlanWords = 36;
 __host__ __device__ inline int grid_plan_capacity(int n) { return n / 8; }
 
 __host__ __device__ inline int grid_chunk_points(int n) {
@@ -38,7 +38,7 @@ struct GridWs {
   // kernel's workgroup jj answers centroid order[jj]); keys of the counting sort behind it
   int *order;
   int *order_key;
-  // [b][n / 8][32] query plans of the centroids sampled from this cloud, in launch order
+  // [b][n / 8][36] query plans of the centroids sampled from this cloud, in launch order
   unsigned *plan;
   size_t bytes;
 };
@@ -96,12 +96,12 @@ __device__ inline int query_cost_class(const int *st, float cx, float cy, float 
 }
 
 // The QUERY PLAN of a centroid: everything grid_query_kernel's wave needs before its row loads, as
-// ONE 64-byte scalar load (a second half for the centroids that need it) -- written by the kernel
+// ONE 64-byte scalar load (a second part for the centroids that need it) -- written by the kernel
 // that knows both the centroids and the lists (the sampling kernel, next to the launch order;
 // entry jj of a cloud = the centroid its workgroup jj answers).  Without it the wave walks
 // order -> centroid -> cell coordinates -> row offsets: three dependent trips to the L2 and ~45
 // vector + ~90 scalar instructions.
-// A plan is a sequence of PASSES of nine loads of at most 63 records each (a lane mask of 64
+// A query is a sequence of PASSES of nine loads of at most 63 records each (a lane mask of 64
 // lanes does not come out of s_bfm_b64), all nine in flight before the first test:
 //   words 0..8 : byte offset of row r's first record in the cloud's record array
 //   word  9    : pass 0, lengths of loads 0..4, six bits each
@@ -111,14 +111,17 @@ __device__ inline int query_cost_class(const int *st, float cx, float cy, float 
 //   word 11    : centroid j | m << 16 (the m it was made for: a wave that finds another m here
 //                does not use the plan)
 //   words 12..14: the centroid's coordinates
-//   word 15    : the query's cost class | further passes << 8 | (one of them is the wrapped cells) << 16
-// Further passes (dense clouds: rows of 64 records and more; walls at the lattice seam with
-// points on both sides: the cell that wraps around): pass t = 1, 2, ... reads records
-// 63 t .. 63 t + 62 of every row -- the same nine offsets + 1008 t bytes -- and its two words of
-// lengths are words 16 + 2 (t - 1), ...; with wrapped cells, words 16..24 are THEIR nine offsets,
-// the length pairs start at word 25 and the last pass is theirs.  Room: 8 further passes (rows of
-// up to 567 records), 3 with wrapped cells; beyond that, or a wrapped cell of 64 records: kind 1.
+//   word 15    : the query's cost class | (63-record chunks of the further passes) << 8
+// Further passes (kind 2 -- dense clouds: rows of 64 records and more; walls at the lattice seam
+// with points on both sides: the cell that wraps around): what pass 0 left unread is 18 RANGES of
+// records -- words 16..24: the rest of row r (from its 64th record on), words 25..33: the wrapped
+// cell of row r -- each as first record | length << 17.  The wave cuts them into chunks of 63
+// records and reads the chunks nine per pass, whatever range they belong to: a neighbourhood of
+// one crowded cell and 26 ordinary ones costs (its records) / 567 passes, not (its longest row) /
+// 63.  Beyond kPlanChunks chunks, or a range of 2^15 records: kind 1.
 constexpr int kPlanRecords = kWave - 1;  // records per load
+constexpr int kPlanRanges = 18;
+constexpr int kPlanChunks = 63;          // chunks of the further passes at most (seven passes)
 __device__ inline void write_query_plan(unsigned *rec, const int *st, float cx, float cy, float cz,
                                         float inv_side, int j, int m, int cost) {
   const int gx = cell_coord(cx, inv_side) & (kG - 1);
@@ -127,50 +130,39 @@ __device__ inline void write_query_plan(unsigned *rec, const int *st, float cx, 
   const bool seam = gx == 0 || gx == kG - 1;
   unsigned w[kPlanWords];
   for (int i = 0; i < kPlanWords; ++i) w[i] = 0u;
-  int len[9], lenw[9], sw[9];
-  int longest = 0, longest_w = 0;
+  auto pack = [&](int word, int r, int l) {  // six bits per load, five loads in the first word
+    w[word + (r < 5 ? 0 : 1)] |= (unsigned)l << (6 * (r < 5 ? r : r - 5));
+  };
+  int chunks = 0;
+  bool ok = true;
+  auto range = [&](int word, int from, int len) {
+    ok = ok && len < (1 << 15) && from < (1 << 17);
+    chunks += (len + kPlanRecords - 1) / kPlanRecords;
+    w[word] = len > 0 ? (unsigned)from | (unsigned)len << 17 : 0u;
+  };
   for (int r = 0; r < 9; ++r) {
     const int rz = r / 3;
     const int rowbase = (((gz + rz - 1) & (kG - 1)) * kG + ((gy + (r - 3 * rz) - 1) & (kG - 1))) * kG;
     const int s0 = st[rowbase + xa];
-    len[r] = st[rowbase + xb + 1] - s0;
-    sw[r] = 0; lenw[r] = 0;
+    const int len = st[rowbase + xb + 1] - s0;
+    w[r] = (unsigned)s0 * 16u;
+    pack(9, r, len < kPlanRecords ? len : kPlanRecords);
+    range(16 + r, s0 + kPlanRecords, len > kPlanRecords ? len - kPlanRecords : 0);
     if (seam) {
       const int c = rowbase + (gx == 0 ? kG - 1 : 0);
-      sw[r] = st[c];
-      lenw[r] = st[c + 1] - sw[r];
+      range(25 + r, st[c], st[c + 1] - st[c]);
     }
-    w[r] = (unsigned)s0 * 16u;
-    longest = len[r] > longest ? len[r] : longest;
-    longest_w = lenw[r] > longest_w ? lenw[r] : longest_w;
   }
-  const bool has_w = longest_w > 0;
-  const int main_passes = longest > 0 ? (longest + kPlanRecords - 1) / kPlanRecords : 1;
-  const int further = main_passes - 1 + (has_w ? 1 : 0);
-  const bool ok = longest_w <= kPlanRecords && further <= (has_w ? 3 : 8);
-  auto pack = [&](int word, int r, int l) {  // six bits per load, five loads in the first word
-    w[word + (r < 5 ? 0 : 1)] |= (unsigned)l << (6 * (r < 5 ? r : r - 5));
-  };
-  auto clamp63 = [](int v) { return v < 0 ? 0 : (v < kPlanRecords ? v : kPlanRecords); };
-  for (int r = 0; r < 9; ++r) pack(9, r, clamp63(len[r]));
-  if (ok && further > 0) {
-    const int pairs = has_w ? 25 : 16;
-    for (int t = 1; t < main_passes; ++t)
-      for (int r = 0; r < 9; ++r) pack(pairs + 2 * (t - 1), r, clamp63(len[r] - kPlanRecords * t));
-    if (has_w)
-      for (int r = 0; r < 9; ++r) {
-        w[16 + r] = (unsigned)sw[r] * 16u;
-        pack(pairs + 2 * (main_passes - 1), r, lenw[r]);
-      }
-  }
-  w[10] |= (ok ? (further > 0 ? 2u : 0u) : 1u) << 24;
+  ok = ok && chunks <= kPlanChunks;
+  w[10] |= (ok ? (chunks > 0 ? 2u : 0u) : 1u) << 24;
   w[11] = (unsigned)j | (unsigned)m << 16;
   w[12] = __builtin_bit_cast(unsigned, cx);
   w[13] = __builtin_bit_cast(unsigned, cy);
   w[14] = __builtin_bit_cast(unsigned, cz);
-  w[15] = (unsigned)(cost & 0xff) | (ok ? (unsigned)further << 8 | (has_w ? 1u << 16 : 0u) : 0u);
+  w[15] = (unsigned)(cost & 0xff) | (ok ? (unsigned)chunks << 8 : 0u);
   uint4 *o = reinterpret_cast<uint4 *>(rec);
-  for (int i = 0; i < kPlanWords / 4; ++i) o[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+  const int quads = ok && chunks > 0 ? kPlanWords / 4 : 4;  // (the second part is read by kind 2 only)
+  for (int i = 0; i < quads; ++i) o[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
 
 }  // namespace grid

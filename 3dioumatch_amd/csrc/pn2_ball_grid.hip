@@ -375,7 +375,6 @@ grid_query_kernel(const QueryArgs a) {
     float cx = 0.f, cy = 0.f, cz = 0.f;
     bool have_centre = false, planned = false;
     int plan_kind = 1;
-    unsigned plan_more = 0;  // further passes << 8 | (the last one reads the wrapped cells) << 16
     unsigned p_start[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, p_len0 = 0, p_len1 = 0;
     const grid_i32x4 *pl = nullptr;
     if (PLAN) {
@@ -399,7 +398,6 @@ grid_query_kernel(const QueryArgs a) {
         have_centre = true;
         plan_kind = (int)(w10 >> 24);
         planned = plan_kind != 1;
-        plan_more = w15;
         p_start[0] = w0; p_start[1] = w1; p_start[2] = w2; p_start[3] = w3; p_start[4] = w4;
         p_start[5] = w5; p_start[6] = w6; p_start[7] = w7; p_start[8] = w8;
         p_len0 = w9; p_len1 = w10;
@@ -466,7 +464,7 @@ grid_query_kernel(const QueryArgs a) {
     // VALU write of EXEC 4 (six instructions follow the v_cmpx), a VMEM read of an SGPR a VALU
     // wrote 5 (the row starts are read nine instructions ahead of their loads).
     static_assert(WPB == 1, "the list may overflow into a neighbour's LDS");
-#define GRID_ROW(LEN, Q0, Q1, Q2, Q3, WAIT, CUR, NEXT)                                             \
+#define GRID_ROW(LEN, CUT, Q0, Q1, Q2, Q3, WAIT, CUR, NEXT)                                        \
         LEN                                                                                        \
         "s_bfm_b64 exec, %[tmp], 0\n"                                                              \
         "s_waitcnt vmcnt(" #WAIT ")\n"                                                              \
@@ -477,12 +475,15 @@ grid_query_kernel(const QueryArgs a) {
         "v_add_f32 v24, v24, v25\n"                                                                 \
         "v_add_f32 v24, v24, v26\n"                                                                 \
         "v_cmpx_gt_f32 vcc, %[r2], v24\n"                                                           \
+        CUT(Q3)                                                                                    \
         "s_bcnt1_i32_b64 %[tmp], vcc\n"                                                             \
         "s_lshl4_add_u32 %[" NEXT "], %[tmp], %[" CUR "]\n"                                         \
         "v_mbcnt_lo_u32_b32 v24, vcc_lo, 0\n"                                                       \
         "v_mbcnt_hi_u32_b32 v24, vcc_hi, v24\n"                                                     \
         "v_lshl_add_u32 v24, v24, 4, %[" CUR "]\n"                                                  \
         "ds_write_b128 v24, v[" #Q0 ":" #Q3 "]\n"
+#define GRID_NOCUT(Q3)
+#define GRID_CUT(Q3) "v_cmpx_gt_u32 vcc, %[cut], v" #Q3 "\n"  /* ... and index < cut (EXEC = the hits) */
 #define GRID_ROWS_LOADS                                                                            \
         "buffer_load_dwordx4 v[28:31], %[lane16], %[rsrc], %[so0] offen\n"                          \
         "buffer_load_dwordx4 v[32:35], %[lane16], %[rsrc], %[so1] offen\n"                          \
@@ -498,61 +499,139 @@ grid_query_kernel(const QueryArgs a) {
         "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46",   \
         "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",   \
         "v60", "v61", "v62", "v63"
+    // a pass whose nine row starts (byte offsets) and lengths sit in lanes 0..8 of two registers
+#define GRID_LEN_LANE(R) "v_readlane_b32 %[tmp], %[len], " #R "\n"
+#define GRID_LANE_PASS(AT_OUT, START16, LEN, FROM, CUT, ...)                                       \
+      asm volatile(                                                                                \
+          "s_mov_b32 %[at2], %[lds]\n"                                                             \
+          "v_readlane_b32 %[so0], %[start], 0\n"                                                   \
+          "v_readlane_b32 %[so1], %[start], 1\n"                                                   \
+          "v_readlane_b32 %[so2], %[start], 2\n"                                                   \
+          "v_readlane_b32 %[so3], %[start], 3\n"                                                   \
+          "v_readlane_b32 %[so4], %[start], 4\n"                                                   \
+          "v_readlane_b32 %[so5], %[start], 5\n"                                                   \
+          "v_readlane_b32 %[so6], %[start], 6\n"                                                   \
+          "v_readlane_b32 %[so7], %[start], 7\n"                                                   \
+          "v_readlane_b32 %[so8], %[start], 8\n"                                                   \
+          GRID_ROWS_LOADS                                                                          \
+          GRID_ROW(GRID_LEN_LANE(0), CUT, 28, 29, 30, 31, 8, "at2", "at")                           \
+          GRID_ROW(GRID_LEN_LANE(1), CUT, 32, 33, 34, 35, 7, "at", "at2")                           \
+          GRID_ROW(GRID_LEN_LANE(2), CUT, 36, 37, 38, 39, 6, "at2", "at")                           \
+          GRID_ROW(GRID_LEN_LANE(3), CUT, 40, 41, 42, 43, 5, "at", "at2")                           \
+          GRID_ROW(GRID_LEN_LANE(4), CUT, 44, 45, 46, 47, 4, "at2", "at")                           \
+          GRID_ROW(GRID_LEN_LANE(5), CUT, 48, 49, 50, 51, 3, "at", "at2")                           \
+          GRID_ROW(GRID_LEN_LANE(6), CUT, 52, 53, 54, 55, 2, "at2", "at")                           \
+          GRID_ROW(GRID_LEN_LANE(7), CUT, 56, 57, 58, 59, 1, "at", "at2")                           \
+          GRID_ROW(GRID_LEN_LANE(8), CUT, 60, 61, 62, 63, 0, "at2", "at")                           \
+          "s_mov_b64 exec, -1\n"                                                                   \
+          : [at] "=&s"(AT_OUT), [at2] "=&s"(lp_at2), [tmp] "=&s"(lp_tmp), [so0] "=&s"(lp_so0),     \
+            [so1] "=&s"(lp_so1), [so2] "=&s"(lp_so2), [so3] "=&s"(lp_so3), [so4] "=&s"(lp_so4),    \
+            [so5] "=&s"(lp_so5), [so6] "=&s"(lp_so6), [so7] "=&s"(lp_so7), [so8] "=&s"(lp_so8)     \
+          : [start] "v"(START16), [len] "v"(LEN), [lane16] "v"(lane16), [rsrc] "s"(rsrc),          \
+            [cxy] "s"(cxy), [cz] "s"(cz), [r2] "s"(radius2), [lds] "s"(FROM) __VA_ARGS__           \
+          : GRID_ROWS_CLOBBERS)
+    unsigned lp_at2, lp_tmp, lp_so0, lp_so1, lp_so2, lp_so3, lp_so4, lp_so5, lp_so6, lp_so7, lp_so8;  // scalar temporaries
     if (PLAN && planned) {
       // row starts and lengths come as scalars from the plan: no lane reads at all
 #define GRID_LEN_PLAN(SRC, SHIFT) "s_bfe_u32 %[tmp], %[" SRC "], " #SHIFT "\n"
-#define GRID_PLAN_PASS(AT_OUT, S, L0, L1, FROM, HEAD)                                               \
+#define GRID_PLAN_PASS(AT_OUT, S, L0, L1, FROM, HEAD, CUT)                                          \
       asm volatile(                                                                                \
           HEAD "s_mov_b32 %[at2], %[lds]\n"                                                        \
           GRID_ROWS_LOADS                                                                          \
-          GRID_ROW(GRID_LEN_PLAN("lp0", 0x60000), 28, 29, 30, 31, 8, "at2", "at")                   \
-          GRID_ROW(GRID_LEN_PLAN("lp0", 0x60006), 32, 33, 34, 35, 7, "at", "at2")                   \
-          GRID_ROW(GRID_LEN_PLAN("lp0", 0x6000c), 36, 37, 38, 39, 6, "at2", "at")                   \
-          GRID_ROW(GRID_LEN_PLAN("lp0", 0x60012), 40, 41, 42, 43, 5, "at", "at2")                   \
-          GRID_ROW(GRID_LEN_PLAN("lp0", 0x60018), 44, 45, 46, 47, 4, "at2", "at")                   \
-          GRID_ROW(GRID_LEN_PLAN("lp1", 0x60000), 48, 49, 50, 51, 3, "at", "at2")                   \
-          GRID_ROW(GRID_LEN_PLAN("lp1", 0x60006), 52, 53, 54, 55, 2, "at2", "at")                   \
-          GRID_ROW(GRID_LEN_PLAN("lp1", 0x6000c), 56, 57, 58, 59, 1, "at", "at2")                   \
-          GRID_ROW(GRID_LEN_PLAN("lp1", 0x60012), 60, 61, 62, 63, 0, "at2", "at")                   \
+          GRID_ROW(GRID_LEN_PLAN("lp0", 0x60000), CUT, 28, 29, 30, 31, 8, "at2", "at")              \
+          GRID_ROW(GRID_LEN_PLAN("lp0", 0x60006), CUT, 32, 33, 34, 35, 7, "at", "at2")              \
+          GRID_ROW(GRID_LEN_PLAN("lp0", 0x6000c), CUT, 36, 37, 38, 39, 6, "at2", "at")              \
+          GRID_ROW(GRID_LEN_PLAN("lp0", 0x60012), CUT, 40, 41, 42, 43, 5, "at", "at2")              \
+          GRID_ROW(GRID_LEN_PLAN("lp0", 0x60018), CUT, 44, 45, 46, 47, 4, "at2", "at")              \
+          GRID_ROW(GRID_LEN_PLAN("lp1", 0x60000), CUT, 48, 49, 50, 51, 3, "at", "at2")              \
+          GRID_ROW(GRID_LEN_PLAN("lp1", 0x60006), CUT, 52, 53, 54, 55, 2, "at2", "at")              \
+          GRID_ROW(GRID_LEN_PLAN("lp1", 0x6000c), CUT, 56, 57, 58, 59, 1, "at", "at2")              \
+          GRID_ROW(GRID_LEN_PLAN("lp1", 0x60012), CUT, 60, 61, 62, 63, 0, "at2", "at")              \
           "s_mov_b64 exec, -1\n"                                                                   \
           : [at] "=&s"(AT_OUT), [at2] "=&s"(at2), [tmp] "=&s"(stmp)                                \
           : [so0] "s"(S[0]), [so1] "s"(S[1]), [so2] "s"(S[2]), [so3] "s"(S[3]), [so4] "s"(S[4]),   \
             [so5] "s"(S[5]), [so6] "s"(S[6]), [so7] "s"(S[7]), [so8] "s"(S[8]), [lp0] "s"(L0),     \
             [lp1] "s"(L1), [lane16] "v"(lane16), [rsrc] "s"(rsrc), [cxy] "s"(cxy), [cz] "s"(cz),   \
-            [r2] "s"(radius2), [lds] "s"(FROM)                                                     \
+            [r2] "s"(radius2), [lds] "s"(FROM), [cut] "s"(cut)                                     \
           : GRID_ROWS_CLOBBERS)
       unsigned at, at2, stmp;
-      GRID_PLAN_PASS(at, p_start, p_len0, p_len1, lds_list, "");
-      if (plan_kind == 2) {
-        // further passes (grid_common.h): records 63 t .. of every row -- dense clouds -- and the
-        // cells that wrap around the lattice seam.  (After pass 0's asm -- a store to anything,
-        // for the compiler -- the plan's second half comes by vector loads: lane reads.)
-        auto sgpr = [](int v) { return (unsigned)__builtin_amdgcn_readfirstlane(v); };
-        const int further = (int)((plan_more >> 8) & 0xffu);
-        const bool has_w = ((plan_more >> 16) & 1u) != 0u;
+      unsigned cut = 0xffffffffu;  // a second round keeps the hits with index < cut
+      GRID_PLAN_PASS(at, p_start, p_len0, p_len1, lds_list, "", GRID_NOCUT);
+      total = (int)((at - lds_list) >> 4);
+      if (plan_kind == 2 || total > MAXH) {
+        // Further passes (grid_common.h): what pass 0 left unread -- the rows' records from the
+        // 64th on, the cells that wrap around the lattice seam -- is 18 ranges of records, cut
+        // into chunks of 63 and read nine chunks per pass whatever range they belong to.
+        // (After pass 0's asm -- a store to anything, for the compiler -- the plan comes by
+        // vector loads: lane l holds word l / range l, and a lane read per word used.)
         const int *words = reinterpret_cast<const int *>(pl);
-        const int pairs = has_w ? 25 : 16;
+        const int wv = words[lane < 16 ? lane : 0];
+        auto word = [&](int k) { return (unsigned)__builtin_amdgcn_readlane(wv, k); };
+        unsigned rg = 0u;
+        if (plan_kind == 2) rg = (unsigned)words[16 + (lane < kPlanRanges ? lane : 0)];
+        if (lane >= kPlanRanges) rg = 0u;
+        const int rfrom = (int)(rg & 0x1ffffu), rlen = (int)(rg >> 17);
+        const int nch = (rlen + kPlanRecords - 1) / kPlanRecords;
+        const int ch_incl = wave_inclusive_scan(nch), ch_excl = ch_incl - nch;
+        const int n_chunks = __builtin_amdgcn_readlane(ch_incl, kWave - 1);
+        const int rend = rfrom + rlen;
 #pragma unroll 1
-        for (int t = 1; t <= further; ++t) {
-          unsigned b_start[9];
-          if (has_w && t == further) {
+        for (int round = 0;; ++round) {
+          if (round == 1) {  // pass 0 again, below the cut
+            unsigned b_start[9];
 #pragma unroll
-            for (int r = 0; r < 9; ++r) b_start[r] = sgpr(words[16 + r]);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 9; ++r) b_start[r] = p_start[r] + (unsigned)(16 * kPlanRecords * t);
+            for (int r = 0; r < 9; ++r) b_start[r] = word(r);
+            const unsigned b_len0 = word(9), b_len1 = word(10);
+            unsigned at_b;
+            // (row offsets written by v_readlane: five wait states before a load reads them)
+            GRID_PLAN_PASS(at_b, b_start, b_len0, b_len1, lds_list, "s_nop 4\n", GRID_CUT);
+            at = at_b;
           }
-          const unsigned b_len0 = sgpr(words[pairs + 2 * (t - 1)]), b_len1 = sgpr(words[pairs + 2 * (t - 1) + 1]);
-          unsigned at_b;
-          // (row offsets possibly written by v_readfirstlane: five wait states before a load reads them)
-          GRID_PLAN_PASS(at_b, b_start, b_len0, b_len1, at, "s_nop 4\n");
-          at = at_b;
-          if ((int)((at - lds_list) >> 4) > MAXH) break;  // the list is full: the general path decides
+#pragma unroll 1
+          for (int g0 = 0; g0 < n_chunks && (int)((at - lds_list) >> 4) <= MAXH; g0 += 9) {
+            // lane q < 9: chunk g0 + q -> its range r (ch_excl[r] <= chunk < ch_incl[r]; 18 = past
+            // the end: an empty load), first record, length
+            const int c = g0 + lane;
+            int r = 0;
+#pragma unroll
+            for (int k = 0; k < kPlanRanges; ++k) r += __builtin_amdgcn_readlane(ch_incl, k) <= c ? 1 : 0;
+            const int base = __shfl(rfrom, r, kWave) + (c - __shfl(ch_excl, r, kWave)) * kPlanRecords;
+            int ln = __shfl(rend, r, kWave) - base;
+            ln = ln < 0 ? 0 : (ln < kPlanRecords ? ln : kPlanRecords);
+            const int start16 = base << 4;
+            unsigned at_b;
+            GRID_LANE_PASS(at_b, start16, ln, at, GRID_CUT, , [cut] "s"(cut));
+            at = at_b;
+          }
+          total = (int)((at - lds_list) >> 4);
+          if (total <= MAXH || round == 1) break;
+          // More hits than the list holds.  Only the nsample SMALLEST indices matter
+          // (ball_query_gpu.cu:24-47 stops at cnt == nsample): the list's first MAXH entries are a
+          // sample of the hits with at least nsample members, so the end of the index bucket where
+          // the sample's running count reaches nsample bounds every index that can matter -- all
+          // passes again, keeping the hits below it.  (The overflow ran over tmp / cnt / off.)
+          L.cnt[lane] = 0;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int e = lane; e < MAXH; e += kWave)
+            atomicAdd(&L.cnt[__umulhi(__builtin_bit_cast(unsigned, L.list[e].w), bucket_mul) & (kWave - 1)], 1);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          const int incl = wave_inclusive_scan(L.cnt[lane]);
+          const int T = __builtin_ctzll(__builtin_amdgcn_ballot_w64(incl >= nsample));
+          // every index of the buckets 0..T is below (T + 2) n / 64 (bucket = floor(index *
+          // floor(64 2^32 / n) / 2^32) >= index 64 / n - 1): a superset is as good as the set
+          if (T + 2 >= kWave) break;  // no bound below the cloud's end: the general path refines it
+          cut = (unsigned)((T + 2) * n) / kWave + 1u;
+          at = lds_list;
         }
+        L.cnt[lane] = 0;  // (the ranking's counters)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
 #undef GRID_PLAN_PASS
 #undef GRID_LEN_PLAN
-      total = (int)((at - lds_list) >> 4);
       listed = total <= MAXH;
     }
     // the compiler's version of the single-load path: both ranges of a seam centroid's rows in one
@@ -640,37 +719,8 @@ grid_query_kernel(const QueryArgs a) {
 #if GRID_ASM_ROWS
         // row starts and lengths sit in lanes 0..8 of two registers: lane reads
         const int start16 = vrow << 4;
-        unsigned at, at2, stmp, so0, so1, so2, so3, so4, so5, so6, so7, so8;  // scalar temporaries of the block
-#define GRID_LEN_LANE(R) "v_readlane_b32 %[tmp], %[len], " #R "\n"
-        asm volatile(
-            "s_mov_b32 %[at2], %[lds]\n"
-            "v_readlane_b32 %[so0], %[start], 0\n"
-            "v_readlane_b32 %[so1], %[start], 1\n"
-            "v_readlane_b32 %[so2], %[start], 2\n"
-            "v_readlane_b32 %[so3], %[start], 3\n"
-            "v_readlane_b32 %[so4], %[start], 4\n"
-            "v_readlane_b32 %[so5], %[start], 5\n"
-            "v_readlane_b32 %[so6], %[start], 6\n"
-            "v_readlane_b32 %[so7], %[start], 7\n"
-            "v_readlane_b32 %[so8], %[start], 8\n"
-            GRID_ROWS_LOADS
-            GRID_ROW(GRID_LEN_LANE(0), 28, 29, 30, 31, 8, "at2", "at")
-            GRID_ROW(GRID_LEN_LANE(1), 32, 33, 34, 35, 7, "at", "at2")
-            GRID_ROW(GRID_LEN_LANE(2), 36, 37, 38, 39, 6, "at2", "at")
-            GRID_ROW(GRID_LEN_LANE(3), 40, 41, 42, 43, 5, "at", "at2")
-            GRID_ROW(GRID_LEN_LANE(4), 44, 45, 46, 47, 4, "at2", "at")
-            GRID_ROW(GRID_LEN_LANE(5), 48, 49, 50, 51, 3, "at", "at2")
-            GRID_ROW(GRID_LEN_LANE(6), 52, 53, 54, 55, 2, "at2", "at")
-            GRID_ROW(GRID_LEN_LANE(7), 56, 57, 58, 59, 1, "at", "at2")
-            GRID_ROW(GRID_LEN_LANE(8), 60, 61, 62, 63, 0, "at2", "at")
-            "s_mov_b64 exec, -1\n"
-            : [at] "=&s"(at), [at2] "=&s"(at2), [tmp] "=&s"(stmp), [so0] "=&s"(so0), [so1] "=&s"(so1),
-              [so2] "=&s"(so2), [so3] "=&s"(so3), [so4] "=&s"(so4), [so5] "=&s"(so5), [so6] "=&s"(so6),
-              [so7] "=&s"(so7), [so8] "=&s"(so8)
-            : [start] "v"(start16), [len] "v"(lrow), [lane16] "v"(lane16), [rsrc] "s"(rsrc),
-              [cxy] "s"(cxy), [cz] "s"(cz), [r2] "s"(radius2), [lds] "s"(lds_list)
-            : GRID_ROWS_CLOBBERS);
-#undef GRID_LEN_LANE
+        unsigned at;
+        GRID_LANE_PASS(at, start16, lrow, lds_list, GRID_NOCUT);
         total = (int)((at - lds_list) >> 4);
         if (total > MAXH) fast = false;
 #else
@@ -680,7 +730,11 @@ grid_query_kernel(const QueryArgs a) {
         total = one_load_rows(std::true_type{});
       }
     }
+#undef GRID_LANE_PASS
+#undef GRID_LEN_LANE
 #undef GRID_ROW
+#undef GRID_CUT
+#undef GRID_NOCUT
 #undef GRID_ROWS_LOADS
 #undef GRID_ROWS_CLOBBERS
 #ifdef GRID_PROBE

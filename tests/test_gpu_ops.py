@@ -368,6 +368,39 @@ def test_query_plans_left_by_the_sampling_kernel(ext, oracle_omp, synth, kind, s
     assert np.array_equal(idx_m.cpu().numpy(), oracle_omp.ball_query(new_xyz.cpu().numpy(), xyz, r, ns))
 
 
+@pytest.mark.parametrize("ns", [64, 128])
+def test_query_plans_dense_balls(ext, oracle_omp, synth, ns):
+    """Balls with far more hits than the hit list holds, answered from the plans: blobs of 2000 and
+    600 points with indices spread over the cloud (the sample's index histogram gives a cut, all
+    passes run again below it), one blob of 2500 CONSECUTIVE indices (one index bucket alone
+    overflows the list: the general path's bucket refinement decides) and one at the lattice seam
+    (x around 0: wrapped cells AND long rows).  Rows = the oracle's (ball_query_gpu.cu:24-47 stops
+    at cnt == nsample: only the nsample smallest indices matter)."""
+    g = np.random.default_rng(77 + ns)
+    b, n, m, r = 2, 40000, 2048, 0.2
+    xyz = synth.cloud_uniform(b, n, 3.0, seed=9)
+    perm = g.permutation(n)
+    xyz[0, perm[:2000]] = 1.0 + g.random((2000, 3), dtype=np.float32) * 0.1
+    xyz[0, perm[2000:2600]] = np.array([2.0, 1.5, 0.7], np.float32) + g.random((600, 3), dtype=np.float32) * 0.15
+    xyz[1, 5000:7500] = 1.7 + g.random((2500, 3), dtype=np.float32) * 0.12
+    xyz[1, perm[:900]] = np.array([-0.05, 1.0, 1.0], np.float32) + g.random((900, 3), dtype=np.float32) * 0.12
+    d_xyz = dev(xyz)
+    fps, lists = ext.furthest_point_sampling_with_grid(d_xyz, m, r)
+    new_xyz = ext.gather_points(d_xyz.transpose(1, 2).contiguous(), fps).transpose(1, 2).contiguous()
+    lists.mark_centroids(new_xyz, fps)
+    assert lists.centroids_are_picks(new_xyz)
+    feat = torch.rand(b, 1, n, device=d_xyz.device)
+    idx, grouped = ext.query_and_group(new_xyz, d_xyz, feat, r, ns, False, None, lists)
+    cen = new_xyz.cpu().numpy()
+    want = oracle_omp.ball_query(cen, xyz, r, ns)
+    # (the blobs hold picks: some balls have hundreds of hits)
+    d2 = ((xyz[0][None, :, :] - cen[0][:, None, :]) ** 2).sum(-1)
+    assert int(((d2 < r * r).sum(1) > 256).sum()) >= 1
+    assert np.array_equal(idx.cpu().numpy(), want)
+    ref = np.take_along_axis(xyz[:, None, :, :], want[:, :, :, None].astype(np.int64), axis=2) - cen[:, :, None, :]
+    assert np.array_equal(bits(grouped[:, :3].permute(0, 2, 3, 1).cpu().numpy()), bits(ref.astype(np.float32)))
+
+
 def test_query_plans_need_room(ext, oracle_omp, synth):
     """More centroids than the object has plans for (m > n / 8): the sampling kernel writes none and
     pn2_query_and_group_picks is pn2_query_and_group_prebuilt."""

@@ -77,6 +77,7 @@ for kind in ("U", "R", "step"):
     r = {"classes": {}}
     for name, msk in (("plan_one_pass", path == 1), ("plan_two_passes", path == 2),
                       ("computed_single_load", path == 3), ("computed_seam", path == 4),
+                      ("index_order_scan", path == 5),
                       ("fast", sweeps == 0), ("general_1_8_chunks", (sweeps > 0) & (chunks <= 8)),
                       ("general_9_16_chunks", (sweeps > 0) & (chunks > 8) & (chunks <= 16)),
                       ("general_17_24_chunks", (sweeps > 0) & (chunks > 16) & (chunks <= 24)),
