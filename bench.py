@@ -680,7 +680,7 @@ def main():
                 rows = {r["kernel"]: r for r in csv.DictReader(open(ss))}
                 for op_name, kern in (
                         ("fps_40000_2048_with_cell_lists", "fps_bucket_rounds_kernel<8, 2, 2>"),
-                        ("query_and_group_sa1_fused_kernel", "grid_query_kernel<192, 1, true>"),
+                        ("query_and_group_sa1_fused_kernel", "grid_query_kernel<192, 1, true, true, 1>"),
                         ("group_grad_sa2_c128", "group_points_grad_sorted_kernel<32>"),
                         ("group_inverse_sa2", "group_inverse_kernel"),
                         ("three_interpolate_gridconv", "three_interpolate_lds_kernel<8>"),
@@ -693,23 +693,32 @@ def main():
                         table[op_name]["in_step_us_per_launch"] = round(float(r_["us_per_step"]) / n_l, 2)
                         table[op_name]["in_step_kernel"] = "%s (%s launches per step; profiles/%s)" % (
                             kern, r_["launches_per_step"], os.path.basename(ss))
+            # the same kernel inside the timed step (beside the main stream's GEMMs), from the
+            # committed rocprofv3 summary of the timed steps -- not from this run
+            in_step = table.get("query_and_group_sa1_fused_kernel", {}).get("in_step_us_per_launch")
             out["roofline"] = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": source,
-                "kernel": "grid_query_kernel<192,1,true>: ball_query + group_points(xyz,C=3) + "
+                "kernel": "grid_query_kernel<192,1,true,true,1>: ball_query + group_points(xyz,C=3) + "
                           "group_points(feat,C=1) in ONE launch @ B=8 N=40000 m=2048 ns=64, on the "
-                          "cell lists the layer's furthest-point-sampling kernel leaves behind; "
-                          "duration = the slowest of cloud U(L), cloud R and the timed step's own "
-                          "batch (here: %s)" % worst,
+                          "cell lists and query plans the layer's furthest-point-sampling kernel "
+                          "leaves behind; duration = the slowest of cloud U(L), cloud R and the "
+                          "timed step's own batch (here: %s)" % worst,
                 "algorithmic_bytes": PAIR_BYTES, "duration_us": round(layer_us, 2),
+                "in_step_us": in_step,
+                "in_step_frac": None if not in_step else round(PAIR_BYTES / (in_step * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "in_step_source": None if not ss else "profiles/%s (rocprofv3 --kernel-trace of the timed steps: "
+                                  "the kernel runs on the prefetch stream beside the main stream's GEMMs)"
+                                  % os.path.basename(ss),
                 # how far this decomposition (one wave per centroid on cell lists) can go: a skeleton
                 # of the nine row loads + the stores of the pair alone (no tests, no ranking)
                 "floor": {"us": 13.0, "frac": round(PAIR_BYTES / 13.0e-6 / 1e9 / HBM_PEAK_GBS, 4),
                           "source": "tools/micro/td_rate.py (profiles/r3_vector_memory_microbench.json: "
-                                    "12.8-13.3 us for 16 384 waves x 9 row loads + the pair's stores); the "
-                                    "kernel itself is instruction-issue bound: ~700 wave instructions per "
-                                    "centroid x 4 cycles x 16 centroids per SIMD = 18.7 us"},
+                                    "12.8-13.3 us for 16 384 waves x 9 row loads + the pair's stores); "
+                                    "round 6: 186 vector + 250 scalar instructions per centroid "
+                                    "(profiles/r6_pair_sq_counters.csv; rounds 4-5: 345 + 288), texture "
+                                    "data path ~70 % busy"},
                 "forms": {k: {"us": round(v, 2),
                               "frac": round(PAIR_BYTES / (v * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
                           for k, v in forms.items()},

@@ -20,8 +20,9 @@ PAIR_BYTES = 38516736
 KERNELS = {  # substring -> role
     "grid_split_kernel": "cell-list build, pass 1 (split by z-layer)",
     "grid_bin_kernel": "cell-list build, pass 2 (CSR rows of a layer)",
-    "grid_query_kernel<192, 1, true>": "fused ball query + gathers (the dominant kernel)",
-    "grid_query_kernel<192, 1, false>": "ball query only (reference operator surface)",
+    "grid_query_kernel<192, 1, true, true, 1>": "fused ball query + gathers from the sampling kernel's query plans (the dominant kernel: the `layer` form)",
+    "grid_query_kernel<192, 1, true, false, 1>": "fused ball query + gathers, rows computed by the wave (self-contained form)",
+    "grid_query_kernel<192, 1, false, false, 1>": "ball query only (reference operator surface)",
     "group_points_lds_kernel": "group_points (reference operator surface), two launches per pair",
 }
 
@@ -53,7 +54,8 @@ def main():
                                "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
                                "hbm_bytes_corrected": int((2 * f + w) * 1024),
                                "avg_us_under_profiler": None if d is None else round(d, 2)})
-    fused = next((k for k in out["kernels"] if "1, true>" in k["kernel"]), None)
+    fused = next((k for k in out["kernels"] if "1, true, true, 1>" in k["kernel"]), None) or \
+        next((k for k in out["kernels"] if "1, true, false, 1>" in k["kernel"]), None)
     if fused:
         out["traffic_bytes_fused_kernel"] = fused["hbm_bytes_corrected"]
         out["traffic_over_algorithmic"] = round(fused["hbm_bytes_corrected"] / PAIR_BYTES, 3)

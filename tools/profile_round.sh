@@ -14,21 +14,21 @@ run step rocprofv3 --kernel-trace --stats --output-format csv -d $P/step -o step
 python tools/step_breakdown.py $P/step/step_kernel_trace.csv 20 400 $O/${TAG}_train_step_timed_summary.csv > $O/step_breakdown.txt 2>&1
 run semi rocprofv3 --kernel-trace --stats --output-format csv -d $P/semi -o step -- python bench.py --workload semi --steps 20 --warmup 5 --no-kernels --no-cpu-baseline
 python tools/step_breakdown.py $P/semi/step_kernel_trace.csv 20 400 $O/${TAG}_semi_step_timed_summary.csv > $O/semi_breakdown.txt 2>&1
-# -- the north-star pair
-run pair_stats rocprofv3 --kernel-trace --stats --output-format csv -d $P/pair -o pair -- python tools/pair_bench.py 10 --plain
+# -- the north-star pair: the `layer` form ALONE (one form per kernel name in every stats / counter file)
+run pair_stats rocprofv3 --kernel-trace --stats --output-format csv -d $P/pair -o pair -- python tools/pair_bench.py 10 --plain --only layer
 cp $P/pair/pair_kernel_stats.csv $O/${TAG}_pair_kernel_stats.csv
 cp $P/pair/pair_kernel_stats.csv $O/${TAG}_pair_kernel_stats_U.csv
 # -- the same on cloud R and on the timed step's own batch (bench.pair_cloud)
 for c in R step; do
-  run pair_stats_$c rocprofv3 --kernel-trace --stats --output-format csv -d $P/pair_$c -o pair -- python tools/pair_bench.py 10 --plain --cloud $c
+  run pair_stats_$c rocprofv3 --kernel-trace --stats --output-format csv -d $P/pair_$c -o pair -- python tools/pair_bench.py 10 --plain --only layer --cloud $c
   cp $P/pair_$c/pair_kernel_stats.csv $O/${TAG}_pair_kernel_stats_$c.csv
 done
-timeout 120 python tools/micro/grid_probe.py $O/${TAG}_pair_centroid_clocks.json > /dev/null 2> $O/grid_probe.log; echo "grid_probe rc=$?"
-run pair_fetch rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pf -o pair -- python tools/pair_bench.py 5 --plain
-run pair_write rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pw -o pair -- python tools/pair_bench.py 5 --plain
+timeout 120 python tools/micro/grid_probe.py $O/${TAG}_pair_centroid_clocks.json --layer > /dev/null 2> $O/grid_probe.log; echo "grid_probe rc=$?"
+run pair_fetch rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pf -o pair -- python tools/pair_bench.py 5 --plain --only layer
+run pair_write rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pw -o pair -- python tools/pair_bench.py 5 --plain --only layer
 python tools/pair_pmc.py $P/pf/pair_counter_collection.csv $P/pw/pair_counter_collection.csv $P/pair/pair_kernel_stats.csv $O/${TAG}_pair_pmc.json > $O/pair_pmc.txt 2>&1
-run pair_sq rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $P/psq -o pair -- python tools/pair_bench.py 3 --plain
-run pair_mem rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TD_TD_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum SQ_BUSY_CYCLES SQ_LDS_IDX_ACTIVE --output-format csv -d $P/pmem -o pair -- python tools/pair_bench.py 3 --plain
+run pair_sq rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $P/psq -o pair -- python tools/pair_bench.py 3 --plain --only layer
+run pair_mem rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TD_TD_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum SQ_BUSY_CYCLES SQ_LDS_IDX_ACTIVE --output-format csv -d $P/pmem -o pair -- python tools/pair_bench.py 3 --plain --only layer
 python tools/pmc_table.py $O/${TAG}_pair_sq_counters.csv --filter grid_ $P/psq/pair_counter_collection.csv $P/pmem/pair_counter_collection.csv > /dev/null 2>&1
 # -- VALU-bound operators
 run ops_valu rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d $P/ops -o ops -- python tools/op_bench.py 3
