@@ -42,9 +42,14 @@ def test_bench_default_line_has_roofline_and_cpu_baseline():
     # the pair's algorithmic bytes -- it never re-reads the index array and reads 16-byte records
     assert roof["traffic"] is None or (roof["traffic_source"] and 0 < roof["traffic"] < 2 * roof["algorithmic_bytes"])
     forms = roof["forms"]
-    assert set(forms) == {"layer", "self_contained", "reference_api_3_calls",
+    assert set(forms) == {"layer", "layer_no_plan", "self_contained", "reference_api_3_calls",
                           "reference_api_3_calls_cached_lists", "layer_rotating_inputs",
                           "layer_cloud_R", "layer_cloud_step"}
+    # the sampling kernel's query plans pay (round 6); the step's own launch of the kernel rides
+    # along, from the committed rocprofv3 summary of the timed steps
+    assert forms["layer"]["us"] < 1.05 * forms["layer_no_plan"]["us"]
+    assert roof["in_step_us"] is None or (roof["in_step_source"] and abs(
+        roof["in_step_frac"] - roof["algorithmic_bytes"] / (roof["in_step_us"] * 1e-6) / 8e12) < 1e-3)
     # (replays on one input set find their reads in L2 / MALL; twelve rotating sets do not)
     assert 0.8 * forms["layer"]["us"] < forms["layer_rotating_inputs"]["us"] < 2.5 * forms["layer"]["us"]
     # the headline duration is the SLOWEST of the three clouds the kernel is quoted on
