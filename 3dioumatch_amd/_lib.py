@@ -58,16 +58,16 @@ _SIGNATURES = {
     "pn2_error_string": [_c_int],
     "mlp_bn_workspace_floats": [_c_int, _c_int, _c_int],
     "mlp_bn_train_stats": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _c_float, _c_float, _vp, _vp, _vp,
-                           _vp, _vp, _vp, _vp, _vp],
+                           _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_bn_eval_coeff": [_c_int, _vp, _vp, _c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_bn_relu_apply": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "mlp_bn_relu_pool": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_bn_relu_backward": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                             _vp, _vp, _vp, _vp, _vp],
+                             _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_bn_relu_pool_backward": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp,
-                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_bn_relu_backward_stats": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp,
-                                   _vp, _vp, _vp, _vp, _vp, _vp],
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_gemm_forward": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp, _vp, _vp],
     "mlp_gemm_forward_stats_parts": [_c_int, _c_int, _c_int, _c_int, _vp],
     "mlp_gemm_forward_stats": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp, _vp, _vp, _vp],
@@ -90,7 +90,6 @@ _SIGNATURES = {
     "mlp_gemm_forward_stats_pool_supported": [_c_int, _c_int, _c_int, _c_int, _c_int],
     "mlp_gemm_forward_stats_pool": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c_int,
                                     _vp, _vp, _vp],
-    "mlp_bn_reset_tickets": [],
     "mlp_pool_gram_supported": [_c_int, _c_int, _c_int, _c_int, _c_int],
     "mlp_pool_gram_parts": [_c_int, _c_int],
     "mlp_pool_gram_workspace_floats": [_c_int, _c_int],

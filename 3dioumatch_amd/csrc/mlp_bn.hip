@@ -48,10 +48,11 @@ __device__ __forceinline__ void block_sum2(float &a, float &b, float *scratch) {
 // workgroup takes a ticket for its channel (an agent-scope release fence, then an atomic add) and
 // the one that draws the last ticket reads all partials of the channel back -- in the same fixed
 // order as the separate kernel, so the result does not depend on who is last -- and finalizes.
-// The counters return to zero (the last workgroup resets its own), so launches on one stream
-// need no memset; the families use separate counters.
-constexpr int kMaxTicketChannels = 4096;
-__device__ int bn_tickets[kMaxTicketChannels];  // default counters (see tickets_for)
+// The counters return to zero (the last workgroup resets its own), so launches that are ordered
+// one after the other need no memset and may share an array.  The array is the CALLER's
+// (include/mlp_hip.h, `tickets`): the library keeps no counters of its own and no table keyed by
+// stream -- two launches that may overlap (two streams, two graphs replayed side by side) are
+// given two arrays by whoever owns the modules they belong to.
 
 // Partials travel between workgroups (possibly on different XCDs, whose L2s are not coherent with
 // one another) as agent-scope RELAXED atomics: write-through stores (sc1) and cache-bypassing
@@ -106,7 +107,7 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 }
 
 struct FwdFinalize {
-  int *tickets;  // one counter per channel, zero between launches (tickets_for(stream))
+  int *tickets;  // one counter per channel, zero between launches (the caller's array)
   const float *gamma, *beta;
   float eps, momentum;
   float *running_mean, *running_var, *mean_out, *invstd_out, *scale_out, *shift_out;
@@ -405,7 +406,7 @@ pool_from_extrema_kernel(int c, int groups, long long total, const float *__rest
 // dgamma = s2, dbeta = s1, and the per-channel coefficients of dy (training mode); one wave
 // per channel
 struct BwdFinalize {
-  int *tickets;  // one counter per channel, zero between launches (tickets_for(stream))
+  int *tickets;  // one counter per channel, zero between launches (the caller's array)
   double count;
   int training;
   const float *gamma, *invstd;
@@ -591,90 +592,8 @@ int slices_for(int r) {
 
 }  // namespace
 
-#include <mutex>
-#include <unordered_map>
-
-// Ticket counters of a launch.  Launches on ONE stream run one after the other and may share an
-// array (every launch leaves it zeroed); launches on different streams may overlap, so every stream
-// gets its own array on first use (a stream first seen while it is being captured into a graph
-// cannot allocate: it shares the default array, which is safe as long as that graph is not
-// replayed beside another user of the default array -- the train step runs these kernels on its
-// main stream only).
-namespace {
-struct TicketKey {
-  int device; hipStream_t stream;
-  bool operator==(const TicketKey &o) const { return device == o.device && stream == o.stream; }
-};
-struct TicketKeyHash {
-  size_t operator()(const TicketKey &k) const {
-    return std::hash<const void *>()(k.stream) * 31u + (size_t)k.device;
-  }
-};
-std::mutex ticket_mu;
-std::unordered_map<TicketKey, int *, TicketKeyHash> ticket_table;   // (device, stream) -> own array
-std::unordered_map<int, int *> ticket_fallback;                     // device -> its bn_tickets symbol
-}  // namespace
-
-// The arrays are per DEVICE (the __device__ symbol has one instance per device: its address is
-// resolved with that device current -- the launch that follows runs there) and per stream.
-static int *tickets_for(hipStream_t stream) {
-  std::lock_guard<std::mutex> lock(ticket_mu);
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  int *fallback = nullptr;
-  auto fb = ticket_fallback.find(dev);
-  if (fb != ticket_fallback.end()) {
-    fallback = fb->second;
-  } else {
-    if (hipGetSymbolAddress(reinterpret_cast<void **>(&fallback), HIP_SYMBOL(bn_tickets)) != hipSuccess)
-      return nullptr;
-    ticket_fallback.emplace(dev, fallback);
-  }
-  if (stream == nullptr) return fallback;
-  const TicketKey key = {dev, stream};
-  auto it = ticket_table.find(key);
-  if (it != ticket_table.end()) return it->second;
-  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone || ticket_table.size() >= 256)
-    return fallback;
-  int *buf = nullptr;
-  // cleared ON the stream that will use it: a hipMemset on the null stream is not ordered before a
-  // kernel on a non-blocking stream (the first launch on a fresh stream met counters that were
-  // still being cleared: tests/test_gpu_mlp.py::test_reductions_on_two_streams_at_once, 1 run in 4)
-  if (hipMalloc(reinterpret_cast<void **>(&buf), sizeof(int) * kMaxTicketChannels) != hipSuccess)
-    return fallback;
-  if (hipMemsetAsync(buf, 0, sizeof(int) * kMaxTicketChannels, stream) != hipSuccess) {
-    (void)hipFree(buf);
-    return fallback;
-  }
-  ticket_table.emplace(key, buf);
-  return buf;
-}
 
 #define MLP_API extern "C" __attribute__((visibility("default")))
-
-// Zero every ticket array of the CURRENT device (after a faulted / aborted launch left a counter
-// non-zero: no workgroup would ever be "last" again).  Synchronises the device.  Returns 0 or a
-// HIP error.
-MLP_API int mlp_bn_reset_tickets(void) {
-  std::lock_guard<std::mutex> lock(ticket_mu);
-  int dev = 0;
-  hipError_t rc = hipGetDevice(&dev);
-  if (rc != hipSuccess) return (int)rc;
-  rc = hipDeviceSynchronize();
-  if (rc != hipSuccess) return (int)rc;
-  auto fb = ticket_fallback.find(dev);
-  if (fb != ticket_fallback.end()) {
-    rc = hipMemset(fb->second, 0, sizeof(int) * kMaxTicketChannels);
-    if (rc != hipSuccess) return (int)rc;
-  }
-  for (auto &kv : ticket_table) {
-    if (kv.first.device != dev) continue;
-    rc = hipMemset(kv.second, 0, sizeof(int) * kMaxTicketChannels);
-    if (rc != hipSuccess) return (int)rc;
-  }
-  return (int)hipDeviceSynchronize();
-}
 
 // number of floats of scratch the statistics kernels need
 MLP_API size_t mlp_bn_workspace_floats(int b, int c, int r) {
@@ -685,12 +604,11 @@ MLP_API size_t mlp_bn_workspace_floats(int b, int c, int r) {
 MLP_API int mlp_bn_train_stats(int b, int c, int r, const float *y, const float *gamma,
                                const float *beta, float eps, float momentum, float *running_mean,
                                float *running_var, float *mean, float *invstd, float *scale,
-                               float *shift, float *workspace, void *stream_) {
+                               float *shift, float *workspace, int *tickets, void *stream_) {
   if (b <= 0 || c <= 0 || r <= 0) return 0;
   hipStream_t stream = (hipStream_t)stream_;
   const int slices = slices_for(r);
-  if (c > kMaxTicketChannels) return (int)hipErrorInvalidValue;
-  const FwdFinalize fin = {tickets_for(stream), gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
+  const FwdFinalize fin = {tickets, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
   if (fin.tickets == nullptr) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(bn_partial_stats_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream, c,
                      r, slices, y, workspace, fin);
@@ -710,7 +628,7 @@ MLP_API int mlp_bn_finalize_pairs(int c, int parts, int n_part, const float *pai
                                   float *invstd, float *scale, float *shift, void *scratch,
                                   void *stream_) {
   if (c <= 0 || parts <= 0 || n_part <= 0) return 0;
-  if (!scratch || c > kMaxTicketChannels * kWave) return (int)hipErrorInvalidValue;
+  if (!scratch) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
   double *sums = reinterpret_cast<double *>(scratch);
   const FwdFinalize fin = {nullptr, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
@@ -771,14 +689,14 @@ MLP_API int mlp_bn_relu_backward(int b, int c, int r, int training, const float 
                                  const float *dz, const float *gamma, const float *scale,
                                  const float *shift, const float *mean, const float *invstd,
                                  float *dy, float *dgamma, float *dbeta, float *coef,
-                                 float *workspace, void *stream_) {
+                                 float *workspace, int *tickets, void *stream_) {
   if (b <= 0 || c <= 0 || r <= 0) return 0;
-  if (c > kMaxTicketChannels) return (int)hipErrorInvalidValue;
+  if (tickets == nullptr) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
   const int slices = slices_for(r);
   hipLaunchKernelGGL(bn_relu_bwd_partial_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream,
                      c, r, slices, y, dz, scale, shift, mean, invstd, workspace,
-                     BwdFinalize{tickets_for(stream), (double)b * (double)r, training, gamma, invstd, dgamma, dbeta, coef});
+                     BwdFinalize{tickets, (double)b * (double)r, training, gamma, invstd, dgamma, dbeta, coef});
   if (r % 4 == 0)
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<true>, dim3(pn2_ceil_div(r, 1024), c, b), dim3(256),
                        0, stream, c, r, y, dz, scale, shift, mean, invstd, coef, dy);
@@ -793,14 +711,14 @@ MLP_API int mlp_bn_relu_backward_stats(int b, int c, int r, int training, const 
                                        const float *dz, const float *gamma, const float *scale,
                                        const float *shift, const float *mean, const float *invstd,
                                        float *dgamma, float *dbeta, float *coef, float *workspace,
-                                       void *stream_) {
+                                       int *tickets, void *stream_) {
   if (b <= 0 || c <= 0 || r <= 0) return 0;
-  if (c > kMaxTicketChannels) return (int)hipErrorInvalidValue;
+  if (tickets == nullptr) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
   const int slices = slices_for(r);
   hipLaunchKernelGGL(bn_relu_bwd_partial_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream,
                      c, r, slices, y, dz, scale, shift, mean, invstd, workspace,
-                     BwdFinalize{tickets_for(stream), (double)b * (double)r, training, gamma, invstd, dgamma, dbeta, coef});
+                     BwdFinalize{tickets, (double)b * (double)r, training, gamma, invstd, dgamma, dbeta, coef});
   return pn2_launch_status();
 }
 
@@ -834,13 +752,13 @@ MLP_API int mlp_bn_relu_pool_backward(int b, int c, int m, int ns, int training,
                                       const float *gamma, const float *scale, const float *shift,
                                       const float *mean, const float *invstd, float *dy,
                                       float *dgamma, float *dbeta, float *coef, float *workspace,
-                                      void *stream_) {
+                                      int *tickets, void *stream_) {
   if (b <= 0 || c <= 0 || m <= 0 || ns <= 0) return 0;
-  if (c > kMaxTicketChannels) return (int)hipErrorInvalidValue;
+  if (tickets == nullptr) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
   hipLaunchKernelGGL(pool_bwd_partial_kernel, dim3(1, c, b), dim3(kBnThreads), 0, stream, c, m,
                      dpooled, ymax, scale, shift, mean, invstd, workspace,
-                     BwdFinalize{tickets_for(stream), (double)b * (double)m * (double)ns, training, gamma, invstd,
+                     BwdFinalize{tickets, (double)b * (double)m * (double)ns, training, gamma, invstd,
                                  dgamma, dbeta, coef});
   if (dy == nullptr) return pn2_launch_status();  // statistics only (mlp_gemm_*_pooled form dy)
   const long long r = (long long)m * ns;

@@ -22,7 +22,34 @@ def _ws(y, b, c, r):
     return torch.empty(max(n, 1), dtype=torch.float32, device=y.device)
 
 
-def bn_coefficients(y, gamma, beta, running_mean, running_var, momentum, eps, training):
+def new_tickets(channels, device):
+    """The counters of the one-launch reductions (include/mlp_hip.h, `tickets`): `channels` ints,
+    zero between launches.  Owned by whoever owns the layers -- the library keeps none."""
+    return torch.zeros(max(int(channels), 1), dtype=torch.int32, device=device)
+
+
+def tickets_of(module, channels, device):
+    """The ticket array of `module`: a plain attribute `_pn2_tickets`, created on first use on the
+    device of the module's input (again after a move), copied by deepcopy -- not a registered
+    buffer, so named_buffers() / state_dict() stay the reference's.  One array per module: two
+    modules -- a student and its teacher -- may run side by side on any two streams."""
+    t = module.__dict__.get("_pn2_tickets")
+    if t is None or t.device != device or t.numel() < channels:
+        t = new_tickets(channels, device)
+        module.__dict__["_pn2_tickets"] = t
+    return t
+
+
+def _tk(tickets, c, ref):
+    if tickets is None:  # a caller without a module (tests, tools): a fresh zeroed array per call
+        return new_tickets(c, ref.device)
+    if tickets.dtype != torch.int32 or tickets.device != ref.device or tickets.numel() < c or \
+            not tickets.is_contiguous():
+        raise RuntimeError("tickets must be a contiguous int32 tensor of >= %d zeros on %s" % (c, ref.device))
+    return tickets
+
+
+def bn_coefficients(y, gamma, beta, running_mean, running_var, momentum, eps, training, tickets=None):
     """y (B,C,...) -> per-channel (mean, invstd, scale, shift); training=True uses (and folds
     into running_*) the batch statistics, otherwise the running statistics."""
     _f32c(y, "y")
@@ -38,7 +65,8 @@ def bn_coefficients(y, gamma, beta, running_mean, running_var, momentum, eps, tr
             _L.check(_lib.mlp_bn_train_stats(b, c, r, y.data_ptr(), gamma.data_ptr(),
                                              beta.data_ptr(), float(eps), float(momentum), rm, rv,
                                              mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
-                                             shift.data_ptr(), ws.data_ptr(), _stream(y)),
+                                             shift.data_ptr(), ws.data_ptr(),
+                                             _tk(tickets, c, y).data_ptr(), _stream(y)),
                      "mlp_bn_train_stats")
         else:
             _L.check(_lib.mlp_bn_eval_coeff(c, gamma.data_ptr(), beta.data_ptr(), float(eps),
@@ -71,7 +99,7 @@ def bn_relu_pool(y, scale, shift):
     return pooled, argmax, ymax
 
 
-def bn_relu_backward(y, dz, gamma, scale, shift, mean, invstd, training):
+def bn_relu_backward(y, dz, gamma, scale, shift, mean, invstd, training, tickets=None):
     _f32c(dz, "dz")
     b, c = y.shape[0], y.shape[1]
     r = y.numel() // (b * c)
@@ -83,12 +111,14 @@ def bn_relu_backward(y, dz, gamma, scale, shift, mean, invstd, training):
                                            dz.data_ptr(), gamma.data_ptr(), scale.data_ptr(),
                                            shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                            dy.data_ptr(), small[0].data_ptr(), small[1].data_ptr(),
-                                           small[2:].data_ptr(), ws.data_ptr(), _stream(y)),
+                                           small[2:].data_ptr(), ws.data_ptr(),
+                                           _tk(tickets, c, y).data_ptr(), _stream(y)),
                  "mlp_bn_relu_backward")
     return dy, small[0], small[1]
 
 
-def bn_relu_pool_backward(y, dpooled, argmax, ymax, gamma, scale, shift, mean, invstd, training):
+def bn_relu_pool_backward(y, dpooled, argmax, ymax, gamma, scale, shift, mean, invstd, training,
+                          tickets=None):
     _f32c(dpooled, "dpooled")
     b, c, m, ns = y.shape
     dy = torch.empty_like(y)
@@ -101,13 +131,14 @@ def bn_relu_pool_backward(y, dpooled, argmax, ymax, gamma, scale, shift, mean, i
                                                 scale.data_ptr(), shift.data_ptr(),
                                                 mean.data_ptr(), invstd.data_ptr(), dy.data_ptr(),
                                                 small[0].data_ptr(), small[1].data_ptr(),
-                                                small[2:].data_ptr(), ws.data_ptr(), _stream(y)),
+                                                small[2:].data_ptr(), ws.data_ptr(),
+                                                _tk(tickets, c, y).data_ptr(), _stream(y)),
                  "mlp_bn_relu_pool_backward")
     return dy, small[0], small[1]
 
 
 def bn_relu_pool_backward_stats(y, dpooled, argmax, ymax, gamma, scale, shift, mean, invstd,
-                                training, ns=None):
+                                training, ns=None, tickets=None):
     """-> dgamma, dbeta, coef (C,3) of the pooled last layer; dy itself is formed inside
     gemm_dgrad / gemm_wgrad (pooled=...).  y is only asked for its shape (B,C,m,ns): with ns given
     it may be None (a layer whose raw output was never stored)."""
@@ -126,7 +157,8 @@ def bn_relu_pool_backward_stats(y, dpooled, argmax, ymax, gamma, scale, shift, m
                                                 scale.data_ptr(), shift.data_ptr(),
                                                 mean.data_ptr(), invstd.data_ptr(), None,
                                                 small[0].data_ptr(), small[1].data_ptr(),
-                                                small[2:].data_ptr(), ws.data_ptr(), _stream(y)),
+                                                small[2:].data_ptr(), ws.data_ptr(),
+                                                _tk(tickets, c, y).data_ptr(), _stream(y)),
                  "mlp_bn_relu_pool_backward(stats)")
     return small[0], small[1], small[2:]
 
@@ -234,7 +266,8 @@ def gemm_forward(w, x, coeff=None):
     return y
 
 
-def gemm_forward_bn(w, x, coeff, gamma, beta, running_mean, running_var, momentum, eps, pool=False):
+def gemm_forward_bn(w, x, coeff, gamma, beta, running_mean, running_var, momentum, eps, pool=False,
+                    tickets=None):
     """Training-mode layer: y = gemm_forward(w, x, coeff) and the BatchNorm coefficients of y
     (mean, invstd, scale, shift), with the batch statistics reduced in the GEMM epilogue when the
     shape allows (no second pass over y), else by bn_coefficients.
@@ -251,7 +284,7 @@ def gemm_forward_bn(w, x, coeff, gamma, beta, running_mean, running_var, momentu
     if parts <= 0:
         y = gemm_forward(w, x, coeff)
         return (y,) + tuple(bn_coefficients(y, gamma, beta, running_mean, running_var, momentum,
-                                            eps, True)) + ((None,) if pool else ())
+                                            eps, True, tickets)) + ((None,) if pool else ())
     ns = x.shape[3] if (pool and x.dim() == 4) else 0
     pooled = bool(ns) and coeff is not None and w.data_ptr() % 16 == 0 and \
         bool(_lib.mlp_gemm_forward_stats_pool_supported(b, m, k, r, ns))
@@ -302,7 +335,7 @@ def pool_from_extrema(ext, scale, shift):
     return pooled, argmax, ymax
 
 
-def bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, training):
+def bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, training, tickets=None):
     """-> dgamma, dbeta, coef (C,3): everything the on-the-fly dy needs."""
     _f32c(dz, "dz")
     b, c = y.shape[0], y.shape[1]
@@ -315,7 +348,8 @@ def bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, training):
                                                  shift.data_ptr(), mean.data_ptr(),
                                                  invstd.data_ptr(), small[0].data_ptr(),
                                                  small[1].data_ptr(), small[2:].data_ptr(),
-                                                 ws.data_ptr(), _stream(y)),
+                                                 ws.data_ptr(), _tk(tickets, c, y).data_ptr(),
+                                                 _stream(y)),
                  "mlp_bn_relu_backward_stats")
     return small[0], small[1], small[2:]
 

@@ -94,13 +94,13 @@ class _BNReLU(Function):
     four per-channel vectors; the ReLU mask and x-hat are recomputed in the backward."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, momentum, eps, training):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, momentum, eps, training, tickets=None):
         from pointnet2 import _mlp_ext as K
         y = y.contiguous()
         mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, running_mean, running_var,
-                                                       momentum, eps, training)
+                                                       momentum, eps, training, tickets)
         ctx.save_for_backward(y, gamma, scale, shift, mean, invstd)
-        ctx.training = training
+        ctx.training, ctx.tickets = training, tickets
         return K.bn_relu_apply(y, scale, shift)
 
     @staticmethod
@@ -108,22 +108,22 @@ class _BNReLU(Function):
         from pointnet2 import _mlp_ext as K
         y, gamma, scale, shift, mean, invstd = ctx.saved_tensors
         dy, dgamma, dbeta = K.bn_relu_backward(y, dz.contiguous(), gamma, scale, shift, mean,
-                                               invstd, ctx.training)
-        return dy, dgamma, dbeta, None, None, None, None, None
+                                               invstd, ctx.training, ctx.tickets)
+        return dy, dgamma, dbeta, None, None, None, None, None, None
 
 
 class _BNReLUMaxPool(Function):
     """(B,C,m,ns) -> (B,C,m): max over nsample of relu(batch_norm(y)) in one pass."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, momentum, eps, training):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, momentum, eps, training, tickets=None):
         from pointnet2 import _mlp_ext as K
         y = y.contiguous()
         mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, running_mean, running_var,
-                                                       momentum, eps, training)
+                                                       momentum, eps, training, tickets)
         pooled, argmax, ymax = K.bn_relu_pool(y, scale, shift)
         ctx.save_for_backward(y, gamma, scale, shift, mean, invstd, argmax, ymax)
-        ctx.training = training
+        ctx.training, ctx.tickets = training, tickets
         return pooled
 
     @staticmethod
@@ -131,8 +131,8 @@ class _BNReLUMaxPool(Function):
         from pointnet2 import _mlp_ext as K
         y, gamma, scale, shift, mean, invstd, argmax, ymax = ctx.saved_tensors
         dy, dgamma, dbeta = K.bn_relu_pool_backward(y, dpooled.contiguous(), argmax, ymax, gamma,
-                                                    scale, shift, mean, invstd, ctx.training)
-        return dy, dgamma, dbeta, None, None, None, None, None
+                                                    scale, shift, mean, invstd, ctx.training, ctx.tickets)
+        return dy, dgamma, dbeta, None, None, None, None, None, None
 
 
 class _FusedMLPChain(Function):
@@ -142,7 +142,10 @@ class _FusedMLPChain(Function):
     gradient (backward) on the fly.  Per layer only the raw GEMM output y_i is kept; no
     normalised / rectified activation and no mask is ever written to memory.
 
-    apply(x, pool, training, momenta, epss, pre, w_0, g_0, b_0, rm_0, rv_0, w_1, ...)
+    apply(x, pool, training, momenta, epss, pre, tickets, w_0, g_0, b_0, rm_0, rv_0, w_1, ...)
+
+    tickets = the module's counters for the one-launch reductions (_mlp_ext.tickets_of; None: a
+    fresh zeroed array per reduction).
 
     pre = None, or (idx (B,m,ns) int32, inverse (B,entries) int32, n): the first layer is applied
     BEFORE the gather (csrc/mlp_pregather.hip) -- x is then the packed point-major operand
@@ -150,9 +153,10 @@ class _FusedMLPChain(Function):
     which is never formed: y_0 = (W_0 . src_ext)[.., idx] - (W_0 . src_ext)[.., n + j]."""
 
     @staticmethod
-    def forward(ctx, x, pool, training, momenta, epss, pre, *params):
+    def forward(ctx, x, pool, training, momenta, epss, pre, tickets, *params):
         from pointnet2 import _mlp_ext as K
         n_layers = len(params) // 5
+        ctx.tickets = tickets
         x = x.contiguous()
         ys, coefs = [], []
         cur, cur_coeff = x, None
@@ -207,7 +211,7 @@ class _FusedMLPChain(Function):
                 z = K.gemm_forward(w2[:, 3:].contiguous(), x)
                 y = _ext.three_interpolate_affine(z, q_idx, q_weight, w2[:, :3].contiguous(), rel).view(shape)
                 mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, momenta[0], epss[0],
-                                                               training)
+                                                               training, tickets)
                 ys.append(y)
                 coefs.append((mean, invstd, scale, shift))
                 cur, cur_coeff = y, (scale, shift)
@@ -221,7 +225,7 @@ class _FusedMLPChain(Function):
                 else:
                     y = K.pregather_forward(z, idx, npts)
                     mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, momenta[0],
-                                                                   epss[0], False)
+                                                                   epss[0], False, tickets)
                 ys.append(y)
                 coefs.append((mean, invstd, scale, shift))
                 cur, cur_coeff = y, (scale, shift)
@@ -245,14 +249,14 @@ class _FusedMLPChain(Function):
             if training and pool and i == n_layers - 1:
                 # ... and so do the per-group extrema the max over nsample needs
                 y, mean, invstd, scale, shift, ext = K.gemm_forward_bn(
-                    w2, cur, cur_coeff, gamma, beta, rm, rv, momenta[i], epss[i], pool=True)
+                    w2, cur, cur_coeff, gamma, beta, rm, rv, momenta[i], epss[i], pool=True, tickets=tickets)
             elif training:  # batch statistics come out of the GEMM epilogue where the shape allows
                 y, mean, invstd, scale, shift = K.gemm_forward_bn(w2, cur, cur_coeff, gamma, beta,
-                                                                  rm, rv, momenta[i], epss[i])
+                                                                  rm, rv, momenta[i], epss[i], tickets=tickets)
             else:
                 y = K.gemm_forward(w2, cur, cur_coeff)
                 mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, momenta[i],
-                                                               epss[i], training)
+                                                               epss[i], training, tickets)
             ys.append(y)
             coefs.append((mean, invstd, scale, shift))
             cur, cur_coeff = y, (scale, shift)
@@ -310,7 +314,8 @@ class _FusedMLPChain(Function):
                 # the layer's raw output does not exist: both products of its backward from the Gram
                 # matrix of its input and one sparse column per (channel, group)
                 dgamma, dbeta, coef = K.bn_relu_pool_backward_stats(
-                    None, dz, extra[0], extra[1], gamma, scale, shift, mean, invstd, training, ns=ctx.ns)
+                    None, dz, extra[0], extra[1], gamma, scale, shift, mean, invstd, training, ns=ctx.ns,
+                    tickets=ctx.tickets)
                 grads[5 * i + 1], grads[5 * i + 2] = dgamma, dbeta
                 dz, dw_last, below = K.pool_gram_backward(
                     w2, ys[i - 1], coefs[i - 1], params[5 * (i - 1) + 1], coef, coefs[i], dz, extra[0],
@@ -321,7 +326,8 @@ class _FusedMLPChain(Function):
                 # dz of the pooled layer is one value per (channel, group): the GEMM operand
                 # loads rebuild dy from y, dpooled and the arg-max, nothing dense is written
                 dgamma, dbeta, coef = K.bn_relu_pool_backward_stats(
-                    ys[i], dz, extra[0], extra[1], gamma, scale, shift, mean, invstd, training)
+                    ys[i], dz, extra[0], extra[1], gamma, scale, shift, mean, invstd, training,
+                    tickets=ctx.tickets)
                 dy_tensor, fly = None, None
                 pooled = (ys[i], dz, extra[0], scale, shift, mean, invstd, coef)
             else:
@@ -335,11 +341,11 @@ class _FusedMLPChain(Function):
                     # a small layer: dy written once and read by the pair launch, instead of
                     # re-formed by each of its tiles (_mlp_ext.small_backward_prefers_dy)
                     dy_tensor, dgamma, dbeta = K.bn_relu_backward(ys[i], dz, gamma, scale, shift, mean,
-                                                                  invstd, training)
+                                                                  invstd, training, ctx.tickets)
                     coef = None
                 else:
                     dgamma, dbeta, coef = K.bn_relu_backward_stats(ys[i], dz, gamma, scale, shift,
-                                                                   mean, invstd, training)
+                                                                   mean, invstd, training, ctx.tickets)
                 fly = None if dy_tensor is not None else (ys[i], dz, scale, shift, mean, invstd, coef)
             grads[5 * i + 1], grads[5 * i + 2] = dgamma, dbeta
             m, k = w2.shape
@@ -396,7 +402,7 @@ class _FusedMLPChain(Function):
             else:
                 grads[5 * i] = K.gemm_wgrad(m, k, src, src_coeff, dy_tensor, fly, pooled).view_as(w)
                 dz = K.gemm_dgrad(w2, dy_tensor, fly, pooled)  # gradient w.r.t. relu(bn(y_{i-1}))
-        return (dx if need_dx else None, None, None, None, None, None, *grads)
+        return (dx if need_dx else None, None, None, None, None, None, None, *grads)
 
 
 _deferred_counters = None
@@ -505,7 +511,11 @@ class SharedMLP(nn.Sequential):
                 and _fused_enabled() and all(self._fusable(layer) for layer in self))
 
     def _run(self, x, pool, pre=None):
+        from pointnet2 import _mlp_ext as K
         layers = list(self)
+        # the module's own counters for the one-launch reductions of its layers (include/mlp_hip.h
+        # `tickets`): nothing in the library is keyed by stream
+        tickets = K.tickets_of(self, max(layer.conv.out_channels for layer in layers), x.device)
         if _mfma_enabled():
             bns = [next(layer.bn.children()) for layer in layers]
             training = bns[0].training
@@ -517,7 +527,7 @@ class SharedMLP(nn.Sequential):
                     params += [layer.conv.weight, bn.weight, bn.bias, bn.running_mean,
                                bn.running_var]
                 return _FusedMLPChain.apply(x, pool, training, [bn.momentum for bn in bns],
-                                            [bn.eps for bn in bns], pre, *params)
+                                            [bn.eps for bn in bns], pre, tickets, *params)
         for i, layer in enumerate(layers):
             bn = next(layer.bn.children())
             y = layer.conv(x)
@@ -526,7 +536,7 @@ class SharedMLP(nn.Sequential):
                 bump_batches_tracked(bn.num_batches_tracked)
             op = _BNReLUMaxPool if (pool and i == len(layers) - 1) else _BNReLU
             x = op.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum,
-                         bn.eps, training)
+                         bn.eps, training, tickets)
         return x
 
     def forward(self, x):

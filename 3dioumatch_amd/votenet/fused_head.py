@@ -26,11 +26,12 @@ def _enabled():
 
 
 class _HeadChain(Function):
-    """apply(x, training, mom1, eps1, mom2, eps2,
-             w1, b1, g1, be1, rm1, rv1,  w2, b2, g2, be2, rm2, rv2,  w3, b3)"""
+    """apply(x, training, mom1, eps1, mom2, eps2, tickets,
+             w1, b1, g1, be1, rm1, rv1,  w2, b2, g2, be2, rm2, rv2,  w3, b3)
+    tickets: the chain's counters for its one-launch reductions (_mlp_ext.tickets_of)"""
 
     @staticmethod
-    def forward(ctx, x, training, mom1, eps1, mom2, eps2, w1, b1, g1, be1, rm1, rv1, w2, b2, g2,
+    def forward(ctx, x, training, mom1, eps1, mom2, eps2, tickets, w1, b1, g1, be1, rm1, rv1, w2, b2, g2,
                 be2, rm2, rv2, w3, b3):
         from pointnet2 import _mlp_ext as K
         x = x.contiguous()
@@ -38,7 +39,7 @@ class _HeadChain(Function):
 
         def bn(y, bias, gamma, beta, rm, rv, momentum, eps):
             mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, momentum, eps,
-                                                           training)
+                                                           training, tickets)
             if bias is not None:
                 if training:
                     from pointnet2.pytorch_utils import deferred_axpy
@@ -56,7 +57,7 @@ class _HeadChain(Function):
         if b3 is not None:
             y3 += b3.detach().view(1, -1, 1)
         ctx.save_for_backward(x, y1, y2, *c1, *c2, w1, w2, w3, g1, g2)
-        ctx.training = training
+        ctx.training, ctx.tickets = training, tickets
         ctx.has_bias = (b1 is not None, b2 is not None, b3 is not None)
         return y3
 
@@ -83,9 +84,11 @@ class _HeadChain(Function):
             (dgamma, dbeta, coef, operand keywords) -- dy written once where the pair launch would
             otherwise re-form it in every tile (_mlp_ext.small_backward_prefers_dy), else on the fly"""
             if K.small_backward_prefers_dy(wm, y):
-                dy, dg, dbe = K.bn_relu_backward(y, dz, gamma, scale, shift, mean, invstd, training)
+                dy, dg, dbe = K.bn_relu_backward(y, dz, gamma, scale, shift, mean, invstd, training,
+                                                 ctx.tickets)
                 return dg, dbe, None, dict(dy=dy)
-            dg, dbe, coef = K.bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, training)
+            dg, dbe, coef = K.bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, training,
+                                                     ctx.tickets)
             return dg, dbe, coef, dict(fly=(y, dz, scale, shift, mean, invstd, coef))
 
         dw3, dz2 = both(w3m, y2, (scale2, shift2), dy=dy3)
@@ -111,7 +114,7 @@ class _HeadChain(Function):
 
         db2 = dbias(ctx.has_bias[1], coef2, dbe2, g2, invstd2)
         db1 = dbias(ctx.has_bias[0], coef1, dbe1, g1, invstd1)
-        return (dx, None, None, None, None, None, dw1, db1, dg1, dbe1, None, None, dw2, db2, dg2,
+        return (dx, None, None, None, None, None, None, dw1, db1, dg1, dbe1, None, None, dw2, db2, dg2,
                 dbe2, None, None, dw3, db3)
 
 
@@ -139,7 +142,9 @@ def head_chain(x, conv1, bn1, conv2, bn2, conv3):
         from pointnet2.pytorch_utils import bump_batches_tracked
         bump_batches_tracked(bn1.num_batches_tracked)
         bump_batches_tracked(bn2.num_batches_tracked)
-    return _HeadChain.apply(x, training, bn1.momentum, bn1.eps, bn2.momentum, bn2.eps,
+    from pointnet2 import _mlp_ext as K
+    tickets = K.tickets_of(bn1, max(conv1.out_channels, conv2.out_channels), x.device)
+    return _HeadChain.apply(x, training, bn1.momentum, bn1.eps, bn2.momentum, bn2.eps, tickets,
                             conv1.weight, conv1.bias, bn1.weight, bn1.bias, bn1.running_mean,
                             bn1.running_var, conv2.weight, conv2.bias, bn2.weight, bn2.bias,
                             bn2.running_mean, bn2.running_var, conv3.weight, conv3.bias)

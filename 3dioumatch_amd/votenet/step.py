@@ -840,8 +840,7 @@ class SemiSupervisedStep(SupervisedStep):
         dev = self.device
         cur = torch.cuda.current_stream(dev)
         if self._teacher_stream is None:
-            self._teacher_stream = self._stream_apart_from(
-                cur, self._side, torch.cuda.graph.default_capture_stream)
+            self._teacher_stream = self._another_stream(cur, self._side)
         ts = self._teacher_stream
         # No random draw inside the two forward graphs: torch keeps ONE device-side (seed, offset)
         # pair per generator and every graph replay fills it on the replaying stream -- of two
@@ -865,8 +864,9 @@ class SemiSupervisedStep(SupervisedStep):
             inputs.update(self._noise)
             return inputs
 
-        # once eagerly ON that stream: per-stream state of the kernel library (the BatchNorm ticket
-        # counters) must exist before a capture, and must not be the one the student's graph uses
+        # once eagerly on that stream (whatever a module creates on first use -- its ticket
+        # counters, _mlp_ext.tickets_of -- exists before the capture; the kernel library itself
+        # keeps no state per stream: include/mlp_hip.h, `tickets`)
         ts.wait_stream(cur)
         with torch.cuda.stream(ts):
             self._teacher_forward(make_inputs())
@@ -886,56 +886,66 @@ class SemiSupervisedStep(SupervisedStep):
                 self._apply()
         self._pick_teacher_replay_stream()
 
-    def _stream_apart_from(self, *others):
-        """A stream whose HANDLE is none of `others`'.  torch.cuda.Stream() hands out the streams of
-        a pool of 32 round-robin, so the seventh graph runner of a process got, as its teacher
-        stream, the very stream torch.cuda.graph captures on by default: the teacher's and the
-        student's graphs then shared one array of BatchNorm ticket counters (the kernel library
-        keys them by stream) and, replayed side by side, corrupted each other's statistics (seen
-        once in sixteen runs of tools/semi_step_branches.py with a second process on the GPU)."""
+    def _another_stream(self, *others):
+        """A stream whose HANDLE is none of `others`' (torch.cuda.Stream() hands out the streams of
+        a pool of 32 round-robin).  Performance only: a teacher stream that IS the main or the
+        prefetch stream would run the teacher's graph behind their work instead of beside it; any
+        stream gives the same numbers (the modules own their ticket counters)."""
         taken = {s.cuda_stream for s in others if s is not None}
+        stream = torch.cuda.Stream(device=self.device)
         for _ in range(64):
-            stream = torch.cuda.Stream(device=self.device)
             if stream.cuda_stream not in taken:
-                return stream
-        raise RuntimeError("no stream apart from %d others in 64 draws" % len(taken))
+                break
+            stream = torch.cuda.Stream(device=self.device)
+        return stream
 
     def _pick_teacher_replay_stream(self):
         """HIP maps streams onto a few hardware queues in creation order; a stream that shares the
         main stream's queue runs the teacher's graph AFTER the student's instead of beside it (seen
         when this runner is the third of a process: 10.9 instead of 9.8 ms per step).  A graph can be
         replayed on any stream, so the pair of forward graphs is timed on a few and the fastest
-        keeps the job (every side effect of these replays is undone with the capture's)."""
+        keeps the job (the replays' side effects are put back here, whatever happens)."""
         dev = self.device
         self._teacher_replay = self._teacher_stream
         if os.environ.get("STEP_SEMI_TEACHER_PROBE", "1") == "0":
             return
         cur = torch.cuda.current_stream(dev)
         side = self.side_stream()
-        candidates = [self._teacher_stream] + [torch.cuda.Stream(device=dev) for _ in range(3)]
+        candidates = [self._teacher_stream]
+        for _ in range(3):  # distinct handles, none of them the main or the prefetch stream
+            candidates.append(self._another_stream(cur, side, *candidates))
         times = []
-        for s in candidates:
-            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            for rep in range(3):
-                if rep == 1:
-                    torch.cuda.synchronize(dev)
-                    t0.record(cur)
-                # as in the running loop: the next batch's index chain (4 ms of serial sampling
-                # rounds) is in flight on the prefetch stream -- a candidate that shares ITS queue
-                # would run the teacher behind it
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    self._slots[0]["graph"].replay()
-                s.wait_stream(cur)
-                with torch.cuda.stream(s):
-                    self._gt.replay()
-                self._g1a.replay()
-                cur.wait_stream(s)
-            t1.record(cur)
+        # the probe's replays move the BatchNorm buffers: put back whatever happens
+        state = self._state()
+        saved = [t.clone() for t in state]
+        try:
+            for s in candidates:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for rep in range(3):
+                    if rep == 1:
+                        torch.cuda.synchronize(dev)
+                        t0.record(cur)
+                    # as in the running loop: the next batch's index chain (4 ms of serial sampling
+                    # rounds) is in flight on the prefetch stream -- a candidate that shares ITS queue
+                    # would run the teacher behind it
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        self._slots[0]["graph"].replay()
+                    s.wait_stream(cur)
+                    with torch.cuda.stream(s):
+                        self._gt.replay()
+                    self._g1a.replay()
+                    cur.wait_stream(s)
+                t1.record(cur)
+                torch.cuda.synchronize(dev)
+                times.append(t0.elapsed_time(t1) / 2)
+        finally:
             torch.cuda.synchronize(dev)
-            times.append(t0.elapsed_time(t1) / 2)
+            for t, v in zip(state, saved):
+                t.copy_(v)
         self._teacher_probe_ms = times
         self._teacher_replay = candidates[times.index(min(times))]
+        self._teacher_probe_pick = times.index(min(times))
         if os.environ.get("STEP_DEBUG"):
             sys.stderr.write("teacher replay stream probe (ms per pair of forward graphs): %s\n"
                              % ", ".join("%.3f" % t for t in times))

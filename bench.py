@@ -757,6 +757,11 @@ def main():
                     "per_gpu_batch": wscenes, "ms_per_step": round(wel * 1e3 / wsteps, 3),
                     "value": round(wscenes * wsteps / wel, 3), "unit": "scenes/s",
                     "hip_graphs": bool(wstep.runner.graphs)}
+                probe_ms = getattr(wstep.runner, "_teacher_probe_ms", None)
+                if probe_ms:  # which stream replays the teacher's graph (votenet/step.py)
+                    out["workloads"][name]["teacher_replay_stream_probe"] = {
+                        "ms_per_pair_of_forward_graphs": [round(t, 3) for t in probe_ms],
+                        "picked": wstep.runner._teacher_probe_pick}
                 del wstep, wbatch
                 torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline and args.workload == "pretrain":

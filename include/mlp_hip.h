@@ -25,6 +25,16 @@ extern "C" {
  * nn.BatchNorm2d (pytorch_utils.py:42-67) */
 size_t mlp_bn_workspace_floats(int b, int c, int r);
 
+/* `tickets` (mlp_bn_train_stats, mlp_bn_relu_backward, mlp_bn_relu_backward_stats,
+ * mlp_bn_relu_pool_backward): c ints of device memory OWNED BY THE CALLER, all zero at entry and
+ * left all zero at exit.  These launches reduce in one kernel -- every workgroup draws a ticket
+ * for its channel and the last one finalizes -- and the library keeps no counters of its own: no
+ * global or per-stream state, as the reference's launchers (ball_query_gpu.cu:54: a launch on the
+ * caller's stream and nothing else).  Launches ordered one after the other may share an array;
+ * launches that may overlap (two streams, two graphs replayed side by side) need one each -- in
+ * this package every shared-MLP module owns one (pointnet2/pytorch_utils.py).  NULL is refused.
+ * An aborted launch can leave a counter non-zero: zero the array before using it again. */
+
 /* replaces the statistics half of nn.BatchNorm2d in training mode (pytorch_utils.py:53-57 via
  * torch.nn.functional.batch_norm): batch mean / biased variance per channel (Welford-quality:
  * shifted partial sums combined with Chan's formula in double), running_mean / running_var
@@ -33,7 +43,7 @@ size_t mlp_bn_workspace_floats(int b, int c, int r);
 int mlp_bn_train_stats(int b, int c, int r, const float *y, const float *gamma, const float *beta,
                        float eps, float momentum, float *running_mean, float *running_var,
                        float *mean, float *invstd, float *scale, float *shift, float *workspace,
-                       void *stream);
+                       int *tickets, void *stream);
 
 /* eval-mode coefficients from the running statistics (nn.BatchNorm2d.eval(), pytorch_utils.py:53-57) */
 int mlp_bn_eval_coeff(int c, const float *gamma, const float *beta, float eps,
@@ -58,7 +68,7 @@ int mlp_bn_relu_pool(int b, int c, int m, int ns, const float *y, const float *s
 int mlp_bn_relu_backward(int b, int c, int r, int training, const float *y, const float *dz,
                          const float *gamma, const float *scale, const float *shift,
                          const float *mean, const float *invstd, float *dy, float *dgamma,
-                         float *dbeta, float *coef, float *workspace, void *stream);
+                         float *dbeta, float *coef, float *workspace, int *tickets, void *stream);
 
 /* replaces the autograd backward of max_pool2d + ReLU + BatchNorm2d of the last layer
  * (pointnet2_modules.py:256-262): dpooled (b,c,m) -> dy (b,c,m,ns), dgamma, dbeta.  dy == NULL:
@@ -67,7 +77,8 @@ int mlp_bn_relu_pool_backward(int b, int c, int m, int ns, int training, const f
                               const float *dpooled, const int *argmax, const float *ymax,
                               const float *gamma, const float *scale, const float *shift,
                               const float *mean, const float *invstd, float *dy, float *dgamma,
-                              float *dbeta, float *coef, float *workspace, void *stream);
+                              float *dbeta, float *coef, float *workspace, int *tickets,
+                              void *stream);
 
 /* as mlp_bn_relu_backward but only the per-channel results (dgamma, dbeta, coef = a, c1, c2);
  * the dy tensor itself is then formed inside the operand loads of mlp_gemm_dgrad / _wgrad
@@ -75,7 +86,7 @@ int mlp_bn_relu_pool_backward(int b, int c, int m, int ns, int training, const f
 int mlp_bn_relu_backward_stats(int b, int c, int r, int training, const float *y, const float *dz,
                                const float *gamma, const float *scale, const float *shift,
                                const float *mean, const float *invstd, float *dgamma, float *dbeta,
-                               float *coef, float *workspace, void *stream);
+                               float *coef, float *workspace, int *tickets, void *stream);
 
 /* ---- the 1x1 convolution itself, on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32) ----
  * X (b,k,r), W (m,k) row-major, Y (b,m,r).  Replaces nn.Conv2d(kernel 1x1, no bias) of a
@@ -228,11 +239,6 @@ int mlp_pool_gram_backward(int b, int r, int ns, const float *w3, const float *y
                            const float *invstd3, const int *argmax, const float *dpooled,
                            const float *ymax, float *dq, float *dw3, float *stats_part,
                            float *workspace, void *stream);
-/* Zero the "last workgroup finalizes" ticket counters of the current device (every stream's
- * array) after a faulted or aborted launch left one non-zero; synchronises the device.  The
- * reductions stand in for nn.BatchNorm2d's statistics (pytorch_utils.py:42-67); no reference
- * counterpart. */
-int mlp_bn_reset_tickets(void);
 /* pooled, argmax, ymax (b,c,groups) as mlp_bn_relu_pool returns them, from ext
  * (replaces F.max_pool2d of pointnet2_modules.py:256-262 after BatchNorm + ReLU) */
 int mlp_bn_pool_from_extrema(int b, int c, int groups, const float *ext, const float *scale,

@@ -179,12 +179,12 @@ int pn2_query_and_group_prebuilt(int b, int n, int m, int c, float radius, int n
                                  const float *features, int *idx, float *out, const void *grid,
                                  size_t grid_bytes, void *stream);
 
-/* pn2_query_and_group_prebuilt for the case the set-abstraction layer is in (pointnet2_modules.py:
- * 236-250): `grid` was left behind by pn2_furthest_point_sampling_grid(b, n, m, xyz, idxs, ...) and
+/* pn2_query_and_group_prebuilt for the case the set-abstraction layer is in
+ * (pointnet2_modules.py:236-250): `grid` was left behind by pn2_furthest_point_sampling_grid(b, n, m, xyz, idxs, ...) and
  * new_xyz[i][j] == xyz[i][idxs[i][j]] -- the centroids ARE that call's picks, in pick order.  The
  * sampling kernel then also left, per centroid, a QUERY PLAN next to the lists (row offsets and
- * lengths of its nine cell rows, the centroid, its place in the launch order -- 64 bytes,
- * csrc/grid_common.h), and a query wave starts from one scalar load instead of walking
+ * lengths of its nine cell rows, the centroid, its place in the launch order -- 64 bytes, 144
+ * for a neighbourhood that needs more than one pass of nine loads; csrc/grid_common.h), and a query wave starts from one scalar load instead of walking
  * order -> centroid -> cell -> row offsets.  Same rows, same bits as pn2_query_and_group_prebuilt
  * (which this call becomes when the object holds no plan for m: m > n / 8, or lists from
  * pn2_grid_build).  With other centroids the result is undefined: use _prebuilt. */

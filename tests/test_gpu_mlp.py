@@ -768,9 +768,11 @@ def test_sa1_chain_and_gram_vs_float64_torch(b, m, ns):
 
 def test_reductions_on_two_streams_at_once():
     """The BatchNorm reductions finalize in their last workgroup through per-channel ticket
-    counters; launches on different streams may overlap and must not share counters (one array
-    per stream).  Two streams run statistics + backward sums of different tensors back to back,
-    forty times each; every result equals the one computed alone."""
+    counters; launches that may overlap must not share counters, and the counters are the
+    CALLER's (include/mlp_hip.h `tickets`; nothing in the library is keyed by stream).  Two streams
+    run statistics + backward sums of different tensors back to back, forty times each, every
+    stream with its own array: every result equals the one computed alone, the arrays are zero
+    afterwards."""
     load_pkg()
     K = importlib.import_module("pointnet2._mlp_ext")
     g = torch.Generator().manual_seed(5)
@@ -780,13 +782,13 @@ def test_reductions_on_two_streams_at_once():
         dz = torch.randn(4, c, r, generator=g).to(DEV)
         gamma = (torch.rand(c, generator=g) + 0.5).to(DEV)
         beta = (torch.randn(c, generator=g) * 0.3).to(DEV)
-        cases.append((y, dz, gamma, beta))
+        cases.append((y, dz, gamma, beta, K.new_tickets(c, DEV)))
 
     def work(case):
-        y, dz, gamma, beta = case
+        y, dz, gamma, beta, tickets = case
         rm, rv = torch.zeros_like(gamma), torch.ones_like(gamma)
-        mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, 0.1, 1e-5, True)
-        dgamma, dbeta, coef = K.bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, True)
+        mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, 0.1, 1e-5, True, tickets)
+        dgamma, dbeta, coef = K.bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, True, tickets)
         return [mean, invstd, dgamma, dbeta, coef]
 
     alone = [[t.clone() for t in work(cs)] for cs in cases]
@@ -799,9 +801,67 @@ def test_reductions_on_two_streams_at_once():
                 got[si].append(work(cases[si]))
     torch.cuda.synchronize()
     for si in range(2):
+        assert int(cases[si][4].abs().sum()) == 0
         for res in got[si]:
             for a, b in zip(res, alone[si]):
                 assert torch.equal(a, b)
+    # a wrong array is refused, not read
+    y, dz, gamma, beta, _ = cases[0]
+    with pytest.raises(RuntimeError, match="tickets"):
+        K.bn_coefficients(y, gamma, beta, None, None, 0.1, 1e-5, True, torch.zeros(8, dtype=torch.int32, device=DEV))
+
+
+def test_two_modules_replayed_side_by_side_on_any_streams():
+    """Two shared-MLP modules (a student's and a teacher's), each captured into a HIP graph -- one
+    of them on torch's default capture stream, the handle every capture without a stream argument
+    uses -- and replayed side by side on two streams, 32 times: every replay returns exactly what
+    the module returns alone.  Each module owns the counters of its reductions
+    (_mlp_ext.tickets_of): in round 5 two graphs captured on one stream handle shared an array
+    keyed by that stream and corrupted each other's statistics."""
+    load_pkg()
+    pu = importlib.import_module("pointnet2.pytorch_utils")
+    torch.manual_seed(21)
+    mods = [pu.SharedMLP([16, 64, 64, 128], bn=True).to(DEV).train() for _ in range(2)]
+    xs = [torch.randn(4, 16, 256, 32, device=DEV) for _ in range(2)]
+
+    def state(m):
+        return [b.clone() for b in m.buffers()]
+
+    def restore(m, saved):
+        for b, v in zip(m.buffers(), saved):
+            b.copy_(v)
+
+    with torch.no_grad():
+        for m, x in zip(mods, xs):  # lazy initialisation outside the captures
+            m.forward_pooled(x)
+    saved = [state(m) for m in mods]
+    alone = []
+    with torch.no_grad():
+        for m, x, sv in zip(mods, xs, saved):
+            restore(m, sv)
+            alone.append(m.forward_pooled(x).clone())
+    tickets = [m._pn2_tickets for m in mods]
+    assert tickets[0].data_ptr() != tickets[1].data_ptr()
+    capture_streams = [torch.cuda.graph.default_capture_stream, torch.cuda.Stream()]
+    graphs, outs = [], []
+    torch.cuda.synchronize()
+    for m, x, cs in zip(mods, xs, capture_streams):
+        g = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(g, stream=cs):
+            outs.append(m.forward_pooled(x))
+        graphs.append(g)
+    replay_streams = [torch.cuda.Stream(), torch.cuda.graph.default_capture_stream]
+    for _ in range(32):
+        for m, sv in zip(mods, saved):
+            restore(m, sv)
+        torch.cuda.synchronize()
+        for g, st in zip(graphs, replay_streams):
+            with torch.cuda.stream(st):
+                g.replay()
+        torch.cuda.synchronize()
+        for o, a, t in zip(outs, alone, tickets):
+            assert torch.equal(o, a)
+            assert int(t.abs().sum()) == 0
 
 
 def test_queued_weight_gradient_reductions_equal_immediate_ones():
