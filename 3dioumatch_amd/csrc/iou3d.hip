@@ -17,6 +17,7 @@
 //    scan runs on the device in a single wavefront, so nms needs no device->host mask copy.
 #include "common.h"
 #include "box_geom.h"
+#include <mutex>
 
 namespace {
 
@@ -173,23 +174,26 @@ __device__ __forceinline__ float nms_iou(const float *a, const float *b, const B
   return s_overlap / fmaxf(sa + sb - s_overlap, 1e-8f);
 }
 
-// One workgroup = 16 rows x one 64-column tile; each wave walks 4 rows, its 64 lanes are
-// the 64 columns; the mask word is the wave ballot.  Lower-triangle tiles are skipped
-// unless FULL (the scan never reads them, iou3d_nms.cpp:129-131).
+// One workgroup = kMaskRows rows x one 64-column tile; each wave walks kMaskRows / 4 rows, its 64
+// lanes are the 64 columns; the mask word is the wave ballot.  Lower-triangle tiles are skipped
+// unless FULL (the scan never reads them, iou3d_nms.cpp:129-131).  (Four rows per workgroup instead
+// of 16 -- four times the workgroups for the 1024-box case -- was measured in round 6: 88 us
+// against 76; profiles/r6_ops_time.json.)
+constexpr int kMaskRows = 16;
 template <bool NORMAL>
 __global__ void __launch_bounds__(256)
 nms_mask_kernel(int n, float thresh, int full, const float *__restrict__ boxes,
                 unsigned long long *__restrict__ mask) {
   __shared__ float poly[kPolySlots * 256];
-  __shared__ BoxPre pre[80];
-  __shared__ float raw[80 * 7];
+  __shared__ BoxPre pre[64 + kMaskRows];
+  __shared__ float raw[(64 + kMaskRows) * 7];
   const int tid = threadIdx.x;
   const int cb = blockIdx.x;
-  const int row0 = blockIdx.y * 16;
+  const int row0 = blockIdx.y * kMaskRows;
   const int rb = row0 >> 6;
   if (!full && cb < rb) return;  // uniform for the whole workgroup
   const int col_blocks = (n + 63) / 64;
-  if (tid < 80) {
+  if (tid < 64 + kMaskRows) {
     const int g = tid < 64 ? cb * 64 + tid : row0 + (tid - 64);
     const float *src = boxes + (size_t)(g < n ? g : 0) * 7;
     float bx[7];
@@ -201,8 +205,8 @@ nms_mask_kernel(int n, float thresh, int full, const float *__restrict__ boxes,
   const int lane = tid & 63, wave = tid >> 6;
   const int gc = cb * 64 + lane;
   LdsPoly st{poly + tid};
-  for (int it = 0; it < 4; ++it) {
-    const int rl = wave * 4 + it;
+  for (int it = 0; it < kMaskRows / 4; ++it) {
+    const int rl = wave * (kMaskRows / 4) + it;
     const int gr = row0 + rl;
     if (gr >= n) break;  // wave-uniform
     bool bit = false;
@@ -215,24 +219,132 @@ nms_mask_kernel(int n, float thresh, int full, const float *__restrict__ boxes,
   }
 }
 
-// Greedy scan, iou3d_nms.cpp:121-134, in one wavefront.  remv lives in LDS.
-__global__ void __launch_bounds__(64)
+// Greedy scan, iou3d_nms.cpp:121-134, in one wavefront, BLOCK BY BLOCK of 64 boxes.
+// The reference walks the boxes one at a time and ORs a kept box's mask row into `remv` -- as a
+// device loop that is one dependent trip to memory per kept box (0.5 us each: 330 us for 660
+// survivors of 1024, against 35 us for the mask itself).  Here, for block nb:
+//   * lane l holds the DIAGONAL word of row nb * 64 + l (who of the same block it suppresses).
+//     The block's survivors are the unique fixed point of K = candidates & ~OR_{i in K} diag_i
+//     (the matrix is strictly upper triangular: box i depends on lower numbers only), reached by
+//     iterating from K = candidates -- the lowest undecided box is decided in every round, in
+//     practice a handful of rounds of one wave-wide OR each (DPP), no memory, no 64-step loop;
+//   * the survivors' rows are ORed into remv for the later blocks with lane = column word: up to
+//     1024 boxes the whole mask sits in LDS (copied in one trip: all loads in flight) and a row is
+//     one LDS read; beyond, eight independent row loads from memory in flight at a time and the
+//     next block's diagonal words requested before this block's rounds start.
+// Same keep list, same order (ascending box number) as the reference's scan.
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+  auto step = [](unsigned x, auto ctrl, auto row_mask) {
+    return x | (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, decltype(ctrl)::value, decltype(row_mask)::value,
+                                                     0xf, false);
+  };
+  v = step(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});  // row_shr:1
+  v = step(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});  // row_shr:2
+  v = step(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});  // row_shr:4
+  v = step(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});  // row_shr:8
+  v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});  // row_bcast:15
+  v = step(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});  // row_bcast:31
+  return (unsigned)__builtin_amdgcn_readlane((int)v, kWave - 1);
+}
+
+// LDSM: the whole mask (n x col_blocks words, <= 128 KB: n <= 1024) is copied into LDS first --
+// every load in flight at once, one trip to memory for the whole scan -- and remv lives in a
+// register (lane c holds word c).  Otherwise: any size, rows from memory.
+template <bool LDSM>
+__global__ void __launch_bounds__(LDSM ? 1024 : 64)
 nms_scan_kernel(const unsigned long long *__restrict__ mask, int n, int col_blocks,
                 long long *__restrict__ keep, int *__restrict__ num_out) {
-  extern __shared__ unsigned long long remv[];
+  extern __shared__ unsigned long long lds_words[];  // LDSM: the mask; else remv
   const int lane = threadIdx.x;
-  for (int l = lane; l < col_blocks; l += kWave) remv[l] = 0ull;
+  unsigned long long *remv = lds_words;
+  if (LDSM) {  // 16 waves copy (<= 16 words per lane, one trip to memory); wave 0 scans
+    const int words = n * col_blocks;
+    unsigned long long v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int t = u * 1024 + (int)threadIdx.x;
+      v[u] = t < words ? mask[t] : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int t = u * 1024 + (int)threadIdx.x;
+      if (t < words) lds_words[t] = v[u];
+    }
+  } else {
+    for (int l = lane; l < col_blocks; l += kWave) remv[l] = 0ull;
+  }
   __syncthreads();
+  if (LDSM && threadIdx.x >= kWave) return;
+  auto word_at = [&](int r, int c) -> unsigned long long {
+    return LDSM ? lds_words[r * col_blocks + c] : mask[(size_t)r * col_blocks + c];
+  };
+  auto diagonal = [&](int nb) -> unsigned long long {
+    const int r = nb * kWave + lane;
+    return nb < col_blocks && r < n ? word_at(r, nb) : 0ull;
+  };
+  auto uniform64 = [](unsigned long long v, int from) -> unsigned long long {
+    return (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), from) << 32 |
+           (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, from);
+  };
   int num = 0;
-  for (int i = 0; i < n; ++i) {
-    const int nblock = i >> 6, inblock = i & 63;
-    const unsigned long long w = remv[nblock];
-    if (!((w >> inblock) & 1ull)) {  // wave-uniform
-      if (lane == 0) keep[num] = i;
-      ++num;
-      const unsigned long long *p = mask + (size_t)i * col_blocks;
-      for (int l = nblock + lane; l < col_blocks; l += kWave) remv[l] |= p[l];
+  unsigned long long removed = 0ull;  // LDSM: lane c holds remv[c]
+  unsigned long long diag = diagonal(0);
+  for (int nb = 0; nb < col_blocks; ++nb) {
+    const unsigned long long diag_next = LDSM ? 0ull : diagonal(nb + 1);
+    // removed so far (wave-uniform); boxes past the end count as removed
+    unsigned long long w = LDSM ? uniform64(removed, nb) : uniform64(remv[nb], 0);
+    const int in_block = n - nb * kWave;
+    if (in_block < kWave) w |= ~0ull << in_block;
+    const unsigned long long cand = ~w;
+    unsigned long long kept = cand;
+    for (;;) {  // wave-uniform
+      const bool in = (kept >> lane) & 1ull;
+      const unsigned lo = wave_or_u32(in ? (unsigned)diag : 0u), hi = wave_or_u32(in ? (unsigned)(diag >> 32) : 0u);
+      const unsigned long long next = cand & ~((unsigned long long)hi << 32 | lo);
+      if (next == kept) break;
+      kept = next;
+    }
+    if ((kept >> lane) & 1ull)
+      keep[num + __popcll(kept & ((1ull << lane) - 1ull))] = (long long)nb * kWave + lane;
+    num += __popcll(kept);
+    if (LDSM) {
+      // the survivors' rows into remv: lane = column word (col_blocks <= 16 < 64 lanes)
+      const bool mine = lane > nb && lane < col_blocks;
+      const unsigned long long *col = lds_words + (mine ? lane : 0);
+      unsigned long long acc = 0ull;
+      unsigned long long k = kept;
+      while (k) {  // wave-uniform: one LDS read per survivor, all independent
+        const int i = __builtin_ctzll(k);
+        k &= k - 1ull;
+        acc |= col[(nb * kWave + i) * col_blocks];
+      }
+      if (mine) removed |= acc;
+      diag = diagonal(nb + 1);
+    } else {
+      // the survivors' rows into remv[nb + 1 ..]: lane = column word
+      for (int c0 = 0; c0 < col_blocks; c0 += kWave) {
+        const int c = c0 + lane;
+        if (c0 + kWave - 1 <= nb) continue;  // wave-uniform: nothing right of the diagonal here
+        const bool mine = c > nb && c < col_blocks;
+        const unsigned long long *col = mask + (mine ? c : 0);
+        unsigned long long acc = 0ull;
+        unsigned long long k = kept;
+        while (k) {  // wave-uniform
+          unsigned long long v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {  // branch-free: eight loads in flight
+            const bool have = k != 0ull;
+            const int i = have ? __builtin_ctzll(k) : 0;
+            k &= k - 1ull;
+            const unsigned long long x = col[(size_t)(nb * kWave + i) * col_blocks];
+            v[u] = have ? x : 0ull;
+          }
+          acc |= (v[0] | v[1]) | (v[2] | v[3]) | ((v[4] | v[5]) | (v[6] | v[7]));
+        }
+        if (mine) remv[c] |= acc;
+      }
       __syncthreads();
+      diag = diag_next;
     }
   }
   if (lane == 0) *num_out = num;
@@ -284,7 +396,7 @@ IOU3D_API int iou3d_scene_best_iou3d(int scenes, int num_a, const float *boxes_a
 static int launch_mask(const float *boxes, unsigned long long *mask, int n, float thresh,
                        bool normal, int full, hipStream_t stream) {
   if (n <= 0) return 0;
-  dim3 grid((n + 63) / 64, pn2_ceil_div(n, 16));
+  dim3 grid((n + 63) / 64, pn2_ceil_div(n, kMaskRows));
   if (normal)
     hipLaunchKernelGGL(nms_mask_kernel<true>, grid, dim3(256), 0, stream, n, thresh, full, boxes,
                        mask);
@@ -312,8 +424,24 @@ IOU3D_API int iou3d_nms(const float *boxes, int boxes_num, float thresh, int nor
   int rc = launch_mask(boxes, mask_ws, boxes_num, thresh, normal != 0, 0, stream);
   if (rc != 0) return rc;
   const int col_blocks = (boxes_num + 63) / 64;
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), sizeof(unsigned long long) * col_blocks,
-                     stream, mask_ws, boxes_num, col_blocks, keep_dev, num_out_dev);
+  if (col_blocks <= 16) {  // the mask fits the LDS
+    static std::mutex mu;
+    static bool attr_set = false;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nms_scan_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 16 * 8);
+        attr_set = true;
+      }
+    }
+    hipLaunchKernelGGL(nms_scan_kernel<true>, dim3(1), dim3(1024),
+                       sizeof(unsigned long long) * (size_t)boxes_num * col_blocks, stream, mask_ws, boxes_num,
+                       col_blocks, keep_dev, num_out_dev);
+  } else {
+    hipLaunchKernelGGL(nms_scan_kernel<false>, dim3(1), dim3(64), sizeof(unsigned long long) * col_blocks,
+                       stream, mask_ws, boxes_num, col_blocks, keep_dev, num_out_dev);
+  }
   return pn2_launch_status();
 }
 

@@ -52,7 +52,11 @@ __global__ void __launch_bounds__(256) pseudo_select_kernel(LhsPseudoArgs a) {
     const float x = a.iou[sk * a.NI + (a.NI > 1 ? cls : 0)];
     const float iou = 1.0f / (1.0f + expf(-x));
     const bool ok = max_cls > a.cls_threshold && pos > a.obj_threshold && iou > a.iou_threshold;
-    key[k] = (pos * max_cls) * (ok ? 1.0f : 0.0f);
+    // (a NaN / Inf logit makes the key NaN: every comparison of the ranking below is then false,
+    //  several proposals take rank 0 and other slots are never written -- the tensor path's
+    //  argsort always yields a permutation.  Such a proposal is not a pseudo label: key 0.)
+    const float v = pos * max_cls;
+    key[k] = (ok && isfinite(v)) ? v : 0.0f;
   }
   __syncthreads();
   // pass 2: rank, and the slots

@@ -269,6 +269,12 @@ group_points_grad_lds_big_kernel(int c, int n, int mns, const float *__restrict_
 // in LDS and scans the WHOLE index array for hits in it -- the index / gradient rows are read
 // `slices` times from L2 (1 MB each at SA1) in exchange for `slices` times the workgroups and a
 // fraction of the same-address pressure: 153 -> 34 us at B = 8, C = 4, n = 40 000, m*ns = 131 072.
+// (Round 6, measured and not kept: all channels of a cloud in ONE workgroup per range, the index
+// array scanned once in batches, the runs that hit the range compacted into an LDS list and added
+// in a second phase with independent gradient loads -- 69 .. 100 us against this kernel's 50: the
+// scan of the whole index array by 256-512 workgroups costs more vector instructions than the
+// re-read gradient rows cost bandwidth, and a returning LDS atomic per lane on ONE address, the
+// list's counter, alone took 67 us before it was aggregated per wave; profiles/r6_ops_time.json.)
 template <bool VEC>
 __global__ void __launch_bounds__(1024)
 group_points_grad_lds_range_kernel(int c, int n, int mns, int slices, const float *__restrict__ grad_out,
@@ -329,18 +335,59 @@ int inverse_chunk(int mns) {
   return chunk;
 }
 
+// VEC: m*ns is a multiple of 4.  A lane then owns whole int4 quads of the index array -- ALL of
+// its quads are loaded before the first LDS atomic (one trip to the L2 instead of one per pass
+// and element) and equal neighbours inside a quad are counted and ranked as ONE run: first-hit
+// padding repeats an index up to nsample times in a row, and every repeat was a same-address LDS
+// atomic (32 us at SA2's 8 x 1024 x 32; the order of a point's entries is free -- the sorted
+// backward adds them up whatever it is).
+template <bool VEC>
 __global__ void __launch_bounds__(1024)
 group_inverse_kernel(int n, int mns, int chunk_log2, const int *__restrict__ idx,
                      unsigned *__restrict__ inv) {
   __shared__ int cnt[kInvMaxPoints];
   __shared__ int wave_tot[16];
+  // the sorted entries are put together in LDS (scattered 4-byte writes) and leave as whole rows
+  __shared__ unsigned stage[VEC ? kInvMaxEntries : 1];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int *ib = idx + (size_t)b * mns;
   unsigned *out = inv + ((size_t)b << (chunk_log2 + 10));
   const int chunk_mask = (1 << chunk_log2) - 1;
+  constexpr int Q = kInvMaxEntries / 4096;  // quads per lane at most
+  int4 v[Q];
+  if (VEC) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int e = (q * 1024 + tid) * 4;
+      v[q] = e < mns ? *reinterpret_cast<const int4 *>(ib + e) : make_int4(-1, -1, -1, -1);
+    }
+  }
   for (int t = tid; t < kInvMaxPoints; t += 1024) cnt[t] = 0;
   __syncthreads();
-  for (int e = tid; e < mns; e += 1024) atomicAdd(&cnt[ib[e]], 1);
+  // runs of a quad: (key, length) of the run that STARTS at element u, length 0 elsewhere
+  auto runs = [](const int4 &q, int len[4]) {
+    const int k[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int u = 3; u >= 0; --u)
+      len[u] = 1 + ((u < 3 && k[u + 1] == k[u]) ? len[u + 1] : 0);
+#pragma unroll
+    for (int u = 3; u >= 1; --u)
+      if (k[u] == k[u - 1]) len[u] = 0;
+  };
+  if (VEC) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (v[q].x < 0) continue;
+      int len[4];
+      runs(v[q], len);
+      const int k[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (len[u] > 0) atomicAdd(&cnt[k[u]], len[u]);
+    }
+  } else {
+    for (int e = tid; e < mns; e += 1024) atomicAdd(&cnt[ib[e]], 1);
+  }
   __syncthreads();
   {  // exclusive scan of the counters, four per lane
     int c4[4], sum = 0;
@@ -360,13 +407,39 @@ group_inverse_kernel(int n, int mns, int chunk_log2, const int *__restrict__ idx
     for (int q = 0; q < 4; ++q) { cnt[tid * 4 + q] = run; run += c4[q]; }
   }
   __syncthreads();
-  for (int e = tid; e < mns; e += 1024) {
-    const int k = ib[e];
-    const int s = atomicAdd(&cnt[k], 1);
-    out[((s & chunk_mask) << 10) + (s >> chunk_log2)] = ((unsigned)k << 16) | (unsigned)e;
+  auto put = [&](int s, int k, int e) {
+    (VEC ? stage : out)[((s & chunk_mask) << 10) + (s >> chunk_log2)] = ((unsigned)k << 16) | (unsigned)e;
+  };
+  if (VEC) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (v[q].x < 0) continue;
+      int len[4];
+      runs(v[q], len);
+      const int k[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+      const int e = (q * 1024 + tid) * 4;
+      int s = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (len[u] > 0) s = atomicAdd(&cnt[k[u]], len[u]);  // a run's first element draws its slots
+        put(s, k[u], e + u);
+        ++s;
+      }
+    }
+  } else {
+    for (int e = tid; e < mns; e += 1024) {
+      const int k = ib[e];
+      put(atomicAdd(&cnt[k], 1), k, e);
+    }
   }
   for (int s = mns + tid; s < (1024 << chunk_log2); s += 1024)
-    out[((s & chunk_mask) << 10) + (s >> chunk_log2)] = kInvPad;
+    (VEC ? stage : out)[((s & chunk_mask) << 10) + (s >> chunk_log2)] = kInvPad;
+  if (VEC) {
+    __syncthreads();
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(stage);
+    uint4 *o4 = reinterpret_cast<uint4 *>(out);
+    for (int t = tid; t < (256 << chunk_log2); t += 1024) o4[t] = s4[t];
+  }
 }
 
 template <int CHUNK>
@@ -783,8 +856,12 @@ PN2_API int pn2_group_inverse_build(int b, int n, int npoints, int nsample, cons
   if (!pn2_group_inverse_supported(n, npoints, nsample)) return (int)hipErrorInvalidValue;
   const int chunk = inverse_chunk(npoints * nsample);
   const int chunk_log2 = chunk == 4 ? 2 : chunk == 8 ? 3 : chunk == 16 ? 4 : 5;
-  hipLaunchKernelGGL(group_inverse_kernel, dim3(b), dim3(1024), 0, (hipStream_t)stream_, n,
-                     npoints * nsample, chunk_log2, idx, inv);
+  if ((npoints * nsample) % 4 == 0)
+    hipLaunchKernelGGL(group_inverse_kernel<true>, dim3(b), dim3(1024), 0, (hipStream_t)stream_, n,
+                       npoints * nsample, chunk_log2, idx, inv);
+  else
+    hipLaunchKernelGGL(group_inverse_kernel<false>, dim3(b), dim3(1024), 0, (hipStream_t)stream_, n,
+                       npoints * nsample, chunk_log2, idx, inv);
   return pn2_launch_status();
 }
 

@@ -96,6 +96,28 @@ def scene_best_iou3d_gpu(boxes_a, boxes_b, best_iou, best_idx):
     return 1
 
 
+def nms_device(boxes, thresh, normal=False):
+    """The same NMS with the keep list LEFT ON THE DEVICE: boxes (N,7) sorted by score desc ->
+    (keep (N,) int64 GPU tensor, kept count).  One 4-byte device -> host copy (the count) instead of
+    the reference interface's blocking copy of the list into a CPU tensor (iou3d_nms.cpp:90-138)
+    that iou3d_nms_utils.nms_gpu sends straight back to the device."""
+    _chk_gpu(boxes, "boxes")
+    n = boxes.shape[0]
+    dev = boxes.device
+    if n == 0:
+        return torch.empty(0, dtype=torch.int64, device=dev), 0
+    col_blocks = (n + 63) // 64
+    with torch.cuda.device(dev):
+        mask = torch.empty(n * col_blocks, dtype=torch.int64, device=dev)
+        keep_dev = torch.empty(n, dtype=torch.int64, device=dev)
+        num_dev = torch.empty(1, dtype=torch.int32, device=dev)
+        _L.check(_lib.iou3d_nms(boxes.data_ptr(), n, float(thresh), 1 if normal else 0,
+                                mask.data_ptr(), keep_dev.data_ptr(), num_dev.data_ptr(),
+                                _L.current_stream_ptr(dev)), "nms_device")
+        num = int(num_dev.item())  # synchronises
+    return keep_dev, num
+
+
 def _nms(boxes, keep, thresh, normal):
     _chk_gpu(boxes, "boxes")
     if keep.is_cuda or not keep.is_contiguous():

@@ -64,6 +64,12 @@ def _nms_common(fn, boxes, scores, thresh, pre_maxsize=None):
     if pre_maxsize is not None:
         order = order[:pre_maxsize]
     boxes = boxes[order].contiguous()
+    device_form = getattr(iou3d_nms_cuda, "nms_device", None)
+    if device_form is not None and fn in (iou3d_nms_cuda.nms_gpu, iou3d_nms_cuda.nms_normal_gpu):
+        # the keep list stays on the device: one 4-byte copy (the count) instead of the list's round
+        # trip through the CPU tensor of the reference interface (iou3d_nms_utils.py:90-104)
+        keep, num_out = device_form(boxes, thresh, fn is iou3d_nms_cuda.nms_normal_gpu)
+        return order[keep[:num_out]].contiguous(), None
     keep = torch.empty(boxes.size(0), dtype=torch.int64)
     num_out = fn(boxes, keep, thresh)
     return order[keep[:num_out].to(boxes.device)].contiguous(), None

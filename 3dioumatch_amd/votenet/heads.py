@@ -83,22 +83,30 @@ class _DecodeScores(torch.autograd.Function):
                 b, k, nh, ns, nc, net.data_ptr(), mean_size.data_ptr(),
                 *[g.data_ptr() if g is not None else None for g in grads], d_net.data_ptr(),
                 torch.cuda.current_stream(net.device).cuda_stream), "votenet_decode_scores_grad")
-        return d_net, grads[1], None, None, None, None
+        # (center = aggregated_vote_xyz + offset: the centre's gradient, where one is wanted)
+        return d_net, (grads[1] if ctx.needs_input_grad[1] else None), None, None, None, None
 
 
-def _decode_fused(net, mean_size, width):
+def _decode_fused(net, mean_size, width, agg_xyz, num_size_cluster):
+    """The one-launch decode takes raw pointers: float32 tensors on net's device, net (B, width, K),
+    aggregated_vote_xyz (B, K, 3), mean_size (num_size_cluster, 3) -- anything else (a float64 or
+    CPU mean_size, another layout of the vote centres) is the tensor path's."""
     import os
     _L = _fused_front_end()
     return (os.environ.get("VOTENET_FUSED_DECODE", "1") != "0" and net.is_cuda and net.dtype == torch.float32
-            and _L is not None and hasattr(_L.lib, "votenet_decode_scores") and net.shape[1] == width
-            and mean_size.is_cuda and mean_size.is_contiguous())
+            and net.dim() == 3 and _L is not None and hasattr(_L.lib, "votenet_decode_scores")
+            and net.shape[1] == width
+            and mean_size.device == net.device and mean_size.dtype == torch.float32
+            and mean_size.is_contiguous() and tuple(mean_size.shape) == (num_size_cluster, 3)
+            and torch.is_tensor(agg_xyz) and agg_xyz.device == net.device and agg_xyz.dtype == torch.float32
+            and tuple(agg_xyz.shape) == (net.shape[0], net.shape[2], 3))
 
 
 def decode_scores(net, end_points, num_class, num_heading_bin, num_size_cluster, mean_size):
     """Split the proposal head output (B, C, K) into the named predictions
     (proposal_module.py:24-54); mean_size is a (num_size_cluster, 3) tensor."""
     nh, ns = num_heading_bin, num_size_cluster
-    if _decode_fused(net, mean_size, 5 + nh * 2 + ns * 4 + num_class):
+    if _decode_fused(net, mean_size, 5 + nh * 2 + ns * 4 + num_class, end_points.get('aggregated_vote_xyz'), ns):
         (objectness, center, heading_scores, hrn, hr, size_scores, srn, sr, sem) = _DecodeScores.apply(
             net, end_points['aggregated_vote_xyz'], mean_size, nh, ns, num_class)
         end_points['objectness_scores'] = objectness

@@ -237,7 +237,11 @@ def get_unlabeled_loss(end_points, ema_end_points, config, config_dict, labels_o
     fused = None
     if ema_end_points['center'].is_cuda and os.environ.get("VOTENET_FUSED_PSEUDO_LABELS", "1") != "0":
         from . import pseudo_nms
-        if pseudo_nms.pseudo_labels_supported(ema_end_points['center'][tail], aug[3]) and \
+        teacher = [ema_end_points[k][tail] for k in (
+            'objectness_scores', 'sem_cls_scores', 'iou_scores', 'heading_scores', 'heading_residuals',
+            'size_scores', 'size_residuals', 'aggregated_vote_xyz')]
+        if pseudo_nms.pseudo_labels_supported(ema_end_points['center'][tail], aug[3], f32=teacher + [aug[2]],
+                                              i64=aug[:2], sem_cls=teacher[1], iou_scores=teacher[2]) and \
                 _lhs_nms.__module__ == __name__:  # (tests substitute the NMS: the tensor form calls it)
             fused = pseudo_nms.pseudo_labels_gpu(
                 ema_end_points['objectness_scores'][tail], ema_end_points['sem_cls_scores'][tail],

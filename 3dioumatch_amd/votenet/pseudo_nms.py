@@ -77,10 +77,22 @@ class LhsPseudoArgs(ctypes.Structure):  # field order == include/lhs_hip.h
                                     "size_residual_label", "iou_label", "pseudo_gt_ratio")])
 
 
-def pseudo_labels_supported(pred_center, scale):
-    """The two-launch form covers GPU tensors, 64 <= K <= 1024 proposals and a per-axis scale (S,1,3)."""
-    return pred_center.is_cuda and 64 <= pred_center.shape[1] <= 1024 and \
-        tuple(scale.shape) == (pred_center.shape[0], 1, 3)
+def pseudo_labels_supported(pred_center, scale, f32=(), i64=(), sem_cls=None, iou_scores=None):
+    """The two-launch form covers GPU tensors, 64 <= K <= 1024 proposals, a per-axis scale (S,1,3),
+    float32 network outputs (`f32`), int64 flip flags (`i64`) on the same device and one IoU score
+    per proposal or per class.  Anything else -- bool flags, an autocast teacher -- is the tensor
+    implementation's (get_pseudo_labels), not an error."""
+    dev = pred_center.device
+    if not (pred_center.is_cuda and 64 <= pred_center.shape[1] <= 1024 and
+            tuple(scale.shape) == (pred_center.shape[0], 1, 3)):
+        return False
+    if any(t.dtype != torch.float32 or t.device != dev for t in (pred_center, scale, *f32)):
+        return False
+    if any(t.dtype != torch.int64 or t.device != dev for t in i64):
+        return False
+    if sem_cls is not None and iou_scores is not None and iou_scores.shape[2] not in (1, sem_cls.shape[2]):
+        return False
+    return True
 
 
 def pseudo_labels_gpu(objectness, sem_cls, iou_scores, heading_scores, heading_residuals, size_scores,

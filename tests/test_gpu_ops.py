@@ -152,6 +152,27 @@ def test_group_vs_oracle(ext, oracle, c, n, m, ns):
     np.testing.assert_allclose(got, oracle.group_points_grad(gout, idx, n), rtol=0, atol=1e-4)
 
 
+@pytest.mark.parametrize("c,n,m,ns", [(4, 40000, 2048, 64), (3, 20000, 1024, 16), (8, 40000, 512, 32)])
+def test_group_grad_few_rows_hot_spots(ext, oracle, c, n, m, ns):
+    """The few-row scatter-add (ranges of destination points per workgroup, equal neighbours merged):
+    ball-query style rows, a cloud whose indices alternate between two points (nothing to merge,
+    every element lands in ONE range), a cloud on one point, points nobody refers to.  Sums in
+    another order than the oracle's: bounded by the float64 sum and the mass added."""
+    g = np.random.default_rng(c + n + m)
+    idx = g.integers(0, n - n // 4, (3, m, ns)).astype(np.int32)
+    idx[:, :, ns // 2:] = idx[:, :, :1]
+    idx[1] = (np.arange(m * ns, dtype=np.int32) % 2).reshape(m, ns) * 7 + 3
+    idx[2] = n - 1
+    gout = g.standard_normal((3, c, m, ns)).astype(np.float32)
+    got = ext.group_points_grad(dev(gout), dev(idx), n).cpu().numpy()
+    np.testing.assert_allclose(got[:1], oracle.group_points_grad(gout[:1], idx[:1], n), rtol=0, atol=1e-4)
+    truth = np.zeros((3, c, n)); mass = np.zeros((3, c, n))
+    for bi in range(3):
+        np.add.at(truth[bi], (slice(None), idx[bi].reshape(-1)), gout[bi].reshape(c, -1).astype(np.float64))
+        np.add.at(mass[bi], (slice(None), idx[bi].reshape(-1)), np.abs(gout[bi].reshape(c, -1)).astype(np.float64))
+    assert np.all(np.abs(got - truth) <= 1e-5 + 2e-7 * mass)
+
+
 @pytest.mark.parametrize("c,n,m,ns", [(128, 2048, 1024, 32), (256, 1024, 512, 16), (256, 512, 256, 16),
                                       (7, 4096, 511, 64), (1, 1, 3, 5), (3, 100, 7, 128),
                                       (130, 257, 256, 128)])
@@ -726,6 +747,27 @@ def test_nms_wrapper_and_stress_size(oracle, synth):
     k1, _ = ut.nms_gpu(dev(boxes), dev(scores), 0.25, pre_maxsize=100)
     w1, _ = oracle.nms(boxes[:100], 0.25)
     assert np.array_equal(k1.cpu().numpy(), w1)
+
+
+@pytest.mark.parametrize("n,spread", [(1, 8.0), (63, 2.0), (64, 2.0), (65, 2.0), (130, 1.0), (1000, 8.0),
+                                      (1024, 3.0), (1025, 8.0), (1500, 4.0), (2300, 6.0)])
+def test_nms_scan_block_by_block(iou_ext, oracle, synth, n, spread):
+    """The device scan decides a block of 64 boxes per step (fixed point of the suppression inside
+    the block, rows of the survivors ORed into the removed set): the reference's one-box-at-a-time
+    loop (iou3d_nms.cpp:121-134) gives the same list.  Sizes around the block width, both forms
+    of the kernel (rows in registers up to 1024 boxes, any size beyond), sparse scenes and dense
+    ones (small spread: long suppression chains inside a block)."""
+    boxes, scores = synth.boxes_scored(n, seed=100 + n, spread=spread)
+    d = dev(boxes)
+    for thr in (0.1, 0.25):
+        for normal in (False, True):
+            keep, num = iou_ext.nms_device(d, thr, normal)
+            want, _ = (oracle.nms_normal if normal else oracle.nms)(boxes, thr)
+            assert num == len(want), (n, thr, normal, num, len(want))
+            assert np.array_equal(keep[:num].cpu().numpy(), want)
+            host = torch.empty(n, dtype=torch.int64)
+            assert (iou_ext.nms_normal_gpu if normal else iou_ext.nms_gpu)(d, host, thr) == num
+            assert np.array_equal(host[:num].numpy(), want)
 
 
 def test_streams_and_second_device_context(ext, oracle, synth):
