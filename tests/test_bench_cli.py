@@ -68,6 +68,9 @@ def test_bench_default_line_has_roofline_and_cpu_baseline():
         w = d["workloads"][name]
         assert w["per_gpu_batch"] == scenes and w["hip_graphs"] is True and w["value"] > 0
         assert abs(w["value"] - scenes * 1000.0 / w["ms_per_step"]) <= 0.02 * w["value"]
+        # the loop that feeds data, as the headline; host time and bytes per step ride along
+        assert 0 < w["host_ms_per_step"] < 20 and w["h2d_bytes_per_step"] > scenes * 20000 * 12
+        assert 0.7 * w["value_resident"] < w["value"] < 1.3 * w["value_resident"]
     assert d["ms_per_step_no_prefetch"] > d["ms_per_step"]
     kernels = d["kernels"]
     for name in ("fps_40000_2048", "ball_query_sa1", "group_xyz_sa1", "group_feat_sa1",

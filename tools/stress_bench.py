@@ -44,13 +44,27 @@ def main():
     t["group_feat_c1"] = bench.time_op(lambda: ext.group_points(feat, idx), iters=10, warm=2)
     t["query_and_group_fused"] = bench.time_op(
         lambda: ext.query_and_group(new_xyz, xyz, feat, 0.2, NS, True), iters=5, warm=1)
+    # ... and as a set-abstraction layer runs it: on the cell lists and query plans its own sampling
+    # call leaves behind (no build between sampling and grouping; bench.py's `layer` form)
+    linds, lists = ext.furthest_point_sampling_with_grid(xyz, M, 0.2)
+    assert torch.equal(linds, inds)
+    lists.mark_centroids(new_xyz, linds)
+    idx_l, grouped_l = ext.query_and_group(new_xyz, xyz, feat, 0.2, NS, True, None, lists)
+    assert torch.equal(idx_l, idx)
+    assert torch.allclose(grouped_l[:, :3], (grouped - new_xyz.transpose(1, 2).unsqueeze(-1)) / 0.2, rtol=0, atol=1e-5)
+    t["query_and_group_layer"] = bench.time_op(
+        lambda: ext.query_and_group(new_xyz, xyz, feat, 0.2, NS, True, None, lists), iters=5, warm=1)
     pair_bytes = 12 * B * N + 12 * B * M + 4 * B * M * NS + 2 * 4 * B * M * NS \
         + 4 * B * 3 * N + 4 * B * 3 * M * NS + 4 * B * N + 4 * B * M * NS
     pair_us = t["ball_query_ns128"] + t["group_xyz"] + t["group_feat_c1"]
     out["pair"] = {"algorithmic_bytes": pair_bytes, "us": round(pair_us, 1),
                    "GBps": round(pair_bytes / pair_us / 1e3, 1),
                    "fused_us": round(t["query_and_group_fused"], 1),
-                   "fused_GBps": round(pair_bytes / t["query_and_group_fused"] / 1e3, 1)}
+                   "fused_GBps": round(pair_bytes / t["query_and_group_fused"] / 1e3, 1),
+                   "fused_frac_of_8TBs": round(pair_bytes / t["query_and_group_fused"] / 8e6, 4),
+                   "layer_us": round(t["query_and_group_layer"], 1),
+                   "layer_GBps": round(pair_bytes / t["query_and_group_layer"] / 1e3, 1),
+                   "layer_frac_of_8TBs": round(pair_bytes / t["query_and_group_layer"] / 8e6, 4)}
     a, b = synth.boxes_pair(K, seed=3)
     a_d, b_d = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
     t["iou3d_1024x1024"] = bench.time_op(lambda: ut.boxes_iou3d_gpu(a_d, b_d), iters=10, warm=2)
