@@ -94,6 +94,10 @@ _SIGNATURES = {
     "mlp_pool_gram_parts": [_c_int, _c_int],
     "mlp_pool_gram_workspace_floats": [_c_int, _c_int],
     "mlp_pool_gram_backward": [_c_int, _c_int, _c_int] + [_vp] * 19,
+    "mlp_pool_gram256_supported": [_c_int, _c_int, _c_int, _c_int, _c_int],
+    "mlp_pool_gram256_parts": [_c_int, _c_int],
+    "mlp_pool_gram256_workspace_floats": [_c_int, _c_int, _c_int],
+    "mlp_pool_gram256_backward": [_c_int, _c_int, _c_int] + [_vp] * 19,
     "mlp_chain_lin4_parts": [_c_int, _c_int, _c_int, _c_int, _vp],
     "mlp_chain_lin4_image_bytes": [],
     "mlp_chain_lin4_prepare": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -161,7 +165,7 @@ _SIGNATURES = {
     "iou3d_nms": [_vp, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp],
     "iou3d_boxes_iou_bev_cpu": [_c_int, _vp, _c_int, _vp, _vp],
 }
-_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_grid_bytes": _sz, "pn2_fps_workspace_bytes": _sz, "mlp_bn_workspace_floats": _sz, "mlp_gemm_wgrad_workspace_floats": _sz, "mlp_wgrad_first4_workspace_bytes": _sz, "mlp_gemm_backward_fused_workspace_floats": _sz, "mlp_bn_finalize_pairs_scratch_bytes": _sz, "mlp_chain_lin4_image_bytes": _sz, "mlp_weight_image_elems": _sz, "mlp_pool_gram_workspace_floats": _sz, "pn2_error_string": ctypes.c_char_p}
+_RESTYPE = {"pn2_ball_query_workspace_bytes": _sz, "pn2_grid_bytes": _sz, "pn2_fps_workspace_bytes": _sz, "mlp_bn_workspace_floats": _sz, "mlp_gemm_wgrad_workspace_floats": _sz, "mlp_wgrad_first4_workspace_bytes": _sz, "mlp_gemm_backward_fused_workspace_floats": _sz, "mlp_bn_finalize_pairs_scratch_bytes": _sz, "mlp_chain_lin4_image_bytes": _sz, "mlp_weight_image_elems": _sz, "mlp_pool_gram_workspace_floats": _sz, "mlp_pool_gram256_workspace_floats": _sz, "pn2_error_string": ctypes.c_char_p}
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -423,18 +423,23 @@ gemm_nn2_kernel(int m_total, int k_total, int r, const float *__restrict__ a, in
     __syncthreads();  // buffer cur is free again, buffer cur^1 is complete
   }
   // C/D layout of the 32x32 block: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
-  float *cb = c + (size_t)b * b_stride_out;
+  // (c == nullptr, pooled form only: the raw output is not stored at all -- statistics and extrema
+  // are everything the layer leaves behind; its backward runs from the Gram matrix of its input,
+  // mlp_pool_gram256.hip)
+  if (POOL == 0 || c != nullptr) {
+    float *cb = c + (size_t)b * b_stride_out;
 #pragma unroll
-  for (int i = 0; i < MB; ++i)
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int col = r0 + (wn * NB + j) * 32 + (lane & 31);
+      for (int j = 0; j < NB; ++j) {
+        const int col = r0 + (wn * NB + j) * 32 + (lane & 31);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = m0 + (wm * MB + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        if (row < m_total) __builtin_nontemporal_store(acc[i][j][q], &cb[(size_t)row * r + col]);
+        for (int q = 0; q < 16; ++q) {
+          const int row = m0 + (wm * MB + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+          if (row < m_total) __builtin_nontemporal_store(acc[i][j][q], &cb[(size_t)row * r + col]);
+        }
       }
-    }
+  }
   // per output row (mean, M2) of this wave's NB*32 columns; the WN wave columns of a row are
   // merged by one lane per row (equal counts), and the workgroup writes TM contiguous pairs.
   // Where a wave owns 64 x 64 of the tile the sums come out of the row scan below (the
@@ -1493,7 +1498,8 @@ MLP_API int mlp_gemm_forward_stats_pool_supported(int b, int m, int k, int r, in
 // mlp_gemm_forward_stats (mode 1: x = raw output of the previous layer) that also leaves, per
 // channel and group of ns columns, the raw output that wins the max-pool after BatchNorm (gamma:
 // the layer's BatchNorm weight, whose sign decides between largest and smallest) and its first
-// index: ext = 2 planes of b*m*(r/ns) 4-byte values
+// index: ext = 2 planes of b*m*(r/ns) 4-byte values.  y may be NULL: the raw output is then not
+// stored (the layer leaves its statistics and extrema only)
 MLP_API int mlp_gemm_forward_stats_pool(int b, int m, int k, int r, const float *w, const float *x,
                                         const float *scale, const float *shift, float *y,
                                         float *pairs, int ns, const float *gamma, float *ext,

@@ -267,13 +267,15 @@ def gemm_forward(w, x, coeff=None):
 
 
 def gemm_forward_bn(w, x, coeff, gamma, beta, running_mean, running_var, momentum, eps, pool=False,
-                    tickets=None):
+                    tickets=None, store=True):
     """Training-mode layer: y = gemm_forward(w, x, coeff) and the BatchNorm coefficients of y
     (mean, invstd, scale, shift), with the batch statistics reduced in the GEMM epilogue when the
     shape allows (no second pass over y), else by bn_coefficients.
     pool=True (x is (B,K,m,ns), the layer is followed by the max over nsample): returns a sixth
     value, the extrema planes for pool_from_extrema -- or None when the shape has no such epilogue
-    and the caller pools with bn_relu_pool."""
+    and the caller pools with bn_relu_pool.
+    store=False (pool=True and forward_pool_supported only): y is None -- the raw output is not
+    stored at all (its backward then runs from the Gram matrix of its input, pool_gram_backward)."""
     import ctypes
     _f32c(x, "x"); _f32c(w, "w")
     b, k = x.shape[0], x.shape[1]
@@ -289,7 +291,9 @@ def gemm_forward_bn(w, x, coeff, gamma, beta, running_mean, running_var, momentu
     pooled = bool(ns) and coeff is not None and w.data_ptr() % 16 == 0 and \
         bool(_lib.mlp_gemm_forward_stats_pool_supported(b, m, k, r, ns))
     ext = torch.empty((2, b, m, r // ns), dtype=torch.float32, device=x.device) if pooled else None
-    y = torch.empty((b, m) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    if not store and not pooled:
+        raise RuntimeError("gemm_forward_bn(store=False): the pooled epilogue does not cover this layer")
+    y = torch.empty((b, m) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device) if store else None
     pairs = torch.empty((parts, m, 2), dtype=torch.float32, device=x.device)
     out = torch.empty((4, m), dtype=torch.float32, device=x.device)
     scratch = torch.empty(int(_lib.mlp_bn_finalize_pairs_scratch_bytes(m)), dtype=torch.uint8,
@@ -299,7 +303,7 @@ def gemm_forward_bn(w, x, coeff, gamma, beta, running_mean, running_var, momentu
         if pooled:
             _L.check(_lib.mlp_gemm_forward_stats_pool(b, m, k, r, w.data_ptr(), x.data_ptr(),
                                                       scale.data_ptr(), shift.data_ptr(),
-                                                      y.data_ptr(), pairs.data_ptr(), ns,
+                                                      _ptr(y), pairs.data_ptr(), ns,
                                                       gamma.data_ptr(), ext.data_ptr(), _stream(x)),
                      "mlp_gemm_forward_stats_pool")
         else:
@@ -318,6 +322,15 @@ def gemm_forward_bn(w, x, coeff, gamma, beta, running_mean, running_var, momentu
     if pool:
         return y, out[0], out[1], out[2], out[3], ext
     return y, out[0], out[1], out[2], out[3]
+
+
+def forward_pool_supported(w, x, coeff):
+    """Does gemm_forward_bn(w, x, coeff, ..., pool=True) leave the pooled extrema behind (x (B,K,m,ns))?"""
+    if x.dim() != 4 or coeff is None or w.data_ptr() % 16 != 0:
+        return False
+    b, k, _, ns = x.shape
+    r = x.numel() // (b * k)
+    return bool(_lib.mlp_gemm_forward_stats_pool_supported(b, w.shape[0], k, r, ns))
 
 
 def pool_from_extrema(ext, scale, shift):
@@ -745,44 +758,65 @@ def chain_lin4_forward(x4, w0, coeff0, layer1, layer2, store=True, store_last=Tr
     return y1, (out1[0], out1[1], out1[2], out1[3]), y2, (out2[0], out2[1], out2[2], out2[3]), ext
 
 
+def _gram_entry(w):
+    """The C entry points for a pooled last layer of this shape: (128,64) csrc/mlp_pool_gram.hip,
+    (256,128) csrc/mlp_pool_gram256.hip."""
+    shape = tuple(w.shape)
+    if shape == (128, 64):
+        return (_lib.mlp_pool_gram_supported, _lib.mlp_pool_gram_parts, _lib.mlp_pool_gram_workspace_floats,
+                _lib.mlp_pool_gram_backward, "mlp_pool_gram_backward")
+    if shape == (256, 128):
+        return (_lib.mlp_pool_gram256_supported, _lib.mlp_pool_gram256_parts,
+                _lib.mlp_pool_gram256_workspace_floats, _lib.mlp_pool_gram256_backward,
+                "mlp_pool_gram256_backward")
+    return None
+
+
 def pool_gram_supported(w, y_in, ns):
-    """Can the backward of the pooled last layer (w (128,64) on y_in (B,64,m,ns)) run without that
-    layer's raw output (csrc/mlp_pool_gram.hip)?"""
-    if os.environ.get("MLP_POOL_GRAM", "1") == "0" or tuple(w.shape) != (128, 64):
+    """Can the backward of the pooled last layer (w (128,64) on y_in (B,64,m,ns), or w (256,128) on
+    y_in (B,128,m,ns)) run without that layer's raw output (csrc/mlp_pool_gram.hip,
+    csrc/mlp_pool_gram256.hip)?"""
+    entry = _gram_entry(w)
+    if os.environ.get("MLP_POOL_GRAM", "1") == "0" or entry is None or y_in.shape[1] != w.shape[1]:
         return False
-    b = y_in.shape[0]
-    r = y_in.numel() // (b * 64)
-    return bool(_lib.mlp_pool_gram_supported(b, 128, 64, r, int(ns)))
+    b, k = y_in.shape[0], w.shape[1]
+    r = y_in.numel() // (b * k)
+    return bool(entry[0](b, w.shape[0], k, r, int(ns)))
 
 
 def pool_gram_backward(w, y_in, in_coeff, in_gamma, coef, coeff, dpooled, argmax, ymax, ns, training):
     """Backward of a pooled last layer y = w . relu(bn(y_in)) from y_in and the pooled tensors alone.
-    y_in (B,64,m,ns) raw output of the layer below, in_coeff = its (mean, invstd, scale, shift),
-    in_gamma its BatchNorm weight; coef (128,3) and coeff = (mean, invstd, scale, shift) of THIS
-    layer's BatchNorm; dpooled / argmax / ymax (B,128,m).
-    -> (d relu(bn(y_in)) (B,64,m,ns), dw (128,64), below = (dgamma, dbeta, coef) of the layer below)."""
+    y_in (B,K,m,ns) raw output of the layer below, in_coeff = its (mean, invstd, scale, shift),
+    in_gamma its BatchNorm weight; coef (M,3) and coeff = (mean, invstd, scale, shift) of THIS
+    layer's BatchNorm; dpooled / argmax / ymax (B,M,m); (M,K) = (128,64) or (256,128).
+    -> (d relu(bn(y_in)) (B,K,m,ns), dw (M,K), below = (dgamma, dbeta, coef) of the layer below)."""
     _f32c(w, "w"); _f32c(y_in, "y_in"); _f32c(dpooled, "dpooled"); _f32c(ymax, "ymax")
+    entry = _gram_entry(w)
+    if entry is None or y_in.shape[1] != w.shape[1]:
+        raise RuntimeError("pool_gram_backward: layer shape %s not covered" % (tuple(w.shape),))
+    _, parts_fn, ws_fn, backward_fn, name = entry
+    mo, k = w.shape
     b = y_in.shape[0]
-    r = y_in.numel() // (b * 64)
+    r = y_in.numel() // (b * k)
     dev = y_in.device
     mean_i, invstd_i, scale_i, shift_i = in_coeff
     mean, invstd, scale, shift = coeff
-    parts = int(_lib.mlp_pool_gram_parts(b, r))
+    parts = int(parts_fn(b, r))
     dq = torch.empty_like(y_in)
-    dw = torch.empty((128, 64), dtype=torch.float32, device=dev)
-    sp = torch.empty((64, parts, 2), dtype=torch.float32, device=dev)
-    small = torch.empty((5, 64), dtype=torch.float32, device=dev)
+    dw = torch.empty((mo, k), dtype=torch.float32, device=dev)
+    sp = torch.empty((k, parts, 2), dtype=torch.float32, device=dev)
+    small = torch.empty((5, k), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        ws = torch.empty(int(_lib.mlp_pool_gram_workspace_floats(b, r)), dtype=torch.float32, device=dev)
+        ws_floats = ws_fn(b, r, int(ns)) if mo == 256 else ws_fn(b, r)
+        ws = torch.empty(int(ws_floats), dtype=torch.float32, device=dev)
         st = _stream(y_in)
-        _L.check(_lib.mlp_pool_gram_backward(b, r, int(ns), w.data_ptr(), y_in.data_ptr(), scale_i.data_ptr(),
-                                             shift_i.data_ptr(), mean_i.data_ptr(), invstd_i.data_ptr(),
-                                             coef.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                             mean.data_ptr(), invstd.data_ptr(), argmax.data_ptr(),
-                                             dpooled.data_ptr(), ymax.data_ptr(), dq.data_ptr(),
-                                             dw.data_ptr(), sp.data_ptr(), ws.data_ptr(), st),
-                 "mlp_pool_gram_backward")
-        _L.check(_lib.mlp_bn_backward_finalize(64, parts, float(b) * float(r), 1 if training else 0,
+        _L.check(backward_fn(b, r, int(ns), w.data_ptr(), y_in.data_ptr(), scale_i.data_ptr(),
+                             shift_i.data_ptr(), mean_i.data_ptr(), invstd_i.data_ptr(),
+                             coef.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                             mean.data_ptr(), invstd.data_ptr(), argmax.data_ptr(),
+                             dpooled.data_ptr(), ymax.data_ptr(), dq.data_ptr(),
+                             dw.data_ptr(), sp.data_ptr(), ws.data_ptr(), st), name)
+        _L.check(_lib.mlp_bn_backward_finalize(k, parts, float(b) * float(r), 1 if training else 0,
                                                sp.data_ptr(), in_gamma.data_ptr(), invstd_i.data_ptr(),
                                                small[0].data_ptr(), small[1].data_ptr(), small[2:].data_ptr(),
                                                st), "mlp_bn_backward_finalize")

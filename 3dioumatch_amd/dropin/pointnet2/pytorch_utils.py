@@ -178,7 +178,7 @@ class _FusedMLPChain(Function):
                                           params[5].reshape(params[5].shape[0], -1),
                                           params[10].reshape(params[10].shape[0], -1), x, x.shape[3]))
         ext = None
-        gram_last = False
+        gram_last, gram_ns = False, 0
         for i in range(n_layers):
             w, gamma, beta, rm, rv = params[5 * i:5 * i + 5]
             w2 = w.reshape(w.shape[0], -1)
@@ -247,9 +247,18 @@ class _FusedMLPChain(Function):
                 cur, cur_coeff = y, (scale, shift)
                 continue
             if training and pool and i == n_layers - 1:
-                # ... and so do the per-group extrema the max over nsample needs
+                # ... and so do the per-group extrema the max over nsample needs.  Where the layer's
+                # backward can run from the Gram matrix of its input (SA2 - SA4: 128 -> 256,
+                # csrc/mlp_pool_gram256.hip) the raw output is not stored at all: 268 MB at SA2
+                gram = (i >= 1 and cur is not None and cur.dim() == 4 and cur.numel() > 0
+                        and K.pool_gram_supported(w2, cur, cur.shape[3])
+                        and K.forward_pool_supported(w2, cur, cur_coeff))
                 y, mean, invstd, scale, shift, ext = K.gemm_forward_bn(
-                    w2, cur, cur_coeff, gamma, beta, rm, rv, momenta[i], epss[i], pool=True, tickets=tickets)
+                    w2, cur, cur_coeff, gamma, beta, rm, rv, momenta[i], epss[i], pool=True, tickets=tickets,
+                    store=not gram)
+                if gram:
+                    y = x.new_empty(0)  # never materialised
+                    gram_last, gram_ns = True, cur.shape[3]
             elif training:  # batch statistics come out of the GEMM epilogue where the shape allows
                 y, mean, invstd, scale, shift = K.gemm_forward_bn(w2, cur, cur_coeff, gamma, beta,
                                                                   rm, rv, momenta[i], epss[i], tickets=tickets)
@@ -274,7 +283,7 @@ class _FusedMLPChain(Function):
         ctx.n_layers, ctx.pool, ctx.training = n_layers, pool, training
         ctx.moments = moments  # not None: the first layer is virtual (ys[0] is a placeholder)
         ctx.gram_last = gram_last  # the last layer's raw output was not stored (ys[-1] is a placeholder)
-        ctx.ns = x.shape[3] if x.dim() == 4 else 0
+        ctx.ns = gram_ns if gram_ns else (x.shape[3] if x.dim() == 4 else 0)
         ctx.pre = pre
         return out
 

@@ -179,7 +179,8 @@ int mlp_gemm_forward_stats_pool_supported(int b, int m, int k, int r, int ns);
 /* mlp_gemm_forward_stats (mode 1) that also writes ext: 2 planes of (b, m, r/ns) -- the raw output
  * that wins the pool per channel and group of ns columns (the largest where gamma >= 0, the
  * smallest where gamma < 0: gamma = the weight of the BatchNorm that follows) and its first
- * index (replaces the read of y in the max-pool of pointnet2_modules.py:256-262) */
+ * index (replaces the read of y in the max-pool of pointnet2_modules.py:256-262).  y may be NULL:
+ * the raw output is then not stored at all (its backward: mlp_pool_gram256_backward) */
 int mlp_gemm_forward_stats_pool(int b, int m, int k, int r, const float *w, const float *x,
                                 const float *scale, const float *shift, float *y, float *pairs,
                                 int ns, const float *gamma, float *ext, void *stream);
@@ -239,6 +240,21 @@ int mlp_pool_gram_backward(int b, int r, int ns, const float *w3, const float *y
                            const float *invstd3, const int *argmax, const float *dpooled,
                            const float *ymax, float *dq, float *dw3, float *stats_part,
                            float *workspace, void *stream);
+/* The same for (m, k) = (256, 128) -- the last layer of SA2 / SA3 / SA4 (pointnet2_modules.py:256-262
+ * after pytorch_utils.py:14-39,70-124), ns 16 / 32 (csrc/mlp_pool_gram256.hip: two passes over y2,
+ * data gradient + BatchNorm-backward sums of the layer below, then weight-gradient sums).
+ * mlp_pool_gram256_parts: parts of stats_part (128, parts, 2). */
+int mlp_pool_gram256_supported(int b, int m, int k, int r, int ns);
+int mlp_pool_gram256_parts(int b, int r);
+size_t mlp_pool_gram256_workspace_floats(int b, int r, int ns);
+/* dq (b,128,r), dw3 (256,128), stats_part (128,parts,2); y2 (b,128,r) raw; coef3 (256,3); argmax /
+ * dpooled / ymax (b,256,r/ns) (autograd of pytorch_utils.py:14-39 + pointnet2_modules.py:256-262) */
+int mlp_pool_gram256_backward(int b, int r, int ns, const float *w3, const float *y2, const float *sc2,
+                              const float *sh2, const float *mean2, const float *invstd2,
+                              const float *coef3, const float *sc3, const float *sh3,
+                              const float *mean3, const float *invstd3, const int *argmax,
+                              const float *dpooled, const float *ymax, float *dq, float *dw3,
+                              float *stats_part, float *workspace, void *stream);
 /* pooled, argmax, ymax (b,c,groups) as mlp_bn_relu_pool returns them, from ext
  * (replaces F.max_pool2d of pointnet2_modules.py:256-262 after BatchNorm + ReLU) */
 int mlp_bn_pool_from_extrema(int b, int c, int groups, const float *ext, const float *scale,
