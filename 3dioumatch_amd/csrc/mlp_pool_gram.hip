@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256, 1) pool_gram_bwd_kernel(const GramArgs a)
   constexpr int SIMG = M * RP, QIMG = K * RP;
   constexpr int RAWP = (TN + 4) * 4;       // raw copy row pitch, bytes
   constexpr int BUF = 3 * (SIMG + QIMG) + K * RAWP;
-  constexpr int RCOFF = 2 * BUF;
+  constexpr int RCOFF = 2 * BUF, VOFF = RCOFF + K * 16;  // per row of a2: (sc, sh, mu, is); v
   constexpr int NG = 12;                   // MFMA groups per chunk of either role
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
@@ -107,7 +107,12 @@ __global__ void __launch_bounds__(256, 1) pool_gram_bwd_kernel(const GramArgs a)
 
   // ---- once per workgroup: the S images start empty
   for (int t = tid; t < 2 * BUF / 16; t += 256) reinterpret_cast<uint4 *>(lds)[t] = make_uint4(0u, 0u, 0u, 0u);
-  if (tid < K) reinterpret_cast<float4 *>(lds + RCOFF)[tid] = make_float4(a.sc2[tid], a.sh2[tid], a.mean2[tid], a.invstd2[tid]);
+  if (tid < K) {
+    reinterpret_cast<float4 *>(lds + RCOFF)[tid] = make_float4(a.sc2[tid], a.sh2[tid], a.mean2[tid], a.invstd2[tid]);
+    // (v in LDS, not in 16 registers of every lane: the kernel's two roles share one register budget,
+    // and with it the weight-side waves spilled fragments to scratch INSIDE the chunk loop)
+    reinterpret_cast<float *>(lds + VOFF)[tid] = a.v[tid];
+  }
   RowCoef qc[2];
   size_t q_lane[2];
 #pragma unroll
@@ -123,7 +128,6 @@ __global__ void __launch_bounds__(256, 1) pool_gram_bwd_kernel(const GramArgs a)
   // waves 0 / 1: fragments of M3 (step s: k' = 16 s + 8 lhi + 0..7) and of W3^T (step s: channels
   // 16 s + 8 lhi + 0..7) for da2 rows 32 wave + l31, split once; v
   Split3 msp[K / 16], wsp[M / 16];
-  float vreg[16];
   if (dgrad_wave) {
     const float *mr = a.m3 + (size_t)(32 * wave + l31) * K;
 #pragma unroll
@@ -138,19 +142,20 @@ __global__ void __launch_bounds__(256, 1) pool_gram_bwd_kernel(const GramArgs a)
       for (int j = 0; j < 8; ++j) w8[j] = wc[(size_t)(16 * s + 8 * lhi + j) * K];
       wsp[s] = split3(w8);
     }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) vreg[q] = a.v[32 * wave + 4 * lhi + (q & 3) + 8 * (q >> 2)];
   }
   // waves 2 / 3: R blocks (row block 2 (wave - 2) + i, column block j), Gram blocks (wave - 2, j)
-  f32x16 accR[2][2], accC[2];
+  // (the two roles' accumulators that live across all chunks share registers: the weight-side waves'
+  // six blocks, of which the data-side waves use two as their BatchNorm sums -- declared apart they
+  // cost 32 registers more and the kernel spilled fragments inside the chunk loop)
+  f32x16 accX[6];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < 6; ++j)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { accR[0][j][q] = 0.f; accR[1][j][q] = 0.f; accC[j][q] = 0.f; }
+    for (int q = 0; q < 16; ++q) accX[j][q] = 0.f;
+  f32x16 (&accR)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&accX[0]);
+  f32x16 (&accC)[2] = *reinterpret_cast<f32x16 (*)[2]>(&accX[4]);
+  f32x16 &st1 = accX[0], &st2 = accX[1];
   float s2acc[2] = {0.f, 0.f};
-  float st1[16], st2[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) { st1[q] = 0.f; st2[q] = 0.f; }
 
   const int per = (a.total_chunks + (int)gridDim.x - 1) / (int)gridDim.x;
   const int c_lo = (int)blockIdx.x * per;
@@ -321,9 +326,9 @@ __global__ void __launch_bounds__(256, 1) pool_gram_bwd_kernel(const GramArgs a)
       for (int q = 0; q < 16; ++q) {
         // this lane: column l31, row 32 wave + 4 lhi + (q & 3) + 8 (q >> 2)
         const int ro = (q & 3) + 8 * (q >> 2);
-        const float d = accD[q] + vreg[q];
-        __builtin_nontemporal_store(d, &dst[(size_t)ro * a.r]);
         const int row = 32 * wave + 4 * lhi + ro;
+        const float d = accD[q] + reinterpret_cast<const float *>(lds + VOFF)[row];
+        __builtin_nontemporal_store(d, &dst[(size_t)ro * a.r]);
         const float4 c4 = rc[row];
         const float yv = *reinterpret_cast<const float *>(raw + (size_t)row * RAWP + l31 * 4);
         const float gg = __fmaf_rn(yv, c4.x, c4.y) > 0.f ? d : 0.f;
@@ -359,7 +364,11 @@ __global__ void __launch_bounds__(256, 1) pool_gram_bwd_kernel(const GramArgs a)
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          mfma_x6(accC[j], sq[i0], sq[j]);
+          // (sq[i0] with the wave's number as the index put the fragments into scratch memory: six
+          // 16-byte stores and three loads per step, each behind a wait for every outstanding load
+          // and store of the wave -- a uniform branch instead)
+          if (i0 == 0) mfma_x6(accC[j], sq[0], sq[j]);
+          else mfma_x6(accC[j], sq[1], sq[j]);
           between(g);
           ++g;
         }
@@ -477,7 +486,7 @@ int gram_workgroups(int b, int r) {
   return (int)(g < 1 ? 1 : g);
 }
 
-constexpr size_t kGramLds = 2 * (3 * (128 + 64) * 80 + 64 * 144) + 64 * 16;
+constexpr size_t kGramLds = 2 * (3 * (128 + 64) * 80 + 64 * 144) + 64 * 16 + 64 * 4;
 
 }  // namespace
 

@@ -775,13 +775,13 @@ def _gram_entry(w):
 def pool_gram_supported(w, y_in, ns):
     """Can the backward of the pooled last layer (w (128,64) on y_in (B,64,m,ns), or w (256,128) on
     y_in (B,128,m,ns)) run without that layer's raw output (csrc/mlp_pool_gram.hip,
-    csrc/mlp_pool_gram256.hip)?"""
+    csrc/mlp_pool_gram256.hip)?  Only the (B, *, m, ns) extent of y_in is looked at (the chained SA1
+    form asks with its 4-channel input: the layer's own input never exists there)."""
     entry = _gram_entry(w)
-    if os.environ.get("MLP_POOL_GRAM", "1") == "0" or entry is None or y_in.shape[1] != w.shape[1]:
+    if os.environ.get("MLP_POOL_GRAM", "1") == "0" or entry is None or y_in.dim() != 4:
         return False
-    b, k = y_in.shape[0], w.shape[1]
-    r = y_in.numel() // (b * k)
-    return bool(entry[0](b, w.shape[0], k, r, int(ns)))
+    b, r = y_in.shape[0], y_in.shape[2] * y_in.shape[3]
+    return bool(entry[0](b, w.shape[0], w.shape[1], r, int(ns)))
 
 
 def pool_gram_backward(w, y_in, in_coeff, in_gamma, coef, coeff, dpooled, argmax, ymax, ns, training):

@@ -550,6 +550,9 @@ def test_virtual_first_layer_chain_vs_sequential(pool, monkeypatch):
     calls = []
     real = K.first4_moments
     monkeypatch.setattr(K, "first4_moments", lambda t: (calls.append(1), real(t))[1])
+    gram_calls = []
+    real_gram = K.pool_gram_backward
+    monkeypatch.setattr(K, "pool_gram_backward", lambda *a, **k: (gram_calls.append(1), real_gram(*a, **k))[1])
     out = mlp.forward_pooled(x) if pool else mlp(x)
     assert calls, "the first layer was materialised"
     monkeypatch.setenv("MLP_FIRST4_VIRTUAL", "0")
@@ -561,6 +564,8 @@ def test_virtual_first_layer_chain_vs_sequential(pool, monkeypatch):
     close(out, want, 2e-4)
     wgt = torch.randn_like(want)
     (out * wgt).sum().backward()
+    # (pooled: layers 2 + 3 chained, the last raw output not stored, its backward from the Gram matrix)
+    assert len(gram_calls) == (1 if pool else 0), "SA1's pooled last layer did not take the Gram path"
     (out2 * wgt).sum().backward()
     (want * wgt).sum().backward()
     z64 = torch.nn.Sequential.forward(ref64, x.double())

@@ -48,7 +48,12 @@ def main():
     # call leaves behind (no build between sampling and grouping; bench.py's `layer` form)
     linds, lists = ext.furthest_point_sampling_with_grid(xyz, M, 0.2)
     assert torch.equal(linds, inds)
-    lists.mark_centroids(new_xyz, linds)
+    layer_form = "cell lists + query plans left by the sampling kernel"
+    if lists is None:  # (N = 80 000 is outside the sampling kernel's by-product range: lists built once,
+        lists = ext.build_grid(xyz, 0.2)  # ahead of the timed query; no query plans)
+        layer_form = "cell lists built ahead of the query (pn2_grid_build), no query plans"
+    else:
+        lists.mark_centroids(new_xyz, linds)
     idx_l, grouped_l = ext.query_and_group(new_xyz, xyz, feat, 0.2, NS, True, None, lists)
     assert torch.equal(idx_l, idx)
     assert torch.allclose(grouped_l[:, :3], (grouped - new_xyz.transpose(1, 2).unsqueeze(-1)) / 0.2, rtol=0, atol=1e-5)
@@ -62,6 +67,7 @@ def main():
                    "fused_us": round(t["query_and_group_fused"], 1),
                    "fused_GBps": round(pair_bytes / t["query_and_group_fused"] / 1e3, 1),
                    "fused_frac_of_8TBs": round(pair_bytes / t["query_and_group_fused"] / 8e6, 4),
+                   "layer_form": layer_form,
                    "layer_us": round(t["query_and_group_layer"], 1),
                    "layer_GBps": round(pair_bytes / t["query_and_group_layer"] / 1e3, 1),
                    "layer_frac_of_8TBs": round(pair_bytes / t["query_and_group_layer"] / 8e6, 4)}
