@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256, 1) pool_gram_bwd_kernel(const GramArgs a)
   // this thread's (channel, overlapping group) of the sparse gradient
   const int lc3 = tid & (M - 1), lgi = tid >> 7;
   const float l_sc3 = a.sc3[lc3], l_sh3 = a.sh3[lc3], l_a3 = a.coef3[lc3 * 3];
-  int s_written[2] = {-1, -1};  // the column this thread's entry occupies in buffer 0 / 1
+  int s_written[2] = {TN, TN};  // the column this thread's entry occupies in buffer 0 / 1 (TN: none)
 
   // waves 0 / 1: fragments of M3 (step s: k' = 16 s + 8 lhi + 0..7) and of W3^T (step s: channels
   // 16 s + 8 lhi + 0..7) for da2 rows 32 wave + l31, split once; v
@@ -180,6 +180,24 @@ __global__ void __launch_bounds__(256, 1) pool_gram_bwd_kernel(const GramArgs a)
       l_base = g * a.ns - col0;
     }
   };
+  // the winner's column in the chunk gets a dpooled -- unless it lies outside the chunk or the ReLU
+  // behind the pool was shut: then the entry goes to column 32, the rows' padding, which no fragment
+  // read touches (no branch: the piece sits between two MFMAs)
+  auto stage_sparse = [&](int buf, bool real) {
+    const int sl = l_base + l_am;
+    const bool hit = lgi < G && real && __fmaf_rn(l_ym, l_sc3, l_sh3) > 0.f && sl >= 0 && sl < TN;
+    const int s = hit ? sl : TN;
+    s_written[buf] = s;
+    const float adp = l_a3 * l_dp;
+    const float hf = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, adp) & 0xffff0000u);
+    const float r1 = adp - hf;
+    const float mf = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1) & 0xffff0000u);
+    const float lf = r1 - mf;
+    unsigned short *dst = reinterpret_cast<unsigned short *>(lds + (size_t)buf * BUF + (size_t)lc3 * RP) + s;
+    dst[0] = (unsigned short)(__builtin_bit_cast(unsigned, hf) >> 16);
+    dst[SIMG / 2] = (unsigned short)(__builtin_bit_cast(unsigned, mf) >> 16);
+    dst[SIMG] = (unsigned short)(__builtin_bit_cast(unsigned, lf) >> 16);
+  };
   // (real: the chunk exists -- the pipeline re-stages the last chunk past the end, never consumed)
   auto stage_item = [&](int item, int buf, bool real) {
     char *base = lds + (size_t)buf * BUF;
@@ -202,33 +220,13 @@ __global__ void __launch_bounds__(256, 1) pool_gram_bwd_kernel(const GramArgs a)
       *reinterpret_cast<uint2 *>(dst + 2 * QIMG) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
       *reinterpret_cast<float4 *>(base + 3 * (SIMG + QIMG) + (size_t)row * RAWP + seg_c * 4) = qx[item];
     } else {
-      // the winner's column in the chunk gets a dpooled -- unless it lies outside the chunk or the
-      // ReLU behind the pool was shut
-      int s = -1;
-      if (lgi < G && real) {
-        const int sl = l_base + l_am;
-        if (__fmaf_rn(l_ym, l_sc3, l_sh3) > 0.f && sl >= 0 && sl < TN) s = sl;
-      }
-      s_written[buf] = s;
-      if (s >= 0) {
-        const float adp = l_a3 * l_dp;
-        const float hf = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, adp) & 0xffff0000u);
-        const float r1 = adp - hf;
-        const float mf = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1) & 0xffff0000u);
-        const float lf = r1 - mf;
-        unsigned short *dst = reinterpret_cast<unsigned short *>(base + (size_t)lc3 * RP) + s;
-        dst[0] = (unsigned short)(__builtin_bit_cast(unsigned, hf) >> 16);
-        dst[SIMG / 2] = (unsigned short)(__builtin_bit_cast(unsigned, mf) >> 16);
-        dst[SIMG] = (unsigned short)(__builtin_bit_cast(unsigned, lf) >> 16);
-      }
+      stage_sparse(buf, real);
     }
   };
-  auto clear_entry = [&](int buf) {  // after the chunk's MFMAs: the S image is empty again
-    const int s = s_written[buf];
-    if (s >= 0) {
-      unsigned short *dst = reinterpret_cast<unsigned short *>(lds + (size_t)buf * BUF + (size_t)lc3 * RP) + s;
-      dst[0] = 0; dst[SIMG / 2] = 0; dst[SIMG] = 0;
-    }
+  // the S image is empty again after the chunk's MFMAs: this thread clears its entry
+  auto clear_entry = [&](int buf) {
+    unsigned short *dst = reinterpret_cast<unsigned short *>(lds + (size_t)buf * BUF + (size_t)lc3 * RP) + s_written[buf];
+    dst[0] = 0; dst[SIMG / 2] = 0; dst[SIMG] = 0;
   };
   auto clampc = [&](int c) { return c < c_hi ? c : c_hi - 1; };
   __syncthreads();  // the zero fill is complete
@@ -246,22 +244,67 @@ __global__ void __launch_bounds__(256, 1) pool_gram_bwd_kernel(const GramArgs a)
   const int tr_off = (8 * lhi + ((lane & 15) >> 2)) * RP + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
   const int rw_off = l31 * RP + 8 * lhi * 2;
 
-  auto chunk = [&](auto curt, int c) {
+  float pv[4], ph_[4], pm[4], pl[4];  // a y2 slice between the pieces of its staging
+  // (the role is a compile-time argument and the loop over the chunks is written once per role: with
+  // the role tested inside one common loop both roles' long-lived registers -- 144 of fragments here,
+  // 96 of accumulators there -- were live across it, and the kernel spilled inside the loop)
+  auto chunk = [&](auto curt, auto rolet, int c) {
     constexpr int cur = decltype(curt)::value;
+    constexpr bool kDgrad = decltype(rolet)::value;
     const char *Sc = lds + (size_t)cur * BUF, *Qc = Sc + 3 * SIMG;
     const int ahead = clampc(c + 2);
-    // buffer cur ^ 1 still holds this thread's entry of chunk c - 1 (read by everyone before the
-    // barrier that ended that chunk): clear it before the buffer is staged again below
-    clear_entry(cur ^ 1);
-    auto between = [&](int g) {
-      if (g < 3) {
-        stage_item(g, cur ^ 1, c + 1 < c_hi);
-        fetch_item(g, ahead);
+    // The next chunk's staging in FOURTEEN pieces of a few vector instructions, one behind each of the
+    // first pairs of MFMAs of either role (36 pairs per chunk), a scheduling barrier behind every piece:
+    // left to itself the compiler issues a step's MFMAs back to back and the staging after them, where
+    // (one wave per SIMD) nothing is in flight to hide it -- 125 of the kernel's 475 us at SA1.
+    // Pieces 0-4 / 5-9: a y2 slice (transform; first term; second and third; images; raw copy + the
+    // load of the chunk after); 10: this thread's entry of chunk c - 1 in buffer cur ^ 1 cleared (read
+    // by everyone before the barrier that ended that chunk); 11: the next entry written; 12: its loads.
+    const bool next_real = c + 1 < c_hi;
+    auto piece = [&](int k) {
+#if !defined(GRAM_ABL) || GRAM_ABL != 1   // (timing ablation 1: no staging / loads inside the loop)
+      char *base = lds + (size_t)(cur ^ 1) * BUF;
+      if (k < 10) {
+        const int item = k / 5, ph = k % 5, row = seg_row + 32 * item;
+        if (ph == 0) {
+          const float xv[4] = {qx[item].x, qx[item].y, qx[item].z, qx[item].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pv[e] = transform<OP_BNRELU>(xv[e], 0.f, qc[item]);
+          if (next_real) s2acc[item] += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+        } else if (ph == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            ph_[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, pv[e]) & 0xffff0000u);
+            pv[e] = pv[e] - ph_[e];
+          }
+        } else if (ph == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            pm[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, pv[e]) & 0xffff0000u);
+            pl[e] = pv[e] - pm[e];
+          }
+        } else if (ph == 3) {
+          char *dst = base + 3 * SIMG + (size_t)row * RP + seg_c * 2;
+          *reinterpret_cast<uint2 *>(dst) = make_uint2(pack_hi16(ph_[0], ph_[1]), pack_hi16(ph_[2], ph_[3]));
+          *reinterpret_cast<uint2 *>(dst + QIMG) = make_uint2(pack_hi16(pm[0], pm[1]), pack_hi16(pm[2], pm[3]));
+          *reinterpret_cast<uint2 *>(dst + 2 * QIMG) = make_uint2(pack_hi16(pl[0], pl[1]), pack_hi16(pl[2], pl[3]));
+        } else {
+          *reinterpret_cast<float4 *>(base + 3 * (SIMG + QIMG) + (size_t)row * RAWP + seg_c * 4) = qx[item];
+          fetch_item(item, ahead);
+        }
+      } else if (k == 10) {
+        clear_entry(cur ^ 1);
+      } else if (k == 11) {
+        stage_sparse(cur ^ 1, next_real);
+      } else if (k == 12) {
+        fetch_item(2, ahead);
       }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
     };
     const int b = c / a.chunks_per_cloud;
     const int col0 = (c - b * a.chunks_per_cloud) * TN;
-    if (dgrad_wave) {
+    if constexpr (kDgrad) {
       f32x16 accD;
 #pragma unroll
       for (int q = 0; q < 16; ++q) accD[q] = 0.f;
@@ -302,20 +345,20 @@ __global__ void __launch_bounds__(256, 1) pool_gram_bwd_kernel(const GramArgs a)
           step_frag(g + 2, pf[((g >> 1) + 1) & 1]);
           step_frag(g + 3, pg[((g >> 1) + 1) & 1]);
         }
+        __builtin_amdgcn_sched_barrier(0);  // (the fragment reads of the NEXT two steps stay up here)
         const Split3 b0 = operand(pf[(g >> 1) & 1]), b1 = operand(pg[(g >> 1) & 1]);
         const Split3 &a0 = step_operand(g), &a1 = step_operand(g + 1);
-#define GR_STEP(AT, BT)                                                                             \
+#define GR_STEP(AT, BT, SLOT)                                                                       \
   accD = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.AT, b0.BT, accD, 0, 0, 0);                      \
-  accE = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.AT, b1.BT, accE, 0, 0, 0)
-        GR_STEP(lo, hi);
-        GR_STEP(hi, lo);
-        GR_STEP(mid, mid);
-        GR_STEP(mid, hi);
-        GR_STEP(hi, mid);
-        GR_STEP(hi, hi);
+  accE = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.AT, b1.BT, accE, 0, 0, 0);                      \
+  piece(6 * (g >> 1) + SLOT)
+        GR_STEP(lo, hi, 0);
+        GR_STEP(hi, lo, 1);
+        GR_STEP(mid, mid, 2);
+        GR_STEP(mid, hi, 3);
+        GR_STEP(hi, mid, 4);
+        GR_STEP(hi, hi, 5);
 #undef GR_STEP
-        between(g);
-        between(g + 1);
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) accD[q] += accE[q];
@@ -328,7 +371,9 @@ __global__ void __launch_bounds__(256, 1) pool_gram_bwd_kernel(const GramArgs a)
         const int ro = (q & 3) + 8 * (q >> 2);
         const int row = 32 * wave + 4 * lhi + ro;
         const float d = accD[q] + reinterpret_cast<const float *>(lds + VOFF)[row];
+#if !defined(GRAM_ABL) || GRAM_ABL != 2   // (timing ablation 2: no stores of the tile)
         __builtin_nontemporal_store(d, &dst[(size_t)ro * a.r]);
+#endif
         const float4 c4 = rc[row];
         const float yv = *reinterpret_cast<const float *>(raw + (size_t)row * RAWP + l31 * 4);
         const float gg = __fmaf_rn(yv, c4.x, c4.y) > 0.f ? d : 0.f;
@@ -338,7 +383,6 @@ __global__ void __launch_bounds__(256, 1) pool_gram_bwd_kernel(const GramArgs a)
     } else {
       // R blocks += S rows x a2 rows, Gram blocks += a2 rows x a2 rows (row-wise reads)
       const int i0 = wave - 2;
-      int g = 0;
       auto rows = [&](const char *img, int term_bytes, int blk, int s) {
         Split3 f;
         const char *p0 = img + (size_t)(blk * 32) * RP + rw_off + 16 * s * 2;
@@ -347,40 +391,54 @@ __global__ void __launch_bounds__(256, 1) pool_gram_bwd_kernel(const GramArgs a)
         f.lo = *reinterpret_cast<const bf16x8 *>(p0 + 2 * term_bytes);
         return f;
       };
+      // six MFMAs of a block in three pairs, a staging piece behind each
+#define X6_PAIRS(ACC, A, B, SLOT0)                                                                  \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).lo, (B).hi, ACC, 0, 0, 0);                      \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).hi, (B).lo, ACC, 0, 0, 0);                      \
+  piece(SLOT0);                                                                                     \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).mid, (B).mid, ACC, 0, 0, 0);                    \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).mid, (B).hi, ACC, 0, 0, 0);                     \
+  piece(SLOT0 + 1);                                                                                 \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).hi, (B).mid, ACC, 0, 0, 0);                     \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).hi, (B).hi, ACC, 0, 0, 0);                      \
+  piece(SLOT0 + 2)
 #pragma unroll
       for (int s = 0; s < TN / 16; ++s) {
-        Split3 sq[2];
+        Split3 sq[2], sp[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) sq[j] = rows(Qc, QIMG, j, s);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const Split3 sp = rows(Sc, SIMG, 2 * i0 + i, s);
+        for (int i = 0; i < 2; ++i) sp[i] = rows(Sc, SIMG, 2 * i0 + i, s);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            mfma_x6(accR[i][j], sp, sq[j]);
-            between(g);
-            ++g;
-          }
-        }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) { X6_PAIRS(accR[i][j], sp[i], sq[j], 18 * s + 6 * i + 3 * j); }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           // (sq[i0] with the wave's number as the index put the fragments into scratch memory: six
           // 16-byte stores and three loads per step, each behind a wait for every outstanding load
           // and store of the wave -- a uniform branch instead)
-          if (i0 == 0) mfma_x6(accC[j], sq[0], sq[j]);
-          else mfma_x6(accC[j], sq[1], sq[j]);
-          between(g);
-          ++g;
+          if (i0 == 0) { X6_PAIRS(accC[j], sq[0], sq[j], 18 * s + 12 + 3 * j); }
+          else { X6_PAIRS(accC[j], sq[1], sq[j], 18 * s + 12 + 3 * j); }
         }
       }
+#undef X6_PAIRS
     }
     __syncthreads();  // chunk c read by everyone, chunk c+1 staged by everyone
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
-  for (int c = c_lo; c < c_hi; c += 2) {
-    chunk(B0{}, c);
-    if (c + 1 < c_hi) chunk(B1{}, c + 1);
+  if (dgrad_wave) {
+    for (int c = c_lo; c < c_hi; c += 2) {
+      chunk(B0{}, std::true_type{}, c);
+      if (c + 1 < c_hi) chunk(B1{}, std::true_type{}, c + 1);
+    }
+  } else {
+    for (int c = c_lo; c < c_hi; c += 2) {
+      chunk(B0{}, std::false_type{}, c);
+      if (c + 1 < c_hi) chunk(B1{}, std::false_type{}, c + 1);
+    }
   }
 
   // ---- per-workgroup partials
