@@ -13,7 +13,7 @@ K = importlib.import_module("pointnet2._mlp_ext")
 import bench
 dev = torch.device("cuda:0")
 out = {}
-for name, b, m, ns in (("sa2", 8, 1024, 32), ("sa3", 8, 512, 16), ("sa4", 8, 256, 16), ("sun_sa2", 16, 1024, 32)):
+for name, b, m, ns in (("sa2", 8, 1024, 32), ("semi_sa2", 12, 1024, 32), ("sun_sa2", 16, 1024, 32)):
     g = torch.Generator().manual_seed(1)
     y2 = (torch.randn(b, 128, m, ns, generator=g) * 1.3 + 0.2).to(dev)
     w3 = (torch.randn(256, 128, generator=g) / 11).to(dev)

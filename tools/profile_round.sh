@@ -47,4 +47,9 @@ run chain_pmc rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CY
 python tools/pmc_kernel.py $P/chain/p_counter_collection.csv chain_lin4 $O/${TAG}_chain_pmc.json > /dev/null 2>&1
 run gram_pmc rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --output-format csv -d $P/gram -o p -- python tools/gram_bench.py
 python tools/pmc_kernel.py $P/gram/p_counter_collection.csv "" $O/${TAG}_gram_pmc.json > /dev/null 2>&1
+# -- SA2's pooled 128 -> 256 layer without its raw output (round 6): both passes, durations + SQ counters
+timeout 300 bash tools/gram256_prof.sh $O/gram256 > /dev/null 2>&1; echo "gram256_prof rc=$?"
+cp $O/gram256/gram256_kernel_stats.csv $O/${TAG}_gram256_kernel_stats.csv 2>/dev/null
+cp $O/gram256/gram256_pmc.json $O/${TAG}_gram256_pmc.json 2>/dev/null
+timeout 120 python tools/gram256_bench.py $O/${TAG}_gram256_bench.json > $O/gram256_bench.log 2>&1; echo "gram256_bench rc=$?"
 ls -la $O | head -60
