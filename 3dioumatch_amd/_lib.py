@@ -108,6 +108,8 @@ _SIGNATURES = {
     "mlp_bn_pool_from_extrema": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mlp_wgrad_first4_workspace_bytes": [_c_int, _c_int],
     "mlp_wgrad_first4": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mlp_gemm_backward_fused_lin4_gated": [],
+    "mlp_wgrad_first4_from_gated": [_c_int] + [_vp] * 9,
     "mlp_first4_moments_doubles": [],
     "mlp_first4_moments": [_c_int, _c_int, _vp, _vp, _vp],
     "mlp_first4_bn": [_vp, ctypes.c_double, _vp, _vp, _vp, _c_float, _c_float, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -34,6 +34,11 @@
 #include "mlp_bwd_x6.h"
 #include <stdlib.h>
 
+#ifndef MLP_LIN4_OCC
+#define MLP_LIN4_OCC 1  // workgroups per CU of the gated (64,64) form: at 2 (256 registers) it spills inside the chunk loop and
+                        // gains nothing over the form that writes dQ; at 1: step -0.05 ms (profiles/r6_step_experiments.json)
+#endif
+
 namespace {
 
 // X6: the products run as six bf16 MFMAs on an exact three-term split of the fp32 fragments
@@ -41,7 +46,7 @@ namespace {
 // indices -- eight 4-byte LDS reads from the same conflict-free tiles -- and an MFMA step covers
 // 16 of them, so a chunk is M/16 dgrad steps and TN/16 wgrad steps.
 template <int MB, int KB, int KBD, int NB, int PMODE, int QMODE, int OCC, bool STATS, bool DGRAD = true,
-          bool X6 = false>
+          bool X6 = false, bool GATED = true>
 __global__ void __launch_bounds__(256, OCC)
 gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud, int xyz,
                       OperandB opp, OperandB opq, const float *__restrict__ w,
@@ -77,9 +82,19 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
   // recomputed from the 4-channel input x4 (b,4,r) (raw: STATS is on, the tile holds raw rows)
   constexpr bool QLIN = QMODE == OP_LIN4;
   static_assert(!QLIN || (STATS && KB * 32 == 64), "recomputed rows: the 64-channel layer only");
+  // QLIN: the layer below is VIRTUAL, so nobody reads dQ but (i) its BatchNorm-backward sums and (ii)
+  // its weight gradient, dW1[k][c] ~ G[k][c] = sum_n gate[k][n] dQ[k][n] x4[c][n] (mlp_first4.hip).
+  // Both are taken from the blocks in the accumulators and dQ (268 MB at SA1) is NOT WRITTEN: the
+  // dgrad runs in "T form" -- the MFMA's two operands swapped, same fragments -- so that a lane owns
+  // ONE row k of the block and 16 of its columns: the sums and the four G entries of the row are
+  // in-lane accumulations (2 + 4 registers instead of 32), the column's x4 a broadcast LDS read.
+  // `dq` then receives the G partials: (2 gridDim.x, 64, 4) floats.
+  // (GATED = false: the round-5 form -- dQ written, the sums only -- kept for A/B, MLP_LIN4_GATED=0)
+  constexpr bool TF = QLIN && GATED;
   constexpr bool RAWQ = STATS;  // the Q tile then holds raw rows, rectified as fragments are read
   constexpr int SROWS = STATS ? 32 * KBD : 1;
   __shared__ float4 Rc[SROWS];       // per Q row: sc, sh, mu, is
+  __shared__ float4 X4s[TF ? 2 : 1][TF ? TN : 1];  // TF: the four input channels of every column of a chunk
   __shared__ float Wx[3 * M];        // the coordinate columns of W (xyz == 3)
   __shared__ float red[8 * 3 * 32];  // partial dot products of the coordinate rows
 
@@ -239,6 +254,10 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
         const float c3[4] = {qx[q][i][3].x, qx[q][i][3].y, qx[q][i][3].z, qx[q][i][3].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) xv[e] = lin4(qw[q], c0[e], c1[e], c2[e], c3[e]);
+        if (TF && row == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) X4s[buf][seg_c + 4 * i + e] = make_float4(c0[e], c1[e], c2[e], c3[e]);
+        }
       } else {
         xv[0] = qx[q][i][0].x; xv[1] = qx[q][i][0].y; xv[2] = qx[q][i][0].z; xv[3] = qx[q][i][0].w;
       }
@@ -249,8 +268,19 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
     }
   };
 
-  constexpr int SQ = STATS ? 16 : 1;
+  constexpr int SQ = (STATS && !TF) ? 16 : 1;
   float st1[DK][SQ], st2[DK][SQ];
+  float gx[TF ? DK : 1][4];  // TF: this lane's row of G
+#pragma unroll
+  for (int e = 0; e < (TF ? DK : 1); ++e)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gx[e][k] = 0.f;
+  float4 trc[TF ? DK : 1];   // TF: (sc, sh, mu, is) of this lane's row
+#pragma unroll
+  for (int e = 0; e < (TF ? DK : 1); ++e) {
+    const int row = 32 * (KBD >= 4 ? wave * DK + e : (wave >> 1)) + l31;
+    trc[e] = TF ? make_float4(Q.scale[row], Q.shift[row], Q.mean[row], Q.invstd[row]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 #pragma unroll
   for (int e = 0; e < DK; ++e)
 #pragma unroll
@@ -279,11 +309,13 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
     // LDS buffer) and reloads the registers with chunk c+2, so staging costs no time of its own
     // (two co-resident workgroups run in lock-step and do not hide it for each other).
     auto between = [&](int g) {
+#if !defined(BWDF_ABL) || BWDF_ABL != 1   // (timing ablation 1: no staging / loads inside the loop)
 #pragma unroll
       for (int sl = g * NS / NG; sl < (g + 1) * NS / NG; ++sl) {
         stage_slice(sl, cur ^ 1);
         fetch_slice(sl, ahead);
       }
+#endif
     };
     const int b = c / chunks_per_cloud;
     const int col0 = (c - b * chunks_per_cloud) * TN;
@@ -323,7 +355,10 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
             for (int j = 0; j < 8; ++j) w8[j] = wreg[e][g * 8 + j];
             const Split3 sa = split3(w8);
 #pragma unroll
-            for (int n = 0; n < DN; ++n) mfma_x6(accD[e][n], sa, sb[n]);
+            for (int n = 0; n < DN; ++n) {
+              if constexpr (TF) mfma_x6(accD[e][n], sb[n], sa);  // block[column][row]
+              else mfma_x6(accD[e][n], sa, sb[n]);
+            }
           }
           between(g);
         }
@@ -350,14 +385,16 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
           for (int e = 0; e < DK; ++e)
 #pragma unroll
             for (int n = 0; n < DN; ++n)
-              accD[e][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[e][g * DU + u], bp[g & 1][u][n],
-                                                                accD[e][n], 0, 0, 0);
+              accD[e][n] = TF ? __builtin_amdgcn_mfma_f32_32x32x2f32(bp[g & 1][u][n], wreg[e][g * DU + u],
+                                                                     accD[e][n], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[e][g * DU + u], bp[g & 1][u][n],
+                                                                     accD[e][n], 0, 0, 0);
         between(g);
         __builtin_amdgcn_sched_barrier(0);
       }
       }
 #pragma unroll
-      for (int e = 0; e < DK; ++e) {
+      for (int e = 0; e < (TF ? 0 : DK); ++e) {  // (TF: the blocks are not written)
         const int kbd = KBD >= 4 ? wave * DK + e : (wave >> 1);
 #pragma unroll
         for (int n = 0; n < DN; ++n) {
@@ -375,6 +412,28 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
     // rows 32*kbd + 4*lhi + (q&3) + 8*(q>>2) of the block.
     auto stats_row = [&](int q) {
       const int ro = (q & 3) + 8 * (q >> 2);
+      if constexpr (TF) {
+        // T form: register q of a block is column 4 lhi + ro, this lane's row is 32 kbd + l31
+#pragma unroll
+        for (int e = 0; e < DK; ++e) {
+          const int kbd = KBD >= 4 ? wave * DK + e : (wave >> 1);
+#pragma unroll
+          for (int n = 0; n < DN; ++n) {
+            const int nb = KBD >= 4 ? n : (wave & 1);
+            const int col = nb * 32 + 4 * lhi + ro;
+            const float yv = Qc[col * LDQ + 32 * kbd + l31];
+            const float g = __fmaf_rn(yv, trc[e].x, trc[e].y) > 0.f ? accD[e][n][q] : 0.f;
+            st1[e][0] += g;
+            st2[e][0] = __fmaf_rn(g, (yv - trc[e].z) * trc[e].w, st2[e][0]);
+            const float4 xc = X4s[cur][col];
+            gx[e][0] = __fmaf_rn(g, xc.x, gx[e][0]);
+            gx[e][1] = __fmaf_rn(g, xc.y, gx[e][1]);
+            gx[e][2] = __fmaf_rn(g, xc.z, gx[e][2]);
+            gx[e][3] = __fmaf_rn(g, xc.w, gx[e][3]);
+          }
+        }
+        return;
+      }
 #pragma unroll
       for (int e = 0; e < DK; ++e) {
         const int kbd = KBD >= 4 ? wave * DK + e : (wave >> 1);
@@ -495,7 +554,30 @@ gemm_bwd_fused_kernel(int k_total, int r, int total_chunks, int chunks_per_cloud
     __syncthreads();  // chunk c read by everyone, chunk c+1 staged by everyone
   }
 
-  if (STATS && stats_part != nullptr) {
+  if constexpr (TF) {
+    // T form: the two halves of a wave hold the same rows (other columns); one partial per row and
+    // (workgroup, column block); the rows of G go where dQ would have gone
+    constexpr int PPW = KBD >= 4 ? 1 : 2;
+    const int parts = (int)gridDim.x * PPW;
+    const int pidx = (int)blockIdx.x * PPW + (KBD >= 4 ? 0 : (wave & 1));
+#pragma unroll
+    for (int e = 0; e < DK; ++e) {
+      const int row = 32 * (KBD >= 4 ? wave * DK + e : (wave >> 1)) + l31;
+      float a1 = st1[e][0], a2 = st2[e][0];
+      a1 += __shfl_xor(a1, 32, kWave);
+      a2 += __shfl_xor(a2, 32, kWave);
+      float g4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g4[k] = gx[e][k] + __shfl_xor(gx[e][k], 32, kWave);
+      if (lhi == 0) {
+        if (stats_part != nullptr) {
+          stats_part[((size_t)row * parts + pidx) * 2] = a1;
+          stats_part[((size_t)row * parts + pidx) * 2 + 1] = a2;
+        }
+        *reinterpret_cast<float4 *>(dq + ((size_t)pidx * k_total + row) * 4) = make_float4(g4[0], g4[1], g4[2], g4[3]);
+      }
+    }
+  } else if (STATS && stats_part != nullptr) {
     // sum over the 32 columns held by the lanes of a half-wave, one partial per row and
     // workgroup (two when two waves share a row block: KBD == 2)
     constexpr int PPW = KBD >= 4 ? 1 : 2;
@@ -599,6 +681,13 @@ MLP_API int mlp_gemm_backward_fused_supported(int b, int m, int k, int r, int pm
   return 1;
 }
 
+// 1 when mlp_gemm_backward_fused with qmode 4 leaves the gated sums of the virtual layer below in dq
+// (parts x 64 x 4 floats) instead of the data gradient (b, 64, r); 0 with MLP_LIN4_GATED=0 (A/B)
+MLP_API int mlp_gemm_backward_fused_lin4_gated(void) {
+  static const bool off = getenv("MLP_LIN4_GATED") && atoi(getenv("MLP_LIN4_GATED")) == 0;
+  return off ? 0 : 1;
+}
+
 // number of (s1, s2) partials per channel that mlp_gemm_backward_fused leaves in stats_part
 // (k, parts, 2) for the layer below (qmode 1 only; 0 otherwise)
 MLP_API int mlp_gemm_backward_fused_stats_parts(int b, int m, int k, int r) {
@@ -663,7 +752,12 @@ MLP_API int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, 
        else FUSED_X(MB, KB, KBD, NB, PM, QM, OCC, ST, false); } while (0)
   // (the bf16 form wins where the registers hold it; measured per shape, profiles/r4_split_bf16.json)
 #define FUSED_F32(MB, KB, KBD, NB, PM, QM, OCC, ST) FUSED_X(MB, KB, KBD, NB, PM, QM, OCC, ST, false)
-  if (m == 64 && k == 64 && qmode == OP_LIN4) FUSED(2, 2, 2, 2, OP_DY, OP_LIN4, 2, true);
+  if (m == 64 && k == 64 && qmode == OP_LIN4 && !mlp_gemm_backward_fused_lin4_gated()) {
+    if (x6) hipLaunchKernelGGL((gemm_bwd_fused_kernel<2, 2, 2, 2, OP_DY, OP_LIN4, 2, true, true, true, false>), dim3(g),
+                               dim3(256), 0, stream, k, r, total, cpc, s.xyz, P, Q, w, dq, workspace, stats_part);
+    else hipLaunchKernelGGL((gemm_bwd_fused_kernel<2, 2, 2, 2, OP_DY, OP_LIN4, 2, true, true, false, false>), dim3(g),
+                            dim3(256), 0, stream, k, r, total, cpc, s.xyz, P, Q, w, dq, workspace, stats_part);
+  } else if (m == 64 && k == 64 && qmode == OP_LIN4) FUSED(2, 2, 2, 2, OP_DY, OP_LIN4, MLP_LIN4_OCC, true);
   else if (m == 64 && k == 64) FUSED(2, 2, 2, 2, OP_DY, OP_BNRELU, 2, true);
   else if (m == 128 && k == 64) FUSED(4, 2, 2, 2, OP_POOLDY, OP_BNRELU, 1, true);
   else if (m == 128 && k == 128 && pmode == OP_DY) FUSED_F32(4, 4, 4, 1, OP_DY, OP_BNRELU, 2, false);

@@ -282,3 +282,22 @@ MLP_API int mlp_wgrad_first4(int b, int r, const float *w, const float *x, const
                      coef, dw);
   return pn2_launch_status();
 }
+
+// The same weight gradient when the gated sums G come from elsewhere: the one-pass backward of the
+// layer ABOVE (mlp_gemm_backward_fused, qmode 4) forms dz -- the gradient w.r.t. this virtual layer's
+// activated output -- block by block in its accumulators and leaves G as `parts` partials of (64,4)
+// instead of writing dz (268 MB at SA1) for mlp_wgrad_first4 to read.  moments: mlp_first4_moments of
+// x (required); workspace: 256 floats.
+MLP_API int mlp_wgrad_first4_from_gated(int parts, const float *gpart, const float *w, const float *mean,
+                                        const float *invstd, const float *coef, const double *moments,
+                                        float *dw, float *workspace, void *stream_) {
+  if (parts <= 0 || !gpart || !w || !mean || !invstd || !coef || !moments || !dw || !workspace)
+    return (int)hipErrorInvalidValue;
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = mlp_reduce_partials(kF4Rows * 4, parts, gpart, workspace, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(first4_combine_kernel, dim3(1), dim3(256), 0, stream, workspace, moments, w, mean, invstd,
+                     coef, dw);
+  return pn2_launch_status();
+}
+

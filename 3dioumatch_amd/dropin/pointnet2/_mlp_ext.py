@@ -488,8 +488,9 @@ def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None, n
     would return them -- the sums come out of the dgrad epilogue, no pass over (x, dx).
     need_dx=False (a first layer whose input needs no gradient): dx is None.
     lin_w (64,4): the layer below is a 4 -> 64 first layer whose output was never stored; x is then
-    THAT layer's input (B,4,...), xcoeff / xstats its BatchNorm, and dx (B,64,...) the gradient
-    w.r.t. its activated output."""
+    THAT layer's input (B,4,...), xcoeff / xstats its BatchNorm.  The gradient w.r.t. its activated
+    output is not written either: in its place comes a GatedSums -- what wgrad_first4_from_gated needs
+    of it for that layer's weight gradient (`below` carries its BatchNorm sums)."""
     m, k = w.shape
     _f32c(w, "w"); _f32c(x, "x")
     b = x.shape[0]
@@ -509,13 +510,19 @@ def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None, n
         raise RuntimeError("xstats=(mean, invstd, gamma, training) is required with xcoeff")
     xs, xh = xcoeff if xcoeff is not None else (None, None)
     xmean, xinv, xgamma, xtraining = xstats if qmode != 0 else (None, None, None, False)
-    if lin_w is not None:
+    parts = int(_lib.mlp_gemm_backward_fused_stats_parts(b, m, k, r)) if qmode != 0 else 0
+    gated = lin_w is not None and bool(_lib.mlp_gemm_backward_fused_lin4_gated())
+    if gated:
+        _f32c(lin_w, "lin_w")
+        if parts <= 0:
+            raise RuntimeError("gemm_backward_fused(lin_w): no partials for this shape")
+        dx = torch.empty((parts, k, 4), dtype=torch.float32, device=x.device)  # the gated sums' partials
+    elif lin_w is not None:
         _f32c(lin_w, "lin_w")
         dx = torch.empty((b, k) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
     else:
         dx = torch.empty_like(x) if need_dx else None
     dw = torch.empty((m, k), dtype=torch.float32, device=x.device)
-    parts = int(_lib.mlp_gemm_backward_fused_stats_parts(b, m, k, r)) if qmode != 0 else 0
     below = None
     with torch.cuda.device(x.device):
         ws = torch.empty(max(int(_lib.mlp_gemm_backward_fused_workspace_floats(b, m, k, r)), 1),
@@ -538,7 +545,33 @@ def gemm_backward_fused(w, x, xcoeff=None, fly=None, pooled=None, xstats=None, n
                                                    small[2:].data_ptr(), _stream(x)),
                      "mlp_bn_backward_finalize")
             below = (small[0], small[1], small[2:])
+    if gated:
+        dx = GatedSums(dx)
     return dx, dw, below
+
+
+class GatedSums(object):
+    """What the one-pass backward of the layer above leaves of the gradient w.r.t. a VIRTUAL 4 -> 64
+    first layer's output: parts x (64,4) partial sums G = sum_n [gate] dz x^T (the tensor itself,
+    268 MB at SA1, is never written)."""
+
+    def __init__(self, partials):
+        self.partials = partials
+
+
+def wgrad_first4_from_gated(w, gated, mean, invstd, coef, moments):
+    """dw (64,4) of the virtual first layer from the GatedSums of gemm_backward_fused(lin_w=...), its
+    BatchNorm's (mean, invstd), coef (64,3) and the moments of its input (first4_moments)."""
+    _f32c(w, "w")
+    g = gated.partials
+    dw = torch.empty((64, 4), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        ws = torch.empty(256, dtype=torch.float32, device=w.device)
+        _L.check(_lib.mlp_wgrad_first4_from_gated(int(g.shape[0]), g.data_ptr(), w.data_ptr(), mean.data_ptr(),
+                                                  invstd.data_ptr(), coef.data_ptr(), moments.data_ptr(),
+                                                  dw.data_ptr(), ws.data_ptr(), _stream(w)),
+                 "mlp_wgrad_first4_from_gated")
+    return dw
 
 
 def small_backward_prefers_dy(w, y):

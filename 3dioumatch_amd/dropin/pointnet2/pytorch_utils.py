@@ -401,7 +401,12 @@ class _FusedMLPChain(Function):
                 else:
                     dz = both[0]
             elif i == 0:
-                dw0 = K.wgrad_first4(w2, x, fly, ctx.moments) if (fly is not None and not need_dx) else None
+                if isinstance(dz, K.GatedSums):
+                    # the layer above never wrote the gradient w.r.t. this virtual layer's output: its
+                    # one-pass backward left the gated sums the weight gradient needs (and `below`)
+                    dw0 = K.wgrad_first4_from_gated(w2, dz, mean, invstd, coef, ctx.moments)
+                else:
+                    dw0 = K.wgrad_first4(w2, x, fly, ctx.moments) if (fly is not None and not need_dx) else None
                 if dw0 is None and virtual0:
                     raise RuntimeError("the virtual first layer needs mlp_wgrad_first4")
                 if dw0 is None:

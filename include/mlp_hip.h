@@ -281,7 +281,11 @@ size_t mlp_gemm_backward_fused_workspace_floats(int b, int m, int k, int r);
  * or mlp_gemm_dgrad_pooled_nt (pmode 3: y, dz = dpooled (b,m,r/ns), argmax); Q as in
  * mlp_gemm_wgrad (qmode 1: relu(x*xscale + xshift), qmode 0: x; qmode 4, (64,64) only: the layer
  * below is a 4 -> 64 first layer whose output is not stored -- x is ITS input (b,4,r), xlin_w its
- * weight (64,4), and Q = relu((xlin_w . x)*xscale + xshift) is recomputed).
+ * weight (64,4), and Q = relu((xlin_w . x)*xscale + xshift) is recomputed.  With qmode 4 the data
+ * gradient is NOT written -- its only readers are the virtual layer's BatchNorm sums (stats_part) and
+ * weight gradient: dq then receives the gated sums G = sum_n [gate] dq x^T of that layer as parts
+ * partials of (64,4) floats, parts = mlp_gemm_backward_fused_stats_parts(): the input of
+ * mlp_wgrad_first4_from_gated).
  * dq == NULL (only (128,259)): the weight gradient alone, for a first layer whose input needs no
  * gradient.
  * qmode 1 also needs xmean / xinvstd of the layer that produced x, and, for the k = 64 shapes when
@@ -289,6 +293,9 @@ size_t mlp_gemm_backward_fused_workspace_floats(int b, int m, int k, int r);
  * (sum g, sum g*xhat) with g = dq * [x*xscale + xshift > 0], parts =
  * mlp_gemm_backward_fused_stats_parts() -- the input of mlp_bn_backward_finalize, in place of
  * that layer's mlp_bn_relu_backward_stats pass over (x, dq). */
+/* 1: qmode 4 leaves the gated sums in dq (above); 0 (MLP_LIN4_GATED=0): dq (b,64,r) is written as for
+ * the other modes and mlp_wgrad_first4 reads it (the round-5 form, pytorch_utils.py:70-124 unchanged) */
+int mlp_gemm_backward_fused_lin4_gated(void);
 int mlp_gemm_backward_fused(int b, int m, int k, int r, const float *w, int pmode, const float *y,
                             const float *dz, const int *argmax, int ns, const float *scale,
                             const float *shift, const float *mean, const float *invstd,
@@ -417,6 +424,13 @@ int mlp_wgrad_first4(int b, int r, const float *w, const float *x, const float *
                      const float *scale, const float *shift, const float *mean, const float *invstd,
                      const float *coef, const double *moments, float *dw, void *workspace,
                      void *stream);
+/* The same from gated sums formed elsewhere: mlp_gemm_backward_fused with qmode 4 leaves G = sum_n
+ * gate dz x^T as `parts` partials of (64,4) in its dq argument instead of writing dz (the virtual
+ * first layer of pytorch_utils.py:14-39: nobody else reads that gradient); moments as above
+ * (required), workspace 256 floats */
+int mlp_wgrad_first4_from_gated(int parts, const float *gpart, const float *w, const float *mean,
+                                const float *invstd, const float *coef, const double *moments,
+                                float *dw, float *workspace, void *stream);
 
 /* scratch (floats) for mlp_gemm_wgrad: per-slice partial dW tiles (replaces cuDNN's
  * workspace of conv2d backward-weight, pytorch_utils.py:70-124) */
