@@ -9,6 +9,7 @@
 //  * three_interpolate: lanes own consecutive query points j (coalesced idx/weight/out
 //    traffic), and walk a group of channels so idx/weight are fetched once.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -65,6 +66,82 @@ three_nn_kernel(int n, int m, const float *__restrict__ unknown,
     int *oi = idx + ((size_t)b * n + j) * 3;
     od[0] = best1; od[1] = best2; od[2] = best3;
     oi[0] = besti1; oi[1] = besti2; oi[2] = besti3;
+  }
+}
+
+// The same for launches that do not fill the chip (the IoU branch's grid points: 9216 queries x 8
+// clouds = 288 workgroups of the kernel above, ONE wave per SIMD, every candidate a dependent chain
+// of an LDS round trip and ten vector instructions: 125 us for 75 M tests).  Here a workgroup owns 64
+// queries and its four waves each scan a QUARTER of every tile for all of them -- four times the waves
+// in flight -- then wave 0 folds the quarters' sorted triples in, quarter by quarter in index order,
+// with the same strict '<' insertion: a later quarter holds larger indices only, so the earliest
+// index still wins every tie and the result is the sequential scan's, bit for bit.
+__global__ void __launch_bounds__(256)
+three_nn_split_kernel(int n, int m, const float *__restrict__ unknown,
+                      const float *__restrict__ known, float *__restrict__ dist2,
+                      int *__restrict__ idx) {
+  __shared__ float4 tile[kNNTile];
+  __shared__ float pd[3][3][kWave];
+  __shared__ int pi[3][3][kWave];
+  const BlockId blk = xcd_block_id();
+  const int b = blk.y;
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  const int j = blk.x * kWave + lane;
+  const bool live = j < n;
+  const float *kn = known + (size_t)b * m * 3;
+  float ux = 0.f, uy = 0.f, uz = 0.f;
+  if (live) {
+    const float *u = unknown + ((size_t)b * n + j) * 3;
+    ux = u[0]; uy = u[1]; uz = u[2];
+  }
+  float best1 = __builtin_inff(), best2 = __builtin_inff(), best3 = __builtin_inff();
+  int besti1 = 0, besti2 = 0, besti3 = 0;
+  // (branch-free: in a scan of 256 candidates some lane of the wave improves its triple at almost
+  // every step, so the branchy form runs its slow path nearly always -- and diverged)
+  auto insert = [&](float d, int k) {
+    const bool c1 = d < best1, c2 = d < best2, c3 = d < best3;
+    best3 = c2 ? best2 : (c3 ? d : best3);
+    besti3 = c2 ? besti2 : (c3 ? k : besti3);
+    best2 = c1 ? best1 : (c2 ? d : best2);
+    besti2 = c1 ? besti1 : (c2 ? k : besti2);
+    best1 = c1 ? d : best1;
+    besti1 = c1 ? k : besti1;
+  };
+  for (int base = 0; base < m; base += kNNTile) {
+    const int cnt = m - base < kNNTile ? m - base : kNNTile;
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt; t += 256) {
+      const float *p = kn + (size_t)(base + t) * 3;
+      tile[t] = make_float4(p[0], p[1], p[2], 0.f);
+    }
+    __syncthreads();
+    // this wave's quarter of the tile (whole tiles before it were folded into every wave's triple
+    // in index order already: a wave's triple is over its quarters of ALL tiles so far -- the final
+    // fold below therefore goes tile-major only when m <= kNNTile; larger m takes the plain kernel)
+    const int q = (cnt + 3) / 4;
+    const int t0 = w * q, t1 = t0 + q < cnt ? t0 + q : cnt;
+#pragma unroll 4
+    for (int t = t0; t < t1; ++t) {
+      const float4 p = tile[t];
+      insert(sqdist3(ux, uy, uz, p.x, p.y, p.z), base + t);
+    }
+  }
+  if (w > 0) {
+    pd[w - 1][0][lane] = best1; pd[w - 1][1][lane] = best2; pd[w - 1][2][lane] = best3;
+    pi[w - 1][0][lane] = besti1; pi[w - 1][1][lane] = besti2; pi[w - 1][2][lane] = besti3;
+  }
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int qq = 0; qq < 3; ++qq)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) insert(pd[qq][s][lane], pi[qq][s][lane]);
+    if (live) {
+      float *od = dist2 + ((size_t)b * n + j) * 3;
+      int *oi = idx + ((size_t)b * n + j) * 3;
+      od[0] = best1; od[1] = best2; od[2] = best3;
+      oi[0] = besti1; oi[1] = besti2; oi[2] = besti3;
+    }
   }
 }
 
@@ -271,6 +348,15 @@ int interp_channel_groups(int c) {
 PN2_API int pn2_three_nn(int b, int n, int m, const float *unknown, const float *known,
                          float *dist2, int *idx, void *stream_) {
   if (b <= 0 || n <= 0) return 0;
+  // a launch of the plain kernel that leaves most SIMDs with one wave or none: the split form
+  // (one tile of candidates only: its fold assumes the quarters are in index order)
+  static const bool split_off = getenv("PN2_THREE_NN_SPLIT") && atoi(getenv("PN2_THREE_NN_SPLIT")) == 0;
+  if (!split_off && m > 0 && m <= kNNTile && (long long)b * pn2_ceil_div(n, 256) <= 1024) {
+    dim3 grid(pn2_ceil_div(n, kWave), b);
+    hipLaunchKernelGGL(three_nn_split_kernel, grid, dim3(256), 0, (hipStream_t)stream_, n, m, unknown,
+                       known, dist2, idx);
+    return pn2_launch_status();
+  }
   dim3 grid(pn2_ceil_div(n, 256), b);
   hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, (hipStream_t)stream_, n, m, unknown,
                      known, dist2, idx);

@@ -566,7 +566,8 @@ def test_interpolate_on_channel_slices(ext, b, c, m, n, ctot, c0):
     torch.testing.assert_close(got_g, want_g, rtol=0, atol=1e-4)
 
 
-@pytest.mark.parametrize("b,n,m", [(2, 4096, 1024), (1, 1000, 1500), (3, 37, 5), (1, 2500, 2049)])
+@pytest.mark.parametrize("b,n,m", [(2, 4096, 1024), (1, 1000, 1500), (3, 37, 5), (1, 2500, 2049),
+                                   (8, 9216, 1024), (2, 300, 2), (1, 64, 1023), (40, 8192, 512)])
 def test_three_nn_vs_oracle(ext, oracle, synth, b, n, m):
     unk = synth.cloud_uniform(b, n, 2.0, seed=n)
     kn = synth.cloud_uniform(b, m, 2.0, seed=m + 1)
