@@ -195,36 +195,43 @@ __device__ __forceinline__ float softplus1(float x) {  // F.softplus: beta 1, th
   return x > 20.0f ? x : log1pf(expf(x));
 }
 
+// One lane per (cloud, channel, proposal) -- the element order of `net` itself, so the read is one
+// coalesced load per lane and nothing is a loop: with one lane per PROPOSAL (rounds 5: 8 workgroups
+// on 256 CUs, each lane a chain of ~97 dependent strided loads + expf / log1pf) the two kernels took
+// 55 + 60 us for 0.8 MB.
 __global__ void __launch_bounds__(256) decode_scores_kernel(DecodeArgs a) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long long)a.b * a.k) return;
-  const int bi = (int)(i / a.k), ki = (int)(i % a.k);
   const int c_total = 5 + 2 * a.nh + 4 * a.ns + a.nc;
-  const float *col = a.net + ((long long)bi * c_total) * a.k + ki;
-  auto at = [&](int c) { return col[(long long)c * a.k]; };
-  int c = 0;
-  a.objectness[i * 2] = at(0); a.objectness[i * 2 + 1] = at(1);
-  c = 2;
-  for (int d = 0; d < 3; ++d) a.center[i * 3 + d] = a.agg_xyz[i * 3 + d] + at(c + d);
-  c += 3;
-  for (int j = 0; j < a.nh; ++j) a.heading_scores[i * a.nh + j] = at(c + j);
-  c += a.nh;
-  const float per = (float)(M_PI / (double)a.nh);   // np.pi / nh as a Python float, then fp32
-  for (int j = 0; j < a.nh; ++j) {
-    const float v = at(c + j);
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)a.b * c_total * a.k) return;
+  const int ki = (int)(t % a.k);
+  const long long bc = t / a.k;
+  const int c = (int)(bc % c_total), bi = (int)(bc / c_total);
+  const long long i = (long long)bi * a.k + ki;
+  const float v = a.net[t];
+  int j = c;
+  if (j < 2) { a.objectness[i * 2 + j] = v; return; }
+  j -= 2;
+  if (j < 3) { a.center[i * 3 + j] = a.agg_xyz[i * 3 + j] + v; return; }
+  j -= 3;
+  if (j < a.nh) { a.heading_scores[i * a.nh + j] = v; return; }
+  j -= a.nh;
+  if (j < a.nh) {
+    const float per = (float)(M_PI / (double)a.nh);   // np.pi / nh as a Python float, then fp32
     a.heading_resn[i * a.nh + j] = v;
     a.heading_res[i * a.nh + j] = v * per;
+    return;
   }
-  c += a.nh;
-  for (int j = 0; j < a.ns; ++j) a.size_scores[i * a.ns + j] = at(c + j);
-  c += a.ns;
-  for (int j = 0; j < a.ns * 3; ++j) {
-    const float v = softplus1(at(c + j)) - 1.0f;
-    a.size_resn[i * a.ns * 3 + j] = v;
-    a.size_res[i * a.ns * 3 + j] = v * a.mean_size[j];
+  j -= a.nh;
+  if (j < a.ns) { a.size_scores[i * a.ns + j] = v; return; }
+  j -= a.ns;
+  if (j < a.ns * 3) {
+    const float u = softplus1(v) - 1.0f;
+    a.size_resn[i * a.ns * 3 + j] = u;
+    a.size_res[i * a.ns * 3 + j] = u * a.mean_size[j];
+    return;
   }
-  c += a.ns * 3;
-  for (int j = 0; j < a.nc; ++j) a.sem_cls[i * a.nc + j] = at(c + j);
+  j -= a.ns * 3;
+  a.sem_cls[i * a.nc + j] = v;
 }
 
 struct DecodeGradArgs {
@@ -236,33 +243,37 @@ struct DecodeGradArgs {
 };
 
 __global__ void __launch_bounds__(256) decode_scores_grad_kernel(DecodeGradArgs a) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long long)a.b * a.k) return;
-  const int bi = (int)(i / a.k), ki = (int)(i % a.k);
   const int c_total = 5 + 2 * a.nh + 4 * a.ns + a.nc;
-  const long long base = ((long long)bi * c_total) * a.k + ki;
-  auto put = [&](int c, float v) { a.d_net[base + (long long)c * a.k] = v; };
-  auto get = [&](const float *g, long long j) { return g ? g[j] : 0.0f; };
-  put(0, get(a.g_objectness, i * 2)); put(1, get(a.g_objectness, i * 2 + 1));
-  int c = 2;
-  for (int d = 0; d < 3; ++d) put(c + d, get(a.g_center, i * 3 + d));
-  c += 3;
-  for (int j = 0; j < a.nh; ++j) put(c + j, get(a.g_heading_scores, i * a.nh + j));
-  c += a.nh;
-  const float per = (float)(M_PI / (double)a.nh);
-  for (int j = 0; j < a.nh; ++j)
-    put(c + j, get(a.g_heading_resn, i * a.nh + j) + get(a.g_heading_res, i * a.nh + j) * per);
-  c += a.nh;
-  for (int j = 0; j < a.ns; ++j) put(c + j, get(a.g_size_scores, i * a.ns + j));
-  c += a.ns;
-  for (int j = 0; j < a.ns * 3; ++j) {
-    const float x = a.net[base + (long long)(c + j) * a.k];
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)a.b * c_total * a.k) return;
+  const int ki = (int)(t % a.k);
+  const long long bc = t / a.k;
+  const int c = (int)(bc % c_total), bi = (int)(bc / c_total);
+  const long long i = (long long)bi * a.k + ki;
+  auto get = [&](const float *g, long long at) { return g ? g[at] : 0.0f; };
+  int j = c;
+  float out;
+  if (j < 2) {
+    out = get(a.g_objectness, i * 2 + j);
+  } else if ((j -= 2) < 3) {
+    out = get(a.g_center, i * 3 + j);
+  } else if ((j -= 3) < a.nh) {
+    out = get(a.g_heading_scores, i * a.nh + j);
+  } else if ((j -= a.nh) < a.nh) {
+    const float per = (float)(M_PI / (double)a.nh);
+    out = get(a.g_heading_resn, i * a.nh + j) + get(a.g_heading_res, i * a.nh + j) * per;
+  } else if ((j -= a.nh) < a.ns) {
+    out = get(a.g_size_scores, i * a.ns + j);
+  } else if ((j -= a.ns) < a.ns * 3) {
+    const float x = a.net[t];
     const float slope = x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));   // softplus' = sigmoid
     const float g = get(a.g_size_resn, i * a.ns * 3 + j) + get(a.g_size_res, i * a.ns * 3 + j) * a.mean_size[j];
-    put(c + j, g * slope);
+    out = g * slope;
+  } else {
+    j -= a.ns * 3;
+    out = get(a.g_sem_cls, i * a.nc + j);
   }
-  c += a.ns * 3;
-  for (int j = 0; j < a.nc; ++j) put(c + j, get(a.g_sem_cls, i * a.nc + j));
+  a.d_net[t] = out;
 }
 
 }  // namespace
@@ -277,7 +288,8 @@ int votenet_decode_scores(int b, int k, int nh, int ns, int nc, const float *net
   if (nh <= 0 || ns <= 0 || nc <= 0) return (int)hipErrorInvalidValue;
   const DecodeArgs a = {b, k, nh, ns, nc, net, agg_xyz, mean_size, objectness, center, heading_scores,
                         heading_resn, heading_res, size_scores, size_resn, size_res, sem_cls};
-  hipLaunchKernelGGL(decode_scores_kernel, dim3((unsigned)(((long long)b * k + 255) / 256)), dim3(256), 0,
+  const long long total = (long long)b * (5 + 2 * nh + 4 * ns + nc) * k;
+  hipLaunchKernelGGL(decode_scores_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
@@ -294,7 +306,8 @@ int votenet_decode_scores_grad(int b, int k, int nh, int ns, int nc, const float
   const DecodeGradArgs a = {b, k, nh, ns, nc, net, mean_size, g_objectness, g_center, g_heading_scores,
                             g_heading_resn, g_heading_res, g_size_scores, g_size_resn, g_size_res,
                             g_sem_cls, d_net};
-  hipLaunchKernelGGL(decode_scores_grad_kernel, dim3((unsigned)(((long long)b * k + 255) / 256)), dim3(256),
+  const long long total = (long long)b * (5 + 2 * nh + 4 * ns + nc) * k;
+  hipLaunchKernelGGL(decode_scores_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
                      0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
