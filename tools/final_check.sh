@@ -6,3 +6,4 @@ timeout 900 python bench.py > gpurun_out/r6f/bench_line.json 2> gpurun_out/r6f/b
 timeout 600 python tools/stress_bench.py gpurun_out/r6f/r6_stress_config5.json > gpurun_out/r6f/stress.log 2>&1; echo "stress rc=$?"
 timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -3
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 600 python tools/gram256_soak.py 100 2>&1 | tail -1
