@@ -250,14 +250,18 @@ class _FusedMLPChain(Function):
                 # ... and so do the per-group extrema the max over nsample needs.  Where the layer's
                 # backward can run from the Gram matrix of its input (SA2 - SA4: 128 -> 256,
                 # csrc/mlp_pool_gram256.hip) the raw output is not stored at all: 268 MB at SA2
-                gram = (i >= 1 and cur is not None and cur.dim() == 4 and cur.numel() > 0
-                        and K.pool_gram_supported(w2, cur, cur.shape[3])
-                        and K.forward_pool_supported(w2, cur, cur_coeff))
+                epilogue = (i >= 1 and cur is not None and cur.dim() == 4 and cur.numel() > 0
+                            and K.forward_pool_supported(w2, cur, cur_coeff))
+                gram = epilogue and K.pool_gram_supported(w2, cur, cur.shape[3])
+                # ... and in a pass that no backward follows (the EMA teacher, evaluation in training
+                # mode) nobody reads the raw output at all once the extrema are known
+                no_backward = not any(ctx.needs_input_grad)
                 y, mean, invstd, scale, shift, ext = K.gemm_forward_bn(
                     w2, cur, cur_coeff, gamma, beta, rm, rv, momenta[i], epss[i], pool=True, tickets=tickets,
-                    store=not gram)
-                if gram:
+                    store=not (gram or (epilogue and no_backward)))
+                if y is None:
                     y = x.new_empty(0)  # never materialised
+                if gram:
                     gram_last, gram_ns = True, cur.shape[3]
             elif training:  # batch statistics come out of the GEMM epilogue where the shape allows
                 y, mean, invstd, scale, shift = K.gemm_forward_bn(w2, cur, cur_coeff, gamma, beta,
