@@ -350,6 +350,39 @@ def kernel_table(device):
                 "hbm_GBps": round(nbytes / us / 1e3, 1),
                 "frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "backward of the pooled 64 -> 128 layer without y3: Gram matrix + sparse image"}
+    # SA2's pooled 128 -> 256 layer as the step runs it since round 6: forward with statistics + extrema
+    # and NO store, backward from the Gram matrix of its input (csrc/mlp_pool_gram256.hip: two passes)
+    gm, gns = 1024, 32
+    gy2 = torch.randn(B, 128, gm, gns, device=device) * 1.3 + 0.2
+    gw3 = torch.randn(256, 128, device=device) / 11
+    gq2, gq3 = bnp(128), bnp(256)
+    gc2 = K.bn_coefficients(gy2, gq2[0], gq2[1], gq2[2], gq2[3], 0.1, 1e-5, True)
+    if K.pool_gram_supported(gw3, gy2, gns) and K.forward_pool_supported(gw3, gy2, (gc2[2], gc2[3])):
+        gfwd = lambda: K.gemm_forward_bn(gw3, gy2, (gc2[2], gc2[3]), gq3[0], gq3[1], gq3[2], gq3[3], 0.1,  # noqa: E731
+                                         1e-5, pool=True, store=False)
+        us = time_op(gfwd, iters=5, warm=2)
+        gcols = B * gm * gns
+        t["mlp_fwd_sa2_256x128_no_store"] = {
+            "us": round(us, 2), "flops": int(2.0 * gcols * 256 * 128), "bytes": int(4.0 * gcols * 128),
+            "bound": "vector-instruction issue (fragments split per workgroup) -- not its 134 MB",
+            "TFLOPs": round(2.0 * gcols * 256 * 128 / us * 1e-6, 1),
+            "note": "statistics + pooled extrema from the epilogue, y3 (268 MB) not written"}
+        _, gmean3, ginv3, gsc3, gsh3, gext = gfwd()
+        _, gamax, gymax = K.pool_from_extrema(gext, gsc3, gsh3)
+        gdp = torch.randn(B, 256, gm, device=device)
+        _, _, gcoef3 = K.bn_relu_pool_backward_stats(None, gdp, gamax, gymax, gq3[0], gsc3, gsh3, gmean3, ginv3,
+                                                     True, ns=gns)
+        us = time_op(lambda: K.pool_gram_backward(gw3, gy2, gc2, gq2[0], gcoef3, (gmean3, ginv3, gsc3, gsh3), gdp,
+                                                  gamax, gymax, gns, True), iters=5, warm=2)
+        gflops = 2.0 * gcols * (128 * 128 + 128 * 256 + 256 * 128 + 10.0 / 16 * 128 * 128)
+        t["mlp_gram_bwd_sa2_256x128"] = {
+            "us": round(us, 2), "flops": int(gflops), "bytes": int(4.0 * gcols * 128 * 3),
+            "bound": "mfma (192 steps x 6 per 32-column chunk over two passes; floor 134 us at 2.1 GHz)",
+            "TFLOPs": round(gflops / us * 1e-6, 1),
+            "frac_of_mfma_floor": round(134.0 / us, 3),
+            "note": "both passes + prep / pack / reduce / dw; replaces the stored-y3 backward (308 us) and "
+                    "the layer below's 47-us sums pass"}
+        del gy2, gext
     # SA2's first layer applied before the gather (csrc/mlp_pregather.hip): gather of the small
     # GEMM's output with the BatchNorm moments / its backward (BN+ReLU backward on the fly, scatter
     # through the inverse index), at N = 2048 -> m = 1024 x ns = 32, 128 channels

@@ -75,7 +75,8 @@ def test_bench_default_line_has_roofline_and_cpu_baseline():
     kernels = d["kernels"]
     for name in ("fps_40000_2048", "ball_query_sa1", "group_xyz_sa1", "group_feat_sa1",
                  "query_and_group_sa1_fused_kernel", "three_nn_gridconv", "three_interpolate_gridconv",
-                 "iou3d_2048x512", "mlp_fwd_sa2_128x128"):
+                 "iou3d_2048x512", "mlp_fwd_sa2_128x128", "mlp_gram_bwd_sa1_128x64",
+                 "mlp_fwd_sa2_256x128_no_store", "mlp_gram_bwd_sa2_256x128"):
         assert kernels[name]["us"] > 0 and "bound" in kernels[name], name
     assert 0 < kernels["mlp_fwd_sa2_128x128"]["frac"] < 1
     cpu = d["cpu_baseline"]
