@@ -191,8 +191,12 @@ class _FusedMLPChain(Function):
                 # the LAST layer's raw output is not even stored when its backward can run from the
                 # Gram matrix of its input (csrc/mlp_pool_gram.hip): 537 MB at SA1
                 gram = K.pool_gram_supported(lay[1][0], x, x.shape[3])
+                # (a pass that no backward follows -- the EMA teacher -- stores neither raw output:
+                # layer 2's activation goes from one GEMM to the next in registers anyway)
                 y1, c1, y2, c2, ext = K.chain_lin4_forward(x, w0, cur_coeff, lay[0], lay[1],
-                                                           store_last=not gram)
+                                                           store=any(ctx.needs_input_grad), store_last=not gram)
+                if y1 is None:
+                    y1 = x.new_empty(0)  # never materialised
                 if y2 is None:
                     y2 = x.new_empty(0)  # never materialised
                 ys += [y1, y2]
