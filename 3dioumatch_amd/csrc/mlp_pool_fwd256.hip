@@ -1,0 +1,404 @@
+// 3dioumatch_amd/csrc/mlp_pool_fwd256.hip -- forward of the max-pooled LAST shared-MLP layer of
+// SA2 / SA3 / SA4 (128 -> 256 channels: conv(1x1) of pytorch_utils.py:70-124 on relu(bn(y2)), then
+// the max over nsample of pointnet2_modules.py:256-262) when its raw output is NOT stored (gfx950):
+// the layer leaves its BatchNorm (mean, M2) pairs and the pooled extrema only (its backward runs from
+// the Gram matrix of its input, mlp_pool_gram256.hip; the teacher's pass has no backward at all).
+//
+// Reached through mlp_gemm_forward_stats_pool(y = NULL) (mlp_gemm.hip); same pairs (one per channel
+// and 64 columns) and the same ext planes as that entry's tiled kernel.
+//
+// Why a kernel of its own: the tiled kernel stages fp32 tiles, and each of its four waves splits the
+// SAME 64 columns of the operand into bf16 terms again (and the weight, per tile) -- it is bound by
+// vector issue (156-165 us at SA2 against 45-50 us of MFMA time).  Here
+//   * a workgroup is persistent: 8 waves, wave w owns channels 32 w .. 32 w + 31; its rows of W3 are
+//     split ONCE into register fragments (96 registers);
+//   * a chunk of y2 (128 rows x 32 columns) is transformed, split once by the thread that loaded it
+//     and stored as three bf16 images (fragments by transposing LDS reads, as mlp_bwd_x6.h), in one
+//     of THREE buffers: chunk c + 1 is staged while chunk c is multiplied, ONE barrier per chunk in
+//     the middle of the MFMAs, and the first fragments of chunk c + 1 are requested behind chunk c's
+//     last MFMAs.  Image rows are 64 bytes apart, unpadded: the transposing read of a half-wave covers
+//     four consecutive rows x 64 bytes = all 64 banks once, the staging write of a wave 512 contiguous
+//     bytes -- SQ_LDS_BANK_CONFLICT 0 (with the 80-byte pitch of the other kernels: half of the LDS
+//     cycles);
+//   * the product runs in T FORM (the MFMA's operands swapped: A = the chunk's fragment, B = W3's):
+//     a lane then owns ONE channel and 16 of the chunk's 32 columns, so the BatchNorm sums and the
+//     group's extremum are in-lane scans (packed fp32 arithmetic), finished by one exchange with
+//     lane ^ 32 -- no transposition through LDS; what leaves: 8 bytes per channel and 64 columns, and
+//     the extrema of FOUR consecutive groups as one 16-byte store per lane;
+//   * everything but the MFMAs is cut into pieces of about eight vector instructions, one behind
+//     every two MFMAs: the next chunk's staging, and the PREVIOUS chunk's epilogue (software
+//     pipeline: its samples are copied out of the accumulators when its MFMAs have drained);
+//   * two accumulators, alternating: an MFMA that accumulates into the block of the MFMA right before
+//     it is forwarded, but with vector instructions between them it waits for the write-back
+//     (tools/micro/mfma_bf16_peak.py: 2 waves per SIMD, 4 vector instructions per MFMA: 82 % of the
+//     MFMA-only rate with one accumulator, 97 % with two).
+// Measured (B = 8, SA2: 8192 chunks): 90 us against 156 (tiled kernel, store removed); MFMA-only
+// variant of the same loop 66 us, MFMA peak 45.
+#include "common.h"
+#include "mlp_operand.h"
+#include <stdlib.h>
+#include <mutex>
+#include <type_traits>
+
+namespace {
+
+typedef short f_bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f_bf16x4 f_lds_read_tr(const char *p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) f_bf16x4 *)(__attribute__((address_space(3))) char *)p);
+}
+
+constexpr int kFM = 256, kFK = 128, kFTN = 32;
+constexpr int kFRP = kFTN * 2;        // image row pitch (bytes): 64 -- see the note on bank conflicts below
+constexpr int kFIMG = kFK * kFRP;     // bytes per term
+constexpr int kFBUF = 3 * kFIMG;      // one chunk: 30 720 bytes
+
+struct PoolFwdArgs {
+  int r, chunks_per_cloud, total_tiles, groups;
+  const float *w;             // (256, 128)
+  const float *x;             // (b, 128, r) raw output of the layer below
+  const float *sc, *sh;       // (128) its BatchNorm as scale / shift
+  const float *gamma;         // (256) this layer's BatchNorm weight: its sign picks the extremum
+  float *pairs;               // (b * r / 64, 256, 2)
+  float *ext;                 // 2 planes of (b, 256, groups)
+  size_t ext_plane;
+};
+
+typedef float f_f32x2 __attribute__((ext_vector_type(2)));
+
+template <int NS>
+__global__ void __launch_bounds__(512) pool_fwd256_kernel(const PoolFwdArgs a) {
+  constexpr int K = kFK, TN = kFTN, RP = kFRP, IMG = kFIMG, BUF = kFBUF;
+  constexpr int G = TN / NS;    // groups per chunk: 1 or 2
+  constexpr int QG = 16 / G;    // accumulator registers per group
+  static_assert(NS == 16 || NS == 32, "nsample");
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // three chunk buffers
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int seg_row = tid >> 3, seg_c = (tid & 7) * 4;  // staging: rows seg_row, seg_row + 64
+  const int ch = 32 * wave + l31;
+
+  // B fragments: this lane's channel, k = 16 s + 8 lhi + 0..7
+  Split3 wsp[K / 16];
+  {
+    const float *wr = a.w + (size_t)ch * K + 8 * lhi;
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s)
+      wsp[s] = split3(*reinterpret_cast<const float4 *>(wr + 16 * s),
+                      *reinterpret_cast<const float4 *>(wr + 16 * s + 4));
+  }
+  const bool neg = a.gamma[ch] < 0.f;
+  const float sg = neg ? -1.f : 1.f;
+  const f_f32x2 sgn = {sg, sg};
+  const RowCoef rc0 = {a.sc[seg_row], a.sh[seg_row], 0.f, 0.f, 0.f};
+  const RowCoef rc1 = {a.sc[seg_row + 64], a.sh[seg_row + 64], 0.f, 0.f, 0.f};
+
+  // whole blocks of four chunks (two 64-column tiles) per workgroup: the extrema leave four groups at
+  // a time
+  const int blocks = a.total_tiles / 2;
+  const int per = (blocks + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int k_lo = (int)blockIdx.x * per;
+  const int k_hi = k_lo + per < blocks ? k_lo + per : blocks;
+  const int c_lo = 4 * k_lo, c_hi = 4 * k_hi;
+  if (c_lo >= c_hi) return;
+
+  // requests run TWO chunks ahead of their use (qf: the chunk after the next; it moves to qx when
+  // the next chunk's staging has consumed qx): one chunk of MFMAs does not cover a miss to HBM
+  float4 qx0, qx1, qf0, qf1;
+  auto fetch = [&](int c) {
+    const int b = c / a.chunks_per_cloud;
+    const int col0 = (c - b * a.chunks_per_cloud) * TN;
+    const float *src = a.x + ((size_t)b * K + seg_row) * a.r + col0 + seg_c;
+    qf0 = *reinterpret_cast<const float4 *>(src);
+    qf1 = *reinterpret_cast<const float4 *>(src + (size_t)64 * a.r);
+  };
+  auto stage_slice = [&](char *base, int row, const float4 &x, const RowCoef &rc) {
+    const float xv[4] = {x.x, x.y, x.z, x.w};
+    float h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = transform<OP_BNRELU>(xv[e], 0.f, rc);
+      h[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffff0000u);
+      const float r1 = v - h[e];
+      m[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1) & 0xffff0000u);
+      l[e] = r1 - m[e];
+    }
+    char *dst = base + (size_t)row * RP + seg_c * 2;
+    *reinterpret_cast<uint2 *>(dst) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
+    *reinterpret_cast<uint2 *>(dst + IMG) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
+    *reinterpret_cast<uint2 *>(dst + 2 * IMG) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+  };
+  auto stage = [&](char *base) {
+    stage_slice(base, seg_row, qx0, rc0);
+    stage_slice(base, seg_row + 64, qx1, rc1);
+  };
+  auto clampc = [&](int c) { return c < c_hi ? c : c_hi - 1; };
+
+  // transposing reads: the lane's fragment = column l31 of the chunk, k = 16 s + 8 lhi + 0..7
+  const int tr_off = (8 * lhi + ((lane & 15) >> 2)) * RP + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  f_bf16x4 pf[2][3][2];  // ring of two k-steps' fragments
+  auto frag = [&](const char *Q, int s, f_bf16x4 (&dst)[3][2]) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const char *p0 = Q + (size_t)t * IMG + (size_t)(16 * s) * RP + tr_off;
+      dst[t][0] = f_lds_read_tr(p0);
+      dst[t][1] = f_lds_read_tr(p0 + 4 * RP);
+    }
+  };
+  auto operand = [&](const f_bf16x4 (&src)[3][2]) {
+    Split3 sb;
+    sb.hi = __builtin_shufflevector(src[0][0], src[0][1], 0, 1, 2, 3, 4, 5, 6, 7);
+    sb.mid = __builtin_shufflevector(src[1][0], src[1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+    sb.lo = __builtin_shufflevector(src[2][0], src[2][1], 0, 1, 2, 3, 4, 5, 6, 7);
+    return sb;
+  };
+
+  fetch(c_lo);
+  qx0 = qf0; qx1 = qf1;
+  stage(lds);
+  fetch(clampc(c_lo + 1));
+  qx0 = qf0; qx1 = qf1;
+  fetch(clampc(c_lo + 2));
+  __syncthreads();
+  frag(lds, 0, pf[0]);
+
+  float tsh = 0.f;
+  f_f32x2 t1 = {0.f, 0.f}, t2 = {0.f, 0.f};  // shifted sums of the lane's samples of the current tile
+  unsigned held[4] = {0u, 0u, 0u, 0u};       // the last four groups' values (lhi 0) / indices (lhi 1)
+  int cur = 0;
+
+  // ---- the work around the MFMAs, in PIECES of about eight vector instructions: each sits behind two
+  // MFMAs of the chunk in flight with a scheduling barrier behind it (left to itself the compiler issues
+  // the chunk's 48 MFMAs back to back and everything else before or after them, where the matrix pipe
+  // idles: both waves of a SIMD are in step, a barrier per chunk sees to that).
+  // Pieces 0-8: the NEXT chunk (c + 1: transform, split, images; the request for c + 2).
+  // Pieces 9-21: the epilogue of the PREVIOUS chunk (ce = c - 1, its accumulators copied to pv).
+  float sv[4], shh[4], sm[4], sl[4];  // staging state between pieces
+  f_f32x2 pv[8];                      // previous chunk's samples
+  float best[G], mh = 0.f, qh = 0.f, mo = 0.f, qo = 0.f;
+  float ob[G];
+  int at[G], oa[G];
+  char *Qn = lds;
+  int ce = 0;
+  bool real = false;  // chunk ce exists (not the run-in of the pipeline)
+  auto piece = [&](auto nt) {
+    constexpr int n = decltype(nt)::value;
+    if constexpr (n == 0 || n == 4) {
+      const float4 &x = n == 0 ? qx0 : qx1;
+      const RowCoef &rc = n == 0 ? rc0 : rc1;
+      const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sv[e] = transform<OP_BNRELU>(xv[e], 0.f, rc);
+    } else if constexpr (n == 1 || n == 5) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        shh[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, sv[e]) & 0xffff0000u);
+        sv[e] = sv[e] - shh[e];
+      }
+    } else if constexpr (n == 2 || n == 6) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sm[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, sv[e]) & 0xffff0000u);
+        sl[e] = sv[e] - sm[e];
+      }
+    } else if constexpr (n == 3 || n == 7) {
+      char *dst = Qn + (size_t)(seg_row + (n == 7 ? 64 : 0)) * RP + seg_c * 2;
+      *reinterpret_cast<uint2 *>(dst) = make_uint2(pack_hi16(shh[0], shh[1]), pack_hi16(shh[2], shh[3]));
+      *reinterpret_cast<uint2 *>(dst + IMG) = make_uint2(pack_hi16(sm[0], sm[1]), pack_hi16(sm[2], sm[3]));
+      *reinterpret_cast<uint2 *>(dst + 2 * IMG) = make_uint2(pack_hi16(sl[0], sl[1]), pack_hi16(sl[2], sl[3]));
+    } else if constexpr (n == 8) {
+      qx0 = qf0; qx1 = qf1;
+      fetch(clampc(ce + 4));
+    } else if constexpr (n == 9 || n == 10 || n == 11) {
+      if (n == 9 && (ce & 1) == 0) { tsh = pv[0].x; t1 = f_f32x2{0.f, 0.f}; t2 = t1; }
+      const f_f32x2 sh2 = {tsh, tsh};
+#pragma unroll
+      for (int j = 3 * (n - 9); j < (n == 11 ? 8 : 3 * (n - 8)); ++j) {
+        const f_f32x2 d = pv[j] - sh2;
+        t1 += d;
+        t2 = __builtin_elementwise_fma(d, d, t2);
+      }
+    } else if constexpr (n == 12) {
+      // channels with a negative gamma are scanned negated (largest of -y)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pv[j] = pv[j] * sgn;
+    } else if constexpr (n == 13) {
+#pragma unroll
+      for (int gq = 0; gq < G; ++gq) {
+        float b0 = -__builtin_inff();
+#pragma unroll
+        for (int j = gq * QG / 2; j < (gq + 1) * QG / 2; ++j) b0 = fmaxf(b0, fmaxf(pv[j].x, pv[j].y));
+        best[gq] = b0;
+        at[gq] = 64;
+      }
+    } else if constexpr (n == 14 || n == 15) {
+      // the first sample that has the largest value: upper half of the registers, then the lower
+#pragma unroll
+      for (int gq = 0; gq < G; ++gq) {
+        constexpr int HQ = QG / 2;
+        const int q_hi = gq * QG + (n == 14 ? QG : HQ) - 1;
+#pragma unroll
+        for (int q = q_hi; q > q_hi - HQ; --q) {
+          const int nn = (q & 3) + 8 * ((q >> 2) - gq * (QG / 4)) + 4 * lhi;  // sample within the group
+          const float val = (q & 1) ? pv[q >> 1].y : pv[q >> 1].x;
+          at[gq] = val == best[gq] ? nn : at[gq];
+        }
+      }
+    } else if constexpr (n == 16) {
+#pragma unroll
+      for (int gq = 0; gq < G; ++gq) {
+        ob[gq] = __shfl_xor(best[gq], 32, kWave);
+        oa[gq] = __shfl_xor(at[gq], 32, kWave);
+      }
+    } else if constexpr (n == 18) {
+#pragma unroll
+      for (int gq = 0; gq < G; ++gq) {
+        float bb = best[gq];
+        int aa = at[gq];
+        if (ob[gq] > bb || (ob[gq] == bb && oa[gq] < aa)) { bb = ob[gq]; aa = oa[gq]; }
+        if (aa == 64) aa = 0;  // (nothing compares: every sample a NaN)
+        const float out = bb * sg;
+        held[0] = held[1]; held[1] = held[2]; held[2] = held[3];
+        held[3] = lhi == 0 ? __builtin_bit_cast(unsigned, out) : (unsigned)aa;
+      }
+    } else if constexpr (n == 19) {
+      if (ce & 1) {
+        // (mean, M2) of the lane's 32 samples of the tile, then of the channel's 64 (equal counts)
+        const float s1 = t1.x + t1.y, s2 = t2.x + t2.y;
+        mh = tsh + s1 * (1.0f / 32.0f);
+        qh = fmaxf(s2 - s1 * s1 * (1.0f / 32.0f), 0.f);
+        mo = __shfl_xor(mh, 32, kWave);
+        qo = __shfl_xor(qh, 32, kWave);
+      }
+    } else if constexpr (n == 20) {
+      if ((ce & 1) && real && lhi == 0) {
+        const float dlt = mo - mh;
+        const float mean = 0.5f * (mh + mo);
+        const float m2w = (qh + qo) + 16.0f * dlt * dlt;  // n_a n_b / (n_a + n_b) = 16
+        *reinterpret_cast<float2 *>(a.pairs + ((size_t)(ce >> 1) * kFM + ch) * 2) = make_float2(mean, m2w);
+      }
+    } else if constexpr (n == 21) {
+      if ((ce & (4 / G - 1)) == 4 / G - 1 && real) {
+        // four groups of this channel: 16 contiguous bytes per lane (values from the lower half-wave,
+        // indices from the upper)
+        const int b = ce / a.chunks_per_cloud;
+        const int g_last = ((ce - b * a.chunks_per_cloud) * TN) / NS + G - 1;
+        const size_t o = ((size_t)b * kFM + ch) * a.groups + g_last - 3 + (lhi ? a.ext_plane : 0);
+        *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned *>(a.ext) + o) = make_uint4(held[0], held[1], held[2], held[3]);
+      }
+    }
+  };
+#define PF_PIECE(N) do { piece(std::integral_constant<int, (N)>{}); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+#pragma unroll
+  for (int j = 0; j < 8; ++j) pv[j] = f_f32x2{0.f, 0.f};
+  for (int c = c_lo; c < c_hi; ++c) {
+    const int nxt = cur == 2 ? 0 : cur + 1;
+    const char *Qc = lds + (size_t)cur * BUF;
+    // buffer nxt held chunk c - 2: every wave has passed the barrier inside chunk c - 1, so all are
+    // done with it.  (On the last chunk the clamped duplicate is staged: nobody reads it.)
+    Qn = lds + (size_t)nxt * BUF;
+    ce = c - 1;
+    real = c > c_lo;
+    // two accumulators, one per k-step parity: with vector instructions between them, MFMAs that
+    // accumulate into ONE register block wait for one another (tools/micro/mfma_bf16_peak.py)
+    f32x16 acc, acc1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc[q] = 0.f; acc1[q] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) {
+      const int ring = s & 1;
+      // the next k-step's fragments -- behind the chunk's last step the next chunk's first (its image
+      // is complete: the barrier below is behind us)
+      if (s + 1 < K / 16) frag(Qc, s + 1, pf[ring ^ 1]);
+      else frag(Qn, 0, pf[ring ^ 1]);
+      __builtin_amdgcn_sched_barrier(0);  // the reads stay ahead of this step's MFMAs
+      // T form: A = the chunk (rows of the block = its columns), B = W3 (columns = channels)
+      const Split3 x = operand(pf[ring]);
+      const Split3 &w = wsp[s];
+#define PF_MM(AT, BT)                                                                                \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.AT, w.BT, acc, 0, 0, 0);
+#define PF_MM1(AT, BT)                                                                               \
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.AT, w.BT, acc1, 0, 0, 0);
+#define PF_CASE(N) case N: PF_PIECE(N); break
+      PF_MM(lo, hi) PF_MM1(hi, lo)
+      switch (3 * s) {
+        PF_CASE(0); PF_CASE(3); PF_CASE(6); PF_CASE(9); PF_CASE(12); PF_CASE(15); PF_CASE(18); PF_CASE(21);
+      }
+      PF_MM(mid, mid) PF_MM1(mid, hi)
+      switch (3 * s + 1) {
+        PF_CASE(1); PF_CASE(4); PF_CASE(7); PF_CASE(10); PF_CASE(13); PF_CASE(16); PF_CASE(19);
+      }
+      PF_MM(hi, mid) PF_MM1(hi, hi)
+      switch (3 * s + 2) {
+        PF_CASE(2); PF_CASE(5); PF_CASE(8); PF_CASE(11); PF_CASE(14); PF_CASE(20);
+      }
+#undef PF_CASE
+#undef PF_MM
+#undef PF_MM1
+      if (s == 3) __syncthreads();  // every wave has staged chunk c + 1 and is past chunk c - 1
+    }
+    cur = nxt;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pv[j] = f_f32x2{acc[2 * j], acc[2 * j + 1]} + f_f32x2{acc1[2 * j], acc1[2 * j + 1]};
+  }
+  // the last chunk's epilogue
+  ce = c_hi - 1;
+  real = true;
+  PF_PIECE(9); PF_PIECE(10); PF_PIECE(11); PF_PIECE(12); PF_PIECE(13); PF_PIECE(14); PF_PIECE(15);
+  PF_PIECE(16); PF_PIECE(18); PF_PIECE(19); PF_PIECE(20); PF_PIECE(21);
+#undef PF_PIECE
+}
+
+int pool_fwd256_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  return cus;
+}
+
+}  // namespace
+
+// 1 when the no-store form of mlp_gemm_forward_stats_pool runs here: (m, k) = (256, 128), nsample
+// 16 / 32, whole 64-column tiles (MLP_POOL_FWD256=0: the tiled kernel with its store removed)
+int mlp_pool_fwd256_supported(int b, int m, int k, int r, int ns, const float *w, const float *x) {
+  static const bool off = getenv("MLP_POOL_FWD256") && atoi(getenv("MLP_POOL_FWD256")) == 0;
+  if (off || b <= 0 || m != kFM || k != kFK || r <= 0 || r % 256 != 0) return 0;
+  if ((ns != 16 && ns != 32) || r % ns != 0) return 0;
+  return ((reinterpret_cast<size_t>(w) | reinterpret_cast<size_t>(x)) & 15) == 0 ? 1 : 0;
+}
+
+// pairs: (b * r / 64, 256, 2); ext: 2 planes of (b, 256, r / ns) -- as the tiled kernel leaves them
+int mlp_pool_fwd256_launch(int b, int r, int ns, const float *w, const float *x, const float *scale,
+                           const float *shift, const float *gamma, float *pairs, float *ext,
+                           hipStream_t stream) {
+  PoolFwdArgs a = {};
+  a.r = r; a.chunks_per_cloud = r / kFTN; a.total_tiles = b * (r / 64); a.groups = r / ns;
+  a.w = w; a.x = x; a.sc = scale; a.sh = shift; a.gamma = gamma; a.pairs = pairs; a.ext = ext;
+  a.ext_plane = (size_t)b * kFM * (size_t)(r / ns);
+  int grid = pool_fwd256_cus();
+  if (grid > a.total_tiles / 2) grid = a.total_tiles / 2;
+  constexpr size_t kLds = 3 * (size_t)kFBUF;
+  static std::mutex mu;
+  static bool attr_set = false;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pool_fwd256_kernel<16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pool_fwd256_kernel<32>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+      attr_set = true;
+    }
+  }
+  if (ns == 16) hipLaunchKernelGGL(pool_fwd256_kernel<16>, dim3(grid), dim3(512), kLds, stream, a);
+  else hipLaunchKernelGGL(pool_fwd256_kernel<32>, dim3(grid), dim3(512), kLds, stream, a);
+  return pn2_launch_status();
+}
