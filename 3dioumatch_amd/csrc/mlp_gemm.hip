@@ -1508,9 +1508,9 @@ MLP_API int mlp_gemm_forward_stats_pool(int b, int m, int k, int r, const float 
       (reinterpret_cast<size_t>(w) & 15) != 0)
     return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
-  // nothing to store: the persistent T-form kernel (same pairs, same ext)
-  if (y == nullptr && gemm_x6() && mlp_pool_fwd256_supported(b, m, k, r, ns, w, x))
-    return mlp_pool_fwd256_launch(b, r, ns, w, x, scale, shift, gamma, pairs, ext, stream);
+  // (256, 128), nsample 16 / 32: the persistent T-form kernel (same pairs, same ext; y may be NULL)
+  if (gemm_x6() && mlp_pool_fwd256_supported(b, m, k, r, ns, w, x) && (reinterpret_cast<size_t>(y) & 15) == 0)
+    return mlp_pool_fwd256_launch(b, r, ns, w, x, scale, shift, gamma, y, pairs, ext, stream);
   OperandB op = {x, nullptr, scale, shift, nullptr, nullptr, nullptr};
   const size_t in_stride = (size_t)k * r, out_stride = (size_t)m * r;
   const size_t plane = (size_t)b * m * (r / ns);

@@ -191,8 +191,8 @@ int mlp_reduce_partials(int count, int parts, const float *part, float *out, hip
 // mlp_flush_weight_reductions() runs every queued one in ONE launch (a backward pass has ~30 of
 // them at 3-6 us each).  `part` must stay allocated until the flush.
 int mlp_reduce_weight_partials(int count, int parts, const float *part, float *out, hipStream_t stream);
-// the pooled 128 -> 256 layer's forward without its raw output (mlp_pool_fwd256.hip)
+// the pooled 128 -> 256 layer's forward as a persistent T-form kernel (mlp_pool_fwd256.hip); y may be NULL
 int mlp_pool_fwd256_supported(int b, int m, int k, int r, int ns, const float *w, const float *x);
 int mlp_pool_fwd256_launch(int b, int r, int ns, const float *w, const float *x, const float *scale,
-                           const float *shift, const float *gamma, float *pairs, float *ext,
+                           const float *shift, const float *gamma, float *y, float *pairs, float *ext,
                            hipStream_t stream);

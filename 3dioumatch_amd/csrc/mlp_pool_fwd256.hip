@@ -52,7 +52,8 @@ __device__ __forceinline__ f_bf16x4 f_lds_read_tr(const char *p) {
 constexpr int kFM = 256, kFK = 128, kFTN = 32;
 constexpr int kFRP = kFTN * 2;        // image row pitch (bytes): 64 -- see the note on bank conflicts below
 constexpr int kFIMG = kFK * kFRP;     // bytes per term
-constexpr int kFBUF = 3 * kFIMG;      // one chunk: 30 720 bytes
+constexpr int kFBUF = 3 * kFIMG;      // one chunk: 24 576 bytes
+constexpr int kFTP = 32 * 144;        // STORE form: a wave's 32 x 32 tile on its way out
 
 struct PoolFwdArgs {
   int r, chunks_per_cloud, total_tiles, groups;
@@ -63,11 +64,13 @@ struct PoolFwdArgs {
   float *pairs;               // (b * r / 64, 256, 2)
   float *ext;                 // 2 planes of (b, 256, groups)
   size_t ext_plane;
+  float *y;                   // (b, 256, r) raw output, STORE form only
 };
 
 typedef float f_f32x2 __attribute__((ext_vector_type(2)));
+typedef float f_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NS>
+template <int NS, bool STORE>
 __global__ void __launch_bounds__(512) pool_fwd256_kernel(const PoolFwdArgs a) {
   constexpr int K = kFK, TN = kFTN, RP = kFRP, IMG = kFIMG, BUF = kFBUF;
   constexpr int G = TN / NS;    // groups per chunk: 1 or 2
@@ -184,6 +187,16 @@ __global__ void __launch_bounds__(512) pool_fwd256_kernel(const PoolFwdArgs a) {
   char *Qn = lds;
   int ce = 0;
   bool real = false;  // chunk ce exists (not the run-in of the pipeline)
+  f_f32x4 yrow[2];  // STORE: two rows' pieces on their way from the LDS tile to y
+  auto store_rows = [&](int k0) {
+    if (real) {
+      const int b = ce / a.chunks_per_cloud;
+      float *dst = a.y + ((size_t)b * kFM + 32 * wave + (lane >> 3)) * a.r + (ce - b * a.chunks_per_cloud) * TN + 4 * (lane & 7);
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+        __builtin_nontemporal_store(yrow[k2], reinterpret_cast<f_f32x4 *>(dst + (size_t)(8 * (k0 + k2)) * a.r));
+    }
+  };
   auto piece = [&](auto nt) {
     constexpr int n = decltype(nt)::value;
     if constexpr (n == 0 || n == 4) {
@@ -214,6 +227,27 @@ __global__ void __launch_bounds__(512) pool_fwd256_kernel(const PoolFwdArgs a) {
       fetch(clampc(ce + 4));
     } else if constexpr (n == 9 || n == 10 || n == 11) {
       if (n == 9 && (ce & 1) == 0) { tsh = pv[0].x; t1 = f_f32x2{0.f, 0.f}; t2 = t1; }
+      if constexpr (STORE) {
+        // T form hands a lane ONE channel and four runs of four consecutive columns: stored as such
+        // they are 16-byte requests, one per lane (541 us at SA2 against 178).  So the block goes
+        // through a wave-private LDS tile (rows 144 bytes apart) and leaves as rows: a store covers
+        // eight channels x 128 contiguous bytes.  (LDS operations of one wave complete in order: no
+        // barrier between its writes and reads, nor between this chunk's reads and the next one's writes.)
+        char *tp = lds + 3 * BUF + wave * kFTP;
+        if constexpr (n == 9) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f_f32x4 *>(tp + l31 * 144 + 32 * j + 16 * lhi) =
+                f_f32x4{pv[2 * j].x, pv[2 * j].y, pv[2 * j + 1].x, pv[2 * j + 1].y};
+        } else if constexpr (n == 10) {
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2) yrow[k2] = *reinterpret_cast<const f_f32x4 *>(tp + (8 * k2 + (lane >> 3)) * 144 + (lane & 7) * 16);
+        } else {
+          store_rows(0);
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2) yrow[k2] = *reinterpret_cast<const f_f32x4 *>(tp + (8 * (k2 + 2) + (lane >> 3)) * 144 + (lane & 7) * 16);
+        }
+      }
       const f_f32x2 sh2 = {tsh, tsh};
 #pragma unroll
       for (int j = 3 * (n - 9); j < (n == 11 ? 8 : 3 * (n - 8)); ++j) {
@@ -222,6 +256,7 @@ __global__ void __launch_bounds__(512) pool_fwd256_kernel(const PoolFwdArgs a) {
         t2 = __builtin_elementwise_fma(d, d, t2);
       }
     } else if constexpr (n == 12) {
+      if constexpr (STORE) store_rows(2);
       // channels with a negative gamma are scanned negated (largest of -y)
 #pragma unroll
       for (int j = 0; j < 8; ++j) pv[j] = pv[j] * sgn;
@@ -366,10 +401,11 @@ int pool_fwd256_cus() {
 
 }  // namespace
 
-// 1 when the no-store form of mlp_gemm_forward_stats_pool runs here: (m, k) = (256, 128), nsample
-// 16 / 32, whole 64-column tiles (MLP_POOL_FWD256=0: the tiled kernel with its store removed)
+// 1 when mlp_gemm_forward_stats_pool runs here: (m, k) = (256, 128), nsample 16 / 32, whole
+// 256-column blocks per cloud (MLP_POOL_FWD256=0: the tiled kernel)
 int mlp_pool_fwd256_supported(int b, int m, int k, int r, int ns, const float *w, const float *x) {
-  static const bool off = getenv("MLP_POOL_FWD256") && atoi(getenv("MLP_POOL_FWD256")) == 0;
+  const char *env = getenv("MLP_POOL_FWD256");  // (read on every call: the tests compare both kernels)
+  const bool off = env && atoi(env) == 0;
   if (off || b <= 0 || m != kFM || k != kFK || r <= 0 || r % 256 != 0) return 0;
   if ((ns != 16 && ns != 32) || r % ns != 0) return 0;
   return ((reinterpret_cast<size_t>(w) | reinterpret_cast<size_t>(x)) & 15) == 0 ? 1 : 0;
@@ -377,28 +413,38 @@ int mlp_pool_fwd256_supported(int b, int m, int k, int r, int ns, const float *w
 
 // pairs: (b * r / 64, 256, 2); ext: 2 planes of (b, 256, r / ns) -- as the tiled kernel leaves them
 int mlp_pool_fwd256_launch(int b, int r, int ns, const float *w, const float *x, const float *scale,
-                           const float *shift, const float *gamma, float *pairs, float *ext,
+                           const float *shift, const float *gamma, float *y, float *pairs, float *ext,
                            hipStream_t stream) {
   PoolFwdArgs a = {};
   a.r = r; a.chunks_per_cloud = r / kFTN; a.total_tiles = b * (r / 64); a.groups = r / ns;
-  a.w = w; a.x = x; a.sc = scale; a.sh = shift; a.gamma = gamma; a.pairs = pairs; a.ext = ext;
+  a.w = w; a.x = x; a.sc = scale; a.sh = shift; a.gamma = gamma; a.pairs = pairs; a.ext = ext; a.y = y;
   a.ext_plane = (size_t)b * kFM * (size_t)(r / ns);
   int grid = pool_fwd256_cus();
   if (grid > a.total_tiles / 2) grid = a.total_tiles / 2;
-  constexpr size_t kLds = 3 * (size_t)kFBUF;
+  const size_t kLds = 3 * (size_t)kFBUF + (y != nullptr ? 8 * (size_t)kFTP : 0);
+  constexpr size_t kLdsMax = 3 * (size_t)kFBUF + 8 * (size_t)kFTP;
   static std::mutex mu;
   static bool attr_set = false;
   {
     std::lock_guard<std::mutex> lock(mu);
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pool_fwd256_kernel<16>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pool_fwd256_kernel<32>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pool_fwd256_kernel<16, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pool_fwd256_kernel<32, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pool_fwd256_kernel<16, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(pool_fwd256_kernel<32, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
       attr_set = true;
     }
   }
-  if (ns == 16) hipLaunchKernelGGL(pool_fwd256_kernel<16>, dim3(grid), dim3(512), kLds, stream, a);
-  else hipLaunchKernelGGL(pool_fwd256_kernel<32>, dim3(grid), dim3(512), kLds, stream, a);
+  if (y != nullptr) {
+    if (ns == 16) hipLaunchKernelGGL((pool_fwd256_kernel<16, true>), dim3(grid), dim3(512), kLds, stream, a);
+    else hipLaunchKernelGGL((pool_fwd256_kernel<32, true>), dim3(grid), dim3(512), kLds, stream, a);
+  } else {
+    if (ns == 16) hipLaunchKernelGGL((pool_fwd256_kernel<16, false>), dim3(grid), dim3(512), kLds, stream, a);
+    else hipLaunchKernelGGL((pool_fwd256_kernel<32, false>), dim3(grid), dim3(512), kLds, stream, a);
+  }
   return pn2_launch_status();
 }

@@ -645,7 +645,7 @@ def test_chained_forward_vs_layerwise(b, m, ns):
 
 @pytest.mark.parametrize("b,m,ns", [(8, 1024, 32), (3, 200, 32), (12, 1024, 32), (8, 512, 16), (5, 256, 16),
                                      (1, 2048, 16), (16, 1024, 32), (2, 1000, 32)])
-def test_pooled_forward_without_its_raw_output(b, m, ns):
+def test_pooled_forward_without_its_raw_output(b, m, ns, monkeypatch):
     """csrc/mlp_pool_fwd256.hip: the max-pooled 128 -> 256 layer (conv(1x1) of pytorch_utils.py:70-124 on
     relu(bn(y2)), BatchNorm statistics, max over nsample of pointnet2_modules.py:256-262) leaving
     statistics + extrema only == float64 torch, and == the tiled kernel that stores y3: values, the
@@ -689,9 +689,17 @@ def test_pooled_forward_without_its_raw_output(b, m, ns):
     # exact ties: columns 1 and 3 are equal everywhere, columns 0 and ns - 1 in every 7th group
     assert not bool((idx == 3).any())
     assert not bool((idx[:, :, ::7] == ns - 1).any())
-    # against the tiled kernel
-    y3, mean_t, invstd_t, _, _, ext_t = K.gemm_forward_bn(w3, y2, (c2[2], c2[3]), g3, be3, *z(256), 0.1, 1e-5,
+    # the form that also stores y3 (the same kernel): identical statistics and extrema, y3 == float64
+    y3, mean_s, invstd_s, _, _, ext_s = K.gemm_forward_bn(w3, y2, (c2[2], c2[3]), g3, be3, *z(256), 0.1, 1e-5,
                                                           pool=True)
+    assert torch.equal(ext_s, ext) and torch.equal(mean_s, mean) and torch.equal(invstd_s, invstd)
+    assert float((y3.double() - y64).abs().max()) <= 2e-6 * rng
+    # against the tiled kernel (gemm_nn2_kernel with its pooled epilogue)
+    monkeypatch.setenv("MLP_POOL_FWD256", "0")
+    y3_t, mean_t, invstd_t, _, _, ext_t = K.gemm_forward_bn(w3, y2, (c2[2], c2[3]), g3, be3, *z(256), 0.1, 1e-5,
+                                                            pool=True)
+    monkeypatch.delenv("MLP_POOL_FWD256")
+    assert float((y3 - y3_t).abs().max()) <= 2e-6 * rng
     assert float((ext[0] - ext_t[0]).abs().max()) <= 2e-6 * rng
     assert float((ext[1].view(torch.int32) != ext_t[1].view(torch.int32)).float().mean()) < 1e-3
     pooled, argmax, ymax = K.pool_from_extrema(ext, sc, sh)

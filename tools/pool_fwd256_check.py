@@ -21,7 +21,9 @@ for b, m, ns in ((8, 1024, 32), (2, 512, 16), (3, 200, 32), (12, 1024, 32), (8, 
     z = lambda c: (torch.zeros(c, device=dev), torch.ones(c, device=dev))
     c2 = K.bn_coefficients(y2, g2, be2, *z(128), 0.1, 1e-5, True)
     fwd = lambda store: K.gemm_forward_bn(w3, y2, (c2[2], c2[3]), g3, be3, *z(256), 0.1, 1e-5, pool=True, store=store)
+    os.environ["MLP_POOL_FWD256"] = "0"   # the tiled kernel
     y3, mean, invstd, sc, sh, ext = fwd(True)
+    os.environ.pop("MLP_POOL_FWD256")
     if ext is None:
         print("b %d m %d ns %d: no pooled epilogue at this size" % (b, m, ns))
         continue
@@ -46,8 +48,15 @@ for b, m, ns in ((8, 1024, 32), (2, 512, 16), (3, 200, 32), (12, 1024, 32), (8, 
               100 * float((ext_n[1].view(torch.int32) != ext[1].view(torch.int32)).float().mean())), flush=True)
     # exact ties (columns 1 and 3 are equal): never the later one
     assert not bool((idx_n == 3).any())
+    y3n = fwd(True)[0]
+    print("   stored y3 vs f64: %.2e (tiled %.2e)" % (e(y3n, y64) / rng, e(y3, y64) / rng))
+    os.environ["MLP_POOL_FWD256"] = "0"
     t_old = bench.time_op(lambda: fwd(True), iters=5, warm=2)
+    t_old_n = bench.time_op(lambda: fwd(False), iters=5, warm=2)
+    os.environ.pop("MLP_POOL_FWD256")
+    t_new_s = bench.time_op(lambda: fwd(True), iters=5, warm=2)
     t_new = bench.time_op(lambda: fwd(False), iters=5, warm=2)
-    print("   us per call (GEMM + finalize): stored %.1f  no store %.1f" % (t_old, t_new), flush=True)
+    print("   us per call (GEMM + finalize): tiled stored %.1f / no store %.1f; T form stored %.1f / no store %.1f" % (
+        t_old, t_old_n, t_new_s, t_new), flush=True)
     del y2, y3, a2, y64, sel
     torch.cuda.empty_cache()
