@@ -364,9 +364,14 @@ def kernel_table(device):
         gcols = B * gm * gns
         t["mlp_fwd_sa2_256x128_no_store"] = {
             "us": round(us, 2), "flops": int(2.0 * gcols * 256 * 128), "bytes": int(4.0 * gcols * 128),
-            "bound": "vector-instruction issue (fragments split per workgroup) -- not its 134 MB",
+            "bound": "mfma + the vector instructions between them (csrc/mlp_pool_fwd256.hip: 48 MFMAs and ~230 "
+                     "vector instructions per wave and 32-column chunk; a wave's vector instructions do not "
+                     "overlap its MFMAs: profiles/r6_mfma_bf16_peak.json) -- not its 134 MB",
             "TFLOPs": round(2.0 * gcols * 256 * 128 / us * 1e-6, 1),
-            "note": "statistics + pooled extrema from the epilogue, y3 (268 MB) not written"}
+            "frac_of_mfma_floor": round(6.0 * 2.0 * gcols * 256 * 128 / 2.3e15 / (us * 1e-6), 3),
+            "note": "persistent T-form kernel + the two launches that finish the statistics: BatchNorm pairs "
+                    "+ pooled extrema from in-lane scans, y3 (268 MB) not written; floor = six bf16 MFMAs per "
+                    "product at the measured 2.3 PFLOP/s"}
         _, gmean3, ginv3, gsc3, gsh3, gext = gfwd()
         _, gamax, gymax = K.pool_from_extrema(gext, gsc3, gsh3)
         gdp = torch.randn(B, 256, gm, device=device)

@@ -41,6 +41,17 @@ for variant, (acc, vper) in VAR.items():
         flops = blocks * 4 * n * acc * 32768.0
         # cycles per MFMA and SIMD at 2.4 GHz would be 32 at the 2.5 PFLOP/s peak
         res["acc%d_valu%d_wps%d" % (acc, vper, wps)] = {"us": round(us, 1), "TFs": round(flops / us / 1e6, 1)}
+for variant, name in ((10, "x6_chains_of_six"), (11, "x6_two_accumulators_alternating")):
+    for wps in (1, 2):
+        blocks = 256 * wps
+        n = 2000 // wps
+
+        def run():
+            rc = lib.mfma_bf16_peak_launch(variant, blocks, n, out.data_ptr(), inp.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+        us = bench.time_op(run, iters=5, warm=2)
+        res["%s_wps%d" % (name, wps)] = {"us": round(us, 1), "TFs": round(blocks * 4 * n * 24 * 32768.0 / us / 1e6, 1)}
 print(json.dumps(res, indent=1))
 if len(sys.argv) > 1:
     json.dump(res, open(sys.argv[1], "w"), indent=1)
