@@ -1455,7 +1455,6 @@ MLP_API int mlp_gemm_forward_img(int b, int m, int k, int r, const float *w, con
 // Can the forward GEMM of this shape leave BatchNorm partials behind?  Returns the number of
 // (mean, M2) pairs per channel (0: no -- use mlp_bn_train_stats on y) and the columns each covers.
 MLP_API int mlp_gemm_forward_stats_parts(int b, int m, int k, int r, int *cols_per_part) {
-  (void)k;
   const char *v2env = getenv("MLP_GEMM_PIPELINED");
   const char *stenv = getenv("MLP_GEMM_EPILOGUE_STATS");
   if ((v2env && atoi(v2env) == 0) || (stenv && atoi(stenv) == 0)) return 0;
@@ -1463,7 +1462,8 @@ MLP_API int mlp_gemm_forward_stats_parts(int b, int m, int k, int r, int *cols_p
   const long long small_cols = env ? atoll(env) : 16384;
   if (b <= 0 || r % 256 != 0 || (long long)b * r <= small_cols) return 0;
   int tn;
-  if (m == 256) tn = 64;                 // one 256 x 64 tile per column block
+  if (gemm_x6() && mlp_fwd128_enabled_for(b, m, k, r)) tn = 64;  // (128, 128): the persistent T-form kernel
+  else if (m == 256) tn = 64;            // one 256 x 64 tile per column block
   else if (m > 32 && m <= 128) tn = 128; // one 128 x 128 / 64 x 128 tile
   else return 0;                         // several row tiles of different widths: not covered
   if (cols_per_part) *cols_per_part = tn;
@@ -1477,6 +1477,9 @@ MLP_API int mlp_gemm_forward_stats(int b, int m, int k, int r, const float *w, c
                                    float *pairs, void *stream_) {
   if (b <= 0 || m <= 0 || k <= 0 || r <= 0) return 0;
   if (!pairs || mlp_gemm_forward_stats_parts(b, m, k, r, nullptr) == 0) return (int)hipErrorInvalidValue;
+  if (gemm_x6() && mlp_fwd128_enabled_for(b, m, k, r))  // (its pairs cover 64 columns: no other kernel may run)
+    return mlp_fwd128_launch(b, r, 0, mode == OP_DIRECT ? 1 : 0, w, x, scale, shift, nullptr, y, pairs, nullptr,
+                             (hipStream_t)stream_);
   OperandB op = {x, nullptr, scale, shift, nullptr, nullptr, nullptr};
   const size_t in_stride = (size_t)k * r, out_stride = (size_t)m * r;
   if (mode == OP_DIRECT)
@@ -1508,6 +1511,8 @@ MLP_API int mlp_gemm_forward_stats_pool(int b, int m, int k, int r, const float 
       (reinterpret_cast<size_t>(w) & 15) != 0)
     return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
+  if (gemm_x6() && mlp_fwd128_enabled_for(b, m, k, r))  // (128, 128): 64-column pairs, no other kernel may run
+    return mlp_fwd128_launch(b, r, ns, 0, w, x, scale, shift, gamma, y, pairs, ext, stream);
   // (256, 128), nsample 16 / 32: the persistent T-form kernel (same pairs, same ext; y may be NULL)
   if (gemm_x6() && mlp_pool_fwd256_supported(b, m, k, r, ns, w, x) && (reinterpret_cast<size_t>(y) & 15) == 0)
     return mlp_pool_fwd256_launch(b, r, ns, w, x, scale, shift, gamma, y, pairs, ext, stream);

@@ -196,3 +196,8 @@ int mlp_pool_fwd256_supported(int b, int m, int k, int r, int ns, const float *w
 int mlp_pool_fwd256_launch(int b, int r, int ns, const float *w, const float *x, const float *scale,
                            const float *shift, const float *gamma, float *y, float *pairs, float *ext,
                            hipStream_t stream);
+// the (128, 128) layers the same way (fwd128_kernel): statistics as 64-column pairs; ns = 0: not pooled
+int mlp_fwd128_enabled_for(int b, int m, int k, int r);
+int mlp_fwd128_launch(int b, int r, int ns, int direct, const float *w, const float *x, const float *scale,
+                      const float *shift, const float *gamma, float *y, float *pairs, float *ext,
+                      hipStream_t stream);

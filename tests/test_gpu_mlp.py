@@ -707,6 +707,63 @@ def test_pooled_forward_without_its_raw_output(b, m, ns, monkeypatch):
     assert float((pooled - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("b,m,ns,pool,direct", [(8, 1024, 32, False, False), (8, 512, 64, True, False),
+                                                 (8, 512, 16, True, False), (4, 512, 32, True, False),
+                                                 (3, 1000, 32, False, False), (8, 512, 16, False, True),
+                                                 (5, 256, 64, True, False), (16, 512, 16, False, False)])
+def test_forward_128_channels_t_form(b, m, ns, pool, direct, monkeypatch):
+    """csrc/mlp_pool_fwd256.hip (fwd128_kernel): a 128 -> 128 layer (conv(1x1) of pytorch_utils.py:70-124 on
+    relu(bn(x)) or on x itself, BatchNorm statistics, optionally the max over nsample of
+    pointnet2_modules.py:256-262 with nsample 16 / 32 / 64) == float64 torch and == the tiled kernels."""
+    load_pkg()
+    K = importlib.import_module("pointnet2._mlp_ext")
+    g = torch.Generator().manual_seed(b * 5 + m + ns)
+    x = (torch.randn(b, 128, m, ns, generator=g) * 1.3 + 0.2).to(DEV)
+    x[:, :, :, 3] = x[:, :, :, 1]  # pool ties
+    x[:, :, ::7, ns - 1] = x[:, :, ::7, 0]
+    # (the weight at an odd 4-byte offset for some shapes, as inside the optimizer's flat parameter buffer)
+    flat = torch.zeros(128 * 128 + 3, device=DEV)
+    off = (b + m) % 4
+    w = flat[off:off + 128 * 128].view(128, 128)
+    w.copy_((torch.randn(128, 128, generator=g) / 11).to(DEV))
+    g2, be2 = (torch.rand(128, generator=g) + 0.5).to(DEV), (torch.randn(128, generator=g) * 0.3).to(DEV)
+    g3 = torch.rand(128, generator=g) + 0.5
+    g3[::5] *= -1
+    g3 = g3.to(DEV)
+    be3 = (torch.randn(128, generator=g) * 0.3).to(DEV)
+    z = lambda c: (torch.zeros(c, device=DEV), torch.ones(c, device=DEV))  # noqa: E731
+    c2 = K.bn_coefficients(x, g2, be2, *z(128), 0.1, 1e-5, True)
+    coeff = None if direct else (c2[2], c2[3])
+    fwd = lambda: K.gemm_forward_bn(w, x, coeff, g3, be3, *z(128), 0.1, 1e-5, pool=pool)  # noqa: E731
+    monkeypatch.setenv("MLP_FWD128", "1")  # (opt-in: see mlp_fwd128_enabled_for)
+    new = fwd()
+    monkeypatch.delenv("MLP_FWD128")
+    old = fwd()
+    a2 = x.double() if direct else torch.relu(x.double() * c2[2].double().view(1, -1, 1, 1) +
+                                              c2[3].double().view(1, -1, 1, 1))
+    y64 = torch.einsum("ck,bkmn->bcmn", w.double(), a2)
+    rng = float(y64.abs().max())
+    mean64, var64 = y64.mean(dim=(0, 2, 3)), y64.var(dim=(0, 2, 3), unbiased=False)
+    assert float((new[0].double() - y64).abs().max()) <= 2e-6 * rng
+    assert float((new[0] - old[0]).abs().max()) <= 2e-6 * rng
+    assert float((new[1].double() - mean64).abs().max()) <= 1e-6 * rng
+    assert float((new[2].double() * (var64 + 1e-5).sqrt() - 1).abs().max()) <= 1e-5
+    assert float((new[3] - old[3]).abs().max()) <= 1e-5 * float(old[3].abs().max())
+    if pool:
+        ext, ext_t = new[5], old[5]
+        assert (ext is None) == (off != 0) and (ext_t is None) == (off != 0)  # (the pooled epilogue wants aligned rows)
+    if pool and off == 0:
+        sign = torch.where(g3 < 0, -1.0, 1.0).double().view(1, -1, 1)
+        best64 = (y64 * sign.unsqueeze(-1)).max(dim=3).values * sign
+        assert float((ext[0].double() - best64).abs().max()) <= 2e-6 * rng
+        idx = ext[1].view(torch.int32).long()
+        assert int(idx.min()) >= 0 and int(idx.max()) < ns
+        picked = torch.gather(y64, 3, idx.unsqueeze(-1)).squeeze(-1)
+        assert float((picked - best64).abs().max()) <= 2e-6 * rng
+        assert not bool((idx == 3).any()) and not bool((idx[:, :, ::7] == ns - 1).any())  # exact ties: the first
+        assert float((ext[1].view(torch.int32) != ext_t[1].view(torch.int32)).float().mean()) < 1e-3
+
+
 @pytest.mark.parametrize("b,m,ns,kin,mout", [(8, 256, 64, 64, 128), (4, 300, 32, 64, 128), (2, 1024, 16, 64, 128),
                                              (3, 77, 64, 64, 128), (8, 1024, 32, 128, 256),
                                              (2, 512, 16, 128, 256), (3, 200, 32, 128, 256),
