@@ -52,4 +52,12 @@ timeout 300 bash tools/gram256_prof.sh $O/gram256 > /dev/null 2>&1; echo "gram25
 cp $O/gram256/gram256_kernel_stats.csv $O/${TAG}_gram256_kernel_stats.csv 2>/dev/null
 cp $O/gram256/gram256_pmc.json $O/${TAG}_gram256_pmc.json 2>/dev/null
 timeout 120 python tools/gram256_bench.py $O/${TAG}_gram256_bench.json > $O/gram256_bench.log 2>&1; echo "gram256_bench rc=$?"
+# -- the same layer's forward as a persistent T-form kernel (round 6): durations + SQ / LDS counters, micro benchmarks
+timeout 400 bash tools/pool_fwd256_prof.sh $O/pool_fwd256 > /dev/null 2>&1; echo "pool_fwd256_prof rc=$?"
+cp $O/pool_fwd256/pool_fwd256_kernel_stats.csv $O/${TAG}_pool_fwd256_kernel_stats.csv 2>/dev/null
+cp $O/pool_fwd256/pool_fwd256_pmc.json $O/${TAG}_pool_fwd256_pmc.json 2>/dev/null
+cp $O/pool_fwd256/pool_fwd256_pmc2.csv $O/${TAG}_pool_fwd256_lds_counters.csv 2>/dev/null
+grep "^b \|us per\|stored y3" $O/pool_fwd256/stats.log > $O/${TAG}_pool_fwd256_check.txt 2>/dev/null
+timeout 200 python tools/micro/mfma_bf16_peak.py $O/${TAG}_mfma_bf16_peak.json > /dev/null 2>&1; echo "mfma_bf16_peak rc=$?"
+timeout 100 python tools/micro/lds_read_rate.py > $O/${TAG}_lds_read_rate.json 2> /dev/null; echo "lds_read_rate rc=$?"
 ls -la $O | head -60
