@@ -212,16 +212,10 @@ bn_partial_stats_kernel(int c, int r, int slices, const float *__restrict__ y,
 // with one dependent load per step: 0.3 ms for SA1.)
 constexpr int kPairSlices = 32;
 
-// channel ch from the kPairSlices slice sums (one lane per channel)
-__device__ __forceinline__ void pairs_finalize_channel(int ch, int c, int parts, int n_part,
-                                                       const float *__restrict__ pairs,
-                                                       const double *__restrict__ sums,
-                                                       const FwdFinalize &f) {
-  double s1 = 0.0, s2 = 0.0, sm2 = 0.0;
-  for (int q = 0; q < kPairSlices; ++q) {
-    const double *o = sums + ((size_t)q * c + ch) * 3;
-    s1 += o[0]; s2 += o[1]; sm2 += o[2];
-  }
+// channel ch from its three sums over all parts (one lane per channel)
+__device__ __forceinline__ void pairs_finalize_sums(int ch, int parts, int n_part, double s1, double s2,
+                                                    double sm2, const float *__restrict__ pairs,
+                                                    const FwdFinalize &f) {
   const double ref = (double)pairs[(size_t)ch * 2];
   const double P = (double)parts, n = P * (double)n_part;
   const double mean = ref + s1 / P;
@@ -240,6 +234,19 @@ __device__ __forceinline__ void pairs_finalize_channel(int ch, int c, int parts,
     f.running_mean[ch] = (1.f - f.momentum) * f.running_mean[ch] + f.momentum * fmean;
     f.running_var[ch] = (1.f - f.momentum) * f.running_var[ch] + f.momentum * (float)unbiased;
   }
+}
+
+// channel ch from the kPairSlices slice sums (one lane per channel)
+__device__ __forceinline__ void pairs_finalize_channel(int ch, int c, int parts, int n_part,
+                                                       const float *__restrict__ pairs,
+                                                       const double *__restrict__ sums,
+                                                       const FwdFinalize &f) {
+  double s1 = 0.0, s2 = 0.0, sm2 = 0.0;
+  for (int q = 0; q < kPairSlices; ++q) {
+    const double *o = sums + ((size_t)q * c + ch) * 3;
+    s1 += o[0]; s2 += o[1]; sm2 += o[2];
+  }
+  pairs_finalize_sums(ch, parts, n_part, s1, s2, sm2, pairs, f);
 }
 
 // (the ticket form was tried here too: the last slice's serial walk over 32 x 3 doubles per channel
@@ -286,6 +293,44 @@ bn_pairs_stage1_kernel(int c, int parts, const float *__restrict__ pairs,
     for (int q = 1; q < 16; ++q) { s1 += red[q][0][lane]; s2 += red[q][1][lane]; sm2 += red[q][2][lane]; }
     double *o = sums + ((size_t)blockIdx.y * c + ch) * 3;
     o[0] = s1; o[1] = s2; o[2] = sm2;
+  }
+}
+
+// Few parts (the small layers: SA3 / SA4, the vote aggregation): ONE launch -- a workgroup per 64
+// channels walks all parts (its 16 waves every 16th, eight loads in flight: <= 4 rounds at 512 parts)
+// and finishes the channels itself.  Two launches cost ~11 us per layer whatever the size.
+constexpr int kPairsOneLaunch = 512;
+__global__ void __launch_bounds__(1024)
+bn_pairs_one_kernel(int c, int parts, int n_part, const float *__restrict__ pairs, FwdFinalize fin) {
+  __shared__ double red[16][3][kWave];
+  const int lane = lane_id(), w = threadIdx.x / kWave;
+  const int ch = blockIdx.x * kWave + lane;
+  double s1 = 0.0, s2 = 0.0, sm2 = 0.0;
+  if (ch < c) {
+    const double ref = (double)pairs[(size_t)ch * 2];
+    int p = w;
+    for (; p + 7 * 16 < parts; p += 8 * 16) {
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = *reinterpret_cast<const float2 *>(pairs + ((size_t)(p + u * 16) * c + ch) * 2);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const double d = (double)v[u].x - ref;
+        s1 += d; s2 += d * d; sm2 += (double)v[u].y;
+      }
+    }
+    for (; p < parts; p += 16) {
+      const float2 v = *reinterpret_cast<const float2 *>(pairs + ((size_t)p * c + ch) * 2);
+      const double d = (double)v.x - ref;
+      s1 += d; s2 += d * d; sm2 += (double)v.y;
+    }
+  }
+  red[w][0][lane] = s1; red[w][1][lane] = s2; red[w][2][lane] = sm2;
+  __syncthreads();
+  if (w == 0 && ch < c) {
+    for (int q = 1; q < 16; ++q) { s1 += red[q][0][lane]; s2 += red[q][1][lane]; sm2 += red[q][2][lane]; }
+    pairs_finalize_sums(ch, parts, n_part, s1, s2, sm2, pairs, fin);
   }
 }
 
@@ -632,6 +677,13 @@ MLP_API int mlp_bn_finalize_pairs(int c, int parts, int n_part, const float *pai
   hipStream_t stream = (hipStream_t)stream_;
   double *sums = reinterpret_cast<double *>(scratch);
   const FwdFinalize fin = {nullptr, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
+  // (MLP_BN_PAIRS_ONE_LAUNCH = the largest number of parts finished in one launch; 0: always two)
+  static const int one_limit = getenv("MLP_BN_PAIRS_ONE_LAUNCH") ? atoi(getenv("MLP_BN_PAIRS_ONE_LAUNCH")) : kPairsOneLaunch;
+  if (parts <= one_limit) {
+    hipLaunchKernelGGL(bn_pairs_one_kernel, dim3(pn2_ceil_div(c, kWave)), dim3(1024), 0, stream, c, parts, n_part,
+                       pairs, fin);
+    return pn2_launch_status();
+  }
   hipLaunchKernelGGL(bn_pairs_stage1_kernel, dim3(pn2_ceil_div(c, kWave), kPairSlices), dim3(1024),
                      0, stream, c, parts, pairs, sums);
   hipLaunchKernelGGL(bn_pairs_stage2_kernel, dim3(pn2_ceil_div(c, 256)), dim3(256), 0, stream, c,

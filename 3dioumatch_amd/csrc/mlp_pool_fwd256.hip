@@ -755,6 +755,9 @@ int mlp_pool_fwd256_supported(int b, int m, int k, int r, int ns, const float *w
 int mlp_pool_fwd256_launch(int b, int r, int ns, const float *w, const float *x, const float *scale,
                            const float *shift, const float *gamma, float *y, float *pairs, float *ext,
                            hipStream_t stream) {
+  if (!w || !x || !scale || !shift || !gamma || !pairs || !ext || (ns != 16 && ns != 32) || b <= 0 || r <= 0 ||
+      r % 256 != 0)
+    return (int)hipErrorInvalidValue;
   PoolFwdArgs a = {};
   a.r = r; a.chunks_per_cloud = r / kFTN; a.total_tiles = b * (r / 64); a.groups = r / ns;
   a.w = w; a.x = x; a.sc = scale; a.sh = shift; a.gamma = gamma; a.pairs = pairs; a.ext = ext; a.y = y;
