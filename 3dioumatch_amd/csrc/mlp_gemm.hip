@@ -1099,45 +1099,77 @@ gemm_small_backward_pair_kernel(SmallPairArgs t, OperandB opp, OperandB opq) {
 
 // dw[i] = sum_p part[p][i]: a workgroup owns 32 consecutive elements, its 8 lane groups each sum
 // every 8th partial (128-byte rows, eight loads in flight per lane), LDS adds the groups in a
-// fixed order -- deterministic, and a few hundred partials finish in a few microseconds
+// fixed order -- deterministic, and a few hundred partials finish in a few microseconds.
+// VEC (count % 4 == 0, 16-byte aligned rows): a workgroup owns 128 consecutive elements, a lane four of
+// them as ONE 16-byte load per partial -- the same additions in the same order per element, a quarter
+// of the load instructions (the queued reduction of a backward pass reads ~280 MB).
+template <bool VEC>
 __device__ __forceinline__ void reduce_partials_block(int block, int count, int parts,
                                                       const float *__restrict__ part,
                                                       float *__restrict__ out) {
-  __shared__ float sums[8][32];
+  constexpr int W = VEC ? 4 : 1;
+  __shared__ float sums[8][32 * W];
   const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int i = block * 32 + e;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+  const int i = (block * 32 + e) * W;
+  float s[8][W];
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+#pragma unroll
+    for (int c = 0; c < W; ++c) s[u][c] = 0.f;
+  auto row = [&](int p, float (&v)[W]) {
+    if constexpr (VEC) {
+      const float4 t = *reinterpret_cast<const float4 *>(part + (size_t)p * count + i);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+      v[0] = part[(size_t)p * count + i];
+    }
+  };
   if (i < count) {
     int p = grp;
-    const float *col = part + i;
     for (; p + 56 < parts; p += 64) {  // eight rows in flight per lane
-      const float v0 = col[(size_t)p * count], v1 = col[(size_t)(p + 8) * count];
-      const float v2 = col[(size_t)(p + 16) * count], v3 = col[(size_t)(p + 24) * count];
-      const float v4 = col[(size_t)(p + 32) * count], v5 = col[(size_t)(p + 40) * count];
-      const float v6 = col[(size_t)(p + 48) * count], v7 = col[(size_t)(p + 56) * count];
-      s0 += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
+      float v[8][W];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) row(p + 8 * u, v[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int c = 0; c < W; ++c) s[u][c] += v[u][c];
     }
     for (; p + 24 < parts; p += 32) {
-      const float v0 = col[(size_t)p * count], v1 = col[(size_t)(p + 8) * count];
-      const float v2 = col[(size_t)(p + 16) * count], v3 = col[(size_t)(p + 24) * count];
-      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+      float v[4][W];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) row(p + 8 * u, v[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < W; ++c) s[u][c] += v[u][c];
     }
-    for (; p < parts; p += 8) s0 += col[(size_t)p * count];
+    for (; p < parts; p += 8) {
+      float v[W];
+      row(p, v);
+#pragma unroll
+      for (int c = 0; c < W; ++c) s[0][c] += v[c];
+    }
   }
-  sums[grp][e] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+#pragma unroll
+  for (int c = 0; c < W; ++c)
+    sums[grp][e * W + c] = ((s[0][c] + s[1][c]) + (s[2][c] + s[3][c])) + ((s[4][c] + s[5][c]) + (s[6][c] + s[7][c]));
   __syncthreads();
   if (grp == 0 && i < count) {
-    float t = sums[0][e];
 #pragma unroll
-    for (int q = 1; q < 8; ++q) t += sums[q][e];
-    out[i] = t;
+    for (int c = 0; c < W; ++c) {
+      float t = sums[0][e * W + c];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) t += sums[q][e * W + c];
+      out[i + c] = t;
+    }
   }
 }
 
 __global__ void __launch_bounds__(256)
 reduce_partials_kernel(int count, int parts, const float *__restrict__ part,
                        float *__restrict__ out) {
-  reduce_partials_block((int)blockIdx.x, count, parts, part, out);
+  reduce_partials_block<false>((int)blockIdx.x, count, parts, part, out);
 }
 
 // Many reductions in one launch (the queued weight gradients of a backward pass): the table
@@ -1151,13 +1183,16 @@ struct ReduceBatch {
   int parts[kReduceBatch];
   const float *part[kReduceBatch];
   float *out[kReduceBatch];
+  unsigned char vec[kReduceBatch];
 };
 
 __global__ void __launch_bounds__(256) reduce_partials_batch_kernel(const ReduceBatch t) {
   const int blk = (int)blockIdx.x;
   int e = 0;
   while (e + 1 < t.n && blk >= t.first_block[e + 1]) ++e;
-  reduce_partials_block(blk - t.first_block[e], t.count[e], t.parts[e], t.part[e], t.out[e]);
+  // (an entry is vectorised when its rows are 16-byte aligned: its blocks then cover 128 elements)
+  if (t.vec[e]) reduce_partials_block<true>(blk - t.first_block[e], t.count[e], t.parts[e], t.part[e], t.out[e]);
+  else reduce_partials_block<false>(blk - t.first_block[e], t.count[e], t.parts[e], t.part[e], t.out[e]);
 }
 
 // fp32 products as six bf16 MFMAs (see split3): on unless MLP_GEMM_SPLIT_BF16=0 (read once)
@@ -1396,7 +1431,9 @@ int mlp_reduce_weight_partials(int count, int parts, const float *part, float *o
   reduce_queue.parts[e] = parts;
   reduce_queue.part[e] = part;
   reduce_queue.out[e] = out;
-  reduce_queue.first_block[e + 1] = reduce_queue.first_block[e] + (int)pn2_ceil_div((long long)count, 32);
+  const bool vec = count % 4 == 0 && ((reinterpret_cast<size_t>(part) | reinterpret_cast<size_t>(out)) & 15) == 0;
+  reduce_queue.vec[e] = vec ? 1 : 0;
+  reduce_queue.first_block[e + 1] = reduce_queue.first_block[e] + (int)pn2_ceil_div((long long)count, vec ? 128 : 32);
   return 0;
 }
 
