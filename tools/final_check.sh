@@ -7,3 +7,4 @@ timeout 600 python tools/stress_bench.py gpurun_out/r6f/r6_stress_config5.json >
 timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -3
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout 600 python tools/gram256_soak.py 100 2>&1 | tail -1
+timeout 600 python tools/pool_fwd256_soak.py 120 2>&1 | tail -2
