@@ -113,6 +113,8 @@ struct FwdFinalize {
   float *running_mean, *running_var, *mean_out, *invstd_out, *scale_out, *shift_out;
 };
 
+__device__ __forceinline__ void fwd_write_channel(int ch, double n, double mean, double m2, const FwdFinalize &f);
+
 // one wave: Chan-merge the `parts` triples of channel ch, write its statistics and coefficients
 __device__ __forceinline__ void fwd_finalize_channel(int ch, int parts, const float *__restrict__ partial,
                                                      const FwdFinalize &f) {
@@ -132,7 +134,11 @@ __device__ __forceinline__ void fwd_finalize_channel(int ch, int parts, const fl
     acc = (lane & off) ? chan_merge(other, acc) : chan_merge(acc, other);
   }
   if (lane != 0) return;
-  const double n = acc.n, mean = acc.mean, m2 = acc.m2;
+  fwd_write_channel(ch, acc.n, acc.mean, acc.m2, f);
+}
+
+// one lane: the channel's statistics and coefficients from (n, mean, M2)
+__device__ __forceinline__ void fwd_write_channel(int ch, double n, double mean, double m2, const FwdFinalize &f) {
   const double var = n > 0.0 ? m2 / n : 0.0;  // biased, used for normalisation
   const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
   const float fmean = (float)mean;
@@ -146,6 +152,62 @@ __device__ __forceinline__ void fwd_finalize_channel(int ch, int parts, const fl
     f.running_mean[ch] = (1.f - f.momentum) * f.running_mean[ch] + f.momentum * fmean;
     f.running_var[ch] = (1.f - f.momentum) * f.running_var[ch] + f.momentum * (float)unbiased;
   }
+}
+
+// ---- the small layers (FP modules, heads: at most 16384 values per channel): ONE workgroup per
+// channel reads all of its values -- b rows of r floats, at most four float4 per lane of 1024 --, reduces
+// them in double through LDS and finalizes.  No partials, no tickets, no second look at memory: the
+// ticket form is three dependent trips to the memory side (~9-15 us per launch), this one load + one
+// reduction (~5 us).  The backward form keeps y and dz in registers between the sums and dy.
+constexpr int kChThreads = 1024, kChMax = 4 * 4 * kChThreads;  // values per channel
+__device__ __forceinline__ void channel_sum2(double &a, double &b, double (*red)[2]) {
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) { a += shfl_xor_f64(a, off); b += shfl_xor_f64(b, off); }
+  const int w = threadIdx.x / kWave;
+  if (lane_id() == 0) { red[w][0] = a; red[w][1] = b; }
+  __syncthreads();
+  a = 0.0; b = 0.0;
+#pragma unroll
+  for (int q = 0; q < kChThreads / kWave; ++q) { a += red[q][0]; b += red[q][1]; }  // every thread: the same bits
+}
+
+__global__ void __launch_bounds__(kChThreads)
+bn_channel_stats_kernel(int bn, int c, int r, const float *__restrict__ y, FwdFinalize fin) {
+  __shared__ double red[kChThreads / kWave][2];
+  const int ch = blockIdx.x, nv = r >> 2, total = bn * nv;
+  const float shift = y[(size_t)ch * r];  // shifted sums: no cancellation in the variance
+  float4 v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = threadIdx.x + u * kChThreads;
+    v[u] = make_float4(shift, shift, shift, shift);
+    if (i < total) {
+      const int b = i / nv, j = i - b * nv;
+      v[u] = reinterpret_cast<const float4 *>(y + ((size_t)b * c + ch) * r)[j];
+    }
+  }
+  float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float p0 = v[u].x - shift, p1 = v[u].y - shift, p2 = v[u].z - shift, p3 = v[u].w - shift;
+    a1 += (p0 + p1) + (p2 + p3);
+    a2 += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
+  }
+  double s1 = (double)a1, s2 = (double)a2;
+  channel_sum2(s1, s2, red);
+  if (threadIdx.x == 0) {
+    const double n = (double)bn * (double)r;
+    fwd_write_channel(ch, n, (double)shift + s1 / n, fmax(s2 - s1 * s1 / n, 0.0), fin);
+  }
+}
+
+// the per-channel forms cover: whole float4 rows, at most kChMax values per channel, 16-byte aligned
+// tensors (MLP_BN_CHANNEL_FORM=0: the ticket forms)
+static bool channel_form(int b, int c, int r, const void *p0, const void *p1, const void *p2) {
+  const char *env = getenv("MLP_BN_CHANNEL_FORM");  // (read on every call: the tests compare both forms)
+  const bool off = env && atoi(env) == 0;
+  if (off || r % 4 != 0 || (long long)b * r > kChMax || c < 32) return false;
+  return ((reinterpret_cast<size_t>(p0) | reinterpret_cast<size_t>(p1) | reinterpret_cast<size_t>(p2)) & 15) == 0;
 }
 
 // ---- forward statistics (continued): the partial sums; the last workgroup of a channel also
@@ -485,6 +547,68 @@ bn_bwd_finalize_kernel(int c, int parts, const float *__restrict__ partial, BwdF
   bwd_finalize_channel(ch, parts, partial, f);
 }
 
+// sums (+ coefficients) of the BatchNorm + ReLU backward, and with APPLY also dy, per channel
+template <bool APPLY>
+__global__ void __launch_bounds__(kChThreads)
+bn_channel_bwd_kernel(int bn, int c, int r, const float *__restrict__ y, const float *__restrict__ dz,
+                      const float *__restrict__ scale, const float *__restrict__ shift,
+                      const float *__restrict__ mean, const float *__restrict__ invstd,
+                      float *__restrict__ dy, BwdFinalize f) {
+  __shared__ double red[kChThreads / kWave][2];
+  const int ch = blockIdx.x, nv = r >> 2, total = bn * nv;
+  const float sc = scale[ch], sh = shift[ch], mu = mean[ch], is = invstd[ch];
+  float4 yy[4], gg[4];
+  size_t at[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = threadIdx.x + u * kChThreads;
+    yy[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    gg[u] = yy[u];
+    at[u] = 0;
+    if (i < total) {
+      const int b = i / nv, j = i - b * nv;
+      at[u] = ((size_t)b * c + ch) * r + (size_t)j * 4;
+      yy[u] = *reinterpret_cast<const float4 *>(y + at[u]);
+      gg[u] = *reinterpret_cast<const float4 *>(dz + at[u]);
+    }
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {  // (lanes beyond the channel hold zeros: dz = 0 adds nothing)
+    gg[u].x = (yy[u].x * sc + sh > 0.f) ? gg[u].x : 0.f; gg[u].y = (yy[u].y * sc + sh > 0.f) ? gg[u].y : 0.f;
+    gg[u].z = (yy[u].z * sc + sh > 0.f) ? gg[u].z : 0.f; gg[u].w = (yy[u].w * sc + sh > 0.f) ? gg[u].w : 0.f;
+    s1 += (gg[u].x + gg[u].y) + (gg[u].z + gg[u].w);
+    s2 += (gg[u].x * ((yy[u].x - mu) * is) + gg[u].y * ((yy[u].y - mu) * is)) +
+          (gg[u].z * ((yy[u].z - mu) * is) + gg[u].w * ((yy[u].w - mu) * is));
+  }
+  double d1 = (double)s1, d2 = (double)s2;
+  channel_sum2(d1, d2, red);
+  const float a = f.gamma[ch] * f.invstd[ch];
+  // eval mode: statistics are constants, dy = gamma*invstd*dzh
+  const float c1 = f.training ? (float)(d1 / f.count) : 0.f, c2 = f.training ? (float)(d2 / f.count) : 0.f;
+  if (threadIdx.x == 0) {
+    f.dbeta[ch] = (float)d1;
+    f.dgamma[ch] = (float)d2;
+    f.coef[ch * 3 + 0] = a;
+    f.coef[ch * 3 + 1] = c1;
+    f.coef[ch * 3 + 2] = c2;
+  }
+  if constexpr (APPLY) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = threadIdx.x + u * kChThreads;
+      if (i < total) {
+        float4 o;
+        o.x = a * (gg[u].x - c1 - ((yy[u].x - mu) * is) * c2);
+        o.y = a * (gg[u].y - c1 - ((yy[u].y - mu) * is) * c2);
+        o.z = a * (gg[u].z - c1 - ((yy[u].z - mu) * is) * c2);
+        o.w = a * (gg[u].w - c1 - ((yy[u].w - mu) * is) * c2);
+        *reinterpret_cast<float4 *>(dy + at[u]) = o;
+      }
+    }
+  }
+}
+
 // ---- backward sums: s1 = sum dzh, s2 = sum dzh * xhat, dzh = dz * [y*scale+shift > 0] --------
 __global__ void __launch_bounds__(kBnThreads)
 bn_relu_bwd_partial_kernel(int c, int r, int slices, const float *__restrict__ y,
@@ -655,6 +779,10 @@ MLP_API int mlp_bn_train_stats(int b, int c, int r, const float *y, const float 
   const int slices = slices_for(r);
   const FwdFinalize fin = {tickets, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
   if (fin.tickets == nullptr) return (int)hipErrorInvalidValue;
+  if (channel_form(b, c, r, y, nullptr, nullptr)) {
+    hipLaunchKernelGGL(bn_channel_stats_kernel, dim3(c), dim3(kChThreads), 0, stream, b, c, r, y, fin);
+    return pn2_launch_status();
+  }
   hipLaunchKernelGGL(bn_partial_stats_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream, c,
                      r, slices, y, workspace, fin);
   return pn2_launch_status();
@@ -745,6 +873,12 @@ MLP_API int mlp_bn_relu_backward(int b, int c, int r, int training, const float 
   if (b <= 0 || c <= 0 || r <= 0) return 0;
   if (tickets == nullptr) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
+  if (channel_form(b, c, r, y, dz, dy)) {  // sums and dy in one launch, y and dz read once
+    hipLaunchKernelGGL(bn_channel_bwd_kernel<true>, dim3(c), dim3(kChThreads), 0, stream, b, c, r, y, dz, scale,
+                       shift, mean, invstd, dy,
+                       BwdFinalize{tickets, (double)b * (double)r, training, gamma, invstd, dgamma, dbeta, coef});
+    return pn2_launch_status();
+  }
   const int slices = slices_for(r);
   hipLaunchKernelGGL(bn_relu_bwd_partial_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream,
                      c, r, slices, y, dz, scale, shift, mean, invstd, workspace,
@@ -767,6 +901,12 @@ MLP_API int mlp_bn_relu_backward_stats(int b, int c, int r, int training, const 
   if (b <= 0 || c <= 0 || r <= 0) return 0;
   if (tickets == nullptr) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
+  if (channel_form(b, c, r, y, dz, nullptr)) {
+    hipLaunchKernelGGL(bn_channel_bwd_kernel<false>, dim3(c), dim3(kChThreads), 0, stream, b, c, r, y, dz, scale,
+                       shift, mean, invstd, nullptr,
+                       BwdFinalize{tickets, (double)b * (double)r, training, gamma, invstd, dgamma, dbeta, coef});
+    return pn2_launch_status();
+  }
   const int slices = slices_for(r);
   hipLaunchKernelGGL(bn_relu_bwd_partial_kernel, dim3(slices, c, b), dim3(kBnThreads), 0, stream,
                      c, r, slices, y, dz, scale, shift, mean, invstd, workspace,

@@ -707,6 +707,56 @@ def test_pooled_forward_without_its_raw_output(b, m, ns, monkeypatch):
     assert float((pooled - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("b,c,r,training", [(8, 256, 1024, True), (16, 256, 1024, True), (8, 128, 256, True),
+                                              (3, 259, 1000, True), (1, 64, 4096, True), (8, 256, 1024, False),
+                                              (5, 128, 36, True), (12, 32, 1024, True)])
+def test_batchnorm_per_channel_forms(b, c, r, training, monkeypatch):
+    """csrc/mlp_bn.hip, the small layers' forms (one workgroup per channel, no partials, no tickets):
+    training statistics + coefficients (nn.BatchNorm2d of pytorch_utils.py:14-39), the backward sums and
+    dy of BatchNorm + ReLU == float64 torch and == the ticket forms (MLP_BN_CHANNEL_FORM=0)."""
+    load_pkg()
+    K = importlib.import_module("pointnet2._mlp_ext")
+    g = torch.Generator().manual_seed(b * 3 + c + r)
+    y = (torch.randn(b, c, r, generator=g) * 1.7 + 0.4).to(DEV)
+    dz = torch.randn(b, c, r, generator=g).to(DEV)
+    gamma = torch.rand(c, generator=g) + 0.5
+    gamma[::4] *= -1
+    gamma, beta = gamma.to(DEV), (torch.randn(c, generator=g) * 0.3).to(DEV)
+
+    def run():
+        rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        mean, invstd, scale, shift = K.bn_coefficients(y, gamma, beta, rm, rv, 0.1, 1e-5, True)
+        dy, dgamma, dbeta = K.bn_relu_backward(y, dz, gamma, scale, shift, mean, invstd, training)
+        dg2, db2, coef = K.bn_relu_backward_stats(y, dz, gamma, scale, shift, mean, invstd, training)
+        return [t.clone() for t in (mean, invstd, scale, shift, rm, rv, dy, dgamma, dbeta, dg2, db2, coef)]
+
+    new = run()
+    monkeypatch.setenv("MLP_BN_CHANNEL_FORM", "0")
+    old = run()
+    monkeypatch.delenv("MLP_BN_CHANNEL_FORM")
+    y64, dz64 = y.double(), dz.double()
+    mean64, var64 = y64.mean(dim=(0, 2)), y64.var(dim=(0, 2), unbiased=False)
+    n = b * r
+    assert float((new[0].double() - mean64).abs().max()) <= 1e-6 * float(y64.abs().max())
+    assert float((new[1].double() * (var64 + 1e-5).sqrt() - 1).abs().max()) <= 1e-5
+    assert float((new[4].double() - 0.1 * mean64).abs().max()) <= 1e-6 * float(y64.abs().max())
+    assert float((new[5].double() - (0.9 + 0.1 * var64 * n / max(n - 1, 1))).abs().max()) <= 1e-5 * float(var64.max())
+    sc64, sh64 = new[2].double().view(1, -1, 1), new[3].double().view(1, -1, 1)
+    g64 = torch.where(y64 * sc64 + sh64 > 0, dz64, torch.zeros_like(dz64))
+    xhat = (y64 - new[0].double().view(1, -1, 1)) * new[1].double().view(1, -1, 1)
+    s1, s2 = g64.sum(dim=(0, 2)), (g64 * xhat).sum(dim=(0, 2))
+    tol = 3e-6 * float(g64.abs().sum(dim=(0, 2)).max())
+    assert float((new[8].double() - s1).abs().max()) <= tol and float((new[7].double() - s2).abs().max()) <= tol
+    a64 = gamma.double() * new[1].double()
+    c1 = s1 / n if training else torch.zeros_like(s1)
+    c2 = s2 / n if training else torch.zeros_like(s2)
+    dy64 = a64.view(1, -1, 1) * (g64 - c1.view(1, -1, 1) - xhat * c2.view(1, -1, 1))
+    assert float((new[6].double() - dy64).abs().max()) <= 1e-5 * float(dy64.abs().max())
+    for i, (p, q) in enumerate(zip(new, old)):  # the two forms against one another
+        assert float((p - q).abs().max()) <= 1e-5 * float(q.abs().max()) + 1e-7, i
+    assert torch.equal(new[7], new[9]) and torch.equal(new[8], new[10])  # sums-only launch == sums + dy launch
+
+
 @pytest.mark.parametrize("b,m,ns,pool,direct", [(8, 1024, 32, False, False), (8, 512, 64, True, False),
                                                  (8, 512, 16, True, False), (4, 512, 32, True, False),
                                                  (3, 1000, 32, False, False), (8, 512, 16, False, True),
