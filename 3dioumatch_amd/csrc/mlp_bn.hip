@@ -948,6 +948,14 @@ MLP_API int mlp_bn_relu_pool_backward(int b, int c, int m, int ns, int training,
   if (b <= 0 || c <= 0 || m <= 0 || ns <= 0) return 0;
   if (tickets == nullptr) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
+  // the same sums over the pooled tensors: (ymax, dpooled) in the roles of (y, dz), m values per cloud
+  // and channel -- one workgroup per channel where they fit (bn_channel_bwd_kernel)
+  if (channel_form(b, c, m, ymax, dpooled, nullptr))
+    hipLaunchKernelGGL(bn_channel_bwd_kernel<false>, dim3(c), dim3(kChThreads), 0, stream, b, c, m, ymax, dpooled,
+                       scale, shift, mean, invstd, nullptr,
+                       BwdFinalize{tickets, (double)b * (double)m * (double)ns, training, gamma, invstd,
+                                   dgamma, dbeta, coef});
+  else
   hipLaunchKernelGGL(pool_bwd_partial_kernel, dim3(1, c, b), dim3(kBnThreads), 0, stream, c, m,
                      dpooled, ymax, scale, shift, mean, invstd, workspace,
                      BwdFinalize{tickets, (double)b * (double)m * (double)ns, training, gamma, invstd,
