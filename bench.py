@@ -112,6 +112,7 @@ def build_step(V, cfg, device, world, local_rank, workload="pretrain"):
 
 
 TIME_OP_EAGER = []  # names of operators whose graph capture failed (timed as an eager loop)
+COPY_STREAM = {}  # the feeding loops' host -> device stream (one per process)
 
 
 def time_op(fn, iters=20, warm=3, name=None):
@@ -519,7 +520,12 @@ def main():
         and runs step i.  Also returns the host time per iteration measured in a second pass with
         the device idle-waited between iterations (Python + launch time only)."""
         k = len(host_batches)
-        copy_stream = torch.cuda.Stream(device=device)
+        # ONE copy stream per process: HIP maps streams onto a few hardware queues, and a later workload's
+        # fresh stream was seen to share a queue with the step's own streams (the semi-supervised
+        # workload fed 0.4 ms slower as the third runner of the default run than alone)
+        if "stream" not in COPY_STREAM:
+            COPY_STREAM["stream"] = torch.cuda.Stream(device=device)
+        copy_stream = COPY_STREAM["stream"]
         main = torch.cuda.current_stream(device)
         # every batch is ONE pinned byte buffer (what a collate function that writes into a
         # preallocated pinned arena hands over) and every device-side set one byte buffer with typed
