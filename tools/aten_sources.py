@@ -31,7 +31,7 @@ SKIP = ("aten::view", "aten::_unsafe_view", "aten::reshape", "aten::transpose", 
         "aten::select", "aten::expand", "aten::unsqueeze", "aten::squeeze", "aten::detach", "aten::alias",
         "aten::as_strided", "aten::t", "aten::empty", "aten::empty_like", "aten::empty_strided", "aten::size",
         "aten::stride", "aten::is_contiguous", "aten::unbind", "aten::split", "aten::_local_scalar_dense",
-        "aten::lift_fresh", "aten::narrow", "aten::view_as", "aten::numel", "aten::contiguous", "aten::to",
+        "aten::lift_fresh", "aten::narrow", "aten::view_as", "aten::numel", "aten::to",
         "aten::_to_copy", "aten::item", "aten::sym_size", "aten::unflatten", "aten::flatten", "aten::chunk")
 agg = collections.Counter()
 size = collections.Counter()  # elements of the largest tensor argument, summed per (op, line)
